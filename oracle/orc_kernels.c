@@ -1,0 +1,419 @@
+/*
+ * oracle/orc_kernels.c -- the likelihood hot path of the CPU oracle
+ * (TEST INFRASTRUCTURE ONLY, see orc_internal.h).
+ *
+ * Each function is the scalar fp64 restatement of one row of SURVEY.md
+ * section 8a; the call contract is taken from the reference call sites:
+ *   pll_update_prob_matrices           src/tree/treeinfo.c:854
+ *   pll_update_partials                src/tree/treeinfo.c:1037,
+ *                                      src/optimize/pll_optimize.c:748-775
+ *   pll_compute_edge_loglikelihood     src/tree/treeinfo.c:1049
+ *   pll_compute_root_loglikelihood     src/optimize/pll_optimize.c:329
+ *   pll_update_sumtable                src/optimize/pll_optimize.c:800, 1468
+ *   pll_compute_likelihood_derivatives src/optimize/pll_optimize.c:307, 1249
+ *                                      (sign: src/optimize/opt_algorithms.c:208-226)
+ *   pll_compute_node_ancestral         src/tree/treeinfo.c:1698
+ *
+ * Semantics that the reference cannot pin offline and that therefore DEFINE
+ * the behaviour both engines must share (libpll-2 knowledge):
+ *   - scaling: if the parent has a scaler, scaler[n] = s_child1[n]+s_child2[n];
+ *     if all R*S entries of site n are < 2^-256 they are multiplied by 2^256
+ *     and scaler[n] += 1.  lnL subtracts 256*ln2 per count.
+ *   - p-inv: P-matrices use rate/(1-pinv); site likelihood is
+ *     (1-pinv)*L + pinv*pi[invariant[n]].
+ *   - t == 0 gives the identity matrix.
+ */
+#include "orc_internal.h"
+
+#define ORC_LN_SCALE 177.445678223345993274 /* 256 * ln 2 */
+
+int pll_update_prob_matrices(pll_partition_t * p,
+                             const unsigned int * params_indices,
+                             const unsigned int * matrix_indices,
+                             const double * branch_lengths,
+                             unsigned int count)
+{
+  unsigned int S = p->states, Sp = p->states_padded, R = p->rate_cats;
+  unsigned int m, r, i, j, k;
+  double * ex = (double *)malloc(sizeof(double) * S);
+  if (!ex) { orc_set_error(PLL_ERROR_MEM_ALLOC, "pmatrix workspace"); return PLL_FAILURE; }
+
+  for (r = 0; r < R; ++r)
+    if (!p->eigen_decomp_valid[params_indices[r]])
+      if (!orc_update_eigen(p, params_indices[r])) { free(ex); return PLL_FAILURE; }
+
+  for (m = 0; m < count; ++m)
+  {
+    double t = branch_lengths[m];
+    if (matrix_indices[m] >= p->prob_matrices || !(t >= 0.0))
+    {
+      free(ex);
+      orc_set_error(PLL_ERROR_PARAM_INVALID, "Invalid matrix index or branch length");
+      return PLL_FAILURE;
+    }
+    for (r = 0; r < R; ++r)
+    {
+      unsigned int pi_ = params_indices[r];
+      double * P = p->pmatrix[matrix_indices[m]] + (size_t)r * S * Sp;
+      const double * V = p->eigenvecs[pi_], * Vi = p->inv_eigenvecs[pi_];
+      const double * L = p->eigenvals[pi_];
+      double pinv = p->prop_invar[pi_];
+      memset(P, 0, sizeof(double) * S * Sp);
+      if (t == 0.0)
+      {
+        for (i = 0; i < S; ++i) P[i * Sp + i] = 1.0;
+        continue;
+      }
+      double rt = p->rates[r] * t / (1.0 - pinv);
+      for (k = 0; k < S; ++k) ex[k] = exp(L[k] * rt);
+      for (i = 0; i < S; ++i)
+        for (j = 0; j < S; ++j)
+        {
+          double s = 0.0;
+          for (k = 0; k < S; ++k) s += V[i * Sp + k] * ex[k] * Vi[k * Sp + j];
+          P[i * Sp + j] = s;
+        }
+    }
+  }
+  free(ex);
+  return PLL_SUCCESS;
+}
+
+/* per-code lookup for a tip child stored as codes:
+   lut[(r*ncodes + code)*S + i] = sum_j P[r][i][j] * mask(code)[j] */
+static double * tip_lookup(const pll_partition_t * p, const double * P)
+{
+  unsigned int S = p->states, Sp = p->states_padded, R = p->rate_cats;
+  unsigned int nc = p->maxstates, r, c, i, j;
+  double * lut = (double *)malloc(sizeof(double) * (size_t)R * (nc ? nc : 1) * S);
+  if (!lut) return NULL;
+  for (r = 0; r < R; ++r)
+    for (c = 0; c < nc; ++c)
+    {
+      pll_state_t m = p->tipmap[c];
+      for (i = 0; i < S; ++i)
+      {
+        double a = 0.0;
+        for (j = 0; j < S; ++j)
+          if ((m >> j) & 1ULL) a += P[((size_t)r * S + i) * Sp + j];
+        lut[((size_t)r * nc + c) * S + i] = a;
+      }
+    }
+  return lut;
+}
+
+void pll_update_partials(pll_partition_t * p, const pll_operation_t * ops,
+                         unsigned int count)
+{
+  const unsigned int S = p->states, Sp = p->states_padded, R = p->rate_cats;
+  const unsigned int nc = p->maxstates;
+  const int coded = (p->attributes & PLL_ATTRIB_PATTERN_TIP) != 0;
+  unsigned int o;
+
+  for (o = 0; o < count; ++o)
+  {
+    const pll_operation_t * op = &ops[o];
+    double * parent = p->clv[op->parent_clv_index];
+    unsigned int * ps = (op->parent_scaler_index == PLL_SCALE_BUFFER_NONE)
+                            ? NULL : p->scale_buffer[op->parent_scaler_index];
+    const unsigned int * s1 = (op->child1_scaler_index == PLL_SCALE_BUFFER_NONE)
+                            ? NULL : p->scale_buffer[op->child1_scaler_index];
+    const unsigned int * s2 = (op->child2_scaler_index == PLL_SCALE_BUFFER_NONE)
+                            ? NULL : p->scale_buffer[op->child2_scaler_index];
+    const double * P1 = p->pmatrix[op->child1_matrix_index];
+    const double * P2 = p->pmatrix[op->child2_matrix_index];
+    const int tip1 = coded && op->child1_clv_index < p->tips;
+    const int tip2 = coded && op->child2_clv_index < p->tips;
+    const unsigned char * code1 = tip1 ? p->tipchars[op->child1_clv_index] : NULL;
+    const unsigned char * code2 = tip2 ? p->tipchars[op->child2_clv_index] : NULL;
+    const double * c1 = tip1 ? NULL : p->clv[op->child1_clv_index];
+    const double * c2 = tip2 ? NULL : p->clv[op->child2_clv_index];
+    double * lut1 = tip1 ? tip_lookup(p, P1) : NULL;
+    double * lut2 = tip2 ? tip_lookup(p, P2) : NULL;
+    if ((tip1 && !lut1) || (tip2 && !lut2))
+    {
+      free(lut1); free(lut2);
+      orc_set_error(PLL_ERROR_MEM_ALLOC, "tip lookup");
+      return;
+    }
+
+    long n;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (n = 0; n < (long)p->sites; ++n)
+    {
+      double * out = parent + (size_t)n * R * Sp;
+      int all_small = 1;
+      unsigned int r, i, j;
+      for (r = 0; r < R; ++r)
+      {
+        const double * v1 = tip1 ? lut1 + ((size_t)r * nc + code1[n]) * S
+                                 : c1 + ((size_t)n * R + r) * Sp;
+        const double * v2 = tip2 ? lut2 + ((size_t)r * nc + code2[n]) * S
+                                 : c2 + ((size_t)n * R + r) * Sp;
+        for (i = 0; i < S; ++i)
+        {
+          double a, b;
+          if (tip1) a = v1[i];
+          else
+          {
+            const double * row = P1 + ((size_t)r * S + i) * Sp;
+            for (a = 0.0, j = 0; j < S; ++j) a += row[j] * v1[j];
+          }
+          if (tip2) b = v2[i];
+          else
+          {
+            const double * row = P2 + ((size_t)r * S + i) * Sp;
+            for (b = 0.0, j = 0; j < S; ++j) b += row[j] * v2[j];
+          }
+          double v = a * b;
+          out[r * Sp + i] = v;
+          if (!(v < PLL_SCALE_THRESHOLD)) all_small = 0;
+        }
+        for (i = S; i < Sp; ++i) out[r * Sp + i] = 0.0;
+      }
+      if (ps)
+      {
+        unsigned int cnt = (s1 ? s1[n] : 0) + (s2 ? s2[n] : 0);
+        if (all_small)
+        {
+          for (r = 0; r < R; ++r)
+            for (i = 0; i < S; ++i) out[r * Sp + i] *= PLL_SCALE_FACTOR;
+          cnt += 1;
+        }
+        ps[n] = cnt;
+      }
+    }
+    free(lut1);
+    free(lut2);
+  }
+}
+
+/* combine the scaled site likelihood `x` (true value x * 2^(-256 cnt)), the
+   invariant-site term and the pattern weight into a weighted log-likelihood */
+static double site_loglh(double x, unsigned int cnt, double inv_term)
+{
+  if (inv_term > 0.0 && cnt > 0)
+  {
+    /* bring x to true scale; beyond 3 counts it underflows to 0 next to inv */
+    double xt = (cnt <= 3) ? ldexp(x, -256 * (int)cnt) : 0.0;
+    return log(xt + inv_term);
+  }
+  return log(x + inv_term) - (double)cnt * ORC_LN_SCALE;
+}
+
+double pll_compute_edge_loglikelihood(pll_partition_t * p,
+                                      unsigned int pc, int psc,
+                                      unsigned int cc, int csc,
+                                      unsigned int matrix_index,
+                                      const unsigned int * freqs_indices,
+                                      double * persite_lnl)
+{
+  unsigned int S = p->states, Sp = p->states_padded, R = p->rate_cats;
+  unsigned int n, r, i, j;
+  const unsigned int * s1 = (psc == PLL_SCALE_BUFFER_NONE) ? NULL : p->scale_buffer[psc];
+  const unsigned int * s2 = (csc == PLL_SCALE_BUFFER_NONE) ? NULL : p->scale_buffer[csc];
+  const double * P = p->pmatrix[matrix_index];
+  double total = 0.0;
+
+  for (n = 0; n < p->sites; ++n)
+  {
+    double site = 0.0, inv_term = 0.0;
+    for (r = 0; r < R; ++r)
+    {
+      const double * pi = p->frequencies[freqs_indices[r]];
+      double pinv = p->prop_invar[freqs_indices[r]];
+      double lr = 0.0;
+      for (i = 0; i < S; ++i)
+      {
+        double a = 0.0;
+        for (j = 0; j < S; ++j)
+          a += P[((size_t)r * S + i) * Sp + j] * orc_clv_at(p, cc, n, r, j);
+        lr += pi[i] * orc_clv_at(p, pc, n, r, i) * a;
+      }
+      if (pinv > 0.0)
+      {
+        site += p->rate_weights[r] * (1.0 - pinv) * lr;
+        if (p->invariant && p->invariant[n] >= 0)
+          inv_term += p->rate_weights[r] * pinv * pi[p->invariant[n]];
+      }
+      else
+        site += p->rate_weights[r] * lr;
+    }
+    unsigned int cnt = (s1 ? s1[n] : 0) + (s2 ? s2[n] : 0);
+    double l = site_loglh(site, cnt, inv_term);
+    if (persite_lnl) persite_lnl[n] = l;
+    total += l * p->pattern_weights[n];
+  }
+  return total;
+}
+
+double pll_compute_root_loglikelihood(pll_partition_t * p,
+                                      unsigned int clv, int sc,
+                                      const unsigned int * freqs_indices,
+                                      double * persite_lnl)
+{
+  unsigned int S = p->states, R = p->rate_cats, n, r, i;
+  const unsigned int * s1 = (sc == PLL_SCALE_BUFFER_NONE) ? NULL : p->scale_buffer[sc];
+  double total = 0.0;
+  for (n = 0; n < p->sites; ++n)
+  {
+    double site = 0.0, inv_term = 0.0;
+    for (r = 0; r < R; ++r)
+    {
+      const double * pi = p->frequencies[freqs_indices[r]];
+      double pinv = p->prop_invar[freqs_indices[r]];
+      double lr = 0.0;
+      for (i = 0; i < S; ++i) lr += pi[i] * orc_clv_at(p, clv, n, r, i);
+      if (pinv > 0.0)
+      {
+        site += p->rate_weights[r] * (1.0 - pinv) * lr;
+        if (p->invariant && p->invariant[n] >= 0)
+          inv_term += p->rate_weights[r] * pinv * pi[p->invariant[n]];
+      }
+      else
+        site += p->rate_weights[r] * lr;
+    }
+    double l = site_loglh(site, s1 ? s1[n] : 0, inv_term);
+    if (persite_lnl) persite_lnl[n] = l;
+    total += l * p->pattern_weights[n];
+  }
+  return total;
+}
+
+int pll_update_sumtable(pll_partition_t * p,
+                        unsigned int pc, unsigned int cc,
+                        int psc, int csc,
+                        const unsigned int * params_indices,
+                        double * sumtable)
+{
+  unsigned int S = p->states, Sp = p->states_padded, R = p->rate_cats;
+  unsigned int n, r, i, k;
+  (void)psc; (void)csc;
+  for (r = 0; r < R; ++r)
+    if (!p->eigen_decomp_valid[params_indices[r]])
+      if (!orc_update_eigen(p, params_indices[r])) return PLL_FAILURE;
+
+  for (n = 0; n < p->sites; ++n)
+    for (r = 0; r < R; ++r)
+    {
+      unsigned int pi_ = params_indices[r];
+      const double * pi = p->frequencies[pi_];
+      const double * V = p->eigenvecs[pi_], * Vi = p->inv_eigenvecs[pi_];
+      double * out = sumtable + ((size_t)n * R + r) * Sp;
+      for (k = 0; k < S; ++k)
+      {
+        double a = 0.0, b = 0.0;
+        for (i = 0; i < S; ++i)
+        {
+          a += orc_clv_at(p, pc, n, r, i) * pi[i] * V[i * Sp + k];
+          b += Vi[k * Sp + i] * orc_clv_at(p, cc, n, r, i);
+        }
+        out[k] = a * b;
+      }
+      for (k = S; k < Sp; ++k) out[k] = 0.0;
+    }
+  return PLL_SUCCESS;
+}
+
+int pll_compute_likelihood_derivatives(pll_partition_t * p,
+                                       int psc, int csc,
+                                       double t,
+                                       const unsigned int * params_indices,
+                                       const double * sumtable,
+                                       double * d_f, double * dd_f)
+{
+  unsigned int S = p->states, Sp = p->states_padded, R = p->rate_cats;
+  unsigned int n, r, k;
+  const unsigned int * s1 = (psc == PLL_SCALE_BUFFER_NONE) ? NULL : p->scale_buffer[psc];
+  const unsigned int * s2 = (csc == PLL_SCALE_BUFFER_NONE) ? NULL : p->scale_buffer[csc];
+  double * e0 = (double *)malloc(sizeof(double) * 3 * R * S);
+  if (!e0) { orc_set_error(PLL_ERROR_MEM_ALLOC, "derivative workspace"); return PLL_FAILURE; }
+  double * e1 = e0 + (size_t)R * S, * e2 = e1 + (size_t)R * S;
+
+  for (r = 0; r < R; ++r)
+  {
+    unsigned int pi_ = params_indices[r];
+    double pinv = p->prop_invar[pi_];
+    double rho = p->rates[r] / (1.0 - pinv);
+    double wr = p->rate_weights[r] * ((pinv > 0.0) ? (1.0 - pinv) : 1.0);
+    for (k = 0; k < S; ++k)
+    {
+      double lam = p->eigenvals[pi_][k] * rho;
+      double ex = exp(lam * t);
+      e0[r * S + k] = wr * ex;
+      e1[r * S + k] = wr * ex * lam;
+      e2[r * S + k] = wr * ex * lam * lam;
+    }
+  }
+
+  double df = 0.0, ddf = 0.0;
+  for (n = 0; n < p->sites; ++n)
+  {
+    double A = 0.0, B = 0.0, C = 0.0, inv_term = 0.0;
+    for (r = 0; r < R; ++r)
+    {
+      const double * st = sumtable + ((size_t)n * R + r) * Sp;
+      for (k = 0; k < S; ++k)
+      {
+        A += st[k] * e0[r * S + k];
+        B += st[k] * e1[r * S + k];
+        C += st[k] * e2[r * S + k];
+      }
+      unsigned int pi_ = params_indices[r];
+      double pinv = p->prop_invar[pi_];
+      if (pinv > 0.0 && p->invariant && p->invariant[n] >= 0)
+        inv_term += p->rate_weights[r] * pinv * p->frequencies[pi_][p->invariant[n]];
+    }
+    if (inv_term > 0.0)
+    {
+      /* the invariant term is not scaled: bring it to the site's scale */
+      unsigned int cnt = (s1 ? s1[n] : 0) + (s2 ? s2[n] : 0);
+      A += (cnt <= 3) ? ldexp(inv_term, 256 * (int)cnt) : INFINITY;
+    }
+    double w = p->pattern_weights[n];
+    double ba = B / A, ca = C / A;
+    df -= w * ba;
+    ddf += w * (ba * ba - ca);
+  }
+  *d_f = df;
+  *dd_f = ddf;
+  free(e0);
+  return PLL_SUCCESS;
+}
+
+/* marginal ancestral state probabilities at a node: per site and state,
+   sum over rates of w_r pi_i node[n,r,i] * (P other)[n,r,i], normalised */
+int pll_compute_node_ancestral(pll_partition_t * p,
+                               unsigned int node_clv, int node_sc,
+                               unsigned int other_clv, int other_sc,
+                               unsigned int matrix_index,
+                               const unsigned int * freqs_indices,
+                               double * ancestral)
+{
+  unsigned int S = p->states, Sp = p->states_padded, R = p->rate_cats;
+  unsigned int n, r, i, j;
+  const double * P = p->pmatrix[matrix_index];
+  (void)node_sc; (void)other_sc;
+  for (n = 0; n < p->sites; ++n)
+  {
+    double * out = ancestral + (size_t)n * S;
+    double sum = 0.0;
+    for (i = 0; i < S; ++i) out[i] = 0.0;
+    for (r = 0; r < R; ++r)
+    {
+      const double * pi = p->frequencies[freqs_indices[r]];
+      for (i = 0; i < S; ++i)
+      {
+        double a = 0.0;
+        for (j = 0; j < S; ++j)
+          a += P[((size_t)r * S + i) * Sp + j] * orc_clv_at(p, other_clv, n, r, j);
+        out[i] += p->rate_weights[r] * pi[i] * orc_clv_at(p, node_clv, n, r, i) * a;
+      }
+    }
+    for (i = 0; i < S; ++i) sum += out[i];
+    if (sum > 0.0) for (i = 0; i < S; ++i) out[i] /= sum;
+  }
+  return PLL_SUCCESS;
+}
