@@ -408,8 +408,6 @@ PLL_EXPORT extern __thread char pll_errmsg[200];
 PLL_EXPORT extern const pll_state_t pll_map_bin[256];
 PLL_EXPORT extern const pll_state_t pll_map_nt[256];
 PLL_EXPORT extern const pll_state_t pll_map_aa[256];
-PLL_EXPORT extern const unsigned int pll_map_fasta[256];
-PLL_EXPORT extern const unsigned int pll_map_phylip[256];
 
 /* ------------------------------------------------------------------ */
 /* B1: lifecycle and setters                                          */

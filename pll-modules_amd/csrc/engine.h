@@ -1,0 +1,125 @@
+// engine.h -- internal state of the HIP likelihood engine behind include/pll.h.
+//
+// Ownership model (SURVEY.md section 8b "Ownership"):
+//   * CLVs, scalers, tip codes, pattern weights, P-matrices, tip lookup tables
+//     and sumtables live in HBM for the lifetime of the partition.
+//   * The small model arrays of pll_partition_t (rates, rate_weights,
+//     frequencies, prop_invar, eigen*) stay on the host as the source of truth;
+//     every kernel-entry call compares them with a shadow copy and re-uploads
+//     on change, because pll-modules writes them without calling a setter
+//     (src/algorithm/algo_callback.c:44-68, 93-118).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+#include <list>
+#include <utility>
+
+#include "pll.h"
+#include "pllhip.h"
+
+namespace pllhip {
+
+constexpr unsigned MAX_RATE_CATS = 16;   // params_indices travel by value in kernel args
+constexpr unsigned MAX_OPS_PER_LAUNCH = 24;
+constexpr unsigned MAX_PMAT_PER_LAUNCH = 64;
+constexpr unsigned REDUCE_BLOCKS = 1024; // upper bound of per-block partial sums
+constexpr unsigned MAX_SUMTABLES = 4;    // device sumtables kept per partition (LRU)
+
+void set_error(int code, const char * fmt, ...);
+
+// hip error -> pll_errno; returns true on success
+bool hip_ok(hipError_t e, const char * what);
+#define PLLHIP_TRY(call) do { if (!::pllhip::hip_ok((call), #call)) return PLL_FAILURE; } while (0)
+
+// One pruning step with every index already resolved to a device pointer.
+// A child is either an inner/full CLV (clv != nullptr) or a coded tip
+// (codes != nullptr, lut = per-matrix lookup table).
+struct OpDesc
+{
+  const double * clv1;  const uint8_t * codes1;  const double * pmat1;  const double * lut1;
+  const double * clv2;  const uint8_t * codes2;  const double * pmat2;  const double * lut2;
+  const unsigned * scaler1;
+  const unsigned * scaler2;
+  double * parent;
+  unsigned * parent_scaler;
+};
+
+struct OpBatch
+{
+  OpDesc op[MAX_OPS_PER_LAUNCH];
+};
+
+enum class KernelFamily { Generic, S4, S20 };
+
+struct Engine
+{
+  int device = 0;
+  hipStream_t stream = nullptr;
+
+  unsigned S = 0, Sp = 0, R = 0, N = 0;
+  unsigned tips = 0, nodes = 0, nscalers = 0, nmat = 0, nrm = 0;
+  bool coded_tips = false;
+  KernelFamily family = KernelFamily::Generic;
+  unsigned cu_count = 256;
+
+  // --- device-resident data ---
+  std::vector<double *> d_clv;        // [nodes], nullptr for coded tips
+  std::vector<uint8_t *> d_codes;     // [tips], nullptr unless coded
+  unsigned * d_scalers = nullptr;     // [nscalers][N]
+  double * d_pmat = nullptr;          // [nmat][R][S][Sp]
+  double * d_lut = nullptr;           // [nmat][R][lut_codes][S]   (coded tips only)
+  unsigned lut_codes = 0;             // row count the LUTs were built for
+  bool lut_stale = false;             // tipmap grew since the LUTs were built
+  std::vector<double> pmat_brlen;     // last branch length per matrix (NaN = never set)
+  std::vector<std::vector<unsigned>> pmat_params; // params_indices used per matrix
+  unsigned * d_weights = nullptr;     // [N] pattern weights
+  int * d_invariant = nullptr;        // [N], nullptr until needed
+  unsigned long long * d_tipmap = nullptr; // [256] code -> state mask
+
+  // model block: rates[R] weights[R] pinv[nrm] freqs[nrm][Sp] evals[nrm][Sp]
+  //              evecs[nrm][S*Sp] ievecs[nrm][S*Sp]
+  double * d_model = nullptr;
+  std::vector<double> model_shadow;
+  size_t off_rates = 0, off_weights = 0, off_pinv = 0, off_freqs = 0,
+         off_evals = 0, off_evecs = 0, off_ievecs = 0, model_len = 0;
+
+  // pattern weights / invariant shadows (callers may also poke these)
+  std::vector<unsigned> weights_shadow;
+  bool invariant_uploaded = false;
+  const int * invariant_host_seen = nullptr;
+  unsigned tipmap_codes_uploaded = 0;
+
+  // reductions
+  double * d_partials = nullptr;      // [3 * REDUCE_BLOCKS]
+  double * h_partials = nullptr;      // pinned mirror
+  double * d_persite = nullptr;       // [N], allocated on first per-site request
+
+  // caller-keyed device sumtables (pointer value is the key)
+  std::list<std::pair<const void *, double *>> sumtables;
+
+  // host-mirror dirtiness
+  bool pmat_host_dirty = false;
+
+  pllhip_counters_t counters = {};
+};
+
+inline Engine * engine_of(const pll_partition_t * p) { return static_cast<Engine *>(p->engine); }
+
+// --- host side model code (pll_model.cpp) ---
+int update_eigen_host(pll_partition_t * p, unsigned params_index);
+int eigen_decompose(unsigned S, unsigned Sp, const double * ex, const double * pi,
+                    double * evecs, double * ievecs, double * evals);
+
+// --- engine services (pll_core.hip) ---
+Engine * engine_create(pll_partition_t * p);
+void engine_destroy(Engine * e);
+int sync_model(pll_partition_t * p);              // host model arrays -> HBM if changed
+int upload_tip_codes(pll_partition_t * p, unsigned tip);
+int upload_tip_clv(pll_partition_t * p, unsigned tip, const double * host_clv);
+int upload_weights(pll_partition_t * p);
+void invalidate_luts(pll_partition_t * p);
+
+} // namespace pllhip

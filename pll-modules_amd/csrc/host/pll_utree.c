@@ -371,7 +371,7 @@ void pll_utree_reset_template_indices(pll_unode_t * root, unsigned int tip_count
   for (i = 0; i < n; ++i)
   {
     pll_unode_t * node = buf[i];
-    if (node->next && node->back->next && node != root->back)
+    if (node->next && node->back->next && node != root->back && node != root)
       node->pmatrix_index = node->back->pmatrix_index = edge++;
   }
   if (root->back->next)

@@ -1,0 +1,76 @@
+// kernels_common.hpp -- device helpers shared by every kernel family:
+// deterministic block reductions (no float atomics: SPR rounds assert
+// run-to-run reproducibility, src/algorithm/algo_search.c:1453-1457) and the
+// per-site log-likelihood assembly.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace pllhip {
+
+constexpr double SCALE_FACTOR = 115792089237316195423570985008687907853269984665640564039457584007913129639936.0; // 2^256
+constexpr double SCALE_THRESHOLD = 1.0 / SCALE_FACTOR;
+constexpr double LN_SCALE = 177.445678223345993274; // 256 ln 2
+
+// model block offsets, see Engine::d_model
+struct ModelView
+{
+  const double * base;
+  unsigned off_rates, off_weights, off_pinv, off_freqs, off_evals, off_evecs, off_ievecs;
+  unsigned S, Sp;
+  __device__ const double * rates() const { return base + off_rates; }
+  __device__ const double * weights() const { return base + off_weights; }
+  __device__ const double * pinv() const { return base + off_pinv; }
+  __device__ const double * freqs(unsigned m) const { return base + off_freqs + (size_t)m * Sp; }
+  __device__ const double * evals(unsigned m) const { return base + off_evals + (size_t)m * Sp; }
+  __device__ const double * evecs(unsigned m) const { return base + off_evecs + (size_t)m * S * Sp; }
+  __device__ const double * ievecs(unsigned m) const { return base + off_ievecs + (size_t)m * S * Sp; }
+};
+
+struct ParamIdx { unsigned v[16]; };
+
+// a node's conditional likelihoods: full CLV or 1-byte tip codes
+struct NodeRef
+{
+  const double * clv;
+  const uint8_t * codes;
+};
+
+// wave-level sum by butterfly shuffles: every lane ends with the same total,
+// and the association order is fixed by the lane id, hence deterministic
+__device__ inline double wave_sum(double v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// block sum of `v` over 256 threads; result valid in thread 0.
+// scratch: 4 doubles of LDS per reduced quantity.
+__device__ inline double block_sum_256(double v, double * scratch)
+{
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) scratch[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) t = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+  __syncthreads();
+  return t;
+}
+
+// log of the site likelihood.  x is the likelihood carrying `cnt` scaling
+// steps (true value x * 2^(-256 cnt)); inv is the unscaled invariant-site
+// term.  Same case split as the oracle (oracle/orc_kernels.c site_loglh).
+__device__ inline double site_loglh(double x, unsigned cnt, double inv)
+{
+  if (inv > 0.0 && cnt > 0)
+  {
+    const double xt = (cnt <= 3) ? ldexp(x, -256 * (int)cnt) : 0.0;
+    return log(xt + inv);
+  }
+  return log(x + inv) - (double)cnt * LN_SCALE;
+}
+
+} // namespace pllhip

@@ -1,0 +1,453 @@
+// kernels_generic.hpp -- kernels that work for any 2 <= S <= 64 and any R.
+// They are the correctness baseline of the engine and the production path for
+// state counts without a specialised family (kernels_s4.hpp, kernels_s20.hpp).
+//
+// Layouts: CLV [site][rate][Sp] (states fastest), P-matrix [rate][S][Sp]
+// (row = parent state), tip lookup LUT [rate][codes][S] per matrix,
+// sumtable [site][rate][Sp].
+#pragma once
+
+#include "kernels_common.hpp"
+#include "engine.h"
+#include <algorithm>
+
+namespace pllhip {
+
+// ---------------------------------------------------------------------------
+// P-matrices (+ tip lookup tables as a by-product)
+//   P_r(t) = V diag(exp(lambda_k * rate_r * t / (1 - pinv))) V^-1; identity
+//   if t == 0.   grid = (count, R), block = 256
+//   LUT_r[code][i] = sum_{j in mask(code)} P_r[i][j]
+// ---------------------------------------------------------------------------
+struct PmatBatch
+{
+  unsigned midx[MAX_PMAT_PER_LAUNCH];
+  double t[MAX_PMAT_PER_LAUNCH];
+};
+
+__global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, PmatBatch batch,
+                                                 unsigned R, double * pmat, double * lut,
+                                                 unsigned lut_codes,
+                                                 const unsigned long long * tipmap)
+{
+  extern __shared__ double lds[];            // expk[S] | P[S*Sp]
+  const unsigned S = mv.S, Sp = mv.Sp;
+  double * expk = lds;
+  double * Pl = lds + Sp;
+  const unsigned m = batch.midx[blockIdx.x], r = blockIdx.y;
+  const double t = batch.t[blockIdx.x];
+  const unsigned pi_ = params.v[r];
+  const double * V = mv.evecs(pi_), * Vi = mv.ievecs(pi_), * L = mv.evals(pi_);
+  double * P = pmat + ((size_t)m * R + r) * S * Sp;
+
+  if (t == 0.0)
+  {
+    for (unsigned e = threadIdx.x; e < S * Sp; e += blockDim.x)
+      Pl[e] = (e / Sp == e % Sp) ? 1.0 : 0.0;
+  }
+  else
+  {
+    const double rt = mv.rates()[r] * t / (1.0 - mv.pinv()[pi_]);
+    for (unsigned k = threadIdx.x; k < S; k += blockDim.x) expk[k] = exp(L[k] * rt);
+    __syncthreads();
+    for (unsigned e = threadIdx.x; e < S * Sp; e += blockDim.x)
+    {
+      const unsigned i = e / Sp, j = e % Sp;
+      double s = 0.0;
+      if (j < S)
+        for (unsigned k = 0; k < S; ++k) s += V[i * Sp + k] * expk[k] * Vi[k * Sp + j];
+      Pl[e] = s;
+    }
+  }
+  __syncthreads();
+  for (unsigned e = threadIdx.x; e < S * Sp; e += blockDim.x) P[e] = Pl[e];
+  if (lut)
+  {
+    double * T = lut + ((size_t)m * R + r) * lut_codes * S;
+    for (unsigned e = threadIdx.x; e < lut_codes * S; e += blockDim.x)
+    {
+      const unsigned c = e / S, i = e % S;
+      const unsigned long long mask = tipmap[c];
+      double s = 0.0;
+      for (unsigned j = 0; j < S; ++j)
+        if ((mask >> j) & 1ULL) s += Pl[i * Sp + j];
+      T[e] = s;
+    }
+  }
+}
+
+// rebuild every LUT from the stored P-matrices (after the tip code table grew)
+__global__ __launch_bounds__(256) void k_rebuild_lut(unsigned S, unsigned Sp, unsigned R,
+                                                     const double * pmat, double * lut,
+                                                     unsigned lut_codes,
+                                                     const unsigned long long * tipmap)
+{
+  const unsigned m = blockIdx.x, r = blockIdx.y;
+  const double * P = pmat + ((size_t)m * R + r) * S * Sp;
+  double * T = lut + ((size_t)m * R + r) * lut_codes * S;
+  for (unsigned e = threadIdx.x; e < lut_codes * S; e += blockDim.x)
+  {
+    const unsigned c = e / S, i = e % S;
+    const unsigned long long mask = tipmap[c];
+    double s = 0.0;
+    for (unsigned j = 0; j < S; ++j)
+      if ((mask >> j) & 1ULL) s += P[i * Sp + j];
+    T[e] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// partials, generic: one thread per output element (site, rate, state).
+//   parent[n,r,i] = (sum_j P1[r,i,j] c1[n,r,j]) * (sum_j P2[r,i,j] c2[n,r,j])
+//   a coded tip child contributes LUT[r][code[n]][i] instead of the dot product.
+//   scaling: block owns whole sites; LDS flag per site.
+// grid = (site groups, ops), block = 256; a block processes `spb` sites per
+// step, spb * R * Sp <= 256 * GEN_MAX_ELEMS.
+// ---------------------------------------------------------------------------
+constexpr unsigned GEN_MAX_ELEMS = 4;
+
+__global__ __launch_bounds__(256) void k_partials_generic(OpBatch batch, unsigned N, unsigned R,
+                                                          unsigned S, unsigned Sp,
+                                                          unsigned lut_codes, unsigned spb)
+{
+  __shared__ int big[256];                 // big[s] != 0: site s has an entry >= threshold
+  const OpDesc & op = batch.op[blockIdx.y];
+  const unsigned E = R * Sp;               // elements per site
+  const unsigned per_step = spb * E;
+
+  for (unsigned long long n0 = (unsigned long long)blockIdx.x * spb; n0 < N;
+       n0 += (unsigned long long)gridDim.x * spb)
+  {
+    if (threadIdx.x < spb) big[threadIdx.x] = 0;
+    __syncthreads();
+    double val[GEN_MAX_ELEMS];
+#pragma unroll
+    for (unsigned q = 0; q < GEN_MAX_ELEMS; ++q)
+    {
+      const unsigned e = threadIdx.x + q * 256;
+      val[q] = 0.0;
+      if (e >= per_step) continue;
+      const unsigned s = e / E, rem = e % E, r = rem / Sp, i = rem % Sp;
+      const unsigned long long n = n0 + s;
+      if (n >= N || i >= S) continue;
+      double a, b;
+      if (op.codes1)
+        a = op.lut1[((size_t)r * lut_codes + op.codes1[n]) * S + i];
+      else
+      {
+        const double * c = op.clv1 + (n * R + r) * Sp;
+        const double * row = op.pmat1 + ((size_t)r * S + i) * Sp;
+        a = 0.0;
+        for (unsigned j = 0; j < S; ++j) a += row[j] * c[j];
+      }
+      if (op.codes2)
+        b = op.lut2[((size_t)r * lut_codes + op.codes2[n]) * S + i];
+      else
+      {
+        const double * c = op.clv2 + (n * R + r) * Sp;
+        const double * row = op.pmat2 + ((size_t)r * S + i) * Sp;
+        b = 0.0;
+        for (unsigned j = 0; j < S; ++j) b += row[j] * c[j];
+      }
+      val[q] = a * b;
+      if (!(val[q] < SCALE_THRESHOLD)) big[s] = 1;   // benign race: all writers store 1
+    }
+    __syncthreads();
+#pragma unroll
+    for (unsigned q = 0; q < GEN_MAX_ELEMS; ++q)
+    {
+      const unsigned e = threadIdx.x + q * 256;
+      if (e >= per_step) continue;
+      const unsigned s = e / E, rem = e % E;
+      const unsigned long long n = n0 + s;
+      if (n >= N) continue;
+      const bool rescale = op.parent_scaler && !big[s];
+      op.parent[n * E + rem] = rescale ? val[q] * SCALE_FACTOR : val[q];
+      if (rem == 0 && op.parent_scaler)
+      {
+        unsigned cnt = (op.scaler1 ? op.scaler1[n] : 0u) + (op.scaler2 ? op.scaler2[n] : 0u);
+        op.parent_scaler[n] = cnt + (rescale ? 1u : 0u);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// value of state j at (site n, rate r) for a full CLV or a coded tip
+__device__ inline double node_value(const NodeRef & nd, const unsigned long long * tipmap,
+                                    unsigned long long n, unsigned r, unsigned j,
+                                    unsigned R, unsigned Sp)
+{
+  if (nd.codes) return (double)((tipmap[nd.codes[n]] >> j) & 1ULL);
+  return nd.clv[(n * R + r) * Sp + j];
+}
+
+// ---------------------------------------------------------------------------
+// edge / root log-likelihood, generic: one thread per site, fixed-order block
+// reduction, one partial per block.  grid <= REDUCE_BLOCKS, block = 256.
+//   L_n = sum_r w_r [ (1-pinv) sum_i pi_i p[n,r,i] sum_j P[r,i,j] c[n,r,j]
+//                     + pinv * pi[inv(n)] ]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_edge_lnl_generic(ModelView mv, ParamIdx freqs_idx,
+                                                          NodeRef parent, NodeRef child,
+                                                          const double * pmat,   // nullptr: root lnL
+                                                          const double * lut, unsigned lut_codes,
+                                                          const unsigned * ps, const unsigned * cs,
+                                                          const unsigned * weights,
+                                                          const int * invariant,
+                                                          const unsigned long long * tipmap,
+                                                          unsigned N, unsigned R,
+                                                          double * persite, double * block_out)
+{
+  __shared__ double scratch[4];
+  const unsigned S = mv.S, Sp = mv.Sp;
+  double acc = 0.0;
+  for (unsigned long long n = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; n < N;
+       n += (unsigned long long)gridDim.x * blockDim.x)
+  {
+    double site = 0.0, inv = 0.0;
+    for (unsigned r = 0; r < R; ++r)
+    {
+      const unsigned fi = freqs_idx.v[r];
+      const double * pi = mv.freqs(fi);
+      const double pinv = mv.pinv()[fi];
+      double lr = 0.0;
+      for (unsigned i = 0; i < S; ++i)
+      {
+        double a;
+        if (!pmat)
+          a = 1.0;
+        else if (child.codes)
+          a = lut[((size_t)r * lut_codes + child.codes[n]) * S + i];
+        else
+        {
+          const double * row = pmat + ((size_t)r * S + i) * Sp;
+          const double * c = child.clv + (n * R + r) * Sp;
+          a = 0.0;
+          for (unsigned j = 0; j < S; ++j) a += row[j] * c[j];
+        }
+        lr += pi[i] * node_value(parent, tipmap, n, r, i, R, Sp) * a;
+      }
+      const double w = mv.weights()[r];
+      if (pinv > 0.0)
+      {
+        site += w * (1.0 - pinv) * lr;
+        if (invariant && invariant[n] >= 0) inv += w * pinv * pi[invariant[n]];
+      }
+      else
+        site += w * lr;
+    }
+    const unsigned cnt = (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
+    const double l = site_loglh(site, cnt, inv);
+    if (persite) persite[n] = l;
+    acc += l * (double)weights[n];
+  }
+  const double tot = block_sum_256(acc, scratch);
+  if (threadIdx.x == 0) block_out[blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------
+// sumtable, generic: one thread per (site, rate, k)
+//   sum[n,r,k] = (sum_i p[n,r,i] pi_i V[i,k]) * (sum_j V^-1[k,j] c[n,r,j])
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sumtable_generic(ModelView mv, ParamIdx params,
+                                                          NodeRef parent, NodeRef child,
+                                                          const unsigned long long * tipmap,
+                                                          unsigned N, unsigned R, double * sumtable)
+{
+  const unsigned S = mv.S, Sp = mv.Sp;
+  const unsigned long long total = (unsigned long long)N * R * Sp;
+  for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (unsigned long long)gridDim.x * blockDim.x)
+  {
+    const unsigned k = e % Sp;
+    const unsigned long long nr = e / Sp;
+    const unsigned r = nr % R;
+    const unsigned long long n = nr / R;
+    double out = 0.0;
+    if (k < S)
+    {
+      const unsigned pi_ = params.v[r];
+      const double * pi = mv.freqs(pi_), * V = mv.evecs(pi_), * Vi = mv.ievecs(pi_);
+      double a = 0.0, b = 0.0;
+      for (unsigned i = 0; i < S; ++i)
+      {
+        a += node_value(parent, tipmap, n, r, i, R, Sp) * pi[i] * V[i * Sp + k];
+        b += Vi[k * Sp + i] * node_value(child, tipmap, n, r, i, R, Sp);
+      }
+      out = a * b;
+    }
+    sumtable[e] = out;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// derivatives of -lnL, generic: one thread per site; coefficient tables
+// e0/e1/e2[r][k] = w_r' exp(l t) {1, l, l^2}, l = lambda_k rate_r/(1-pinv),
+// are built per block in LDS.   block_out: [3][gridDim.x] (df, ddf)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_derivatives_generic(ModelView mv, ParamIdx params, double t,
+                                                             const double * sumtable,
+                                                             const unsigned * ps, const unsigned * cs,
+                                                             const unsigned * weights,
+                                                             const int * invariant,
+                                                             unsigned N, unsigned R,
+                                                             double * block_out)
+{
+  extern __shared__ double lds[];          // e0 | e1 | e2, each R*S
+  __shared__ double scratch[4];
+  const unsigned S = mv.S, Sp = mv.Sp;
+  double * e0 = lds, * e1 = lds + R * S, * e2 = lds + 2 * R * S;
+  for (unsigned q = threadIdx.x; q < R * S; q += blockDim.x)
+  {
+    const unsigned r = q / S, k = q % S, pi_ = params.v[r];
+    const double pinv = mv.pinv()[pi_];
+    const double lam = mv.evals(pi_)[k] * mv.rates()[r] / (1.0 - pinv);
+    const double wr = mv.weights()[r] * ((pinv > 0.0) ? (1.0 - pinv) : 1.0);
+    const double ex = exp(lam * t);
+    e0[q] = wr * ex;
+    e1[q] = wr * ex * lam;
+    e2[q] = wr * ex * lam * lam;
+  }
+  __syncthreads();
+
+  double df = 0.0, ddf = 0.0;
+  for (unsigned long long n = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; n < N;
+       n += (unsigned long long)gridDim.x * blockDim.x)
+  {
+    double A = 0.0, B = 0.0, C = 0.0, inv = 0.0;
+    for (unsigned r = 0; r < R; ++r)
+    {
+      const double * st = sumtable + (n * R + r) * Sp;
+      for (unsigned k = 0; k < S; ++k)
+      {
+        const double v = st[k];
+        A += v * e0[r * S + k];
+        B += v * e1[r * S + k];
+        C += v * e2[r * S + k];
+      }
+      const unsigned pi_ = params.v[r];
+      const double pinv = mv.pinv()[pi_];
+      if (pinv > 0.0 && invariant && invariant[n] >= 0)
+        inv += mv.weights()[r] * pinv * mv.freqs(pi_)[invariant[n]];
+    }
+    if (inv > 0.0)
+    {
+      const unsigned cnt = (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
+      A += (cnt <= 3) ? ldexp(inv, 256 * (int)cnt) : INFINITY;
+    }
+    const double w = (double)weights[n], ba = B / A, ca = C / A;
+    df -= w * ba;
+    ddf += w * (ba * ba - ca);
+  }
+  const double tdf = block_sum_256(df, scratch);
+  const double tddf = block_sum_256(ddf, scratch);
+  if (threadIdx.x == 0)
+  {
+    block_out[blockIdx.x] = tdf;
+    block_out[gridDim.x + blockIdx.x] = tddf;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// invariant sites: inv[n] = lowest state compatible with every tip, else -1
+// ---------------------------------------------------------------------------
+struct TipTable { const double * const * clv; const uint8_t * const * codes; };
+
+__global__ __launch_bounds__(256) void k_invariant(const double * const * tip_clv,
+                                                   const uint8_t * const * tip_codes,
+                                                   const unsigned long long * tipmap,
+                                                   unsigned tips, unsigned N, unsigned R,
+                                                   unsigned S, unsigned Sp, int * invariant)
+{
+  for (unsigned long long n = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; n < N;
+       n += (unsigned long long)gridDim.x * blockDim.x)
+  {
+    unsigned long long common = ~0ULL;
+    for (unsigned t = 0; t < tips; ++t)
+    {
+      unsigned long long m = 0;
+      if (tip_codes[t])
+        m = tipmap[tip_codes[t][n]];
+      else
+      {
+        const double * c = tip_clv[t] + n * R * Sp;
+        for (unsigned j = 0; j < S; ++j)
+          if (c[j] > 0.0) m |= (1ULL << j);
+      }
+      common &= m;
+    }
+    if (S < 64) common &= ((1ULL << S) - 1ULL);
+    invariant[n] = common ? (int)__builtin_ctzll(common) : -1;
+  }
+}
+
+// expand a coded tip into a 0/1 CLV (host materialisation path)
+__global__ __launch_bounds__(256) void k_expand_codes(const uint8_t * codes,
+                                                      const unsigned long long * tipmap,
+                                                      unsigned N, unsigned R, unsigned S, unsigned Sp,
+                                                      double * out)
+{
+  const unsigned long long total = (unsigned long long)N * R * Sp;
+  for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (unsigned long long)gridDim.x * blockDim.x)
+  {
+    const unsigned j = e % Sp;
+    const unsigned long long n = e / Sp / R;
+    out[e] = (j < S) ? (double)((tipmap[codes[n]] >> j) & 1ULL) : 0.0;
+  }
+}
+
+// --- launchers -------------------------------------------------------------
+
+static int launch_partials_generic(Engine * e, const OpBatch & batch, unsigned nops)
+{
+  const unsigned E = e->R * e->Sp;
+  const unsigned spb = std::max(1u, 256u / E);
+  const unsigned long long groups = ((unsigned long long)e->N + spb - 1) / spb;
+  const unsigned gx = (unsigned)std::max<unsigned long long>(
+      1, std::min<unsigned long long>(groups, e->cu_count * 16ULL));
+  hipLaunchKernelGGL(k_partials_generic, dim3(gx, nops), dim3(256), 0, e->stream,
+                     batch, e->N, e->R, e->S, e->Sp, e->lut_codes, spb);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+static int launch_edge_lnl_generic(Engine * e, const ModelView & mv, const ParamIdx & fidx,
+                                   const NodeRef & parent, const NodeRef & child,
+                                   const double * pm, const double * lut,
+                                   const unsigned * ps, const unsigned * cs,
+                                   double * persite, unsigned nblocks)
+{
+  hipLaunchKernelGGL(k_edge_lnl_generic, dim3(nblocks), dim3(256), 0, e->stream,
+                     mv, fidx, parent, child, pm, lut, e->lut_codes, ps, cs,
+                     e->d_weights, e->d_invariant, e->d_tipmap, e->N, e->R, persite, e->d_partials);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+static int launch_sumtable_generic(Engine * e, const ModelView & mv, const ParamIdx & params,
+                                   const NodeRef & parent, const NodeRef & child, double * d_sum)
+{
+  const unsigned long long total = (unsigned long long)e->N * e->R * e->Sp;
+  const unsigned gx = (unsigned)std::max<unsigned long long>(
+      1, std::min<unsigned long long>((total + 255) / 256, e->cu_count * 32ULL));
+  hipLaunchKernelGGL(k_sumtable_generic, dim3(gx), dim3(256), 0, e->stream,
+                     mv, params, parent, child, e->d_tipmap, e->N, e->R, d_sum);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+static int launch_derivatives_generic(Engine * e, const ModelView & mv, const ParamIdx & params,
+                                      double t, const double * d_sum,
+                                      const unsigned * ps, const unsigned * cs, unsigned nblocks)
+{
+  const size_t lds = sizeof(double) * 3 * e->R * e->S;
+  hipLaunchKernelGGL(k_derivatives_generic, dim3(nblocks), dim3(256), lds, e->stream,
+                     mv, params, t, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->R,
+                     e->d_partials);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+} // namespace pllhip

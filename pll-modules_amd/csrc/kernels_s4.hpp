@@ -1,0 +1,336 @@
+// kernels_s4.hpp -- 4-state (DNA) kernel family, fp64 VALU.
+//
+// Roofline: a 4-state site-update moves 24*4 + 12/R bytes and needs 68 flops
+// (AI 0.69 flop/B): purely HBM-bound, so the design goal is nothing but
+// perfectly streaming access:
+//   * one lane per (site, rate) column; consecutive lanes = consecutive 32-byte
+//     CLV vectors, so a wave reads and writes contiguous 2 KiB runs;
+//   * the lane's rate is invariant under the grid stride (stride is a multiple
+//     of R), so its two 4x4 P-matrices stay in 64 VGPRs for the whole kernel;
+//   * the per-site scaling vote and the sum over rates are R-lane butterfly
+//     shuffles (R is a power of two <= 16 in this family);
+//   * coded tips cost 1 byte per site: the child term is a 32-byte gather from
+//     the 2 KiB per-matrix lookup table (L1/L2 resident).
+#pragma once
+
+#include "kernels_common.hpp"
+#include "engine.h"
+
+namespace pllhip {
+
+struct d4 { double x, y, z, w; };
+
+__device__ inline d4 load4(const double * p)
+{
+  const double4 v = *reinterpret_cast<const double4 *>(p);
+  return d4{v.x, v.y, v.z, v.w};
+}
+
+__device__ inline void store4(double * p, const d4 & v)
+{
+  *reinterpret_cast<double4 *>(p) = make_double4(v.x, v.y, v.z, v.w);
+}
+
+__device__ inline double dot4(const double * row, const d4 & c)
+{
+  return row[0] * c.x + row[1] * c.y + row[2] * c.z + row[3] * c.w;
+}
+
+// OR over the R lanes of a site (R power of two, lanes aligned to R)
+__device__ inline int group_or(int v, unsigned R)
+{
+  for (unsigned off = 1; off < R; off <<= 1) v |= __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ inline double group_sum(double v, unsigned R)
+{
+  for (unsigned off = 1; off < R; off <<= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ inline d4 tip_value4(unsigned long long mask)
+{
+  return d4{(double)(mask & 1ULL), (double)((mask >> 1) & 1ULL),
+            (double)((mask >> 2) & 1ULL), (double)((mask >> 3) & 1ULL)};
+}
+
+// grid = (gx, ops), block = 256.  total columns = N*R; gx*256 is a multiple of R.
+__global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, unsigned R,
+                                                     unsigned lut_codes)
+{
+  const OpDesc & op = batch.op[blockIdx.y];
+  const unsigned long long total = (unsigned long long)N * R;
+  const unsigned long long stride = (unsigned long long)gridDim.x * 256ULL;
+  unsigned long long g = (unsigned long long)blockIdx.x * 256ULL + threadIdx.x;
+  const unsigned r = (unsigned)(g % R);
+
+  double P1[16], P2[16];
+  if (!op.codes1)
+  {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) P1[q] = op.pmat1[r * 16 + q];
+  }
+  if (!op.codes2)
+  {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) P2[q] = op.pmat2[r * 16 + q];
+  }
+
+  // whole waves iterate together so that the shuffles below see full groups
+  const unsigned long long limit = (total + 63ULL) & ~63ULL;
+  for (; g < limit; g += stride)
+  {
+    const bool live = g < total;
+    const unsigned long long n = g / R;
+    d4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+    if (live)
+    {
+      if (op.codes1)
+        a = load4(op.lut1 + ((size_t)r * lut_codes + op.codes1[n]) * 4);
+      else
+      {
+        const d4 c = load4(op.clv1 + g * 4);
+        a = d4{dot4(P1, c), dot4(P1 + 4, c), dot4(P1 + 8, c), dot4(P1 + 12, c)};
+      }
+      if (op.codes2)
+        b = load4(op.lut2 + ((size_t)r * lut_codes + op.codes2[n]) * 4);
+      else
+      {
+        const d4 c = load4(op.clv2 + g * 4);
+        b = d4{dot4(P2, c), dot4(P2 + 4, c), dot4(P2 + 8, c), dot4(P2 + 12, c)};
+      }
+    }
+    d4 v = {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w};
+    if (op.parent_scaler)
+    {
+      int big = live && !(v.x < SCALE_THRESHOLD && v.y < SCALE_THRESHOLD &&
+                          v.z < SCALE_THRESHOLD && v.w < SCALE_THRESHOLD);
+      big = group_or(big, R);
+      if (live)
+      {
+        if (!big) { v.x *= SCALE_FACTOR; v.y *= SCALE_FACTOR; v.z *= SCALE_FACTOR; v.w *= SCALE_FACTOR; }
+        if (r == 0)
+        {
+          const unsigned cnt = (op.scaler1 ? op.scaler1[n] : 0u) + (op.scaler2 ? op.scaler2[n] : 0u);
+          op.parent_scaler[n] = cnt + (big ? 0u : 1u);
+        }
+      }
+    }
+    if (live) store4(op.parent + g * 4, v);
+  }
+}
+
+// edge log-likelihood: lane = (site, rate).  grid = nblocks (<= REDUCE_BLOCKS)
+__global__ __launch_bounds__(256) void k_edge_lnl_s4(ModelView mv, ParamIdx fidx,
+                                                     NodeRef parent, NodeRef child,
+                                                     const double * pmat, const double * lut,
+                                                     unsigned lut_codes,
+                                                     const unsigned * ps, const unsigned * cs,
+                                                     const unsigned * weights, const int * invariant,
+                                                     const unsigned long long * tipmap,
+                                                     unsigned N, unsigned R,
+                                                     double * persite, double * block_out)
+{
+  __shared__ double scratch[4];
+  const unsigned long long total = (unsigned long long)N * R;
+  const unsigned long long stride = (unsigned long long)gridDim.x * 256ULL;
+  unsigned long long g = (unsigned long long)blockIdx.x * 256ULL + threadIdx.x;
+  const unsigned r = (unsigned)(g % R);
+  const unsigned fi = fidx.v[r];
+  const double * pi = mv.freqs(fi);
+  const d4 f = {pi[0], pi[1], pi[2], pi[3]};
+  const double pinv = mv.pinv()[fi];
+  const double wr = mv.weights()[r] * ((pinv > 0.0) ? (1.0 - pinv) : 1.0);
+  const double winv = (pinv > 0.0) ? mv.weights()[r] * pinv : 0.0;
+  double P[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) P[q] = pmat[r * 16 + q];
+
+  double acc = 0.0;
+  const unsigned long long limit = (total + 63ULL) & ~63ULL;
+  for (; g < limit; g += stride)
+  {
+    const bool live = g < total;
+    const unsigned long long n = live ? g / R : 0;
+    double lr = 0.0, inv = 0.0;
+    if (live)
+    {
+      d4 a;
+      if (child.codes)
+        a = load4(lut + ((size_t)r * lut_codes + child.codes[n]) * 4);
+      else
+      {
+        const d4 c = load4(child.clv + g * 4);
+        a = d4{dot4(P, c), dot4(P + 4, c), dot4(P + 8, c), dot4(P + 12, c)};
+      }
+      const d4 pv = parent.codes ? tip_value4(tipmap[parent.codes[n]]) : load4(parent.clv + g * 4);
+      lr = wr * (f.x * pv.x * a.x + f.y * pv.y * a.y + f.z * pv.z * a.z + f.w * pv.w * a.w);
+      if (winv > 0.0 && invariant && invariant[n] >= 0) inv = winv * pi[invariant[n]];
+    }
+    lr = group_sum(lr, R);
+    inv = group_sum(inv, R);
+    if (live && r == 0)
+    {
+      const unsigned cnt = (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
+      const double l = site_loglh(lr, cnt, inv);
+      if (persite) persite[n] = l;
+      acc += l * (double)weights[n];
+    }
+  }
+  const double tot = block_sum_256(acc, scratch);
+  if (threadIdx.x == 0) block_out[blockIdx.x] = tot;
+}
+
+// sumtable: lane = (site, rate)
+__global__ __launch_bounds__(256) void k_sumtable_s4(ModelView mv, ParamIdx params,
+                                                     NodeRef parent, NodeRef child,
+                                                     const unsigned long long * tipmap,
+                                                     unsigned N, unsigned R, double * sumtable)
+{
+  const unsigned long long total = (unsigned long long)N * R;
+  const unsigned long long stride = (unsigned long long)gridDim.x * 256ULL;
+  unsigned long long g = (unsigned long long)blockIdx.x * 256ULL + threadIdx.x;
+  const unsigned r = (unsigned)(g % R);
+  const unsigned pi_ = params.v[r];
+  const double * pi = mv.freqs(pi_), * V = mv.evecs(pi_), * Vi = mv.ievecs(pi_);
+  double L[16], Rm[16];        // L[k][i] = pi_i V[i][k];  Rm[k][j] = Vinv[k][j]
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+      L[k * 4 + i] = pi[i] * V[i * 4 + k];
+      Rm[k * 4 + i] = Vi[k * 4 + i];
+    }
+  for (; g < total; g += stride)
+  {
+    const unsigned long long n = g / R;
+    const d4 pv = parent.codes ? tip_value4(tipmap[parent.codes[n]]) : load4(parent.clv + g * 4);
+    const d4 cv = child.codes ? tip_value4(tipmap[child.codes[n]]) : load4(child.clv + g * 4);
+    const d4 out = {dot4(L, pv) * dot4(Rm, cv), dot4(L + 4, pv) * dot4(Rm + 4, cv),
+                    dot4(L + 8, pv) * dot4(Rm + 8, cv), dot4(L + 12, pv) * dot4(Rm + 12, cv)};
+    store4(sumtable + g * 4, out);
+  }
+}
+
+// derivatives of -lnL: lane = (site, rate); block_out = [df x nblocks | ddf x nblocks]
+__global__ __launch_bounds__(256) void k_derivatives_s4(ModelView mv, ParamIdx params, double t,
+                                                        const double * sumtable,
+                                                        const unsigned * ps, const unsigned * cs,
+                                                        const unsigned * weights, const int * invariant,
+                                                        unsigned N, unsigned R, double * block_out)
+{
+  __shared__ double scratch[4];
+  const unsigned long long total = (unsigned long long)N * R;
+  const unsigned long long stride = (unsigned long long)gridDim.x * 256ULL;
+  unsigned long long g = (unsigned long long)blockIdx.x * 256ULL + threadIdx.x;
+  const unsigned r = (unsigned)(g % R);
+  const unsigned pi_ = params.v[r];
+  const double pinv = mv.pinv()[pi_];
+  const double rho = mv.rates()[r] / (1.0 - pinv);
+  const double wr = mv.weights()[r] * ((pinv > 0.0) ? (1.0 - pinv) : 1.0);
+  const double winv = (pinv > 0.0) ? mv.weights()[r] * pinv : 0.0;
+  double e0[4], e1[4], e2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    const double lam = mv.evals(pi_)[k] * rho, ex = exp(lam * t);
+    e0[k] = wr * ex;
+    e1[k] = wr * ex * lam;
+    e2[k] = wr * ex * lam * lam;
+  }
+  double df = 0.0, ddf = 0.0;
+  const unsigned long long limit = (total + 63ULL) & ~63ULL;
+  for (; g < limit; g += stride)
+  {
+    const bool live = g < total;
+    const unsigned long long n = live ? g / R : 0;
+    double A = 0.0, B = 0.0, C = 0.0, inv = 0.0;
+    if (live)
+    {
+      const d4 s = load4(sumtable + g * 4);
+      A = dot4(e0, s);
+      B = dot4(e1, s);
+      C = dot4(e2, s);
+      if (winv > 0.0 && invariant && invariant[n] >= 0) inv = winv * mv.freqs(pi_)[invariant[n]];
+    }
+    A = group_sum(A, R);
+    B = group_sum(B, R);
+    C = group_sum(C, R);
+    inv = group_sum(inv, R);
+    if (live && r == 0)
+    {
+      if (inv > 0.0)
+      {
+        const unsigned cnt = (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
+        A += (cnt <= 3) ? ldexp(inv, 256 * (int)cnt) : INFINITY;
+      }
+      const double w = (double)weights[n], ba = B / A, ca = C / A;
+      df -= w * ba;
+      ddf += w * (ba * ba - ca);
+    }
+  }
+  const double tdf = block_sum_256(df, scratch);
+  const double tddf = block_sum_256(ddf, scratch);
+  if (threadIdx.x == 0)
+  {
+    block_out[blockIdx.x] = tdf;
+    block_out[gridDim.x + blockIdx.x] = tddf;
+  }
+}
+
+// --- launchers -------------------------------------------------------------
+
+static unsigned s4_grid(const Engine * e, unsigned cap_blocks)
+{
+  const unsigned long long total = (unsigned long long)e->N * e->R;
+  const unsigned long long need = (total + 255ULL) / 256ULL;
+  return (unsigned)std::max<unsigned long long>(1ULL, std::min<unsigned long long>(need, cap_blocks));
+}
+
+static int launch_partials_s4(Engine * e, const OpBatch & batch, unsigned nops)
+{
+  // 256 threads is a multiple of every admissible R, so stride % R == 0
+  const unsigned gx = s4_grid(e, e->cu_count * 16u);
+  hipLaunchKernelGGL(k_partials_s4, dim3(gx, nops), dim3(256), 0, e->stream,
+                     batch, e->N, e->R, e->lut_codes);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+static int launch_edge_lnl_s4(Engine * e, const ModelView & mv, const ParamIdx & fidx,
+                              const NodeRef & parent, const NodeRef & child,
+                              const double * pm, const double * lut,
+                              const unsigned * ps, const unsigned * cs,
+                              double * persite, unsigned nblocks)
+{
+  hipLaunchKernelGGL(k_edge_lnl_s4, dim3(nblocks), dim3(256), 0, e->stream,
+                     mv, fidx, parent, child, pm, lut, e->lut_codes, ps, cs,
+                     e->d_weights, e->d_invariant, e->d_tipmap, e->N, e->R, persite, e->d_partials);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+static int launch_sumtable_s4(Engine * e, const ModelView & mv, const ParamIdx & params,
+                              const NodeRef & parent, const NodeRef & child, double * d_sum)
+{
+  const unsigned gx = s4_grid(e, e->cu_count * 16u);
+  hipLaunchKernelGGL(k_sumtable_s4, dim3(gx), dim3(256), 0, e->stream,
+                     mv, params, parent, child, e->d_tipmap, e->N, e->R, d_sum);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+static int launch_derivatives_s4(Engine * e, const ModelView & mv, const ParamIdx & params, double t,
+                                 const double * d_sum, const unsigned * ps, const unsigned * cs,
+                                 unsigned nblocks)
+{
+  hipLaunchKernelGGL(k_derivatives_s4, dim3(nblocks), dim3(256), 0, e->stream,
+                     mv, params, t, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->R,
+                     e->d_partials);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+} // namespace pllhip

@@ -1,0 +1,968 @@
+// pll_core.hip -- the hot path of include/pll.h (tier B0) on gfx950, plus the
+// engine services behind it and the pllhip_* extension API.
+//
+// Entry points and the reference call sites they serve:
+//   pll_update_prob_matrices           src/tree/treeinfo.c:854 (count = 1 per branch!)
+//   pll_update_partials                src/tree/treeinfo.c:1037,
+//                                      src/optimize/pll_optimize.c:748-775 (count = 1)
+//   pll_compute_edge_loglikelihood     src/tree/treeinfo.c:1049
+//   pll_compute_root_loglikelihood     src/optimize/pll_optimize.c:329
+//   pll_update_sumtable                src/optimize/pll_optimize.c:800, 1468
+//   pll_compute_likelihood_derivatives src/optimize/pll_optimize.c:307, 1151, 1249
+//
+// Execution model: one HIP stream per partition; every call enqueues kernels
+// and returns, except the calls that return a scalar (lnL, derivatives), which
+// copy <= 16 KB of per-block partial sums to pinned host memory, synchronise
+// and finish the sum on the host in a fixed order (bit-reproducible).
+// Operation lists are level-scheduled: ops of one dependency level share one
+// launch (grid.y = op), their descriptors travel by value in the kernel
+// arguments, so no host->device copy sits on the critical path.
+#include "engine.h"
+#include "kernels_common.hpp"
+#include "kernels_generic.hpp"
+#include "kernels_s4.hpp"
+#include "kernels_s20.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+
+namespace pllhip {
+
+static thread_local int g_device = -1;
+
+bool hip_ok(hipError_t e, const char * what)
+{
+  if (e == hipSuccess) return true;
+  set_error(PLL_ERROR_HIP_RUNTIME, "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+  return false;
+}
+
+static int current_device()
+{
+  if (g_device < 0)
+  {
+    const char * env = getenv("PLLHIP_DEVICE");
+    g_device = env ? atoi(env) : 0;
+  }
+  return g_device;
+}
+
+static ModelView model_view(const Engine * e)
+{
+  ModelView mv;
+  mv.base = e->d_model;
+  mv.off_rates = (unsigned)e->off_rates;
+  mv.off_weights = (unsigned)e->off_weights;
+  mv.off_pinv = (unsigned)e->off_pinv;
+  mv.off_freqs = (unsigned)e->off_freqs;
+  mv.off_evals = (unsigned)e->off_evals;
+  mv.off_evecs = (unsigned)e->off_evecs;
+  mv.off_ievecs = (unsigned)e->off_ievecs;
+  mv.S = e->S;
+  mv.Sp = e->Sp;
+  return mv;
+}
+
+template <typename T>
+static bool dev_alloc(T ** ptr, size_t count, const char * what)
+{
+  *ptr = nullptr;
+  if (!count) count = 1;
+  hipError_t err = hipMalloc(reinterpret_cast<void **>(ptr), count * sizeof(T));
+  if (err != hipSuccess)
+  {
+    set_error(PLL_ERROR_MEM_ALLOC, "hipMalloc of %zu bytes for %s failed: %s",
+              count * sizeof(T), what, hipGetErrorString(err));
+    *ptr = nullptr;
+    return false;
+  }
+  return true;
+}
+
+Engine * engine_create(pll_partition_t * p)
+{
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+  {
+    set_error(PLL_ERROR_HIP_NODEVICE,
+              "No HIP device available: the likelihood engine has no CPU fallback");
+    return nullptr;
+  }
+  const int dev = current_device();
+  if (dev >= ndev)
+  {
+    set_error(PLL_ERROR_HIP_NODEVICE, "HIP device %d requested, %d visible", dev, ndev);
+    return nullptr;
+  }
+  if (!hip_ok(hipSetDevice(dev), "hipSetDevice")) return nullptr;
+
+  Engine * e = new (std::nothrow) Engine();
+  if (!e)
+  {
+    set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate engine state");
+    return nullptr;
+  }
+  e->device = dev;
+  e->S = p->states; e->Sp = p->states_padded; e->R = p->rate_cats; e->N = p->sites;
+  e->tips = p->tips; e->nodes = p->nodes; e->nscalers = p->scale_buffers;
+  e->nmat = p->prob_matrices; e->nrm = p->rate_matrices;
+  e->coded_tips = (p->attributes & PLL_ATTRIB_PATTERN_TIP) != 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess) e->cu_count = prop.multiProcessorCount;
+
+  const char * force = getenv("PLLHIP_FORCE_GENERIC");
+  if (force && atoi(force)) e->family = KernelFamily::Generic;
+  else if (e->S == 4 && (e->R & (e->R - 1)) == 0) e->family = KernelFamily::S4;
+  else if (e->S == 20) e->family = KernelFamily::S20;
+  else e->family = KernelFamily::Generic;
+
+  bool ok = hip_ok(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate");
+  const size_t clv_len = (size_t)e->N * e->R * e->Sp;
+  e->d_clv.assign(e->nodes, nullptr);
+  e->d_codes.assign(e->tips, nullptr);
+  for (unsigned i = 0; ok && i < e->nodes; ++i)
+  {
+    if (i < e->tips && e->coded_tips)
+      ok = dev_alloc(&e->d_codes[i], (size_t)e->N, "tip codes") &&
+           hip_ok(hipMemsetAsync(e->d_codes[i], 0, e->N ? e->N : 1, e->stream), "memset codes");
+    else
+      ok = dev_alloc(&e->d_clv[i], clv_len, "CLV") &&
+           hip_ok(hipMemsetAsync(e->d_clv[i], 0, (clv_len ? clv_len : 1) * sizeof(double), e->stream),
+                  "memset CLV");
+  }
+  const size_t pm_len = (size_t)e->nmat * e->R * e->S * e->Sp;
+  ok = ok && dev_alloc(&e->d_scalers, (size_t)e->nscalers * e->N, "scalers");
+  ok = ok && hip_ok(hipMemsetAsync(e->d_scalers, 0,
+                                   std::max<size_t>(1, (size_t)e->nscalers * e->N) * sizeof(unsigned),
+                                   e->stream), "memset scalers");
+  ok = ok && dev_alloc(&e->d_pmat, pm_len, "P-matrices");
+  ok = ok && hip_ok(hipMemsetAsync(e->d_pmat, 0, std::max<size_t>(1, pm_len) * sizeof(double), e->stream),
+                    "memset pmat");
+  ok = ok && dev_alloc(&e->d_weights, (size_t)e->N, "pattern weights");
+  ok = ok && dev_alloc(&e->d_tipmap, (size_t)PLL_ASCII_SIZE, "tipmap");
+  ok = ok && hip_ok(hipMemsetAsync(e->d_tipmap, 0, PLL_ASCII_SIZE * sizeof(unsigned long long), e->stream),
+                    "memset tipmap");
+  ok = ok && dev_alloc(&e->d_partials, (size_t)3 * REDUCE_BLOCKS, "reduction partials");
+  ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void **>(&e->h_partials),
+                                  3 * REDUCE_BLOCKS * sizeof(double), hipHostMallocDefault),
+                    "hipHostMalloc");
+  e->pmat_brlen.assign(e->nmat, std::numeric_limits<double>::quiet_NaN());
+  e->pmat_params.assign(e->nmat, std::vector<unsigned>());
+
+  // model block layout
+  size_t off = 0;
+  e->off_rates = off;   off += e->R;
+  e->off_weights = off; off += e->R;
+  e->off_pinv = off;    off += e->nrm;
+  e->off_freqs = off;   off += (size_t)e->nrm * e->Sp;
+  e->off_evals = off;   off += (size_t)e->nrm * e->Sp;
+  e->off_evecs = off;   off += (size_t)e->nrm * e->S * e->Sp;
+  e->off_ievecs = off;  off += (size_t)e->nrm * e->S * e->Sp;
+  e->model_len = off;
+  ok = ok && dev_alloc(&e->d_model, e->model_len, "model block");
+  e->model_shadow.assign(e->model_len, std::numeric_limits<double>::quiet_NaN());
+
+  if (!ok)
+  {
+    engine_destroy(e);
+    return nullptr;
+  }
+  p->engine = e;
+  if (!upload_weights(p))
+  {
+    p->engine = nullptr;
+    engine_destroy(e);
+    return nullptr;
+  }
+  return e;
+}
+
+void engine_destroy(Engine * e)
+{
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (double * ptr : e->d_clv) if (ptr) (void)hipFree(ptr);
+  for (uint8_t * ptr : e->d_codes) if (ptr) (void)hipFree(ptr);
+  for (auto & kv : e->sumtables) (void)hipFree(kv.second);
+  (void)hipFree(e->d_scalers);
+  (void)hipFree(e->d_pmat);
+  (void)hipFree(e->d_lut);
+  (void)hipFree(e->d_weights);
+  (void)hipFree(e->d_invariant);
+  (void)hipFree(e->d_tipmap);
+  (void)hipFree(e->d_model);
+  (void)hipFree(e->d_partials);
+  (void)hipFree(e->d_persite);
+  if (e->h_partials) (void)hipHostFree(e->h_partials);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int upload_weights(pll_partition_t * p)
+{
+  Engine * e = engine_of(p);
+  if (!e) return PLL_SUCCESS;   // called from the constructor before the engine exists
+  PLLHIP_TRY(hipSetDevice(e->device));
+  e->weights_shadow.assign(p->pattern_weights, p->pattern_weights + e->N);
+  if (e->N)
+    PLLHIP_TRY(hipMemcpyAsync(e->d_weights, p->pattern_weights, (size_t)e->N * sizeof(unsigned),
+                              hipMemcpyHostToDevice, e->stream));
+  return PLL_SUCCESS;
+}
+
+static int upload_tipmap(pll_partition_t * p)
+{
+  Engine * e = engine_of(p);
+  if (!e->coded_tips || e->tipmap_codes_uploaded == p->maxstates) return PLL_SUCCESS;
+  PLLHIP_TRY(hipMemcpyAsync(e->d_tipmap, p->tipmap, PLL_ASCII_SIZE * sizeof(unsigned long long),
+                            hipMemcpyHostToDevice, e->stream));
+  e->tipmap_codes_uploaded = p->maxstates;
+  return PLL_SUCCESS;
+}
+
+int upload_tip_codes(pll_partition_t * p, unsigned tip)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  if (e->N)
+    PLLHIP_TRY(hipMemcpyAsync(e->d_codes[tip], p->tipchars[tip], (size_t)e->N,
+                              hipMemcpyHostToDevice, e->stream));
+  return upload_tipmap(p);
+}
+
+int upload_tip_clv(pll_partition_t * p, unsigned tip, const double * host_clv)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  const size_t len = (size_t)e->N * e->R * e->Sp;
+  if (len)
+  {
+    // the staging buffer is freed by the caller right after: finish the copy
+    PLLHIP_TRY(hipMemcpyAsync(e->d_clv[tip], host_clv, len * sizeof(double),
+                              hipMemcpyHostToDevice, e->stream));
+    PLLHIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  return PLL_SUCCESS;
+}
+
+void invalidate_luts(pll_partition_t * p)
+{
+  Engine * e = engine_of(p);
+  if (e) e->lut_stale = true;
+}
+
+// host model arrays -> device if anything changed since the last call
+int sync_model(pll_partition_t * p)
+{
+  Engine * e = engine_of(p);
+  std::vector<double> cur(e->model_len, 0.0);
+  memcpy(&cur[e->off_rates], p->rates, sizeof(double) * e->R);
+  memcpy(&cur[e->off_weights], p->rate_weights, sizeof(double) * e->R);
+  memcpy(&cur[e->off_pinv], p->prop_invar, sizeof(double) * e->nrm);
+  for (unsigned m = 0; m < e->nrm; ++m)
+  {
+    memcpy(&cur[e->off_freqs + (size_t)m * e->Sp], p->frequencies[m], sizeof(double) * e->Sp);
+    memcpy(&cur[e->off_evals + (size_t)m * e->Sp], p->eigenvals[m], sizeof(double) * e->Sp);
+    memcpy(&cur[e->off_evecs + (size_t)m * e->S * e->Sp], p->eigenvecs[m], sizeof(double) * e->S * e->Sp);
+    memcpy(&cur[e->off_ievecs + (size_t)m * e->S * e->Sp], p->inv_eigenvecs[m], sizeof(double) * e->S * e->Sp);
+  }
+  if (memcmp(cur.data(), e->model_shadow.data(), sizeof(double) * e->model_len) != 0)
+  {
+    // pageable source: the runtime stages it before returning, so `cur` may die
+    PLLHIP_TRY(hipMemcpyAsync(e->d_model, cur.data(), sizeof(double) * e->model_len,
+                              hipMemcpyHostToDevice, e->stream));
+    PLLHIP_TRY(hipStreamSynchronize(e->stream));
+    e->model_shadow.swap(cur);
+    e->counters.model_uploads++;
+  }
+  // pattern weights can be written directly too (src/msa, bootstrap replicates)
+  if (e->N && memcmp(e->weights_shadow.data(), p->pattern_weights, sizeof(unsigned) * e->N) != 0)
+    if (!upload_weights(p)) return PLL_FAILURE;
+  // invariant sites: host array is computed by pll_update_invariant_sites (device
+  // kernel + download), nothing to upload unless the caller replaced the array
+  return PLL_SUCCESS;
+}
+
+static int ensure_eigen(pll_partition_t * p, const unsigned * params_indices)
+{
+  for (unsigned r = 0; r < p->rate_cats; ++r)
+  {
+    const unsigned idx = params_indices[r];
+    if (idx >= p->rate_matrices)
+    {
+      set_error(PLL_ERROR_PARAM_INVALID, "params index %u out of range", idx);
+      return PLL_FAILURE;
+    }
+    if (!p->eigen_decomp_valid[idx])
+      if (!update_eigen_host(p, idx)) return PLL_FAILURE;
+  }
+  return PLL_SUCCESS;
+}
+
+static ParamIdx make_params(const pll_partition_t * p, const unsigned * idx)
+{
+  ParamIdx pi;
+  memset(&pi, 0, sizeof(pi));
+  for (unsigned r = 0; r < p->rate_cats; ++r) pi.v[r] = idx[r];
+  return pi;
+}
+
+// LUT storage exists once tips are coded; (re)build when the code table grew
+static int ensure_luts(pll_partition_t * p)
+{
+  Engine * e = engine_of(p);
+  if (!e->coded_tips) return PLL_SUCCESS;
+  if (!upload_tipmap(p)) return PLL_FAILURE;
+  const unsigned want = std::max(1u, p->maxstates);
+  if (!e->d_lut || e->lut_codes < want)
+  {
+    // grow with head-room so that a few late codes do not re-allocate
+    const unsigned cap = std::min<unsigned>(PLL_ASCII_SIZE, std::max(want, (e->S == 4) ? 16u : want + 8u));
+    if (e->d_lut) { PLLHIP_TRY(hipStreamSynchronize(e->stream)); (void)hipFree(e->d_lut); e->d_lut = nullptr; }
+    if (!dev_alloc(&e->d_lut, (size_t)e->nmat * e->R * cap * e->S, "tip lookup tables")) return PLL_FAILURE;
+    e->lut_codes = cap;
+    e->lut_stale = true;
+  }
+  if (e->lut_stale && e->nmat)
+  {
+    hipLaunchKernelGGL(k_rebuild_lut, dim3(e->nmat, e->R), dim3(256), 0, e->stream,
+                       e->S, e->Sp, e->R, e->d_pmat, e->d_lut, e->lut_codes, e->d_tipmap);
+    PLLHIP_TRY(hipGetLastError());
+  }
+  e->lut_stale = false;
+  return PLL_SUCCESS;
+}
+
+static int ensure_invariant(pll_partition_t * p)
+{
+  Engine * e = engine_of(p);
+  bool need = false;
+  for (unsigned m = 0; m < e->nrm; ++m) if (p->prop_invar[m] > 0.0) need = true;
+  if (!need || !p->invariant) return PLL_SUCCESS;
+  if (!e->d_invariant)
+    if (!dev_alloc(&e->d_invariant, (size_t)e->N, "invariant sites")) return PLL_FAILURE;
+  if (!e->invariant_uploaded)
+  {
+    PLLHIP_TRY(hipMemcpyAsync(e->d_invariant, p->invariant, (size_t)e->N * sizeof(int),
+                              hipMemcpyHostToDevice, e->stream));
+    e->invariant_uploaded = true;
+  }
+  return PLL_SUCCESS;
+}
+
+static NodeRef node_ref(const Engine * e, unsigned clv_index)
+{
+  NodeRef n;
+  n.clv = e->d_clv[clv_index];
+  n.codes = (clv_index < e->tips) ? e->d_codes[clv_index] : nullptr;
+  return n;
+}
+
+static const unsigned * scaler_ptr(const Engine * e, int idx)
+{
+  return (idx == PLL_SCALE_BUFFER_NONE) ? nullptr : e->d_scalers + (size_t)idx * e->N;
+}
+
+static unsigned reduce_grid(const Engine * e)
+{
+  const unsigned long long need = ((unsigned long long)e->N + 255ULL) / 256ULL;
+  return (unsigned)std::max<unsigned long long>(1ULL, std::min<unsigned long long>(need, REDUCE_BLOCKS));
+}
+
+// finish a reduction: copy `n_quant` rows of `nblocks` partials, sum on host
+static int finish_reduction(Engine * e, unsigned nblocks, unsigned n_quant, double * out)
+{
+  PLLHIP_TRY(hipMemcpyAsync(e->h_partials, e->d_partials, sizeof(double) * nblocks * n_quant,
+                            hipMemcpyDeviceToHost, e->stream));
+  PLLHIP_TRY(hipStreamSynchronize(e->stream));
+  for (unsigned q = 0; q < n_quant; ++q)
+  {
+    double s = 0.0;
+    for (unsigned b = 0; b < nblocks; ++b) s += e->h_partials[(size_t)q * nblocks + b];
+    out[q] = s;
+  }
+  return PLL_SUCCESS;
+}
+
+static double * sumtable_device(Engine * e, const void * key, bool create)
+{
+  for (auto it = e->sumtables.begin(); it != e->sumtables.end(); ++it)
+    if (it->first == key)
+    {
+      e->sumtables.splice(e->sumtables.begin(), e->sumtables, it);   // most recently used first
+      return e->sumtables.front().second;
+    }
+  if (!create) return nullptr;
+  double * buf = nullptr;
+  if (e->sumtables.size() >= MAX_SUMTABLES)
+  {
+    // recycle the least recently used table (same size for every key)
+    buf = e->sumtables.back().second;
+    e->sumtables.pop_back();
+  }
+  else if (!dev_alloc(&buf, (size_t)e->N * e->R * e->Sp, "sumtable"))
+    return nullptr;
+  e->sumtables.emplace_front(key, buf);
+  return buf;
+}
+
+static int check_clv_index(const Engine * e, unsigned idx, const char * what)
+{
+  if (idx >= e->nodes)
+  {
+    set_error(PLL_ERROR_PARAM_INVALID, "%s CLV index %u out of range", what, idx);
+    return PLL_FAILURE;
+  }
+  return PLL_SUCCESS;
+}
+
+static int check_scaler_index(const Engine * e, int idx)
+{
+  if (idx != PLL_SCALE_BUFFER_NONE && (idx < 0 || (unsigned)idx >= e->nscalers))
+  {
+    set_error(PLL_ERROR_PARAM_INVALID, "scaler index %d out of range", idx);
+    return PLL_FAILURE;
+  }
+  return PLL_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------
+// partials: level scheduling + launch
+// ---------------------------------------------------------------------------
+static int launch_partials(Engine * e, const OpBatch & batch, unsigned nops)
+{
+  switch (e->family)
+  {
+    case KernelFamily::S4:
+      return launch_partials_s4(e, batch, nops);
+    case KernelFamily::S20:
+      return launch_partials_s20(e, batch, nops);
+    default:
+      break;
+  }
+  return launch_partials_generic(e, batch, nops);
+}
+
+static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops, unsigned count)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  if (!ensure_luts(p)) return PLL_FAILURE;
+
+  // dependency levels: an op runs after the producers of its children and
+  // after every earlier op that touched its output buffers
+  std::vector<int> clv_level(e->nodes, -1), sc_level(e->nscalers, -1), level(count, 0);
+  int max_level = 0;
+  for (unsigned k = 0; k < count; ++k)
+  {
+    const pll_operation_t & op = ops[k];
+    if (!check_clv_index(e, op.parent_clv_index, "parent") ||
+        !check_clv_index(e, op.child1_clv_index, "child1") ||
+        !check_clv_index(e, op.child2_clv_index, "child2") ||
+        !check_scaler_index(e, op.parent_scaler_index) ||
+        !check_scaler_index(e, op.child1_scaler_index) ||
+        !check_scaler_index(e, op.child2_scaler_index))
+      return PLL_FAILURE;
+    if (op.child1_matrix_index >= e->nmat || op.child2_matrix_index >= e->nmat)
+    {
+      set_error(PLL_ERROR_PARAM_INVALID, "matrix index out of range in operation %u", k);
+      return PLL_FAILURE;
+    }
+    if (op.parent_clv_index < e->tips && e->coded_tips)
+    {
+      set_error(PLL_ERROR_PARAM_INVALID, "operation %u writes a coded tip", k);
+      return PLL_FAILURE;
+    }
+    int l = 0;
+    l = std::max(l, clv_level[op.child1_clv_index] + 1);
+    l = std::max(l, clv_level[op.child2_clv_index] + 1);
+    l = std::max(l, clv_level[op.parent_clv_index] + 1);
+    if (op.child1_scaler_index >= 0) l = std::max(l, sc_level[op.child1_scaler_index] + 1);
+    if (op.child2_scaler_index >= 0) l = std::max(l, sc_level[op.child2_scaler_index] + 1);
+    if (op.parent_scaler_index >= 0) l = std::max(l, sc_level[op.parent_scaler_index] + 1);
+    // every buffer touched (read or written) is stamped with this level, so any
+    // later op that touches it again runs in a later launch.  In a tree
+    // traversal a CLV is touched by its producer and its single consumer only,
+    // so this costs no parallelism and covers RAW, WAR and WAW alike.
+    level[k] = l;
+    clv_level[op.parent_clv_index] = l;
+    clv_level[op.child1_clv_index] = std::max(clv_level[op.child1_clv_index], l);
+    clv_level[op.child2_clv_index] = std::max(clv_level[op.child2_clv_index], l);
+    if (op.parent_scaler_index >= 0) sc_level[op.parent_scaler_index] = l;
+    if (op.child1_scaler_index >= 0)
+      sc_level[op.child1_scaler_index] = std::max(sc_level[op.child1_scaler_index], l);
+    if (op.child2_scaler_index >= 0)
+      sc_level[op.child2_scaler_index] = std::max(sc_level[op.child2_scaler_index], l);
+    max_level = std::max(max_level, l);
+  }
+
+  const size_t pm_stride = (size_t)e->R * e->S * e->Sp;
+  const size_t lut_stride = (size_t)e->R * e->lut_codes * e->S;
+  for (int l = 0; l <= max_level; ++l)
+  {
+    OpBatch batch;
+    unsigned nb = 0;
+    for (unsigned k = 0; k <= count; ++k)
+    {
+      if (k < count && level[k] == l)
+      {
+        const pll_operation_t & op = ops[k];
+        OpDesc & d = batch.op[nb++];
+        const bool t1 = e->coded_tips && op.child1_clv_index < e->tips;
+        const bool t2 = e->coded_tips && op.child2_clv_index < e->tips;
+        d.clv1 = t1 ? nullptr : e->d_clv[op.child1_clv_index];
+        d.codes1 = t1 ? e->d_codes[op.child1_clv_index] : nullptr;
+        d.pmat1 = e->d_pmat + pm_stride * op.child1_matrix_index;
+        d.lut1 = t1 ? e->d_lut + lut_stride * op.child1_matrix_index : nullptr;
+        d.clv2 = t2 ? nullptr : e->d_clv[op.child2_clv_index];
+        d.codes2 = t2 ? e->d_codes[op.child2_clv_index] : nullptr;
+        d.pmat2 = e->d_pmat + pm_stride * op.child2_matrix_index;
+        d.lut2 = t2 ? e->d_lut + lut_stride * op.child2_matrix_index : nullptr;
+        d.scaler1 = scaler_ptr(e, op.child1_scaler_index);
+        d.scaler2 = scaler_ptr(e, op.child2_scaler_index);
+        d.parent = e->d_clv[op.parent_clv_index];
+        d.parent_scaler = const_cast<unsigned *>(scaler_ptr(e, op.parent_scaler_index));
+      }
+      if (nb == MAX_OPS_PER_LAUNCH || (k == count && nb))
+      {
+        if (!launch_partials(e, batch, nb)) return PLL_FAILURE;
+        e->counters.partial_launches++;
+        nb = 0;
+      }
+    }
+  }
+  e->counters.partial_ops += count;
+  e->counters.site_updates += (unsigned long long)count * e->N * e->R;
+  return PLL_SUCCESS;
+}
+
+} // namespace pllhip
+
+using namespace pllhip;
+
+// ===========================================================================
+// B0 entry points
+// ===========================================================================
+extern "C" {
+
+int pll_update_prob_matrices(pll_partition_t * p,
+                             const unsigned int * params_indices,
+                             const unsigned int * matrix_indices,
+                             const double * branch_lengths,
+                             unsigned int count)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  if (!ensure_eigen(p, params_indices)) return PLL_FAILURE;
+  if (!sync_model(p)) return PLL_FAILURE;
+  if (e->coded_tips)
+  {
+    // make sure LUT storage exists so that the kernel can fill it in the same pass
+    const bool was_stale = e->lut_stale || !e->d_lut || e->lut_codes < std::max(1u, p->maxstates);
+    if (was_stale && !ensure_luts(p)) return PLL_FAILURE;
+  }
+  for (unsigned m = 0; m < count; ++m)
+    if (matrix_indices[m] >= e->nmat || !(branch_lengths[m] >= 0.0))
+    {
+      set_error(PLL_ERROR_PARAM_INVALID, "Invalid matrix index %u or branch length %g",
+                matrix_indices[m], branch_lengths[m]);
+      return PLL_FAILURE;
+    }
+
+  const ModelView mv = model_view(e);
+  const ParamIdx params = make_params(p, params_indices);
+  const size_t lds = sizeof(double) * ((size_t)e->Sp + (size_t)e->S * e->Sp);
+  for (unsigned base = 0; base < count; base += MAX_PMAT_PER_LAUNCH)
+  {
+    const unsigned nb = std::min(MAX_PMAT_PER_LAUNCH, count - base);
+    PmatBatch batch;
+    for (unsigned q = 0; q < nb; ++q)
+    {
+      batch.midx[q] = matrix_indices[base + q];
+      batch.t[q] = branch_lengths[base + q];
+    }
+    hipLaunchKernelGGL(k_pmatrix, dim3(nb, e->R), dim3(256), lds, e->stream,
+                       mv, params, batch, e->R, e->d_pmat,
+                       e->coded_tips ? e->d_lut : nullptr, e->lut_codes, e->d_tipmap);
+    PLLHIP_TRY(hipGetLastError());
+  }
+  e->pmat_host_dirty = true;
+  e->counters.pmatrix_updates += count;
+  return PLL_SUCCESS;
+}
+
+void pll_update_partials(pll_partition_t * p, const pll_operation_t * ops, unsigned int count)
+{
+  if (!count) return;
+  // void in the reference interface: errors are reported through pll_errno
+  (void)update_partials_impl(p, ops, count);
+}
+
+static double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsigned cc, int csc,
+                                 int matrix_index, const unsigned * freqs_indices,
+                                 double * persite_lnl)
+{
+  Engine * e = engine_of(p);
+  const double fail = -std::numeric_limits<double>::infinity();
+  if (hipSetDevice(e->device) != hipSuccess) { set_error(PLL_ERROR_HIP_RUNTIME, "hipSetDevice"); return fail; }
+  if (!check_clv_index(e, pc, "parent") || !check_scaler_index(e, psc)) return fail;
+  if (matrix_index >= 0)
+  {
+    if (!check_clv_index(e, cc, "child") || !check_scaler_index(e, csc)) return fail;
+    if ((unsigned)matrix_index >= e->nmat) { set_error(PLL_ERROR_PARAM_INVALID, "matrix index out of range"); return fail; }
+  }
+  if (!sync_model(p) || !ensure_luts(p) || !ensure_invariant(p)) return fail;
+  if (persite_lnl && !e->d_persite)
+    if (!dev_alloc(&e->d_persite, (size_t)e->N, "per-site lnL")) return fail;
+
+  const unsigned nblocks = reduce_grid(e);
+  const ModelView mv = model_view(e);
+  const ParamIdx fidx = make_params(p, freqs_indices);
+  const NodeRef parent = node_ref(e, pc);
+  NodeRef child = {nullptr, nullptr};
+  const double * pm = nullptr, * lut = nullptr;
+  if (matrix_index >= 0)
+  {
+    child = node_ref(e, cc);
+    pm = e->d_pmat + (size_t)matrix_index * e->R * e->S * e->Sp;
+    if (child.codes) lut = e->d_lut + (size_t)matrix_index * e->R * e->lut_codes * e->S;
+  }
+  int rc;
+  if (e->family == KernelFamily::S4 && matrix_index >= 0)
+    rc = launch_edge_lnl_s4(e, mv, fidx, parent, child, pm, lut, scaler_ptr(e, psc), scaler_ptr(e, csc),
+                            persite_lnl ? e->d_persite : nullptr, nblocks);
+  else if (e->family == KernelFamily::S20 && matrix_index >= 0)
+    rc = launch_edge_lnl_s20(e, mv, fidx, parent, child, pm, lut, scaler_ptr(e, psc), scaler_ptr(e, csc),
+                             persite_lnl ? e->d_persite : nullptr, nblocks);
+  else
+    rc = launch_edge_lnl_generic(e, mv, fidx, parent, child, pm, lut, scaler_ptr(e, psc),
+                                 (matrix_index >= 0) ? scaler_ptr(e, csc) : nullptr,
+                                 persite_lnl ? e->d_persite : nullptr, nblocks);
+  if (!rc) return fail;
+  if (persite_lnl && e->N)
+    if (!hip_ok(hipMemcpyAsync(persite_lnl, e->d_persite, sizeof(double) * e->N,
+                               hipMemcpyDeviceToHost, e->stream), "persite copy")) return fail;
+  double total = 0.0;
+  if (!finish_reduction(e, nblocks, 1, &total)) return fail;
+  e->counters.lnl_calls++;
+  return total;
+}
+
+double pll_compute_edge_loglikelihood(pll_partition_t * p,
+                                      unsigned int parent_clv_index, int parent_scaler_index,
+                                      unsigned int child_clv_index, int child_scaler_index,
+                                      unsigned int matrix_index,
+                                      const unsigned int * freqs_indices,
+                                      double * persite_lnl)
+{
+  return loglikelihood_impl(p, parent_clv_index, parent_scaler_index, child_clv_index,
+                            child_scaler_index, (int)matrix_index, freqs_indices, persite_lnl);
+}
+
+double pll_compute_root_loglikelihood(pll_partition_t * p, unsigned int clv_index, int scaler_index,
+                                      const unsigned int * freqs_indices, double * persite_lnl)
+{
+  return loglikelihood_impl(p, clv_index, scaler_index, 0, PLL_SCALE_BUFFER_NONE, -1,
+                            freqs_indices, persite_lnl);
+}
+
+int pll_update_sumtable(pll_partition_t * p,
+                        unsigned int parent_clv_index, unsigned int child_clv_index,
+                        int parent_scaler_index, int child_scaler_index,
+                        const unsigned int * params_indices, double * sumtable)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  if (!check_clv_index(e, parent_clv_index, "parent") || !check_clv_index(e, child_clv_index, "child") ||
+      !check_scaler_index(e, parent_scaler_index) || !check_scaler_index(e, child_scaler_index))
+    return PLL_FAILURE;
+  if (!sumtable)
+  {
+    set_error(PLL_ERROR_PARAM_INVALID, "sumtable key must not be NULL");
+    return PLL_FAILURE;
+  }
+  if (!ensure_eigen(p, params_indices) || !sync_model(p)) return PLL_FAILURE;
+  if (e->coded_tips && !ensure_luts(p)) return PLL_FAILURE;
+  double * d_sum = sumtable_device(e, sumtable, true);
+  if (!d_sum) return PLL_FAILURE;
+
+  const ModelView mv = model_view(e);
+  const ParamIdx params = make_params(p, params_indices);
+  const NodeRef parent = node_ref(e, parent_clv_index), child = node_ref(e, child_clv_index);
+  int rc;
+  if (e->family == KernelFamily::S4)
+    rc = launch_sumtable_s4(e, mv, params, parent, child, d_sum);
+  else if (e->family == KernelFamily::S20)
+    rc = launch_sumtable_s20(e, mv, params, parent, child, d_sum);
+  else
+    rc = launch_sumtable_generic(e, mv, params, parent, child, d_sum);
+  e->counters.sumtable_calls++;
+  return rc;
+}
+
+int pll_compute_likelihood_derivatives(pll_partition_t * p,
+                                       int parent_scaler_index, int child_scaler_index,
+                                       double branch_length,
+                                       const unsigned int * params_indices,
+                                       const double * sumtable, double * d_f, double * dd_f)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  if (!check_scaler_index(e, parent_scaler_index) || !check_scaler_index(e, child_scaler_index))
+    return PLL_FAILURE;
+  double * d_sum = sumtable_device(e, sumtable, false);
+  if (!d_sum)
+  {
+    set_error(PLL_ERROR_PARAM_INVALID,
+              "pll_compute_likelihood_derivatives: no sumtable was computed for this buffer");
+    return PLL_FAILURE;
+  }
+  if (!sync_model(p) || !ensure_invariant(p)) return PLL_FAILURE;
+  const unsigned nblocks = reduce_grid(e);
+  const ModelView mv = model_view(e);
+  const ParamIdx params = make_params(p, params_indices);
+  int rc;
+  if (e->family == KernelFamily::S4)
+    rc = launch_derivatives_s4(e, mv, params, branch_length, d_sum, scaler_ptr(e, parent_scaler_index),
+                               scaler_ptr(e, child_scaler_index), nblocks);
+  else if (e->family == KernelFamily::S20)
+    rc = launch_derivatives_s20(e, mv, params, branch_length, d_sum, scaler_ptr(e, parent_scaler_index),
+                                scaler_ptr(e, child_scaler_index), nblocks);
+  else
+    rc = launch_derivatives_generic(e, mv, params, branch_length, d_sum,
+                                    scaler_ptr(e, parent_scaler_index),
+                                    scaler_ptr(e, child_scaler_index), nblocks);
+  if (!rc) return PLL_FAILURE;
+  double out[2] = {0.0, 0.0};
+  if (!finish_reduction(e, nblocks, 2, out)) return PLL_FAILURE;
+  *d_f = out[0];
+  *dd_f = out[1];
+  e->counters.derivative_calls++;
+  return PLL_SUCCESS;
+}
+
+int pll_update_invariant_sites(pll_partition_t * p)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  if (!upload_tipmap(p)) return PLL_FAILURE;
+  if (!p->invariant)
+    p->invariant = static_cast<int *>(malloc(sizeof(int) * (e->N ? e->N : 1)));
+  if (!p->invariant)
+  {
+    set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate invariant sites array");
+    return PLL_FAILURE;
+  }
+  if (!e->d_invariant)
+    if (!dev_alloc(&e->d_invariant, (size_t)e->N, "invariant sites")) return PLL_FAILURE;
+  // device tables of tip pointers
+  std::vector<const double *> h_clv(e->tips ? e->tips : 1, nullptr);
+  std::vector<const uint8_t *> h_codes(e->tips ? e->tips : 1, nullptr);
+  for (unsigned t = 0; t < e->tips; ++t) { h_clv[t] = e->d_clv[t]; h_codes[t] = e->d_codes[t]; }
+  const double ** d_tc = nullptr;
+  const uint8_t ** d_tk = nullptr;
+  if (!dev_alloc(&d_tc, h_clv.size(), "tip table") || !dev_alloc(&d_tk, h_codes.size(), "tip table"))
+    return PLL_FAILURE;
+  PLLHIP_TRY(hipMemcpyAsync(d_tc, h_clv.data(), sizeof(void *) * h_clv.size(), hipMemcpyHostToDevice, e->stream));
+  PLLHIP_TRY(hipMemcpyAsync(d_tk, h_codes.data(), sizeof(void *) * h_codes.size(), hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_invariant, dim3(reduce_grid(e)), dim3(256), 0, e->stream,
+                     d_tc, d_tk, e->d_tipmap, e->tips, e->N, e->R, e->S, e->Sp, e->d_invariant);
+  PLLHIP_TRY(hipGetLastError());
+  if (e->N)
+    PLLHIP_TRY(hipMemcpyAsync(p->invariant, e->d_invariant, sizeof(int) * e->N, hipMemcpyDeviceToHost, e->stream));
+  PLLHIP_TRY(hipStreamSynchronize(e->stream));
+  (void)hipFree(d_tc);
+  (void)hipFree(d_tk);
+  e->invariant_uploaded = true;
+  return PLL_SUCCESS;
+}
+
+int pll_compute_node_ancestral(pll_partition_t *, unsigned int, int, unsigned int, int,
+                               unsigned int, const unsigned int *, double *)
+{
+  set_error(PLL_ERROR_NOT_IMPLEMENTED,
+            "pll_compute_node_ancestral is not implemented by the HIP engine yet");
+  return PLL_FAILURE;
+}
+
+// ===========================================================================
+// pllhip_* extension API
+// ===========================================================================
+
+int pllhip_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int pllhip_set_device(int device)
+{
+  int n = pllhip_device_count();
+  if (device < 0 || device >= n)
+  {
+    set_error(PLL_ERROR_HIP_NODEVICE, "HIP device %d requested, %d visible", device, n);
+    return PLL_FAILURE;
+  }
+  g_device = device;
+  return PLL_SUCCESS;
+}
+
+int pllhip_get_device(void) { return current_device(); }
+
+int pllhip_device_arch(int device, char * out, size_t out_len)
+{
+  hipDeviceProp_t prop;
+  if (!hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) return PLL_FAILURE;
+  snprintf(out, out_len, "%s", prop.gcnArchName);
+  return PLL_SUCCESS;
+}
+
+int pllhip_synchronize(pll_partition_t * p)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  PLLHIP_TRY(hipStreamSynchronize(e->stream));
+  return PLL_SUCCESS;
+}
+
+void * pllhip_stream(pll_partition_t * p) { return engine_of(p)->stream; }
+
+int pllhip_get_clv(pll_partition_t * p, unsigned int clv_index, double * out)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  if (!check_clv_index(e, clv_index, "requested")) return PLL_FAILURE;
+  const size_t len = (size_t)e->N * e->R * e->Sp;
+  if (!len) return PLL_SUCCESS;
+  if (clv_index < e->tips && e->coded_tips)
+  {
+    double * tmp = nullptr;
+    if (!upload_tipmap(p) || !dev_alloc(&tmp, len, "expanded tip")) return PLL_FAILURE;
+    hipLaunchKernelGGL(k_expand_codes, dim3(reduce_grid(e)), dim3(256), 0, e->stream,
+                       e->d_codes[clv_index], e->d_tipmap, e->N, e->R, e->S, e->Sp, tmp);
+    PLLHIP_TRY(hipGetLastError());
+    PLLHIP_TRY(hipMemcpyAsync(out, tmp, len * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    PLLHIP_TRY(hipStreamSynchronize(e->stream));
+    (void)hipFree(tmp);
+    return PLL_SUCCESS;
+  }
+  PLLHIP_TRY(hipMemcpyAsync(out, e->d_clv[clv_index], len * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  PLLHIP_TRY(hipStreamSynchronize(e->stream));
+  return PLL_SUCCESS;
+}
+
+int pllhip_set_clv(pll_partition_t * p, unsigned int clv_index, const double * clv)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  if (!check_clv_index(e, clv_index, "target")) return PLL_FAILURE;
+  if (clv_index < e->tips && e->coded_tips)
+  {
+    set_error(PLL_ERROR_PARAM_INVALID, "CLV %u is a coded tip", clv_index);
+    return PLL_FAILURE;
+  }
+  const size_t len = (size_t)e->N * e->R * e->Sp;
+  if (!len) return PLL_SUCCESS;
+  PLLHIP_TRY(hipMemcpyAsync(e->d_clv[clv_index], clv, len * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  PLLHIP_TRY(hipStreamSynchronize(e->stream));
+  return PLL_SUCCESS;
+}
+
+int pllhip_get_scaler(pll_partition_t * p, unsigned int idx, unsigned int * out)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  if (idx >= e->nscalers) { set_error(PLL_ERROR_PARAM_INVALID, "scaler index out of range"); return PLL_FAILURE; }
+  if (!e->N) return PLL_SUCCESS;
+  PLLHIP_TRY(hipMemcpyAsync(out, e->d_scalers + (size_t)idx * e->N, sizeof(unsigned) * e->N,
+                            hipMemcpyDeviceToHost, e->stream));
+  PLLHIP_TRY(hipStreamSynchronize(e->stream));
+  return PLL_SUCCESS;
+}
+
+int pllhip_set_scaler(pll_partition_t * p, unsigned int idx, const unsigned int * in)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  if (idx >= e->nscalers) { set_error(PLL_ERROR_PARAM_INVALID, "scaler index out of range"); return PLL_FAILURE; }
+  if (!e->N) return PLL_SUCCESS;
+  PLLHIP_TRY(hipMemcpyAsync(e->d_scalers + (size_t)idx * e->N, in, sizeof(unsigned) * e->N,
+                            hipMemcpyHostToDevice, e->stream));
+  PLLHIP_TRY(hipStreamSynchronize(e->stream));
+  return PLL_SUCCESS;
+}
+
+int pllhip_get_sumtable(pll_partition_t * p, const double * key, double * out)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  double * d_sum = sumtable_device(e, key, false);
+  if (!d_sum) { set_error(PLL_ERROR_PARAM_INVALID, "unknown sumtable key"); return PLL_FAILURE; }
+  const size_t len = (size_t)e->N * e->R * e->Sp;
+  if (!len) return PLL_SUCCESS;
+  PLLHIP_TRY(hipMemcpyAsync(out, d_sum, len * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  PLLHIP_TRY(hipStreamSynchronize(e->stream));
+  return PLL_SUCCESS;
+}
+
+int pllhip_sync_to_host(pll_partition_t * p, unsigned int what)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  if ((what & PLLHIP_SYNC_PMATRIX) && e->pmat_host_dirty && e->nmat)
+  {
+    PLLHIP_TRY(hipMemcpyAsync(p->pmatrix[0], e->d_pmat,
+                              sizeof(double) * (size_t)e->nmat * e->R * e->S * e->Sp,
+                              hipMemcpyDeviceToHost, e->stream));
+    PLLHIP_TRY(hipStreamSynchronize(e->stream));
+    e->pmat_host_dirty = false;
+  }
+  if (what & PLLHIP_SYNC_CLV)
+  {
+    const size_t len = (size_t)e->N * e->R * e->Sp;
+    for (unsigned i = 0; i < e->nodes; ++i)
+    {
+      if (i < e->tips && e->coded_tips) continue;   // libpll keeps no CLV for coded tips either
+      if (!p->clv[i]) p->clv[i] = static_cast<double *>(pll_aligned_alloc(sizeof(double) * (len ? len : 1), p->alignment));
+      if (!p->clv[i]) { set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate host CLV mirror"); return PLL_FAILURE; }
+      if (!pllhip_get_clv(p, i, p->clv[i])) return PLL_FAILURE;
+    }
+  }
+  if (what & PLLHIP_SYNC_SCALERS)
+    for (unsigned i = 0; i < e->nscalers; ++i)
+    {
+      if (!p->scale_buffer[i])
+        p->scale_buffer[i] = static_cast<unsigned *>(calloc(e->N ? e->N : 1, sizeof(unsigned)));
+      if (!p->scale_buffer[i]) { set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate host scaler mirror"); return PLL_FAILURE; }
+      if (!pllhip_get_scaler(p, i, p->scale_buffer[i])) return PLL_FAILURE;
+    }
+  return PLL_SUCCESS;
+}
+
+int pllhip_get_counters(const pll_partition_t * p, pllhip_counters_t * out)
+{
+  *out = engine_of(p)->counters;
+  return PLL_SUCCESS;
+}
+
+void pllhip_reset_counters(pll_partition_t * p)
+{
+  engine_of(p)->counters = pllhip_counters_t{};
+}
+
+const char * pllhip_partials_kernel_name(const pll_partition_t * p)
+{
+  switch (engine_of(p)->family)
+  {
+    case KernelFamily::S4: return "s4-valu";
+    case KernelFamily::S20: return "s20-mfma";
+    default: return "generic";
+  }
+}
+
+} // extern "C"

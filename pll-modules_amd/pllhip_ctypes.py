@@ -1,0 +1,609 @@
+"""ctypes binding of the C ABI in include/pll.h + include/pllhip.h, and the
+synthetic workload generator shared by tests/ and bench.py.
+
+The binding is deliberately thin: it mirrors the C structs field by field
+(`pll_partition_t`, `pll_operation_t`, `pll_unode_t`, `pll_utree_t`) and calls
+the exported functions with plain pointers and sizes, i.e. exactly what a C
+caller such as pll-modules' treeinfo.c does.  `PllLib(path)` can wrap any
+shared library that exports the interface; this module itself only knows where
+the PRODUCT library lives (`PRODUCT_LIB`).  The CPU oracle is loaded by tests/
+and by bench.py's cpu_baseline leg, never from here.
+
+Workloads follow SURVEY.md section 8d: splitmix64-seeded random stepwise-addition
+tree (seed 42), branch lengths U(0.01, 0.2) (seed 43), iid uniform tip states
+(seed 44), DNA GTR+G4 / "LG-shaped" protein / GY94-shaped codon models.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PRODUCT_LIB = os.path.join(HERE, "libpll_hip.so")
+
+PLL_SCALE_BUFFER_NONE = -1
+PLL_ATTRIB_PATTERN_TIP = 1 << 4
+PLL_GAMMA_RATES_MEAN = 0
+PLL_TREE_TRAVERSE_POSTORDER = 1
+PLLHIP_SYNC_PMATRIX, PLLHIP_SYNC_CLV, PLLHIP_SYNC_SCALERS = 1, 2, 4
+
+c_double_p = C.POINTER(C.c_double)
+c_uint_p = C.POINTER(C.c_uint)
+
+
+class Partition(C.Structure):
+    _fields_ = [
+        ("tips", C.c_uint), ("clv_buffers", C.c_uint), ("nodes", C.c_uint),
+        ("states", C.c_uint), ("sites", C.c_uint), ("pattern_weight_sum", C.c_uint),
+        ("rate_matrices", C.c_uint), ("prob_matrices", C.c_uint), ("rate_cats", C.c_uint),
+        ("scale_buffers", C.c_uint), ("attributes", C.c_uint),
+        ("alignment", C.c_size_t), ("states_padded", C.c_uint),
+        ("clv", C.POINTER(c_double_p)), ("pmatrix", C.POINTER(c_double_p)),
+        ("rates", c_double_p), ("rate_weights", c_double_p),
+        ("subst_params", C.POINTER(c_double_p)),
+        ("scale_buffer", C.POINTER(c_uint_p)),
+        ("frequencies", C.POINTER(c_double_p)),
+        ("prop_invar", c_double_p), ("invariant", C.POINTER(C.c_int)),
+        ("pattern_weights", c_uint_p),
+        ("eigen_decomp_valid", C.POINTER(C.c_int)),
+        ("eigenvecs", C.POINTER(c_double_p)), ("inv_eigenvecs", C.POINTER(c_double_p)),
+        ("eigenvals", C.POINTER(c_double_p)),
+        ("maxstates", C.c_uint), ("tipchars", C.POINTER(C.POINTER(C.c_ubyte))),
+        ("charmap", C.POINTER(C.c_ubyte)), ("ttlookup", c_double_p),
+        ("tipmap", C.POINTER(C.c_ulonglong)),
+        ("asc_bias_alloc", C.c_int), ("asc_additional_sites", C.c_int),
+        ("repeats", C.c_void_p), ("engine", C.c_void_p),
+    ]
+
+
+class Operation(C.Structure):
+    _fields_ = [
+        ("parent_clv_index", C.c_uint), ("parent_scaler_index", C.c_int),
+        ("child1_clv_index", C.c_uint), ("child1_matrix_index", C.c_uint),
+        ("child1_scaler_index", C.c_int),
+        ("child2_clv_index", C.c_uint), ("child2_matrix_index", C.c_uint),
+        ("child2_scaler_index", C.c_int),
+    ]
+
+
+class UNode(C.Structure):
+    pass
+
+
+UNode._fields_ = [
+    ("label", C.c_char_p), ("length", C.c_double), ("node_index", C.c_uint),
+    ("clv_index", C.c_uint), ("scaler_index", C.c_int), ("pmatrix_index", C.c_uint),
+    ("next", C.POINTER(UNode)), ("back", C.POINTER(UNode)), ("data", C.c_void_p),
+]
+
+
+class UTree(C.Structure):
+    _fields_ = [
+        ("tip_count", C.c_uint), ("inner_count", C.c_uint), ("edge_count", C.c_uint),
+        ("binary", C.c_int), ("nodes", C.POINTER(C.POINTER(UNode))),
+        ("vroot", C.POINTER(UNode)),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_ulonglong) for n in (
+        "partial_ops", "partial_launches", "site_updates", "pmatrix_updates",
+        "lnl_calls", "sumtable_calls", "derivative_calls", "model_uploads")]
+
+
+TRAVERSE_CB = C.CFUNCTYPE(C.c_int, C.POINTER(UNode))
+REDUCE_CB = C.CFUNCTYPE(None, C.c_void_p, c_double_p, C.c_size_t, C.c_int)
+
+# every function the headers declare with PLL_EXPORT, for the symbol test
+PLL_H_FUNCTIONS = """pll_partition_create pll_partition_destroy pll_set_tip_states
+pll_set_tip_clv pll_set_pattern_weights pll_set_asc_bias_type pll_set_asc_state_weights
+pll_set_subst_params pll_set_frequencies pll_set_category_rates pll_set_category_weights
+pll_update_eigen pll_count_invariant_sites pll_update_invariant_sites
+pll_update_invariant_sites_proportion pll_compute_gamma_cats pll_aligned_alloc
+pll_aligned_free pll_get_sites_number pll_get_clv_size pll_update_prob_matrices
+pll_update_partials pll_compute_root_loglikelihood pll_compute_edge_loglikelihood
+pll_update_sumtable pll_compute_likelihood_derivatives pll_compute_node_ancestral
+pll_show_pmatrix pll_show_clv pll_utree_traverse pll_utree_create_operations
+pll_utree_wraptree pll_utree_wraptree_multi pll_utree_destroy pll_utree_graph_clone
+pll_utree_graph_destroy pll_utree_clone pll_utree_reset_template_indices
+pll_utree_check_integrity pll_utree_every pll_utree_parse_newick
+pll_utree_parse_newick_unroot pll_utree_parse_newick_string
+pll_utree_parse_newick_string_unroot pll_utree_export_newick pll_utree_show_ascii
+pll_random_create pll_random_getint pll_random_destroy""".split()
+
+PLLHIP_H_FUNCTIONS = """pllhip_device_count pllhip_set_device pllhip_get_device
+pllhip_device_arch pllhip_eigen_decompose pllhip_sync_to_host pllhip_get_clv
+pllhip_get_scaler pllhip_get_sumtable pllhip_set_clv pllhip_set_scaler pllhip_synchronize
+pllhip_stream pllhip_get_counters pllhip_reset_counters pllhip_partials_kernel_name
+pllhip_comm_get_unique_id pllhip_comm_create pllhip_comm_destroy pllhip_reduce_cb""".split()
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class PllLib:
+    """One loaded implementation of include/pll.h."""
+
+    def __init__(self, path=PRODUCT_LIB):
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                f"{path} not found: build it first (python -c 'import __graft_entry__ as g; g.build()')")
+        self.path = path
+        self.lib = L = C.CDLL(path)
+        self.is_product = hasattr(L, "pllhip_device_count")
+        pp = C.POINTER(Partition)
+        L.pll_partition_create.restype = pp
+        L.pll_partition_create.argtypes = [C.c_uint] * 9
+        L.pll_partition_destroy.argtypes = [pp]
+        L.pll_set_tip_states.argtypes = [pp, C.c_uint, C.POINTER(C.c_ulonglong), C.c_char_p]
+        L.pll_set_tip_clv.argtypes = [pp, C.c_uint, c_double_p, C.c_int]
+        L.pll_set_pattern_weights.argtypes = [pp, c_uint_p]
+        L.pll_set_subst_params.argtypes = [pp, C.c_uint, c_double_p]
+        L.pll_set_frequencies.argtypes = [pp, C.c_uint, c_double_p]
+        L.pll_set_category_rates.argtypes = [pp, c_double_p]
+        L.pll_set_category_weights.argtypes = [pp, c_double_p]
+        L.pll_update_invariant_sites.argtypes = [pp]
+        L.pll_update_invariant_sites_proportion.argtypes = [pp, C.c_uint, C.c_double]
+        L.pll_count_invariant_sites.argtypes = [pp, c_uint_p]
+        L.pll_count_invariant_sites.restype = C.c_uint
+        L.pll_compute_gamma_cats.argtypes = [C.c_double, C.c_uint, c_double_p, C.c_int]
+        L.pll_update_prob_matrices.argtypes = [pp, c_uint_p, c_uint_p, c_double_p, C.c_uint]
+        L.pll_update_partials.argtypes = [pp, C.POINTER(Operation), C.c_uint]
+        L.pll_update_partials.restype = None
+        L.pll_compute_edge_loglikelihood.restype = C.c_double
+        L.pll_compute_edge_loglikelihood.argtypes = [pp, C.c_uint, C.c_int, C.c_uint, C.c_int,
+                                                     C.c_uint, c_uint_p, c_double_p]
+        L.pll_compute_root_loglikelihood.restype = C.c_double
+        L.pll_compute_root_loglikelihood.argtypes = [pp, C.c_uint, C.c_int, c_uint_p, c_double_p]
+        L.pll_update_sumtable.argtypes = [pp, C.c_uint, C.c_uint, C.c_int, C.c_int, c_uint_p, c_double_p]
+        L.pll_compute_likelihood_derivatives.argtypes = [pp, C.c_int, C.c_int, C.c_double, c_uint_p,
+                                                         c_double_p, c_double_p, c_double_p]
+        L.pll_aligned_alloc.restype = C.c_void_p
+        L.pll_aligned_alloc.argtypes = [C.c_size_t, C.c_size_t]
+        L.pll_aligned_free.argtypes = [C.c_void_p]
+        up, tp = C.POINTER(UNode), C.POINTER(UTree)
+        L.pll_utree_parse_newick_string.restype = tp
+        L.pll_utree_parse_newick_string.argtypes = [C.c_char_p]
+        L.pll_utree_parse_newick_string_unroot.restype = tp
+        L.pll_utree_parse_newick_string_unroot.argtypes = [C.c_char_p]
+        L.pll_utree_destroy.argtypes = [tp, C.c_void_p]
+        L.pll_utree_clone.restype = tp
+        L.pll_utree_clone.argtypes = [tp]
+        L.pll_utree_check_integrity.argtypes = [tp]
+        L.pll_utree_traverse.argtypes = [up, C.c_int, TRAVERSE_CB, C.POINTER(up), c_uint_p]
+        L.pll_utree_create_operations.restype = None
+        L.pll_utree_create_operations.argtypes = [C.POINTER(up), C.c_uint, c_double_p, c_uint_p,
+                                                  C.POINTER(Operation), c_uint_p, c_uint_p]
+        L.pll_utree_export_newick.restype = C.c_void_p
+        L.pll_utree_export_newick.argtypes = [up, C.c_void_p]
+        if self.is_product:
+            L.pllhip_device_count.restype = C.c_int
+            L.pllhip_set_device.argtypes = [C.c_int]
+            L.pllhip_device_arch.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+            L.pllhip_eigen_decompose.argtypes = [C.c_uint, C.c_uint, c_double_p, c_double_p,
+                                                 c_double_p, c_double_p, c_double_p]
+            L.pllhip_sync_to_host.argtypes = [pp, C.c_uint]
+            L.pllhip_get_clv.argtypes = [pp, C.c_uint, c_double_p]
+            L.pllhip_set_clv.argtypes = [pp, C.c_uint, c_double_p]
+            L.pllhip_get_scaler.argtypes = [pp, C.c_uint, c_uint_p]
+            L.pllhip_set_scaler.argtypes = [pp, C.c_uint, c_uint_p]
+            L.pllhip_get_sumtable.argtypes = [pp, c_double_p, c_double_p]
+            L.pllhip_synchronize.argtypes = [pp]
+            L.pllhip_stream.restype = C.c_void_p
+            L.pllhip_stream.argtypes = [pp]
+            L.pllhip_get_counters.argtypes = [pp, C.POINTER(Counters)]
+            L.pllhip_reset_counters.argtypes = [pp]
+            L.pllhip_partials_kernel_name.restype = C.c_char_p
+            L.pllhip_partials_kernel_name.argtypes = [pp]
+            L.pllhip_comm_get_unique_id.argtypes = [C.c_char_p]
+            L.pllhip_comm_create.restype = C.c_void_p
+            L.pllhip_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
+            L.pllhip_comm_destroy.argtypes = [C.c_void_p]
+            L.pllhip_reduce_cb.restype = None
+            L.pllhip_reduce_cb.argtypes = [C.c_void_p, c_double_p, C.c_size_t, C.c_int]
+
+    # --- error state ------------------------------------------------------
+    @property
+    def errno(self):
+        return C.c_int.in_dll(self.lib, "pll_errno").value
+
+    @errno.setter
+    def errno(self, v):
+        C.c_int.in_dll(self.lib, "pll_errno").value = v
+
+    @property
+    def errmsg(self):
+        return (C.c_char * 200).in_dll(self.lib, "pll_errmsg").value.decode(errors="replace")
+
+    def gamma_cats(self, alpha, k, mode=PLL_GAMMA_RATES_MEAN):
+        out = np.zeros(k)
+        if not self.lib.pll_compute_gamma_cats(alpha, k, out.ctypes.data_as(c_double_p), mode):
+            raise RuntimeError(self.errmsg)
+        return out
+
+
+class Instance:
+    """A partition plus the index bookkeeping of one (tree, model, alignment)."""
+
+    def __init__(self, lib, tips, states, sites, rate_cats, attributes=0, scalers=True,
+                 rate_matrices=1, prob_matrices=None, clv_buffers=None):
+        self.lib, self.L = lib, lib.lib
+        self.tips, self.S, self.N, self.R = tips, states, sites, rate_cats
+        inner = tips - 2 if clv_buffers is None else clv_buffers
+        nmat = 2 * tips - 3 if prob_matrices is None else prob_matrices
+        self.nscalers = inner if scalers else 0
+        self.p = self.L.pll_partition_create(tips, inner, states, sites, rate_matrices, nmat,
+                                             rate_cats, self.nscalers, attributes)
+        if not self.p:
+            raise RuntimeError(f"pll_partition_create failed: [{lib.errno}] {lib.errmsg}")
+        self.Sp = self.p.contents.states_padded
+        self.params = _u32(np.zeros(rate_cats))
+        self._keep = []
+
+    def close(self):
+        if self.p:
+            self.L.pll_partition_destroy(self.p)
+            self.p = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def params_p(self):
+        return self.params.ctypes.data_as(c_uint_p)
+
+    # --- model ------------------------------------------------------------
+    def set_model(self, subst, freqs, rates, weights=None, idx=0):
+        s, f, r = _f64(subst), _f64(freqs), _f64(rates)
+        self.L.pll_set_subst_params(self.p, idx, s.ctypes.data_as(c_double_p))
+        self.L.pll_set_frequencies(self.p, idx, f.ctypes.data_as(c_double_p))
+        self.L.pll_set_category_rates(self.p, r.ctypes.data_as(c_double_p))
+        if weights is not None:
+            w = _f64(weights)
+            self.L.pll_set_category_weights(self.p, w.ctypes.data_as(c_double_p))
+
+    def set_tip_states(self, tip, charmap, seq_bytes):
+        m = (C.c_ulonglong * 256)(*[int(x) for x in charmap])
+        if not self.L.pll_set_tip_states(self.p, tip, m, bytes(seq_bytes)):
+            raise RuntimeError(f"pll_set_tip_states: {self.lib.errmsg}")
+
+    def set_tip_clv(self, tip, clv, padding=0):
+        a = _f64(clv)
+        if not self.L.pll_set_tip_clv(self.p, tip, a.ctypes.data_as(c_double_p), padding):
+            raise RuntimeError(f"pll_set_tip_clv: {self.lib.errmsg}")
+
+    def set_pattern_weights(self, w):
+        a = _u32(w)
+        self.L.pll_set_pattern_weights(self.p, a.ctypes.data_as(c_uint_p))
+
+    def set_pinv(self, pinv, idx=0):
+        if not self.L.pll_update_invariant_sites_proportion(self.p, idx, pinv):
+            raise RuntimeError(self.lib.errmsg)
+
+    # --- hot path ---------------------------------------------------------
+    def update_pmatrices(self, matrix_indices, brlens, one_by_one=False):
+        mi, bl = _u32(matrix_indices), _f64(brlens)
+        if one_by_one:      # the reference's treeinfo issues count = 1 per branch
+            for k in range(len(mi)):
+                if not self.L.pll_update_prob_matrices(
+                        self.p, self.params_p,
+                        C.cast(mi.ctypes.data + 4 * k, c_uint_p),
+                        C.cast(bl.ctypes.data + 8 * k, c_double_p), 1):
+                    raise RuntimeError(self.lib.errmsg)
+            return
+        if not self.L.pll_update_prob_matrices(self.p, self.params_p, mi.ctypes.data_as(c_uint_p),
+                                               bl.ctypes.data_as(c_double_p), len(mi)):
+            raise RuntimeError(self.lib.errmsg)
+
+    @staticmethod
+    def make_ops(op_tuples):
+        """op_tuples: (parent_clv, parent_scaler, c1_clv, c1_mat, c1_scaler, c2_clv, c2_mat, c2_scaler)"""
+        arr = (Operation * max(1, len(op_tuples)))()
+        for k, t in enumerate(op_tuples):
+            (arr[k].parent_clv_index, arr[k].parent_scaler_index, arr[k].child1_clv_index,
+             arr[k].child1_matrix_index, arr[k].child1_scaler_index, arr[k].child2_clv_index,
+             arr[k].child2_matrix_index, arr[k].child2_scaler_index) = [int(x) for x in t]
+        return arr
+
+    def update_partials(self, ops, count=None):
+        if not isinstance(ops, C.Array):
+            count = len(ops)
+            ops = self.make_ops(ops)
+        self.lib.errno = 0
+        self.L.pll_update_partials(self.p, ops, len(ops) if count is None else count)
+        if self.lib.errno:
+            raise RuntimeError(self.lib.errmsg)
+
+    def edge_lnl(self, pc, psc, cc, csc, matrix, persite=False):
+        buf = np.zeros(self.N) if persite else None
+        v = self.L.pll_compute_edge_loglikelihood(
+            self.p, pc, psc, cc, csc, matrix, self.params_p,
+            buf.ctypes.data_as(c_double_p) if persite else None)
+        return (v, buf) if persite else v
+
+    def root_lnl(self, clv, sc, persite=False):
+        buf = np.zeros(self.N) if persite else None
+        v = self.L.pll_compute_root_loglikelihood(
+            self.p, clv, sc, self.params_p, buf.ctypes.data_as(c_double_p) if persite else None)
+        return (v, buf) if persite else v
+
+    def alloc_sumtable(self):
+        """caller-owned buffer exactly as src/tree/treeinfo.c:336-340 allocates it"""
+        n = self.N * self.R * self.Sp
+        ptr = self.L.pll_aligned_alloc(max(1, n) * 8, self.p.contents.alignment)
+        return C.cast(ptr, c_double_p)
+
+    def free_sumtable(self, st):
+        self.L.pll_aligned_free(C.cast(st, C.c_void_p))
+
+    def update_sumtable(self, pc, cc, psc, csc, st):
+        if not self.L.pll_update_sumtable(self.p, pc, cc, psc, csc, self.params_p, st):
+            raise RuntimeError(self.lib.errmsg)
+
+    def derivatives(self, psc, csc, t, st):
+        df, ddf = C.c_double(), C.c_double()
+        if not self.L.pll_compute_likelihood_derivatives(self.p, psc, csc, t, self.params_p, st,
+                                                         C.byref(df), C.byref(ddf)):
+            raise RuntimeError(self.lib.errmsg)
+        return df.value, ddf.value
+
+    # --- read-back (works for both libraries) -------------------------------
+    def get_clv(self, idx):
+        n = self.N * self.R * self.Sp
+        out = np.zeros(n)
+        if self.lib.is_product:
+            if not self.L.pllhip_get_clv(self.p, idx, out.ctypes.data_as(c_double_p)):
+                raise RuntimeError(self.lib.errmsg)
+        else:
+            ptr = self.p.contents.clv[idx]
+            out[:] = np.ctypeslib.as_array(ptr, shape=(n,))
+        return out.reshape(self.N, self.R, self.Sp)[:, :, :self.S]
+
+    def get_scaler(self, idx):
+        out = np.zeros(self.N, dtype=np.uint32)
+        if self.lib.is_product:
+            if not self.L.pllhip_get_scaler(self.p, idx, out.ctypes.data_as(c_uint_p)):
+                raise RuntimeError(self.lib.errmsg)
+        else:
+            out[:] = np.ctypeslib.as_array(self.p.contents.scale_buffer[idx], shape=(self.N,))
+        return out
+
+    def get_pmatrix(self, idx):
+        if self.lib.is_product:
+            self.L.pllhip_sync_to_host(self.p, PLLHIP_SYNC_PMATRIX)
+        n = self.R * self.S * self.Sp
+        a = np.ctypeslib.as_array(self.p.contents.pmatrix[idx], shape=(n,)).copy()
+        return a.reshape(self.R, self.S, self.Sp)[:, :, :self.S]
+
+    def get_sumtable(self, st):
+        n = self.N * self.R * self.Sp
+        out = np.zeros(n)
+        if self.lib.is_product:
+            if not self.L.pllhip_get_sumtable(self.p, st, out.ctypes.data_as(c_double_p)):
+                raise RuntimeError(self.lib.errmsg)
+        else:
+            out[:] = np.ctypeslib.as_array(st, shape=(n,))
+        return out.reshape(self.N, self.R, self.Sp)[:, :, :self.S]
+
+    def counters(self):
+        c = Counters()
+        self.L.pllhip_get_counters(self.p, C.byref(c))
+        return c
+
+
+# ---------------------------------------------------------------------------
+# synthetic workloads
+# ---------------------------------------------------------------------------
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(seed, n):
+    """n values of the splitmix64 stream started at `seed` (vectorised)."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * np.arange(1, n + 1, dtype=np.uint64)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform01(seed, n):
+    return (splitmix64(seed, n) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+class Tree:
+    """Unrooted binary tree as index arrays.
+
+    tip i -> CLV i; inner node k -> CLV tips+k, scaler k; every edge has a
+    unique P-matrix index 0..2n-4.  `ops` is the post-order
+    operation list towards the root edge (root_a, root_b, root_matrix).
+    """
+
+    def __init__(self, ntips, seed_topology=42, seed_brlen=43, brlen_range=(0.01, 0.2)):
+        assert ntips >= 3
+        self.ntips = ntips
+        rnd = splitmix64(seed_topology, ntips)
+        # edges as [u, v]; start with a star on tips 0,1,2 around inner node n
+        edges = [[0, ntips], [1, ntips], [2, ntips]]
+        for t in range(3, ntips):
+            e = int(rnd[t] % np.uint64(len(edges)))
+            u, v = edges[e]
+            w = ntips + (t - 2)          # new inner node
+            edges[e] = [u, w]
+            edges.append([w, v])
+            edges.append([t, w])
+        self.edges = edges
+        lo, hi = brlen_range
+        self.brlens = lo + (hi - lo) * uniform01(seed_brlen, len(edges))
+        self.nedges = len(edges)
+        adj = {}
+        for k, (u, v) in enumerate(edges):
+            adj.setdefault(u, []).append((v, k))
+            adj.setdefault(v, []).append((u, k))
+        self.adj = adj
+        self.set_root_edge(self.nedges - 1 if ntips > 3 else 2)
+
+    def scaler_of(self, node):
+        return node - self.ntips if node >= self.ntips else PLL_SCALE_BUFFER_NONE
+
+    def _postorder(self, node, parent, out):
+        """iterative post-order of the subtree at `node` seen from `parent`"""
+        stack = [(node, parent, False)]
+        while stack:
+            nd, par, done = stack.pop()
+            if nd < self.ntips:
+                continue
+            kids = [(v, k) for (v, k) in self.adj[nd] if v != par]
+            if done:
+                (c1, m1), (c2, m2) = kids
+                out.append((nd, self.scaler_of(nd), c1, m1, self.scaler_of(c1),
+                            c2, m2, self.scaler_of(c2)))
+            else:
+                stack.append((nd, par, True))
+                for v, _ in kids:
+                    stack.append((v, nd, False))
+
+    def set_root_edge(self, k):
+        u, v = self.edges[k]
+        if u < self.ntips:       # keep an inner node on the "parent" side
+            u, v = v, u
+        self.root_a, self.root_b, self.root_matrix = u, v, k
+        ops = []
+        self._postorder(v, u, ops)
+        self._postorder(u, v, ops)
+        self.ops = ops
+
+    def ops_with_scalers(self, use):
+        if use:
+            return self.ops
+        N = PLL_SCALE_BUFFER_NONE
+        return [(p, N, a, ma, N, b, mb, N) for (p, _, a, ma, _, b, mb, _) in self.ops]
+
+    def newick(self, labels=None):
+        def rec(nd, par, k):
+            if nd < self.ntips:
+                s = labels[nd] if labels else f"t{nd}"
+            else:
+                s = "(" + ",".join(rec(v, nd, kk) for (v, kk) in self.adj[nd] if v != par) + ")"
+            return s + (f":{self.brlens[k]:.6f}" if k is not None else "")
+        root = self.ntips
+        return "(" + ",".join(rec(v, root, kk) for (v, kk) in self.adj[root]) + ");"
+
+
+DNA_GTR_RATES = [1.452176, 0.937951, 0.462880, 0.617729, 1.745312, 1.0]   # blopt-minimal.c:49
+DNA_FREQS = [0.17, 0.19, 0.25, 0.39]                                       # spr-round.c:153
+
+
+def protein_model(seed_rates=46, seed_freqs=47):
+    """'LG-shaped' reversible 20-state model: 190 log-normal exchangeabilities
+    and Dirichlet(5) frequencies.  The real LG table is not available offline
+    (src/util/models_aa.c:29 takes it from libpll), so this is NOT LG."""
+    u = uniform01(seed_rates, 380)
+    z = np.sqrt(-2.0 * np.log(np.maximum(u[0::2], 1e-300))) * np.cos(2 * np.pi * u[1::2])
+    rates = np.exp(z)
+    rates[-1] = 1.0
+    g = -np.log(np.maximum(uniform01(seed_freqs, 100), 1e-300)).reshape(20, 5).sum(axis=1)
+    return rates, g / g.sum()
+
+
+def codon_model(kappa=2.0, omega=0.2, seed_freqs=48):
+    """GY94-shaped 61-state model from the standard genetic code."""
+    bases = "TCAG"
+    aa = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"
+    codons = [(a + b + c) for a in bases for b in bases for c in bases]
+    sense = [(cd, aa[i]) for i, cd in enumerate(codons) if aa[i] != "*"]
+    n = len(sense)
+    assert n == 61
+    transitions = {("T", "C"), ("C", "T"), ("A", "G"), ("G", "A")}
+    rates = []
+    for i in range(n):
+        for j in range(i + 1, n):
+            ci, ai = sense[i]
+            cj, aj = sense[j]
+            diff = [(x, y) for x, y in zip(ci, cj) if x != y]
+            if len(diff) != 1:
+                rates.append(0.0)
+                continue
+            r = 1.0
+            if diff[0] in transitions:
+                r *= kappa
+            if ai != aj:
+                r *= omega
+            rates.append(r)
+    g = -np.log(np.maximum(uniform01(seed_freqs, 61 * 5), 1e-300)).reshape(61, 5).sum(axis=1)
+    return np.array(rates), g / g.sum()
+
+
+def random_codes(ntips, nsites, nstates, seed=44):
+    """iid uniform unambiguous state index per (tip, site) -> uint8 [tips][sites]"""
+    out = np.empty((ntips, nsites), dtype=np.uint8)
+    for t in range(ntips):
+        out[t] = (splitmix64(seed + 1000003 * t, nsites) % np.uint64(nstates)).astype(np.uint8)
+    return out
+
+
+def state_charmap(nstates):
+    """a 256-entry char -> mask map where byte value 48+i ('0'+i) means state i and
+    '-' means every state (so uint8 state arrays + 48 are valid sequences)"""
+    m = np.zeros(256, dtype=np.uint64)
+    for i in range(nstates):
+        m[48 + i] = np.uint64(1) << np.uint64(i)
+    m[ord("-")] = (np.uint64(1) << np.uint64(nstates)) - np.uint64(1) if nstates < 64 else _M64
+    return m
+
+
+CONFIGS = {
+    # name: (states, rate_cats, taxa, sites)   BASELINE.json configs
+    "c1": (4, 1, 10, 1000),
+    "c2": (4, 4, 100, 1_000_000),
+    "c3": (20, 4, 200, 1_000_000),
+    "c5": (61, 4, 50, 200_000),
+}
+
+
+def build_instance(lib, states, rate_cats, ntips, nsites, coded=True, scalers=True, alpha=None,
+                   seed_shift=0, tree=None, pinv=0.0):
+    """partition + tree + model + tips for one synthetic configuration"""
+    tree = tree or Tree(ntips, 42 + seed_shift, 43 + seed_shift)
+    inst = Instance(lib, ntips, states, nsites, rate_cats,
+                    attributes=PLL_ATTRIB_PATTERN_TIP if coded else 0, scalers=scalers)
+    if states == 4:
+        subst, freqs, a = DNA_GTR_RATES, DNA_FREQS, 0.841
+    elif states == 20:
+        (subst, freqs), a = protein_model(), 0.5
+    elif states == 61:
+        (subst, freqs), a = codon_model(), 0.5
+    else:
+        ns = states * (states - 1) // 2
+        subst = 0.5 + uniform01(146 + states, ns)
+        f = 0.5 + uniform01(147 + states, states)
+        freqs, a = f / f.sum(), 0.7
+    alpha = a if alpha is None else alpha
+    rates = lib.gamma_cats(alpha, rate_cats) if rate_cats > 1 else np.ones(1)
+    inst.set_model(subst, freqs, rates)
+    cmap = state_charmap(states)
+    codes = random_codes(ntips, nsites, states, 44 + seed_shift)
+    for t in range(ntips):
+        inst.set_tip_states(t, cmap, (codes[t] + 48).tobytes())
+    if pinv > 0:
+        inst.set_pinv(pinv)
+    inst.tree = tree
+    inst.codes = codes
+    return inst
+
+
+def full_traversal(inst, one_by_one_pmatrices=False):
+    """the W1 workload: all P-matrices, n-2 partial ops, one edge lnL
+    (call pattern of treeinfo_compute_loglh, src/tree/treeinfo.c:946-1079)"""
+    t = inst.tree
+    inst.update_pmatrices(np.arange(t.nedges), t.brlens, one_by_one=one_by_one_pmatrices)
+    inst.update_partials(t.ops_with_scalers(inst.nscalers > 0))
+    sa = t.scaler_of(t.root_a) if inst.nscalers else PLL_SCALE_BUFFER_NONE
+    sb = t.scaler_of(t.root_b) if inst.nscalers else PLL_SCALE_BUFFER_NONE
+    return inst.edge_lnl(t.root_a, sa, t.root_b, sb, t.root_matrix)

@@ -1,0 +1,301 @@
+"""HIP engine vs CPU oracle through the C ABI, on the same seeded inputs.
+
+Tolerances: scalers, tip codes and invariant-site indices are integers and must
+be bit-exact.  Floating point follows BASELINE.json's north star
+(|dlnL| < 1e-6 per site); the tests hold the engine to far tighter bounds:
+CLV / sumtable entries rel 1e-12, lnL rel 1e-12 of |lnL|, derivatives rel 1e-9.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import common
+import pllhip_ctypes as pc
+
+pytestmark = pytest.mark.gpu
+NONE = pc.PLL_SCALE_BUFFER_NONE
+REL_CLV = 1e-12
+REL_LNL = 1e-12
+
+
+def _pair(product, oracle, **kw):
+    a = pc.build_instance(product, **kw)
+    b = pc.build_instance(oracle, **kw, tree=a.tree)
+    return a, b
+
+
+def _compare_full(a, b, check_clvs=True):
+    la = pc.full_traversal(a)
+    lb = pc.full_traversal(b)
+    assert np.isfinite(lb) and lb < 0
+    assert abs(la - lb) <= REL_LNL * abs(lb), (la, lb)
+    if check_clvs:
+        t = a.tree
+        for op in t.ops:
+            ca, cb = a.get_clv(op[0]), b.get_clv(op[0])
+            assert common.rel_err(ca, cb) < REL_CLV, f"CLV {op[0]}"
+            if a.nscalers:
+                assert np.array_equal(a.get_scaler(op[1]), b.get_scaler(op[1])), f"scaler {op[1]}"
+    return la, lb
+
+
+def test_device_is_gfx950(product):
+    buf = C.create_string_buffer(64)
+    assert product.lib.pllhip_device_arch(0, buf, 64)
+    assert buf.value.decode().startswith("gfx950")
+
+
+@pytest.mark.parametrize("name,coded", [("blopt-minimal", False), ("blopt-5states", False),
+                                        ("blopt-5states", True)])
+def test_golden_fixtures_on_gpu(product, name, coded):
+    """P-matrices, lnL and the Newton-Raphson post-optimisation numbers of the
+    reference's golden files, computed by the HIP kernels"""
+    expected, got = common.run_golden_case(product, name, coded=coded)
+    common.check_golden(expected, got)
+
+
+@pytest.mark.parametrize("states,rate_cats", [(4, 4), (4, 1), (4, 2), (20, 4), (20, 1), (5, 4),
+                                              (2, 3), (7, 4), (61, 2)])
+@pytest.mark.parametrize("coded", [True, False])
+def test_full_traversal_parity(product, oracle, states, rate_cats, coded):
+    ntips, nsites = (9, 257) if states > 20 else (14, 1031)
+    a, b = _pair(product, oracle, states=states, rate_cats=rate_cats, ntips=ntips, nsites=nsites,
+                 coded=coded)
+    with a, b:
+        _compare_full(a, b)
+
+
+@pytest.mark.parametrize("states", [4, 20, 5])
+@pytest.mark.parametrize("nsites", [1, 2, 63, 64, 65, 255, 256, 1000, 4097])
+def test_ragged_site_counts(product, oracle, states, nsites):
+    a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=6, nsites=nsites, coded=True)
+    with a, b:
+        _compare_full(a, b)
+
+
+def test_empty_partition(product):
+    with pc.Instance(product, 3, 4, 0, 4, scalers=True) as a:
+        a.set_model(pc.DNA_GTR_RATES, pc.DNA_FREQS, product.gamma_cats(1.0, 4))
+        a.update_pmatrices([0, 1, 2], [0.1, 0.2, 0.3])
+        a.update_partials([(3, 0, 0, 0, NONE, 1, 1, NONE)])
+        assert a.edge_lnl(3, 0, 2, NONE, 2) == 0.0
+
+
+@pytest.mark.parametrize("states,ntips", [(4, 600), (20, 260)])
+def test_deep_tree_scaling_is_bit_exact(product, oracle, states, ntips):
+    """random sequences on a deep tree drive CLVs below 2^-256: scaler counts must
+    agree exactly and lnL must survive"""
+    a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=ntips, nsites=97, coded=True)
+    with a, b:
+        la, lb = _compare_full(a, b)
+        root_sc = a.get_scaler(a.tree.scaler_of(a.tree.root_a))
+        assert root_sc.max() >= 1, "test did not reach the scaling regime"
+
+
+def test_scaling_on_equals_scaling_off(product):
+    kw = dict(states=4, rate_cats=4, ntips=30, nsites=301, coded=True)
+    a = pc.build_instance(product, scalers=True, **kw)
+    b = pc.build_instance(product, scalers=False, **kw)
+    with a, b:
+        la, lb = pc.full_traversal(a), pc.full_traversal(b)
+        assert abs(la - lb) < 1e-9 * abs(la)
+
+
+@pytest.mark.parametrize("states", [4, 20, 5])
+def test_rerooting_invariance(product, states):
+    with pc.build_instance(product, states=states, rate_cats=4, ntips=11, nsites=513, coded=True) as a:
+        ref = pc.full_traversal(a)
+        for k in (0, 3, 7, a.tree.nedges - 1):
+            a.tree.set_root_edge(k)
+            assert abs(pc.full_traversal(a) - ref) < 1e-10 * abs(ref)
+
+
+@pytest.mark.parametrize("states", [4, 20, 5])
+def test_persite_and_pattern_weights(product, oracle, states):
+    a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=8, nsites=333, coded=True)
+    with a, b:
+        w = (pc.splitmix64(5, 333) % np.uint64(7)).astype(np.uint32)
+        a.set_pattern_weights(w)
+        b.set_pattern_weights(w)
+        pc.full_traversal(a); pc.full_traversal(b)
+        t = a.tree
+        la, pa = a.edge_lnl(t.root_a, t.scaler_of(t.root_a), t.root_b, t.scaler_of(t.root_b),
+                            t.root_matrix, persite=True)
+        lb, pb = b.edge_lnl(t.root_a, t.scaler_of(t.root_a), t.root_b, t.scaler_of(t.root_b),
+                            t.root_matrix, persite=True)
+        assert np.allclose(pa, pb, rtol=1e-12, atol=0)
+        assert abs(la - float(np.dot(pa, w))) < 1e-9 * abs(la)
+        assert abs(la - lb) < REL_LNL * abs(lb)
+
+
+@pytest.mark.parametrize("states", [4, 20, 5])
+def test_root_loglikelihood(product, oracle, states):
+    a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=8, nsites=129, coded=False)
+    with a, b:
+        pc.full_traversal(a); pc.full_traversal(b)
+        t = a.tree
+        ra = a.root_lnl(t.root_a, t.scaler_of(t.root_a))
+        rb = b.root_lnl(t.root_a, t.scaler_of(t.root_a))
+        assert abs(ra - rb) < REL_LNL * abs(rb)
+
+
+@pytest.mark.parametrize("states,coded", [(4, True), (4, False), (20, True), (5, True), (20, False)])
+def test_sumtable_and_derivatives(product, oracle, states, coded):
+    a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=10, nsites=515, coded=coded)
+    with a, b:
+        pc.full_traversal(a); pc.full_traversal(b)
+        t = a.tree
+        # the oracle's eigenvectors are injected into the product so that the two
+        # sumtables are comparable entry by entry (eigenvectors are unique only up
+        # to sign/order); the product's own solver is covered by the lnL tests
+        pa, pb = a.p.contents, b.p.contents
+        n = a.S * a.Sp
+        for dst, src, ln in ((pa.eigenvecs[0], pb.eigenvecs[0], n), (pa.inv_eigenvecs[0], pb.inv_eigenvecs[0], n),
+                             (pa.eigenvals[0], pb.eigenvals[0], a.Sp)):
+            if a.Sp == b.Sp:
+                C.memmove(dst, src, 8 * ln)
+            else:
+                s = np.ctypeslib.as_array(src, shape=(ln // a.Sp * b.Sp,)).reshape(-1, b.Sp)
+                d = np.ctypeslib.as_array(dst, shape=(ln,)).reshape(-1, a.Sp)
+                d[:, :b.Sp] = s
+        sa_, sb_ = a.alloc_sumtable(), b.alloc_sumtable()
+        for (pc_, cc_) in ((t.root_a, t.root_b), (t.root_b, t.root_a)):
+            if coded and pc_ < t.ntips and cc_ < t.ntips:
+                continue
+            args = (pc_, cc_, t.scaler_of(pc_), t.scaler_of(cc_))
+            a.update_sumtable(*args, sa_)
+            b.update_sumtable(*args, sb_)
+            if a.Sp == b.Sp:
+                assert common.rel_err(a.get_sumtable(sa_), b.get_sumtable(sb_)) < 1e-10
+            for bl in (1e-4, 0.013, 0.1, 0.77, 5.0, 90.0):
+                da = a.derivatives(args[2], args[3], bl, sa_)
+                db = b.derivatives(args[2], args[3], bl, sb_)
+                assert np.allclose(da, db, rtol=1e-9, atol=1e-9 * a.N), (bl, da, db)
+        a.free_sumtable(sa_); b.free_sumtable(sb_)
+
+
+@pytest.mark.parametrize("states", [4, 20])
+def test_derivatives_match_finite_differences(product, states):
+    with pc.build_instance(product, states=states, rate_cats=4, ntips=7, nsites=200, coded=True) as a:
+        pc.full_traversal(a)
+        t = a.tree
+        st = a.alloc_sumtable()
+        sa, sb = t.scaler_of(t.root_a), t.scaler_of(t.root_b)
+        a.update_sumtable(t.root_a, t.root_b, sa, sb, st)
+        x, h = 0.2, 1e-5
+
+        def neg_lnl(bl):
+            a.update_pmatrices([t.root_matrix], [bl])
+            return -a.edge_lnl(t.root_a, sa, t.root_b, sb, t.root_matrix)
+        df, ddf = a.derivatives(sa, sb, x, st)
+        f0, fp, fm = neg_lnl(x), neg_lnl(x + h), neg_lnl(x - h)
+        assert abs(df - (fp - fm) / (2 * h)) < 1e-5 * max(1.0, abs(df))
+        assert abs(ddf - (fp - 2 * f0 + fm) / (h * h)) < 2e-3 * max(1.0, abs(ddf))
+        a.free_sumtable(st)
+
+
+@pytest.mark.parametrize("states", [4, 20, 5])
+def test_invariant_sites(product, oracle, states):
+    a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=5, nsites=4000, coded=True)
+    with a, b:
+        assert product.lib.pll_update_invariant_sites(a.p) and oracle.lib.pll_update_invariant_sites(b.p)
+        ia = np.ctypeslib.as_array(a.p.contents.invariant, shape=(a.N,))
+        ib = np.ctypeslib.as_array(b.p.contents.invariant, shape=(b.N,))
+        assert np.array_equal(ia, ib)
+        if states <= 5:
+            assert (ib >= 0).any(), "no invariant column in the sample"
+        a.set_pinv(0.25); b.set_pinv(0.25)
+        la, lb = pc.full_traversal(a), pc.full_traversal(b)
+        assert abs(la - lb) < REL_LNL * abs(lb)
+        t = a.tree
+        sa_, sb_ = a.alloc_sumtable(), b.alloc_sumtable()
+        args = (t.root_a, t.root_b, t.scaler_of(t.root_a), t.scaler_of(t.root_b))
+        a.update_sumtable(*args, sa_); b.update_sumtable(*args, sb_)
+        da = a.derivatives(args[2], args[3], 0.1, sa_)
+        db = b.derivatives(args[2], args[3], 0.1, sb_)
+        assert np.allclose(da, db, rtol=1e-8)
+        a.free_sumtable(sa_); b.free_sumtable(sb_)
+
+
+def test_host_model_arrays_are_source_of_truth(product, oracle):
+    """pll-modules writes partition->rates / frequencies / subst_params directly and
+    flips eigen_decomp_valid (src/algorithm/algo_callback.c:44-68): the engine must
+    notice on the next kernel-entry call"""
+    a, b = _pair(product, oracle, states=4, rate_cats=4, ntips=8, nsites=300, coded=True)
+    with a, b:
+        l0 = pc.full_traversal(a)
+        for inst in (a, b):
+            p = inst.p.contents
+            for r in range(4):
+                p.rates[r] = [0.2, 0.6, 1.1, 2.1][r]
+            p.frequencies[0][0], p.frequencies[0][3] = 0.3, 0.26
+            p.subst_params[0][1] = 2.5
+            p.eigen_decomp_valid[0] = 0
+        la, lb = pc.full_traversal(a), pc.full_traversal(b)
+        assert abs(la - l0) > 1e-3
+        assert abs(la - lb) < REL_LNL * abs(lb)
+        assert a.counters().model_uploads >= 2
+
+
+def test_one_by_one_pmatrix_calls_and_single_op_calls(product):
+    """the reference's call granularity: one branch per pll_update_prob_matrices call
+    (src/tree/treeinfo.c:845-865) and one op per pll_update_partials call
+    (src/optimize/pll_optimize.c:773) must give the same numbers as batched calls"""
+    with pc.build_instance(product, states=20, rate_cats=4, ntips=12, nsites=300, coded=True) as a:
+        ref = pc.full_traversal(a)
+        t = a.tree
+        a.update_pmatrices(np.arange(t.nedges), t.brlens, one_by_one=True)
+        for op in t.ops:
+            a.update_partials([op])
+        got = a.edge_lnl(t.root_a, t.scaler_of(t.root_a), t.root_b, t.scaler_of(t.root_b), t.root_matrix)
+        assert got == ref
+        c = a.counters()
+        assert c.partial_ops == 2 * len(t.ops)
+
+
+def test_run_to_run_determinism(product):
+    """SPR rounds assert reproducibility (src/algorithm/algo_search.c:1453-1457)"""
+    with pc.build_instance(product, states=20, rate_cats=4, ntips=20, nsites=5000, coded=True) as a:
+        vals = {pc.full_traversal(a) for _ in range(4)}
+        assert len(vals) == 1
+
+
+def test_specialised_kernels_are_the_ones_running(product):
+    for states, name in ((4, b"s4-valu"), (20, b"s20-mfma"), (5, b"generic")):
+        with pc.Instance(product, 3, states, 8, 4) as a:
+            assert product.lib.pllhip_partials_kernel_name(a.p) == name
+
+
+def test_error_reporting(product):
+    with pc.Instance(product, 3, 4, 8, 4, scalers=False, clv_buffers=1, prob_matrices=3) as a:
+        a.set_model(pc.DNA_GTR_RATES, pc.DNA_FREQS, product.gamma_cats(1.0, 4))
+        mi = np.array([7], dtype=np.uint32); bl = np.array([0.1])
+        assert not product.lib.pll_update_prob_matrices(a.p, a.params_p, mi.ctypes.data_as(pc.c_uint_p),
+                                                        bl.ctypes.data_as(pc.c_double_p), 1)
+        assert product.errno == 113
+        with pytest.raises(RuntimeError):
+            a.update_partials([(9, NONE, 0, 0, NONE, 1, 1, NONE)])
+        st = a.alloc_sumtable()
+        with pytest.raises(RuntimeError):
+            a.derivatives(NONE, NONE, 0.1, st)      # no sumtable computed for this key
+        a.free_sumtable(st)
+
+
+def test_tiled_alignment_scales_linearly(product):
+    """size-independent property at a large site count: an alignment tiled K times
+    has exactly K times the lnL of one tile (same per-site arithmetic, and the
+    final sum is exact to rounding)"""
+    base = pc.build_instance(product, states=4, rate_cats=4, ntips=16, nsites=1000, coded=True)
+    K = 300
+    with base:
+        l1 = pc.full_traversal(base)
+        big = pc.Instance(product, 16, 4, 1000 * K, 4, attributes=pc.PLL_ATTRIB_PATTERN_TIP)
+        with big:
+            big.set_model(pc.DNA_GTR_RATES, pc.DNA_FREQS, product.gamma_cats(0.841, 4))
+            cmap = pc.state_charmap(4)
+            for t in range(16):
+                big.set_tip_states(t, cmap, (np.tile(base.codes[t], K) + 48).tobytes())
+            big.tree = base.tree
+            lk = pc.full_traversal(big)
+            assert abs(lk - K * l1) < 1e-10 * abs(lk)
