@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- CLV site-updates/sec of the likelihood hot path on MI355X.
+
+One "step" = one full likelihood evaluation of the synthetic partition
+(workload W1 of SURVEY.md section 8d, the call pattern of
+treeinfo_compute_loglh, src/tree/treeinfo.c:946-1079): all 2n-3 P-matrices,
+the n-2 partial-likelihood operations of a full post-order traversal, one edge
+log-likelihood and -- with more than one rank -- the all-reduce of the summed
+lnL through the reference's reduce-callback interface (RCCL over xGMI).
+
+Default workload: BASELINE.json's target configuration C3 (20 states, Gamma4,
+200 taxa, 1M sites; the "LG-shaped" seeded model because the real LG table is
+unavailable offline).  `--config c2` selects the DNA configuration.
+
+Multi-GPU: one process per GPU (torch.distributed.run); sites shard across the
+ranks.  `--scaling weak` (default) keeps the per-GPU slice at the configured
+site count; `--scaling strong` splits the configured site count over the ranks.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pll-modules_amd"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c5"])
+    ap.add_argument("--sites", type=int, default=0, help="override the per-configuration site count")
+    ap.add_argument("--taxa", type=int, default=0)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sites", type=int, default=0, help="sites of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(pc, states, rate_cats, ntips, nsites_gpu, cpu_sites):
+    """the oracle (a from-scratch CPU port, NOT libpll) timed on the host cores
+    on a bounded sample of the same workload: same tree, model and tip
+    generator, fewer sites, scaled to ~10-30 s of CPU work"""
+    threads = min(os.cpu_count() or 1, 16)      # the 1-GPU box share of host cores
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    oracle_path = os.path.join(ROOT, "oracle", "_build", "libpll_oracle.so")
+    oracle = pc.PllLib(oracle_path)
+    # per-site-update cost on one core is ~ (4 S^2 + S) flops at ~1-2 GFLOP/s scalar
+    if not cpu_sites:
+        per_update = (4.0 * states * states + states) / 1.5e9
+        budget = 15.0 * threads
+        cpu_sites = int(budget / (per_update * rate_cats * (ntips - 2)))
+        cpu_sites = max(1000, min(nsites_gpu, cpu_sites // 1000 * 1000))
+    inst = pc.build_instance(oracle, states=states, rate_cats=rate_cats, ntips=ntips,
+                             nsites=cpu_sites, coded=True)
+    with inst:
+        pc.full_traversal(inst)                       # warm-up
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            lnl = pc.full_traversal(inst)
+            reps += 1
+            if time.perf_counter() - t0 > 10.0 or reps >= 5:
+                break
+        dt = time.perf_counter() - t0
+    updates = reps * (ntips - 2) * cpu_sites * rate_cats
+    return {"value": updates / dt, "unit": "CLV site-updates/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} full traversals of the same tree/model with {cpu_sites} sites "
+                      f"(oracle/, plain C + OpenMP over sites, {threads} threads); lnL/site "
+                      f"{lnl / cpu_sites:.6f}"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import pllhip_ctypes as pc
+    product = pc.PllLib(pc.PRODUCT_LIB)
+    if product.lib.pllhip_device_count() < 1:
+        raise SystemExit("bench.py: no HIP device visible; the engine has no CPU fallback")
+
+    dist = None
+    comm = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not product.lib.pllhip_set_device(local_rank):
+        raise SystemExit(product.errmsg)
+
+    states, rate_cats, ntips, nsites = pc.CONFIGS[args.config]
+    if args.sites:
+        nsites = args.sites
+    if args.taxa:
+        ntips = args.taxa
+    if args.scaling == "strong" and world > 1:
+        lo = nsites * rank // world
+        hi = nsites * (rank + 1) // world
+        local_sites = hi - lo
+        total_sites = nsites
+    else:
+        local_sites = nsites
+        total_sites = nsites * world
+
+    if world > 1:
+        # the native reduce callback (RCCL in C) gets its unique id through torch's store
+        idbuf = C.create_string_buffer(128)
+        if rank == 0 and not product.lib.pllhip_comm_get_unique_id(idbuf):
+            raise SystemExit(product.errmsg)
+        obj = [idbuf.raw]
+        dist.broadcast_object_list(obj, src=0)
+        comm = product.lib.pllhip_comm_create(obj[0], rank, world, local_rank)
+        if not comm:
+            raise SystemExit(product.errmsg)
+
+    # each rank owns a different slice of the alignment (different tip seed)
+    inst = pc.build_instance(product, states=states, rate_cats=rate_cats, ntips=ntips,
+                             nsites=local_sites, coded=True, seed_shift=0)
+    if world > 1 and rank > 0:
+        cmap = pc.state_charmap(states)
+        codes = pc.random_codes(ntips, local_sites, states, 44 + 7919 * rank)
+        for t in range(ntips):
+            inst.set_tip_states(t, cmap, (codes[t] + 48).tobytes())
+    tree = inst.tree
+    nops = len(tree.ops)
+    lnl_buf = np.zeros(1)
+
+    def step():
+        lnl_buf[0] = pc.full_traversal(inst)
+        if comm:
+            product.lib.pllhip_reduce_cb(comm, lnl_buf.ctypes.data_as(pc.c_double_p), 1, 0)
+        return lnl_buf[0]
+
+    def barrier():
+        product.lib.pllhip_synchronize(inst.p)
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    product.lib.pllhip_profile_partials(inst.p, 1)
+    barrier()
+    t0 = time.perf_counter()
+    lnl = 0.0
+    for _ in range(args.steps):
+        lnl = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = pc.Profile()
+    product.lib.pllhip_profile_read(inst.p, C.byref(prof))
+    product.lib.pllhip_profile_partials(inst.p, 0)
+
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    kernel = product.lib.pllhip_partials_kernel_name(inst.p).decode()
+    updates_per_step = nops * total_sites * rate_cats
+    value = updates_per_step * args.steps / elapsed
+
+    # roofline of the dominant kernel (pll_update_partials), from the HIP events
+    # recorded around its launches during the timed region on rank 0
+    achieved = prof.algorithmic_bytes / (prof.kernel_ms * 1e-3) / 1e9 if prof.kernel_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(f"{args.config}:{kernel}")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "launches": int(prof.launches), "ops": int(prof.ops),
+        "avg_launch_ms": round(prof.kernel_ms / max(1, prof.launches), 4),
+        "algorithmic_bytes_per_launch": round(prof.algorithmic_bytes / max(1, prof.launches)),
+        "kernel_share_of_step": round(prof.kernel_ms * 1e-3 / elapsed, 4),
+    }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(pc, states, rate_cats, ntips, local_sites, args.cpu_sites)
+
+    inst.close()
+    if comm:
+        product.lib.pllhip_comm_destroy(comm)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+    if rank == 0:
+        names = {"c2": "C2 DNA GTR+G4", "c3": "C3 protein 'LG-shaped' GTR20+G4 (real LG table unavailable offline)",
+                 "c5": "C5 codon GY94-shaped+G4"}
+        out = {
+            "metric": "CLV site-updates/sec (sites x rates x edges)",
+            "value": value, "unit": "CLV site-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"{names[args.config]}: {states} states, {rate_cats} rate cats, {ntips} taxa, "
+                            f"{total_sites} sites total ({local_sites} per GPU), full traversal "
+                            f"({nops} ops + {tree.nedges} P-matrices + edge lnL) per step",
+                "config": args.config, "states": states, "rate_cats": rate_cats, "taxa": ntips,
+                "sites_total": total_sites, "sites_per_gpu": local_sites, "ops_per_step": nops,
+                "tips": "1-byte codes", "scalers": "per-site, one per inner node",
+            },
+            "lnl": lnl, "lnl_per_site": lnl / total_sites,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

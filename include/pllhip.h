@@ -101,6 +101,22 @@ PLL_EXPORT int pllhip_get_counters(const pll_partition_t * partition,
                                    pllhip_counters_t * out);
 PLL_EXPORT void pllhip_reset_counters(pll_partition_t * partition);
 
+/* live timing of the pll_update_partials kernel launches with HIP events on the
+   partition's stream.  While enabled, every launch is bracketed by two events;
+   pllhip_profile_read() synchronises, sums the elapsed times, reports them with
+   the algorithmic byte count of those launches and
+   resets the accumulators. */
+typedef struct pllhip_profile
+{
+  unsigned long long launches;
+  unsigned long long ops;
+  double kernel_ms;
+  double algorithmic_bytes;
+} pllhip_profile_t;
+
+PLL_EXPORT int pllhip_profile_partials(pll_partition_t * partition, int enable);
+PLL_EXPORT int pllhip_profile_read(pll_partition_t * partition, pllhip_profile_t * out);
+
 /* kernel family actually used for pll_update_partials on this partition:
    "s4-valu", "s20-mfma", "generic" ... (for tests that must prove the
    specialised path ran) */

@@ -64,6 +64,13 @@ struct Engine
   bool coded_tips = false;
   KernelFamily family = KernelFamily::Generic;
   unsigned cu_count = 256;
+  // S20 family: CLVs/sumtables live in 32-site blocks [block][rate][state][32]
+  // (kernels_s20.hpp); per-site arrays are padded to whole blocks
+  bool blocked = false;
+  unsigned nblk = 0;                  // site blocks (blocked layout only)
+  size_t clv_len = 0;                 // doubles per CLV / sumtable buffer
+  unsigned Nalloc = 0;                // per-site array length (N, or nblk*32)
+  double * d_sum_scratch = nullptr;   // eigen-basis matrices + LUTs of the sumtable kernel
 
   // --- device-resident data ---
   std::vector<double *> d_clv;        // [nodes], nullptr for coded tips
@@ -104,6 +111,13 @@ struct Engine
   bool pmat_host_dirty = false;
 
   pllhip_counters_t counters = {};
+
+  // optional timing of the partials launches with HIP events on `stream`
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;  // pool, reused
+  size_t prof_used = 0;
+  double prof_bytes = 0.0;        // algorithmic bytes of the recorded launches
+  unsigned long long prof_ops = 0;
 };
 
 inline Engine * engine_of(const pll_partition_t * p) { return static_cast<Engine *>(p->engine); }

@@ -358,7 +358,8 @@ __global__ __launch_bounds__(256) void k_invariant(const double * const * tip_cl
                                                    const uint8_t * const * tip_codes,
                                                    const unsigned long long * tipmap,
                                                    unsigned tips, unsigned N, unsigned R,
-                                                   unsigned S, unsigned Sp, int * invariant)
+                                                   unsigned S, unsigned Sp, bool blocked32,
+                                                   int * invariant)
 {
   for (unsigned long long n = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; n < N;
        n += (unsigned long long)gridDim.x * blockDim.x)
@@ -371,9 +372,13 @@ __global__ __launch_bounds__(256) void k_invariant(const double * const * tip_cl
         m = tipmap[tip_codes[t][n]];
       else
       {
-        const double * c = tip_clv[t] + n * R * Sp;
         for (unsigned j = 0; j < S; ++j)
-          if (c[j] > 0.0) m |= (1ULL << j);
+        {
+          // rate 0 of site n: API layout, or the 32-site blocked layout of kernels_s20.hpp
+          const double v = blocked32 ? tip_clv[t][(((n >> 5) * R) * S + j) * 32 + (n & 31)]
+                                     : tip_clv[t][n * R * Sp + j];
+          if (v > 0.0) m |= (1ULL << j);
+        }
       }
       common &= m;
     }

@@ -1,4 +1,34 @@
-// kernels_s20.hpp -- 20-state (protein) kernel family.
+// kernels_s20.hpp -- 20-state (protein) kernel family on the fp64 matrix cores.
+//
+// The P * CLV product of a 20-state partition is a dense [20x20] x [20 x sites]
+// contraction per rate category: the one place on this path where MFMA is a
+// genuine fit (v_mfma_f64_16x16x4_f64; 16 FMAs per lane for one A and one B
+// double per lane, so operand delivery -- not flops -- stops being the limit).
+//
+// Device layout ("blocked", private to this family; the API layout
+// [site][rate][state] only exists in host mirrors):
+//     clv[site_block b][rate r][state j][site-in-block s],  32 sites per block
+//   i.e. one (block, rate) *unit* is a 20 x 32 fp64 matrix (5 KiB), state-major.
+//   With lane l = 16*q + n (q = l>>4, n = l&15) holding the two sites 2n, 2n+1:
+//     * MFMA B operand, k-step ks:  rows j = 4*ks + q  -> address (j*32 + 2n)*8
+//       = ks*1024 + l*16 bytes: ONE fully coalesced global_load_dwordx4 (1 KiB
+//       per wave instruction) feeds two MFMAs (even / odd sites);
+//     * MFMA D result, register v: rows i = q + 4*v    -> same address form:
+//       ONE fully coalesced 1 KiB store per register.
+//   What one operation stores is bit-for-bit what the next one loads: no LDS
+//   staging, no transposes, no bank conflicts for CLV data at all.  LDS holds
+//   only the P-matrices, pre-arranged as per-lane A fragments.
+//
+// Work decomposition: one wavefront owns a site block and walks its R rates
+// (a wave = one site-block x rate unit at a time); waves never synchronise.
+// The per-site scaling vote spans all R*20 entries of a site, which the wave
+// sees after its last rate; the (rare) rescale is a fix-up pass over the 20 KiB
+// it has just written (L2-hot).  Per-state reductions (edge lnL, derivatives)
+// are xor-16/xor-32 shuffles over the four q-groups of a wave.
+//
+// Roofline: inner x inner site-update = 480 B + 12/R B and
+// 1620 flops -> AI 3.4 flop/B: HBM-bound.  At 6.3 TB/s the MFMA pipe is ~42 %
+// busy (40 MFMA per unit incl. the padded rows 20..31 of the second M-tile).
 #pragma once
 
 #include "kernels_common.hpp"
@@ -7,9 +37,466 @@
 
 namespace pllhip {
 
+constexpr unsigned S20_BS = 32;              // sites per block
+constexpr unsigned S20_UNIT = 20 * S20_BS;   // doubles per (block, rate) unit
+constexpr unsigned S20_FRAGS = 10 * 64;      // A-fragment doubles per (child, rate)
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__device__ inline v4d mfma_f64(double a, double b, v4d c)
+{
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// row (state) held by D slot k of lane group q: k = 0..3 -> first M-tile
+// registers, k = 4 -> register 0 of the second M-tile (states 16..19)
+__device__ inline unsigned s20_row(unsigned k, unsigned q) { return (k < 4) ? q + 4 * k : 16 + q; }
+
+// A fragments of one 20x20 row-major matrix set [R][20][20] into LDS:
+//   frag[((r*2 + mt)*5 + ks)*64 + lane] = M[r][ (lane&15)+16*mt ][ 4*ks + (lane>>4) ]  (0 beyond row 19)
+__device__ inline void s20_fill_frags(double * frag, const double * mats, unsigned R)
+{
+  for (unsigned e = threadIdx.x; e < R * S20_FRAGS; e += blockDim.x)
+  {
+    const unsigned lane = e & 63, f = e >> 6, ks = f % 5, mt = (f / 5) & 1, r = f / 10;
+    const unsigned i = (lane & 15) + 16 * mt, j = 4 * ks + (lane >> 4);
+    frag[e] = (i < 20) ? mats[((size_t)r * 20 + i) * 20 + j] : 0.0;
+  }
+}
+
+// child term in D layout: t[k] = {even site, odd site} for row s20_row(k, q)
+__device__ inline void s20_child_inner(const double * unit, const double * frag_r, unsigned lane,
+                                       double2 t[5])
+{
+  const unsigned off = lane * 2;            // doubles: (q*32 + 2n)
+  double2 b[5];
+#pragma unroll
+  for (int ks = 0; ks < 5; ++ks)
+    b[ks] = *reinterpret_cast<const double2 *>(unit + ks * 128 + off);
+  v4d a0e = {0, 0, 0, 0}, a0o = {0, 0, 0, 0}, a1e = {0, 0, 0, 0}, a1o = {0, 0, 0, 0};
+#pragma unroll
+  for (int ks = 0; ks < 5; ++ks)
+  {
+    const double f0 = frag_r[ks * 64 + lane];
+    const double f1 = frag_r[(5 + ks) * 64 + lane];
+    a0e = mfma_f64(f0, b[ks].x, a0e);
+    a0o = mfma_f64(f0, b[ks].y, a0o);
+    a1e = mfma_f64(f1, b[ks].x, a1e);
+    a1o = mfma_f64(f1, b[ks].y, a1o);
+  }
+  t[0] = make_double2(a0e[0], a0o[0]);
+  t[1] = make_double2(a0e[1], a0o[1]);
+  t[2] = make_double2(a0e[2], a0o[2]);
+  t[3] = make_double2(a0e[3], a0o[3]);
+  t[4] = make_double2(a1e[0], a1o[0]);
+}
+
+__device__ inline void s20_child_tip(const double * lut_r, unsigned code_e, unsigned code_o,
+                                     unsigned q, double2 t[5])
+{
+  const double * le = lut_r + code_e * 20, * lo = lut_r + code_o * 20;
+#pragma unroll
+  for (unsigned k = 0; k < 5; ++k)
+  {
+    const unsigned i = s20_row(k, q);
+    t[k] = make_double2(le[i], lo[i]);
+  }
+}
+
+// load a unit in D layout (rows s20_row(k,q)) -- same addresses the stores use
+__device__ inline void s20_load_d(const double * unit, unsigned lane, double2 t[5])
+{
+  const unsigned off = lane * 2;
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+    t[k] = *reinterpret_cast<const double2 *>(unit + k * 128 + off);
+}
+
+__device__ inline void s20_store_d(double * unit, unsigned lane, const double2 t[5])
+{
+  const unsigned off = lane * 2;
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+    *reinterpret_cast<double2 *>(unit + k * 128 + off) = t[k];
+}
+
+__device__ inline void s20_tip_d(unsigned long long mask_e, unsigned long long mask_o, unsigned q,
+                                 double2 t[5])
+{
+#pragma unroll
+  for (unsigned k = 0; k < 5; ++k)
+  {
+    const unsigned i = s20_row(k, q);
+    t[k] = make_double2((double)((mask_e >> i) & 1ULL), (double)((mask_o >> i) & 1ULL));
+  }
+}
+
+// AND over the four q-groups (lanes l, l^16, l^32, l^48)
+__device__ inline int s20_and_q(int v)
+{
+  v &= __shfl_xor(v, 16, 64);
+  v &= __shfl_xor(v, 32, 64);
+  return v;
+}
+
+__device__ inline double s20_sum_q(double v)
+{
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// partials (also used for the sumtable, with eigen-basis matrices in place of
+// the P-matrices).   grid = (gx, ops), block = 256 (4 independent waves)
+// dynamic LDS = 2 * R * S20_FRAGS doubles
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_partials_s20(OpBatch batch, unsigned nblk, unsigned R,
+                                                         unsigned lut_codes)
+{
+  extern __shared__ double frag[];
+  const OpDesc & op = batch.op[blockIdx.y];
+  if (!op.codes1) s20_fill_frags(frag, op.pmat1, R);
+  if (!op.codes2) s20_fill_frags(frag + R * S20_FRAGS, op.pmat2, R);
+  __syncthreads();
+
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, n = lane & 15;
+  const unsigned wstride = gridDim.x * 4;
+  const bool scaling = op.parent_scaler != nullptr;
+
+  for (unsigned blk = blockIdx.x * 4 + wave; blk < nblk; blk += wstride)
+  {
+    const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+    unsigned c1e = 0, c1o = 0, c2e = 0, c2o = 0;
+    if (op.codes1) { c1e = op.codes1[site0]; c1o = op.codes1[site0 + 1]; }
+    if (op.codes2) { c2e = op.codes2[site0]; c2o = op.codes2[site0 + 1]; }
+    int small_e = 1, small_o = 1;
+
+    for (unsigned r = 0; r < R; ++r)
+    {
+      const size_t ubase = ((size_t)blk * R + r) * S20_UNIT;
+      double2 t1[5], t2[5];
+      if (op.codes1) s20_child_tip(op.lut1 + (size_t)r * lut_codes * 20, c1e, c1o, q, t1);
+      else s20_child_inner(op.clv1 + ubase, frag + r * S20_FRAGS, lane, t1);
+      if (op.codes2) s20_child_tip(op.lut2 + (size_t)r * lut_codes * 20, c2e, c2o, q, t2);
+      else s20_child_inner(op.clv2 + ubase, frag + (R + r) * S20_FRAGS, lane, t2);
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+      {
+        t1[k].x *= t2[k].x;
+        t1[k].y *= t2[k].y;
+        small_e &= (t1[k].x < SCALE_THRESHOLD);
+        small_o &= (t1[k].y < SCALE_THRESHOLD);
+      }
+      s20_store_d(op.parent + ubase, lane, t1);
+    }
+
+    if (scaling)
+    {
+      small_e = s20_and_q(small_e);
+      small_o = s20_and_q(small_o);
+      if (__any(small_e | small_o))
+      {
+        // rare: bring the just-written units of the flagged sites up by 2^256
+        const double fe = small_e ? SCALE_FACTOR : 1.0, fo = small_o ? SCALE_FACTOR : 1.0;
+        for (unsigned r = 0; r < R; ++r)
+        {
+          double * unit = op.parent + ((size_t)blk * R + r) * S20_UNIT;
+          double2 t[5];
+          s20_load_d(unit, lane, t);
+#pragma unroll
+          for (int k = 0; k < 5; ++k) { t[k].x *= fe; t[k].y *= fo; }
+          s20_store_d(unit, lane, t);
+        }
+      }
+      if (q == 0)
+      {
+        unsigned ce = small_e ? 1u : 0u, co = small_o ? 1u : 0u;
+        if (op.scaler1) { ce += op.scaler1[site0]; co += op.scaler1[site0 + 1]; }
+        if (op.scaler2) { ce += op.scaler2[site0]; co += op.scaler2[site0 + 1]; }
+        op.parent_scaler[site0] = ce;
+        op.parent_scaler[site0 + 1] = co;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// edge / root log-likelihood.  grid = nblocks (<= REDUCE_BLOCKS), block = 256
+// dynamic LDS = R * S20_FRAGS doubles (unused for the root form)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_edge_lnl_s20(ModelView mv, ParamIdx fidx,
+                                                         NodeRef parent, NodeRef child,
+                                                         const double * pmat, const double * lut,
+                                                         unsigned lut_codes,
+                                                         const unsigned * ps, const unsigned * cs,
+                                                         const unsigned * weights, const int * invariant,
+                                                         const unsigned long long * tipmap,
+                                                         unsigned N, unsigned nblk, unsigned R,
+                                                         double * persite, double * block_out)
+{
+  extern __shared__ double frag[];
+  __shared__ double scratch[4];
+  if (pmat && !child.codes) s20_fill_frags(frag, pmat, R);
+  __syncthreads();
+
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, n = lane & 15;
+  const unsigned wstride = gridDim.x * 4;
+  double acc = 0.0;
+
+  for (unsigned blk = blockIdx.x * 4 + wave; blk < nblk; blk += wstride)
+  {
+    const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+    unsigned cce = 0, cco = 0;
+    unsigned long long pme = 0, pmo = 0;
+    if (child.codes) { cce = child.codes[site0]; cco = child.codes[site0 + 1]; }
+    if (parent.codes) { pme = tipmap[parent.codes[site0]]; pmo = tipmap[parent.codes[site0 + 1]]; }
+    double site_e = 0.0, site_o = 0.0, inv_e = 0.0, inv_o = 0.0;
+    int inv_state_e = -1, inv_state_o = -1;
+    if (invariant)
+    {
+      inv_state_e = (site0 < N) ? invariant[site0] : -1;
+      inv_state_o = (site0 + 1 < N) ? invariant[site0 + 1] : -1;
+    }
+
+    for (unsigned r = 0; r < R; ++r)
+    {
+      const size_t ubase = ((size_t)blk * R + r) * S20_UNIT;
+      const unsigned fi = fidx.v[r];
+      const double * pi = mv.freqs(fi);
+      double2 t[5], pv[5];
+      if (!pmat)
+      {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) t[k] = make_double2(1.0, 1.0);
+      }
+      else if (child.codes) s20_child_tip(lut + (size_t)r * lut_codes * 20, cce, cco, q, t);
+      else s20_child_inner(child.clv + ubase, frag + r * S20_FRAGS, lane, t);
+      if (parent.codes) s20_tip_d(pme, pmo, q, pv);
+      else s20_load_d(parent.clv + ubase, lane, pv);
+      double le = 0.0, lo = 0.0;
+#pragma unroll
+      for (unsigned k = 0; k < 5; ++k)
+      {
+        const double f = pi[s20_row(k, q)];
+        le += f * pv[k].x * t[k].x;
+        lo += f * pv[k].y * t[k].y;
+      }
+      le = s20_sum_q(le);
+      lo = s20_sum_q(lo);
+      const double pinv = mv.pinv()[fi], w = mv.weights()[r];
+      if (pinv > 0.0)
+      {
+        site_e += w * (1.0 - pinv) * le;
+        site_o += w * (1.0 - pinv) * lo;
+        if (inv_state_e >= 0) inv_e += w * pinv * pi[inv_state_e];
+        if (inv_state_o >= 0) inv_o += w * pinv * pi[inv_state_o];
+      }
+      else
+      {
+        site_e += w * le;
+        site_o += w * lo;
+      }
+    }
+    if (q == 0)
+    {
+      if (site0 < N)
+      {
+        const unsigned cnt = (ps ? ps[site0] : 0u) + (cs ? cs[site0] : 0u);
+        const double l = site_loglh(site_e, cnt, inv_e);
+        if (persite) persite[site0] = l;
+        acc += l * (double)weights[site0];
+      }
+      if (site0 + 1 < N)
+      {
+        const unsigned cnt = (ps ? ps[site0 + 1] : 0u) + (cs ? cs[site0 + 1] : 0u);
+        const double l = site_loglh(site_o, cnt, inv_o);
+        if (persite) persite[site0 + 1] = l;
+        acc += l * (double)weights[site0 + 1];
+      }
+    }
+  }
+  const double tot = block_sum_256(acc, scratch);
+  if (threadIdx.x == 0) block_out[blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------
+// sumtable preparation: eigen-basis matrices in the [r][row][col] form the
+// partials kernel consumes, plus their tip lookup tables
+//   Lm[r][k][i] = pi_i V[i][k],   Rm[r][k][j] = V^-1[k][j]
+//   lutL[r][code][k] = sum_{i in mask} Lm[r][k][i]   (same for R)
+// grid = R, block = 256
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sumtable_prep_s20(ModelView mv, ParamIdx params,
+                                                           const unsigned long long * tipmap,
+                                                           unsigned lut_codes, bool want_lut,
+                                                           double * Lm, double * Rm,
+                                                           double * lutL, double * lutR)
+{
+  const unsigned r = blockIdx.x, pi_ = params.v[r];
+  const double * pi = mv.freqs(pi_), * V = mv.evecs(pi_), * Vi = mv.ievecs(pi_);
+  double * L = Lm + (size_t)r * 400, * Rr = Rm + (size_t)r * 400;
+  for (unsigned e = threadIdx.x; e < 400; e += blockDim.x)
+  {
+    const unsigned k = e / 20, i = e % 20;
+    L[e] = pi[i] * V[i * 20 + k];
+    Rr[e] = Vi[k * 20 + i];
+  }
+  if (!want_lut) return;
+  __syncthreads();
+  for (unsigned e = threadIdx.x; e < lut_codes * 20; e += blockDim.x)
+  {
+    const unsigned c = e / 20, k = e % 20;
+    const unsigned long long mask = tipmap[c];
+    double a = 0.0, b = 0.0;
+    for (unsigned i = 0; i < 20; ++i)
+      if ((mask >> i) & 1ULL) { a += pi[i] * V[i * 20 + k]; b += Vi[k * 20 + i]; }
+    lutL[((size_t)r * lut_codes + c) * 20 + k] = a;
+    lutR[((size_t)r * lut_codes + c) * 20 + k] = b;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// derivatives of -lnL from a blocked sumtable.  block_out = [df | ddf]
+// dynamic LDS = 3 * R * 20 doubles
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_derivatives_s20(ModelView mv, ParamIdx params, double t,
+                                                         const double * sumtable,
+                                                         const unsigned * ps, const unsigned * cs,
+                                                         const unsigned * weights, const int * invariant,
+                                                         unsigned N, unsigned nblk, unsigned R,
+                                                         double * block_out)
+{
+  extern __shared__ double coef[];        // e0 | e1 | e2, each [R][20]
+  __shared__ double scratch[4];
+  double * e0 = coef, * e1 = coef + R * 20, * e2 = coef + 2 * R * 20;
+  for (unsigned x = threadIdx.x; x < R * 20; x += blockDim.x)
+  {
+    const unsigned r = x / 20, k = x % 20, pi_ = params.v[r];
+    const double pinv = mv.pinv()[pi_];
+    const double lam = mv.evals(pi_)[k] * mv.rates()[r] / (1.0 - pinv);
+    const double wr = mv.weights()[r] * ((pinv > 0.0) ? (1.0 - pinv) : 1.0);
+    const double ex = exp(lam * t);
+    e0[x] = wr * ex;
+    e1[x] = wr * ex * lam;
+    e2[x] = wr * ex * lam * lam;
+  }
+  __syncthreads();
+
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, n = lane & 15;
+  const unsigned wstride = gridDim.x * 4;
+  double df = 0.0, ddf = 0.0;
+  for (unsigned blk = blockIdx.x * 4 + wave; blk < nblk; blk += wstride)
+  {
+    const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+    double Ae = 0, Be = 0, Ce = 0, Ao = 0, Bo = 0, Co = 0, inv_e = 0, inv_o = 0;
+    for (unsigned r = 0; r < R; ++r)
+    {
+      double2 s[5];
+      s20_load_d(sumtable + ((size_t)blk * R + r) * S20_UNIT, lane, s);
+#pragma unroll
+      for (unsigned k = 0; k < 5; ++k)
+      {
+        const unsigned row = r * 20 + s20_row(k, q);
+        Ae += s[k].x * e0[row]; Be += s[k].x * e1[row]; Ce += s[k].x * e2[row];
+        Ao += s[k].y * e0[row]; Bo += s[k].y * e1[row]; Co += s[k].y * e2[row];
+      }
+      const unsigned pi_ = params.v[r];
+      const double pinv = mv.pinv()[pi_];
+      if (pinv > 0.0 && invariant)
+      {
+        const double w = mv.weights()[r] * pinv;
+        if (site0 < N && invariant[site0] >= 0) inv_e += w * mv.freqs(pi_)[invariant[site0]];
+        if (site0 + 1 < N && invariant[site0 + 1] >= 0) inv_o += w * mv.freqs(pi_)[invariant[site0 + 1]];
+      }
+    }
+    Ae = s20_sum_q(Ae); Be = s20_sum_q(Be); Ce = s20_sum_q(Ce);
+    Ao = s20_sum_q(Ao); Bo = s20_sum_q(Bo); Co = s20_sum_q(Co);
+    if (q == 0)
+    {
+      if (site0 < N)
+      {
+        if (inv_e > 0.0)
+        {
+          const unsigned cnt = (ps ? ps[site0] : 0u) + (cs ? cs[site0] : 0u);
+          Ae += (cnt <= 3) ? ldexp(inv_e, 256 * (int)cnt) : INFINITY;
+        }
+        const double w = (double)weights[site0], ba = Be / Ae, ca = Ce / Ae;
+        df -= w * ba;
+        ddf += w * (ba * ba - ca);
+      }
+      if (site0 + 1 < N)
+      {
+        if (inv_o > 0.0)
+        {
+          const unsigned cnt = (ps ? ps[site0 + 1] : 0u) + (cs ? cs[site0 + 1] : 0u);
+          Ao += (cnt <= 3) ? ldexp(inv_o, 256 * (int)cnt) : INFINITY;
+        }
+        const double w = (double)weights[site0 + 1], ba = Bo / Ao, ca = Co / Ao;
+        df -= w * ba;
+        ddf += w * (ba * ba - ca);
+      }
+    }
+  }
+  const double tdf = block_sum_256(df, scratch);
+  const double tddf = block_sum_256(ddf, scratch);
+  if (threadIdx.x == 0)
+  {
+    block_out[blockIdx.x] = tdf;
+    block_out[gridDim.x + blockIdx.x] = tddf;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// layout converters between the API layout [site][rate][20] and the blocked
+// device layout (host materialisation, tip CLV upload, checkpoint restore)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_s20_to_blocked(const double * api, double * blocked,
+                                                        unsigned N, unsigned nblk, unsigned R)
+{
+  const unsigned long long total = (unsigned long long)nblk * R * S20_UNIT;
+  for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (unsigned long long)gridDim.x * blockDim.x)
+  {
+    const unsigned s = e % S20_BS, j = (e / S20_BS) % 20;
+    const unsigned long long br = e / S20_UNIT;
+    const unsigned r = br % R;
+    const unsigned long long n = (br / R) * S20_BS + s;
+    blocked[e] = (n < N) ? api[(n * R + r) * 20 + j] : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_s20_from_blocked(const double * blocked, double * api,
+                                                          unsigned N, unsigned R)
+{
+  const unsigned long long total = (unsigned long long)N * R * 20;
+  for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (unsigned long long)gridDim.x * blockDim.x)
+  {
+    const unsigned j = e % 20, r = (e / 20) % R;
+    const unsigned long long n = e / 20 / R;
+    api[e] = blocked[(((n / S20_BS) * R + r) * 20 + j) * S20_BS + (n % S20_BS)];
+  }
+}
+
+// --- launchers -------------------------------------------------------------
+
+static unsigned s20_grid(const Engine * e, unsigned blocks_per_cu)
+{
+  const unsigned need = (e->nblk + 3) / 4;
+  return std::max(1u, std::min(need, e->cu_count * blocks_per_cu));
+}
+
 static int launch_partials_s20(Engine * e, const OpBatch & batch, unsigned nops)
 {
-  return launch_partials_generic(e, batch, nops);
+  const size_t lds = sizeof(double) * 2 * e->R * S20_FRAGS;
+  hipLaunchKernelGGL(k_partials_s20, dim3(s20_grid(e, 4), nops), dim3(256), lds, e->stream,
+                     batch, e->nblk, e->R, e->lut_codes);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
 }
 
 static int launch_edge_lnl_s20(Engine * e, const ModelView & mv, const ParamIdx & fidx,
@@ -18,20 +505,55 @@ static int launch_edge_lnl_s20(Engine * e, const ModelView & mv, const ParamIdx 
                                const unsigned * ps, const unsigned * cs,
                                double * persite, unsigned nblocks)
 {
-  return launch_edge_lnl_generic(e, mv, fidx, parent, child, pm, lut, ps, cs, persite, nblocks);
+  const size_t lds = sizeof(double) * e->R * S20_FRAGS;
+  hipLaunchKernelGGL(k_edge_lnl_s20, dim3(nblocks), dim3(256), lds, e->stream,
+                     mv, fidx, parent, child, pm, lut, e->lut_codes, ps, cs,
+                     e->d_weights, e->d_invariant, e->d_tipmap, e->N, e->nblk, e->R,
+                     persite, e->d_partials);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
 }
 
 static int launch_sumtable_s20(Engine * e, const ModelView & mv, const ParamIdx & params,
                                const NodeRef & parent, const NodeRef & child, double * d_sum)
 {
-  return launch_sumtable_generic(e, mv, params, parent, child, d_sum);
+  // scratch: Lm | Rm | lutL | lutR
+  const size_t mats = (size_t)e->R * 400, luts = (size_t)e->R * std::max(1u, e->lut_codes) * 20;
+  if (!e->d_sum_scratch)
+  {
+    hipError_t err = hipMalloc(reinterpret_cast<void **>(&e->d_sum_scratch),
+                               sizeof(double) * 2 * (mats + (size_t)e->R * PLL_ASCII_SIZE * 20));
+    if (err != hipSuccess)
+    {
+      set_error(PLL_ERROR_MEM_ALLOC, "hipMalloc for sumtable scratch failed");
+      return PLL_FAILURE;
+    }
+  }
+  double * Lm = e->d_sum_scratch, * Rm = Lm + mats, * lutL = Rm + mats, * lutR = lutL + luts;
+  const bool want_lut = parent.codes || child.codes;
+  hipLaunchKernelGGL(k_sumtable_prep_s20, dim3(e->R), dim3(256), 0, e->stream,
+                     mv, params, e->d_tipmap, e->lut_codes, want_lut, Lm, Rm, lutL, lutR);
+  PLLHIP_TRY(hipGetLastError());
+  OpBatch batch;
+  OpDesc & d = batch.op[0];
+  d.clv1 = parent.clv; d.codes1 = parent.codes; d.pmat1 = Lm; d.lut1 = lutL;
+  d.clv2 = child.clv;  d.codes2 = child.codes;  d.pmat2 = Rm; d.lut2 = lutR;
+  d.scaler1 = d.scaler2 = nullptr;
+  d.parent = d_sum;
+  d.parent_scaler = nullptr;
+  return launch_partials_s20(e, batch, 1);
 }
 
 static int launch_derivatives_s20(Engine * e, const ModelView & mv, const ParamIdx & params, double t,
                                   const double * d_sum, const unsigned * ps, const unsigned * cs,
                                   unsigned nblocks)
 {
-  return launch_derivatives_generic(e, mv, params, t, d_sum, ps, cs, nblocks);
+  const size_t lds = sizeof(double) * 3 * e->R * 20;
+  hipLaunchKernelGGL(k_derivatives_s20, dim3(nblocks), dim3(256), lds, e->stream,
+                     mv, params, t, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R,
+                     e->d_partials);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
 }
 
 } // namespace pllhip

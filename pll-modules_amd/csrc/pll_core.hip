@@ -116,27 +116,31 @@ Engine * engine_create(pll_partition_t * p)
   const char * force = getenv("PLLHIP_FORCE_GENERIC");
   if (force && atoi(force)) e->family = KernelFamily::Generic;
   else if (e->S == 4 && (e->R & (e->R - 1)) == 0) e->family = KernelFamily::S4;
-  else if (e->S == 20) e->family = KernelFamily::S20;
+  else if (e->S == 20 && e->R <= 8) e->family = KernelFamily::S20;
   else e->family = KernelFamily::Generic;
+  e->blocked = (e->family == KernelFamily::S20);
+  e->nblk = (e->N + S20_BS - 1) / S20_BS;
+  e->Nalloc = e->blocked ? e->nblk * S20_BS : e->N;
 
   bool ok = hip_ok(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate");
-  const size_t clv_len = (size_t)e->N * e->R * e->Sp;
+  const size_t clv_len = e->blocked ? (size_t)e->nblk * e->R * S20_UNIT : (size_t)e->N * e->R * e->Sp;
+  e->clv_len = clv_len;
   e->d_clv.assign(e->nodes, nullptr);
   e->d_codes.assign(e->tips, nullptr);
   for (unsigned i = 0; ok && i < e->nodes; ++i)
   {
     if (i < e->tips && e->coded_tips)
-      ok = dev_alloc(&e->d_codes[i], (size_t)e->N, "tip codes") &&
-           hip_ok(hipMemsetAsync(e->d_codes[i], 0, e->N ? e->N : 1, e->stream), "memset codes");
+      ok = dev_alloc(&e->d_codes[i], (size_t)e->Nalloc, "tip codes") &&
+           hip_ok(hipMemsetAsync(e->d_codes[i], 0, e->Nalloc ? e->Nalloc : 1, e->stream), "memset codes");
     else
       ok = dev_alloc(&e->d_clv[i], clv_len, "CLV") &&
            hip_ok(hipMemsetAsync(e->d_clv[i], 0, (clv_len ? clv_len : 1) * sizeof(double), e->stream),
                   "memset CLV");
   }
   const size_t pm_len = (size_t)e->nmat * e->R * e->S * e->Sp;
-  ok = ok && dev_alloc(&e->d_scalers, (size_t)e->nscalers * e->N, "scalers");
+  ok = ok && dev_alloc(&e->d_scalers, (size_t)e->nscalers * e->Nalloc, "scalers");
   ok = ok && hip_ok(hipMemsetAsync(e->d_scalers, 0,
-                                   std::max<size_t>(1, (size_t)e->nscalers * e->N) * sizeof(unsigned),
+                                   std::max<size_t>(1, (size_t)e->nscalers * e->Nalloc) * sizeof(unsigned),
                                    e->stream), "memset scalers");
   ok = ok && dev_alloc(&e->d_pmat, pm_len, "P-matrices");
   ok = ok && hip_ok(hipMemsetAsync(e->d_pmat, 0, std::max<size_t>(1, pm_len) * sizeof(double), e->stream),
@@ -197,7 +201,9 @@ void engine_destroy(Engine * e)
   (void)hipFree(e->d_model);
   (void)hipFree(e->d_partials);
   (void)hipFree(e->d_persite);
+  (void)hipFree(e->d_sum_scratch);
   if (e->h_partials) (void)hipHostFree(e->h_partials);
+  for (auto & ev : e->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -234,19 +240,55 @@ int upload_tip_codes(pll_partition_t * p, unsigned tip)
   return upload_tipmap(p);
 }
 
+// API layout [site][rate][Sp] on the host -> device layout of the family
+static int store_clv(Engine * e, double * d_dst, const double * host_clv)
+{
+  const size_t len = (size_t)e->N * e->R * e->Sp;
+  if (!len) return PLL_SUCCESS;
+  if (!e->blocked)
+  {
+    PLLHIP_TRY(hipMemcpyAsync(d_dst, host_clv, len * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    PLLHIP_TRY(hipStreamSynchronize(e->stream));
+    return PLL_SUCCESS;
+  }
+  double * tmp = nullptr;
+  if (!dev_alloc(&tmp, len, "layout staging")) return PLL_FAILURE;
+  PLLHIP_TRY(hipMemcpyAsync(tmp, host_clv, len * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_s20_to_blocked, dim3(e->cu_count * 8), dim3(256), 0, e->stream,
+                     tmp, d_dst, e->N, e->nblk, e->R);
+  PLLHIP_TRY(hipGetLastError());
+  PLLHIP_TRY(hipStreamSynchronize(e->stream));
+  (void)hipFree(tmp);
+  return PLL_SUCCESS;
+}
+
+// device layout of the family -> API layout on the host
+static int fetch_clv(Engine * e, const double * d_src, double * host_out)
+{
+  const size_t len = (size_t)e->N * e->R * e->Sp;
+  if (!len) return PLL_SUCCESS;
+  if (!e->blocked)
+  {
+    PLLHIP_TRY(hipMemcpyAsync(host_out, d_src, len * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    PLLHIP_TRY(hipStreamSynchronize(e->stream));
+    return PLL_SUCCESS;
+  }
+  double * tmp = nullptr;
+  if (!dev_alloc(&tmp, len, "layout staging")) return PLL_FAILURE;
+  hipLaunchKernelGGL(k_s20_from_blocked, dim3(e->cu_count * 8), dim3(256), 0, e->stream,
+                     d_src, tmp, e->N, e->R);
+  PLLHIP_TRY(hipGetLastError());
+  PLLHIP_TRY(hipMemcpyAsync(host_out, tmp, len * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  PLLHIP_TRY(hipStreamSynchronize(e->stream));
+  (void)hipFree(tmp);
+  return PLL_SUCCESS;
+}
+
 int upload_tip_clv(pll_partition_t * p, unsigned tip, const double * host_clv)
 {
   Engine * e = engine_of(p);
   PLLHIP_TRY(hipSetDevice(e->device));
-  const size_t len = (size_t)e->N * e->R * e->Sp;
-  if (len)
-  {
-    // the staging buffer is freed by the caller right after: finish the copy
-    PLLHIP_TRY(hipMemcpyAsync(e->d_clv[tip], host_clv, len * sizeof(double),
-                              hipMemcpyHostToDevice, e->stream));
-    PLLHIP_TRY(hipStreamSynchronize(e->stream));
-  }
-  return PLL_SUCCESS;
+  return store_clv(e, e->d_clv[tip], host_clv);
 }
 
 void invalidate_luts(pll_partition_t * p)
@@ -364,12 +406,14 @@ static NodeRef node_ref(const Engine * e, unsigned clv_index)
 
 static const unsigned * scaler_ptr(const Engine * e, int idx)
 {
-  return (idx == PLL_SCALE_BUFFER_NONE) ? nullptr : e->d_scalers + (size_t)idx * e->N;
+  return (idx == PLL_SCALE_BUFFER_NONE) ? nullptr : e->d_scalers + (size_t)idx * e->Nalloc;
 }
 
 static unsigned reduce_grid(const Engine * e)
 {
-  const unsigned long long need = ((unsigned long long)e->N + 255ULL) / 256ULL;
+  // one thread per site (generic, S4) or one wave per 32-site block (S20)
+  const unsigned long long need = e->blocked ? ((unsigned long long)e->nblk + 3ULL) / 4ULL
+                                             : ((unsigned long long)e->N + 255ULL) / 256ULL;
   return (unsigned)std::max<unsigned long long>(1ULL, std::min<unsigned long long>(need, REDUCE_BLOCKS));
 }
 
@@ -404,7 +448,7 @@ static double * sumtable_device(Engine * e, const void * key, bool create)
     buf = e->sumtables.back().second;
     e->sumtables.pop_back();
   }
-  else if (!dev_alloc(&buf, (size_t)e->N * e->R * e->Sp, "sumtable"))
+  else if (!dev_alloc(&buf, e->clv_len, "sumtable"))
     return nullptr;
   e->sumtables.emplace_front(key, buf);
   return buf;
@@ -506,6 +550,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
   {
     OpBatch batch;
     unsigned nb = 0;
+    double batch_bytes = 0.0;
     for (unsigned k = 0; k <= count; ++k)
     {
       if (k < count && level[k] == l)
@@ -526,12 +571,43 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
         d.scaler2 = scaler_ptr(e, op.child2_scaler_index);
         d.parent = e->d_clv[op.parent_clv_index];
         d.parent_scaler = const_cast<unsigned *>(scaler_ptr(e, op.parent_scaler_index));
+        // algorithmic bytes of this op: child vectors in (8*S per
+        // (site,rate); a coded tip is 1 byte per site), parent vector out, scalers,
+        // the two P-matrices (or lookup tables) once per op
+        const double nr = (double)e->N * e->R;
+        batch_bytes += nr * 8.0 * e->S * (1.0 + (t1 ? 0.0 : 1.0) + (t2 ? 0.0 : 1.0));
+        batch_bytes += (double)e->N * ((t1 ? 1.0 : 0.0) + (t2 ? 1.0 : 0.0));
+        batch_bytes += (double)e->N * 4.0 * ((d.scaler1 ? 1 : 0) + (d.scaler2 ? 1 : 0) + (d.parent_scaler ? 1 : 0));
+        batch_bytes += 8.0 * e->R * e->S * ((t1 ? (double)e->lut_codes : (double)e->Sp) +
+                                            (t2 ? (double)e->lut_codes : (double)e->Sp));
       }
       if (nb == MAX_OPS_PER_LAUNCH || (k == count && nb))
       {
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (e->profiling)
+        {
+          if (e->prof_used == e->prof_events.size())
+          {
+            hipEvent_t a, b;
+            PLLHIP_TRY(hipEventCreate(&a));
+            PLLHIP_TRY(hipEventCreate(&b));
+            e->prof_events.emplace_back(a, b);
+          }
+          ev0 = e->prof_events[e->prof_used].first;
+          ev1 = e->prof_events[e->prof_used].second;
+          e->prof_used++;
+          PLLHIP_TRY(hipEventRecord(ev0, e->stream));
+        }
         if (!launch_partials(e, batch, nb)) return PLL_FAILURE;
+        if (e->profiling)
+        {
+          PLLHIP_TRY(hipEventRecord(ev1, e->stream));
+          e->prof_bytes += batch_bytes;
+          e->prof_ops += nb;
+        }
         e->counters.partial_launches++;
         nb = 0;
+        batch_bytes = 0.0;
       }
     }
   }
@@ -635,7 +711,7 @@ static double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsi
   if (e->family == KernelFamily::S4 && matrix_index >= 0)
     rc = launch_edge_lnl_s4(e, mv, fidx, parent, child, pm, lut, scaler_ptr(e, psc), scaler_ptr(e, csc),
                             persite_lnl ? e->d_persite : nullptr, nblocks);
-  else if (e->family == KernelFamily::S20 && matrix_index >= 0)
+  else if (e->family == KernelFamily::S20)
     rc = launch_edge_lnl_s20(e, mv, fidx, parent, child, pm, lut, scaler_ptr(e, psc), scaler_ptr(e, csc),
                              persite_lnl ? e->d_persite : nullptr, nblocks);
   else
@@ -770,7 +846,7 @@ int pll_update_invariant_sites(pll_partition_t * p)
   PLLHIP_TRY(hipMemcpyAsync(d_tc, h_clv.data(), sizeof(void *) * h_clv.size(), hipMemcpyHostToDevice, e->stream));
   PLLHIP_TRY(hipMemcpyAsync(d_tk, h_codes.data(), sizeof(void *) * h_codes.size(), hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(k_invariant, dim3(reduce_grid(e)), dim3(256), 0, e->stream,
-                     d_tc, d_tk, e->d_tipmap, e->tips, e->N, e->R, e->S, e->Sp, e->d_invariant);
+                     d_tc, d_tk, e->d_tipmap, e->tips, e->N, e->R, e->S, e->Sp, e->blocked, e->d_invariant);
   PLLHIP_TRY(hipGetLastError());
   if (e->N)
     PLLHIP_TRY(hipMemcpyAsync(p->invariant, e->d_invariant, sizeof(int) * e->N, hipMemcpyDeviceToHost, e->stream));
@@ -851,9 +927,7 @@ int pllhip_get_clv(pll_partition_t * p, unsigned int clv_index, double * out)
     (void)hipFree(tmp);
     return PLL_SUCCESS;
   }
-  PLLHIP_TRY(hipMemcpyAsync(out, e->d_clv[clv_index], len * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  PLLHIP_TRY(hipStreamSynchronize(e->stream));
-  return PLL_SUCCESS;
+  return fetch_clv(e, e->d_clv[clv_index], out);
 }
 
 int pllhip_set_clv(pll_partition_t * p, unsigned int clv_index, const double * clv)
@@ -866,11 +940,7 @@ int pllhip_set_clv(pll_partition_t * p, unsigned int clv_index, const double * c
     set_error(PLL_ERROR_PARAM_INVALID, "CLV %u is a coded tip", clv_index);
     return PLL_FAILURE;
   }
-  const size_t len = (size_t)e->N * e->R * e->Sp;
-  if (!len) return PLL_SUCCESS;
-  PLLHIP_TRY(hipMemcpyAsync(e->d_clv[clv_index], clv, len * sizeof(double), hipMemcpyHostToDevice, e->stream));
-  PLLHIP_TRY(hipStreamSynchronize(e->stream));
-  return PLL_SUCCESS;
+  return store_clv(e, e->d_clv[clv_index], clv);
 }
 
 int pllhip_get_scaler(pll_partition_t * p, unsigned int idx, unsigned int * out)
@@ -879,7 +949,7 @@ int pllhip_get_scaler(pll_partition_t * p, unsigned int idx, unsigned int * out)
   PLLHIP_TRY(hipSetDevice(e->device));
   if (idx >= e->nscalers) { set_error(PLL_ERROR_PARAM_INVALID, "scaler index out of range"); return PLL_FAILURE; }
   if (!e->N) return PLL_SUCCESS;
-  PLLHIP_TRY(hipMemcpyAsync(out, e->d_scalers + (size_t)idx * e->N, sizeof(unsigned) * e->N,
+  PLLHIP_TRY(hipMemcpyAsync(out, e->d_scalers + (size_t)idx * e->Nalloc, sizeof(unsigned) * e->N,
                             hipMemcpyDeviceToHost, e->stream));
   PLLHIP_TRY(hipStreamSynchronize(e->stream));
   return PLL_SUCCESS;
@@ -891,7 +961,7 @@ int pllhip_set_scaler(pll_partition_t * p, unsigned int idx, const unsigned int 
   PLLHIP_TRY(hipSetDevice(e->device));
   if (idx >= e->nscalers) { set_error(PLL_ERROR_PARAM_INVALID, "scaler index out of range"); return PLL_FAILURE; }
   if (!e->N) return PLL_SUCCESS;
-  PLLHIP_TRY(hipMemcpyAsync(e->d_scalers + (size_t)idx * e->N, in, sizeof(unsigned) * e->N,
+  PLLHIP_TRY(hipMemcpyAsync(e->d_scalers + (size_t)idx * e->Nalloc, in, sizeof(unsigned) * e->N,
                             hipMemcpyHostToDevice, e->stream));
   PLLHIP_TRY(hipStreamSynchronize(e->stream));
   return PLL_SUCCESS;
@@ -903,11 +973,7 @@ int pllhip_get_sumtable(pll_partition_t * p, const double * key, double * out)
   PLLHIP_TRY(hipSetDevice(e->device));
   double * d_sum = sumtable_device(e, key, false);
   if (!d_sum) { set_error(PLL_ERROR_PARAM_INVALID, "unknown sumtable key"); return PLL_FAILURE; }
-  const size_t len = (size_t)e->N * e->R * e->Sp;
-  if (!len) return PLL_SUCCESS;
-  PLLHIP_TRY(hipMemcpyAsync(out, d_sum, len * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  PLLHIP_TRY(hipStreamSynchronize(e->stream));
-  return PLL_SUCCESS;
+  return fetch_clv(e, d_sum, out);
 }
 
 int pllhip_sync_to_host(pll_partition_t * p, unsigned int what)
@@ -953,6 +1019,38 @@ int pllhip_get_counters(const pll_partition_t * p, pllhip_counters_t * out)
 void pllhip_reset_counters(pll_partition_t * p)
 {
   engine_of(p)->counters = pllhip_counters_t{};
+}
+
+int pllhip_profile_partials(pll_partition_t * p, int enable)
+{
+  Engine * e = engine_of(p);
+  e->profiling = enable != 0;
+  e->prof_used = 0;
+  e->prof_bytes = 0.0;
+  e->prof_ops = 0;
+  return PLL_SUCCESS;
+}
+
+int pllhip_profile_read(pll_partition_t * p, pllhip_profile_t * out)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  PLLHIP_TRY(hipStreamSynchronize(e->stream));
+  double ms = 0.0;
+  for (size_t k = 0; k < e->prof_used; ++k)
+  {
+    float t = 0.0f;
+    PLLHIP_TRY(hipEventElapsedTime(&t, e->prof_events[k].first, e->prof_events[k].second));
+    ms += t;
+  }
+  out->launches = e->prof_used;
+  out->ops = e->prof_ops;
+  out->kernel_ms = ms;
+  out->algorithmic_bytes = e->prof_bytes;
+  e->prof_used = 0;
+  e->prof_bytes = 0.0;
+  e->prof_ops = 0;
+  return PLL_SUCCESS;
 }
 
 const char * pllhip_partials_kernel_name(const pll_partition_t * p)

@@ -90,6 +90,11 @@ class Counters(C.Structure):
         "lnl_calls", "sumtable_calls", "derivative_calls", "model_uploads")]
 
 
+class Profile(C.Structure):
+    _fields_ = [("launches", C.c_ulonglong), ("ops", C.c_ulonglong),
+                ("kernel_ms", C.c_double), ("algorithmic_bytes", C.c_double)]
+
+
 TRAVERSE_CB = C.CFUNCTYPE(C.c_int, C.POINTER(UNode))
 REDUCE_CB = C.CFUNCTYPE(None, C.c_void_p, c_double_p, C.c_size_t, C.c_int)
 
@@ -114,7 +119,8 @@ PLLHIP_H_FUNCTIONS = """pllhip_device_count pllhip_set_device pllhip_get_device
 pllhip_device_arch pllhip_eigen_decompose pllhip_sync_to_host pllhip_get_clv
 pllhip_get_scaler pllhip_get_sumtable pllhip_set_clv pllhip_set_scaler pllhip_synchronize
 pllhip_stream pllhip_get_counters pllhip_reset_counters pllhip_partials_kernel_name
-pllhip_comm_get_unique_id pllhip_comm_create pllhip_comm_destroy pllhip_reduce_cb""".split()
+pllhip_comm_get_unique_id pllhip_comm_create pllhip_comm_destroy pllhip_reduce_cb
+pllhip_profile_partials pllhip_profile_read""".split()
 
 
 def _u32(a):
@@ -199,6 +205,8 @@ class PllLib:
             L.pllhip_reset_counters.argtypes = [pp]
             L.pllhip_partials_kernel_name.restype = C.c_char_p
             L.pllhip_partials_kernel_name.argtypes = [pp]
+            L.pllhip_profile_partials.argtypes = [pp, C.c_int]
+            L.pllhip_profile_read.argtypes = [pp, C.POINTER(Profile)]
             L.pllhip_comm_get_unique_id.argtypes = [C.c_char_p]
             L.pllhip_comm_create.restype = C.c_void_p
             L.pllhip_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
@@ -602,8 +610,21 @@ def full_traversal(inst, one_by_one_pmatrices=False):
     """the W1 workload: all P-matrices, n-2 partial ops, one edge lnL
     (call pattern of treeinfo_compute_loglh, src/tree/treeinfo.c:946-1079)"""
     t = inst.tree
-    inst.update_pmatrices(np.arange(t.nedges), t.brlens, one_by_one=one_by_one_pmatrices)
-    inst.update_partials(t.ops_with_scalers(inst.nscalers > 0))
+    key = (id(t), t.root_matrix)
+    if getattr(inst, "_trav_key", None) != key:      # C arrays built once per (tree, root)
+        inst._trav_key = key
+        inst._trav_mi = _u32(np.arange(t.nedges))
+        inst._trav_ops = inst.make_ops(t.ops_with_scalers(inst.nscalers > 0))
+        inst._trav_nops = len(t.ops)
+    if one_by_one_pmatrices:
+        inst.update_pmatrices(inst._trav_mi, t.brlens, one_by_one=True)
+    else:
+        bl = _f64(t.brlens)
+        if not inst.L.pll_update_prob_matrices(inst.p, inst.params_p,
+                                               inst._trav_mi.ctypes.data_as(c_uint_p),
+                                               bl.ctypes.data_as(c_double_p), t.nedges):
+            raise RuntimeError(inst.lib.errmsg)
+    inst.update_partials(inst._trav_ops, inst._trav_nops)
     sa = t.scaler_of(t.root_a) if inst.nscalers else PLL_SCALE_BUFFER_NONE
     sb = t.scaler_of(t.root_b) if inst.nscalers else PLL_SCALE_BUFFER_NONE
     return inst.edge_lnl(t.root_a, sa, t.root_b, sb, t.root_matrix)

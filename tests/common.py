@@ -224,6 +224,18 @@ def check_golden(expected, got):
 
 
 # ---------------------------------------------------------------------------
+def vec_err(a, b):
+    """largest deviation of a CLV-shaped array [..., states], measured against the
+    largest entry of the same (site, rate) vector.  Entries many orders below their
+    vector's maximum (e.g. multi-step codon changes, ~1e-13 of the row) come out of
+    cancelling eigen sums and carry no weight in any likelihood."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    if not a.size:
+        return 0.0
+    scale = np.maximum(np.abs(b).max(axis=-1, keepdims=True), 1e-300)
+    return float(np.max(np.abs(a - b) / scale))
+
+
 def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     denom = np.maximum(np.abs(b), 1e-300)
