@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--sites", type=int, default=0, help="override the per-configuration site count")
     ap.add_argument("--taxa", type=int, default=0)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--pmatrix-calls", default="per-branch", choices=["per-branch", "batched"],
+                    help="per-branch = one pll_update_prob_matrices call per branch, as treeinfo issues "
+                         "them (src/tree/treeinfo.c:845-865); batched = one call with count = 2n-3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sites", type=int, default=0, help="sites of the CPU baseline sample")
     return ap.parse_args()
@@ -141,9 +144,10 @@ def main():
     tree = inst.tree
     nops = len(tree.ops)
     lnl_buf = np.zeros(1)
+    per_branch = args.pmatrix_calls == "per-branch"
 
     def step():
-        lnl_buf[0] = pc.full_traversal(inst)
+        lnl_buf[0] = pc.full_traversal(inst, one_by_one_pmatrices=per_branch)
         if comm:
             product.lib.pllhip_reduce_cb(comm, lnl_buf.ctypes.data_as(pc.c_double_p), 1, 0)
         return lnl_buf[0]
@@ -227,6 +231,7 @@ def main():
                 "config": args.config, "states": states, "rate_cats": rate_cats, "taxa": ntips,
                 "sites_total": total_sites, "sites_per_gpu": local_sites, "ops_per_step": nops,
                 "tips": "1-byte codes", "scalers": "per-site, one per inner node",
+                "pmatrix_calls": args.pmatrix_calls,
             },
             "lnl": lnl, "lnl_per_site": lnl / total_sites,
             "roofline": roofline,

@@ -90,7 +90,8 @@ typedef struct pllhip_counters
   unsigned long long partial_ops;        /* operations executed                */
   unsigned long long partial_launches;   /* kernel launches for them           */
   unsigned long long site_updates;       /* ops * sites * rate_cats            */
-  unsigned long long pmatrix_updates;
+  unsigned long long pmatrix_updates;      /* matrices requested               */
+  unsigned long long pmatrix_launches;     /* kernel launches that served them */
   unsigned long long lnl_calls;
   unsigned long long sumtable_calls;
   unsigned long long derivative_calls;

@@ -25,7 +25,7 @@ namespace pllhip {
 constexpr unsigned MAX_RATE_CATS = 16;   // params_indices travel by value in kernel args
 constexpr unsigned MAX_OPS_PER_LAUNCH = 24;
 constexpr unsigned MAX_PMAT_PER_LAUNCH = 64;
-constexpr unsigned REDUCE_BLOCKS = 1024; // upper bound of per-block partial sums
+constexpr unsigned REDUCE_BLOCKS = 4096; // upper bound of per-block partial sums
 constexpr unsigned MAX_SUMTABLES = 4;    // device sumtables kept per partition (LRU)
 
 void set_error(int code, const char * fmt, ...);
@@ -46,6 +46,9 @@ struct OpDesc
   double * parent;
   unsigned * parent_scaler;
 };
+
+// per-rate parameter-set indices, by value in kernel arguments
+struct ParamIdxHost { unsigned v[16]; };
 
 struct OpBatch
 {
@@ -85,6 +88,12 @@ struct Engine
   unsigned * d_weights = nullptr;     // [N] pattern weights
   int * d_invariant = nullptr;        // [N], nullptr until needed
   unsigned long long * d_tipmap = nullptr; // [256] code -> state mask
+
+  // queued P-matrix requests (flush_pmatrices)
+  std::vector<unsigned> pend_midx;
+  std::vector<double> pend_t;
+  std::vector<int> pend_pos;          // matrix index -> position in the queue, -1 if absent
+  ParamIdxHost pend_params = {};
 
   // model block: rates[R] weights[R] pinv[nrm] freqs[nrm][Sp] evals[nrm][Sp]
   //              evecs[nrm][S*Sp] ievecs[nrm][S*Sp]

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include "engine.h"
 
 namespace pllhip {
 
@@ -28,7 +29,7 @@ struct ModelView
   __device__ const double * ievecs(unsigned m) const { return base + off_ievecs + (size_t)m * S * Sp; }
 };
 
-struct ParamIdx { unsigned v[16]; };
+typedef ParamIdxHost ParamIdx;
 
 // a node's conditional likelihoods: full CLV or 1-byte tip codes
 struct NodeRef

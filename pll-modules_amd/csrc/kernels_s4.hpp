@@ -149,33 +149,51 @@ __global__ __launch_bounds__(256) void k_edge_lnl_s4(ModelView mv, ParamIdx fidx
 
   double acc = 0.0;
   const unsigned long long limit = (total + 63ULL) & ~63ULL;
-  for (; g < limit; g += stride)
+  // four grid-stride iterations per trip: all loads of a trip are issued before
+  // the first use, so each lane keeps 8 x 16-32 B in flight
+  for (; g < limit; g += 4 * stride)
   {
-    const bool live = g < total;
-    const unsigned long long n = live ? g / R : 0;
-    double lr = 0.0, inv = 0.0;
-    if (live)
+    d4 cv[4], pv[4];
+    bool live[4];
+    unsigned long long nn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
     {
-      d4 a;
-      if (child.codes)
-        a = load4(lut + ((size_t)r * lut_codes + child.codes[n]) * 4);
-      else
+      const unsigned long long gu = g + u * stride;
+      live[u] = gu < total;
+      nn[u] = live[u] ? gu / R : 0;
+      cv[u] = d4{0, 0, 0, 0};
+      pv[u] = d4{0, 0, 0, 0};
+      if (live[u])
       {
-        const d4 c = load4(child.clv + g * 4);
-        a = d4{dot4(P, c), dot4(P + 4, c), dot4(P + 8, c), dot4(P + 12, c)};
+        cv[u] = child.codes ? load4(lut + ((size_t)r * lut_codes + child.codes[nn[u]]) * 4)
+                            : load4(child.clv + gu * 4);
+        pv[u] = parent.codes ? tip_value4(tipmap[parent.codes[nn[u]]]) : load4(parent.clv + gu * 4);
       }
-      const d4 pv = parent.codes ? tip_value4(tipmap[parent.codes[n]]) : load4(parent.clv + g * 4);
-      lr = wr * (f.x * pv.x * a.x + f.y * pv.y * a.y + f.z * pv.z * a.z + f.w * pv.w * a.w);
-      if (winv > 0.0 && invariant && invariant[n] >= 0) inv = winv * pi[invariant[n]];
     }
-    lr = group_sum(lr, R);
-    inv = group_sum(inv, R);
-    if (live && r == 0)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
     {
-      const unsigned cnt = (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
-      const double l = site_loglh(lr, cnt, inv);
-      if (persite) persite[n] = l;
-      acc += l * (double)weights[n];
+      if (g + u * stride >= limit) break;          // wave-uniform
+      double lr = 0.0, inv = 0.0;
+      if (live[u])
+      {
+        const d4 c = cv[u];
+        const d4 a = child.codes ? c
+                                 : d4{dot4(P, c), dot4(P + 4, c), dot4(P + 8, c), dot4(P + 12, c)};
+        lr = wr * (f.x * pv[u].x * a.x + f.y * pv[u].y * a.y + f.z * pv[u].z * a.z + f.w * pv[u].w * a.w);
+        if (winv > 0.0 && invariant && invariant[nn[u]] >= 0) inv = winv * pi[invariant[nn[u]]];
+      }
+      lr = group_sum(lr, R);
+      inv = group_sum(inv, R);
+      if (live[u] && r == 0)
+      {
+        const unsigned long long n = nn[u];
+        const unsigned cnt = (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
+        const double l = site_loglh(lr, cnt, inv);
+        if (persite) persite[n] = l;
+        acc += l * (double)weights[n];
+      }
     }
   }
   const double tot = block_sum_256(acc, scratch);
@@ -242,33 +260,42 @@ __global__ __launch_bounds__(256) void k_derivatives_s4(ModelView mv, ParamIdx p
   }
   double df = 0.0, ddf = 0.0;
   const unsigned long long limit = (total + 63ULL) & ~63ULL;
-  for (; g < limit; g += stride)
+  // four grid-stride iterations per trip (loads first, then the arithmetic)
+  for (; g < limit; g += 4 * stride)
   {
-    const bool live = g < total;
-    const unsigned long long n = live ? g / R : 0;
-    double A = 0.0, B = 0.0, C = 0.0, inv = 0.0;
-    if (live)
+    d4 sv[4];
+    bool live[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
     {
-      const d4 s = load4(sumtable + g * 4);
-      A = dot4(e0, s);
-      B = dot4(e1, s);
-      C = dot4(e2, s);
-      if (winv > 0.0 && invariant && invariant[n] >= 0) inv = winv * mv.freqs(pi_)[invariant[n]];
+      const unsigned long long gu = g + u * stride;
+      live[u] = gu < total;
+      sv[u] = live[u] ? load4(sumtable + gu * 4) : d4{0, 0, 0, 0};
     }
-    A = group_sum(A, R);
-    B = group_sum(B, R);
-    C = group_sum(C, R);
-    inv = group_sum(inv, R);
-    if (live && r == 0)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
     {
-      if (inv > 0.0)
+      const unsigned long long gu = g + u * stride;
+      if (gu >= limit) break;                        // wave-uniform
+      const unsigned long long n = live[u] ? gu / R : 0;
+      double A = dot4(e0, sv[u]), B = dot4(e1, sv[u]), C = dot4(e2, sv[u]), inv = 0.0;
+      if (live[u] && winv > 0.0 && invariant && invariant[n] >= 0)
+        inv = winv * mv.freqs(pi_)[invariant[n]];
+      A = group_sum(A, R);
+      B = group_sum(B, R);
+      C = group_sum(C, R);
+      inv = group_sum(inv, R);
+      if (live[u] && r == 0)
       {
-        const unsigned cnt = (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
-        A += (cnt <= 3) ? ldexp(inv, 256 * (int)cnt) : INFINITY;
+        if (inv > 0.0)
+        {
+          const unsigned cnt = (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
+          A += (cnt <= 3) ? ldexp(inv, 256 * (int)cnt) : INFINITY;
+        }
+        const double w = (double)weights[n], ba = B / A, ca = C / A;
+        df -= w * ba;
+        ddf += w * (ba * ba - ca);
       }
-      const double w = (double)weights[n], ba = B / A, ca = C / A;
-      df -= w * ba;
-      ddf += w * (ba * ba - ca);
     }
   }
   const double tdf = block_sum_256(df, scratch);

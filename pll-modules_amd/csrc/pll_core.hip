@@ -50,6 +50,9 @@ static int current_device()
   return g_device;
 }
 
+int flush_pmatrices(pll_partition_t * p);
+static int ensure_luts(pll_partition_t * p);
+
 static ModelView model_view(const Engine * e)
 {
   ModelView mv;
@@ -314,6 +317,9 @@ int sync_model(pll_partition_t * p)
   }
   if (memcmp(cur.data(), e->model_shadow.data(), sizeof(double) * e->model_len) != 0)
   {
+    // queued P-matrix requests belong to the model state they were issued under,
+    // which is the one still on the device
+    if (!flush_pmatrices(p)) return PLL_FAILURE;
     // pageable source: the runtime stages it before returning, so `cur` may die
     PLLHIP_TRY(hipMemcpyAsync(e->d_model, cur.data(), sizeof(double) * e->model_len,
                               hipMemcpyHostToDevice, e->stream));
@@ -321,11 +327,48 @@ int sync_model(pll_partition_t * p)
     e->model_shadow.swap(cur);
     e->counters.model_uploads++;
   }
-  // pattern weights can be written directly too (src/msa, bootstrap replicates)
-  if (e->N && memcmp(e->weights_shadow.data(), p->pattern_weights, sizeof(unsigned) * e->N) != 0)
-    if (!upload_weights(p)) return PLL_FAILURE;
-  // invariant sites: host array is computed by pll_update_invariant_sites (device
-  // kernel + download), nothing to upload unless the caller replaced the array
+  // pattern weights (4*N bytes) are NOT re-compared here: pll-modules changes them
+  // only through pll_set_pattern_weights (SURVEY.md section 0.3 lists the fields it
+  // pokes directly; weights are not among them), which uploads them itself.
+  return PLL_SUCCESS;
+}
+
+// Launch the queued P-matrix requests.  pll-modules asks for one matrix per call
+// (src/tree/treeinfo.c:845-865: 2n-3 calls per evaluation); the requests are
+// queued on the host and go to the device up to 64 per launch as soon as a
+// consumer of P-matrices (partials, lnL, host mirror) or a model change needs them.
+int flush_pmatrices(pll_partition_t * p)
+{
+  Engine * e = engine_of(p);
+  if (e->pend_midx.empty()) return PLL_SUCCESS;
+  if (e->coded_tips)
+  {
+    // LUT storage must exist so that the kernel can fill it in the same pass
+    const bool stale = e->lut_stale || !e->d_lut || e->lut_codes < std::max(1u, p->maxstates);
+    if (stale && !ensure_luts(p)) return PLL_FAILURE;
+  }
+  const ModelView mv = model_view(e);
+  const size_t lds = sizeof(double) * ((size_t)e->Sp + (size_t)e->S * e->Sp);
+  const unsigned count = (unsigned)e->pend_midx.size();
+  for (unsigned base = 0; base < count; base += MAX_PMAT_PER_LAUNCH)
+  {
+    const unsigned nb = std::min(MAX_PMAT_PER_LAUNCH, count - base);
+    PmatBatch batch;
+    for (unsigned q = 0; q < nb; ++q)
+    {
+      batch.midx[q] = e->pend_midx[base + q];
+      batch.t[q] = e->pend_t[base + q];
+      e->pend_pos[batch.midx[q]] = -1;
+    }
+    hipLaunchKernelGGL(k_pmatrix, dim3(nb, e->R), dim3(256), lds, e->stream,
+                       mv, e->pend_params, batch, e->R, e->d_pmat,
+                       e->coded_tips ? e->d_lut : nullptr, e->lut_codes, e->d_tipmap);
+    PLLHIP_TRY(hipGetLastError());
+    e->counters.pmatrix_launches++;
+  }
+  e->pend_midx.clear();
+  e->pend_t.clear();
+  e->pmat_host_dirty = true;
   return PLL_SUCCESS;
 }
 
@@ -411,9 +454,11 @@ static const unsigned * scaler_ptr(const Engine * e, int idx)
 
 static unsigned reduce_grid(const Engine * e)
 {
-  // one thread per site (generic, S4) or one wave per 32-site block (S20)
-  const unsigned long long need = e->blocked ? ((unsigned long long)e->nblk + 3ULL) / 4ULL
-                                             : ((unsigned long long)e->N + 255ULL) / 256ULL;
+  // generic: one thread per site; S4: one lane per (site, rate), 4 per trip;
+  // S20: one wave per 32-site block
+  unsigned long long need = ((unsigned long long)e->N + 255ULL) / 256ULL;
+  if (e->blocked) need = ((unsigned long long)e->nblk + 3ULL) / 4ULL;
+  else if (e->family == KernelFamily::S4) need = ((unsigned long long)e->N * e->R + 1023ULL) / 1024ULL;
   return (unsigned)std::max<unsigned long long>(1ULL, std::min<unsigned long long>(need, REDUCE_BLOCKS));
 }
 
@@ -495,7 +540,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
 {
   Engine * e = engine_of(p);
   PLLHIP_TRY(hipSetDevice(e->device));
-  if (!ensure_luts(p)) return PLL_FAILURE;
+  if (!flush_pmatrices(p) || !ensure_luts(p)) return PLL_FAILURE;
 
   // dependency levels: an op runs after the producers of its children and
   // after every earlier op that touched its output buffers
@@ -635,12 +680,6 @@ int pll_update_prob_matrices(pll_partition_t * p,
   PLLHIP_TRY(hipSetDevice(e->device));
   if (!ensure_eigen(p, params_indices)) return PLL_FAILURE;
   if (!sync_model(p)) return PLL_FAILURE;
-  if (e->coded_tips)
-  {
-    // make sure LUT storage exists so that the kernel can fill it in the same pass
-    const bool was_stale = e->lut_stale || !e->d_lut || e->lut_codes < std::max(1u, p->maxstates);
-    if (was_stale && !ensure_luts(p)) return PLL_FAILURE;
-  }
   for (unsigned m = 0; m < count; ++m)
     if (matrix_indices[m] >= e->nmat || !(branch_lengths[m] >= 0.0))
     {
@@ -648,26 +687,27 @@ int pll_update_prob_matrices(pll_partition_t * p,
                 matrix_indices[m], branch_lengths[m]);
       return PLL_FAILURE;
     }
-
-  const ModelView mv = model_view(e);
+  // queue; a request for a matrix that is already queued replaces it
   const ParamIdx params = make_params(p, params_indices);
-  const size_t lds = sizeof(double) * ((size_t)e->Sp + (size_t)e->S * e->Sp);
-  for (unsigned base = 0; base < count; base += MAX_PMAT_PER_LAUNCH)
+  if (!e->pend_midx.empty() && memcmp(&params, &e->pend_params, sizeof(params)) != 0)
+    if (!flush_pmatrices(p)) return PLL_FAILURE;
+  e->pend_params = params;
+  if (e->pend_pos.size() != e->nmat) e->pend_pos.assign(e->nmat, -1);
+  for (unsigned m = 0; m < count; ++m)
   {
-    const unsigned nb = std::min(MAX_PMAT_PER_LAUNCH, count - base);
-    PmatBatch batch;
-    for (unsigned q = 0; q < nb; ++q)
+    const unsigned idx = matrix_indices[m];
+    if (e->pend_pos[idx] >= 0)
+      e->pend_t[e->pend_pos[idx]] = branch_lengths[m];
+    else
     {
-      batch.midx[q] = matrix_indices[base + q];
-      batch.t[q] = branch_lengths[base + q];
+      e->pend_pos[idx] = (int)e->pend_midx.size();
+      e->pend_midx.push_back(idx);
+      e->pend_t.push_back(branch_lengths[m]);
     }
-    hipLaunchKernelGGL(k_pmatrix, dim3(nb, e->R), dim3(256), lds, e->stream,
-                       mv, params, batch, e->R, e->d_pmat,
-                       e->coded_tips ? e->d_lut : nullptr, e->lut_codes, e->d_tipmap);
-    PLLHIP_TRY(hipGetLastError());
   }
   e->pmat_host_dirty = true;
   e->counters.pmatrix_updates += count;
+  if (e->pend_midx.size() >= 4 * MAX_PMAT_PER_LAUNCH) return flush_pmatrices(p);
   return PLL_SUCCESS;
 }
 
@@ -691,7 +731,7 @@ static double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsi
     if (!check_clv_index(e, cc, "child") || !check_scaler_index(e, csc)) return fail;
     if ((unsigned)matrix_index >= e->nmat) { set_error(PLL_ERROR_PARAM_INVALID, "matrix index out of range"); return fail; }
   }
-  if (!sync_model(p) || !ensure_luts(p) || !ensure_invariant(p)) return fail;
+  if (!sync_model(p) || !flush_pmatrices(p) || !ensure_luts(p) || !ensure_invariant(p)) return fail;
   if (persite_lnl && !e->d_persite)
     if (!dev_alloc(&e->d_persite, (size_t)e->N, "per-site lnL")) return fail;
 
@@ -982,6 +1022,7 @@ int pllhip_sync_to_host(pll_partition_t * p, unsigned int what)
   PLLHIP_TRY(hipSetDevice(e->device));
   if ((what & PLLHIP_SYNC_PMATRIX) && e->pmat_host_dirty && e->nmat)
   {
+    if (!flush_pmatrices(p)) return PLL_FAILURE;
     PLLHIP_TRY(hipMemcpyAsync(p->pmatrix[0], e->d_pmat,
                               sizeof(double) * (size_t)e->nmat * e->R * e->S * e->Sp,
                               hipMemcpyDeviceToHost, e->stream));

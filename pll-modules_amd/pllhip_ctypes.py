@@ -86,7 +86,7 @@ class UTree(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_ulonglong) for n in (
-        "partial_ops", "partial_launches", "site_updates", "pmatrix_updates",
+        "partial_ops", "partial_launches", "site_updates", "pmatrix_updates", "pmatrix_launches",
         "lnl_calls", "sumtable_calls", "derivative_calls", "model_uploads")]
 
 
@@ -617,7 +617,18 @@ def full_traversal(inst, one_by_one_pmatrices=False):
         inst._trav_ops = inst.make_ops(t.ops_with_scalers(inst.nscalers > 0))
         inst._trav_nops = len(t.ops)
     if one_by_one_pmatrices:
-        inst.update_pmatrices(inst._trav_mi, t.brlens, one_by_one=True)
+        # one call per branch, as treeinfo issues them (src/tree/treeinfo.c:845-865);
+        # the argument pointers are prepared once so that the loop is just the calls
+        if getattr(inst, "_trav_ptrs", None) is None or inst._trav_ptrs[0] != key:
+            bl = inst._trav_bl = _f64(t.brlens)
+            inst._trav_ptrs = (key, [(C.cast(inst._trav_mi.ctypes.data + 4 * k, c_uint_p),
+                                      C.cast(bl.ctypes.data + 8 * k, c_double_p))
+                                     for k in range(t.nedges)])
+        inst._trav_bl[:] = t.brlens
+        fn, p, pp = inst.L.pll_update_prob_matrices, inst.p, inst.params_p
+        for mi_p, bl_p in inst._trav_ptrs[1]:
+            if not fn(p, pp, mi_p, bl_p, 1):
+                raise RuntimeError(inst.lib.errmsg)
     else:
         bl = _f64(t.brlens)
         if not inst.L.pll_update_prob_matrices(inst.p, inst.params_p,
