@@ -34,6 +34,7 @@
 #include "kernels_common.hpp"
 #include "kernels_generic.hpp"
 #include "engine.h"
+#include <cstdlib>
 
 namespace pllhip {
 
@@ -151,10 +152,12 @@ __device__ inline double s20_sum_q(double v)
 // the P-matrices).   grid = (gx, ops), block = 256 (4 independent waves)
 // dynamic LDS = 2 * R * S20_FRAGS doubles
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_partials_s20(OpBatch batch, unsigned nblk, unsigned R,
+template <unsigned RT>   // RT > 0: rate count known at compile time (rate loop unrolled)
+__global__ __launch_bounds__(256, 2) void k_partials_s20(OpBatch batch, unsigned nblk, unsigned Rrt,
                                                          unsigned lut_codes)
 {
   extern __shared__ double frag[];
+  const unsigned R = RT ? RT : Rrt;
   const OpDesc & op = batch.op[blockIdx.y];
   if (!op.codes1) s20_fill_frags(frag, op.pmat1, R);
   if (!op.codes2) s20_fill_frags(frag + R * S20_FRAGS, op.pmat2, R);
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void k_partials_s20(OpBatch batch, unsigned
     if (op.codes2) { c2e = op.codes2[site0]; c2o = op.codes2[site0 + 1]; }
     int small_e = 1, small_o = 1;
 
+#pragma unroll
     for (unsigned r = 0; r < R; ++r)
     {
       const size_t ubase = ((size_t)blk * R + r) * S20_UNIT;
@@ -486,6 +490,8 @@ __global__ __launch_bounds__(256) void k_s20_from_blocked(const double * blocked
 
 static unsigned s20_grid(const Engine * e, unsigned blocks_per_cu)
 {
+  static const int env_bpc = getenv("PLLHIP_S20_BPC") ? atoi(getenv("PLLHIP_S20_BPC")) : 0;
+  if (env_bpc > 0) blocks_per_cu = (unsigned)env_bpc;
   const unsigned need = (e->nblk + 3) / 4;
   return std::max(1u, std::min(need, e->cu_count * blocks_per_cu));
 }
@@ -493,8 +499,13 @@ static unsigned s20_grid(const Engine * e, unsigned blocks_per_cu)
 static int launch_partials_s20(Engine * e, const OpBatch & batch, unsigned nops)
 {
   const size_t lds = sizeof(double) * 2 * e->R * S20_FRAGS;
-  hipLaunchKernelGGL(k_partials_s20, dim3(s20_grid(e, 4), nops), dim3(256), lds, e->stream,
-                     batch, e->nblk, e->R, e->lut_codes);
+  static const int no_unroll = getenv("PLLHIP_S20_NOUNROLL") ? atoi(getenv("PLLHIP_S20_NOUNROLL")) : 0;
+  if (e->R == 4 && !no_unroll)
+    hipLaunchKernelGGL(k_partials_s20<4>, dim3(s20_grid(e, 4), nops), dim3(256), lds, e->stream,
+                       batch, e->nblk, e->R, e->lut_codes);
+  else
+    hipLaunchKernelGGL(k_partials_s20<0>, dim3(s20_grid(e, 4), nops), dim3(256), lds, e->stream,
+                       batch, e->nblk, e->R, e->lut_codes);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

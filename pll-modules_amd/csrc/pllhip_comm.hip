@@ -77,7 +77,6 @@ void pllhip_reduce_cb(void * ctx, double * data, size_t n, int op)
 {
   pllhip_comm_t * c = static_cast<pllhip_comm_t *>(ctx);
   if (!c || !n) return;
-  if (c->nranks == 1) return;
   (void)hipSetDevice(c->device);
   const ncclRedOp_t rop = (op == PLLHIP_REDUCE_MAX) ? ncclMax : (op == PLLHIP_REDUCE_MIN) ? ncclMin : ncclSum;
   for (size_t off = 0; off < n; off += c->cap)

