@@ -6,6 +6,8 @@
  * that also links those files resolves its symbols.  Every one of them fails
  * loudly: it sets pll_errno = PLL_ERROR_NOT_IMPLEMENTED and returns
  * NULL / PLL_FAILURE.  Nothing on the likelihood path calls them.
+ * (The SPR / NNI topology primitives that pllmod_algo_spr_round needs are real:
+ * pll_utree_moves.c.)
  */
 #include "pll.h"
 
@@ -41,7 +43,3 @@ NI_PTR(pll_msa_t *, pll_phylip_load, (const char * f, pll_bool_t i))
 NI_VOID(pll_msa_destroy, (pll_msa_t * m))
 NI_PTR(unsigned int *, pll_compress_site_patterns, (char ** s, const pll_state_t * m, int c, int * l))
 
-NI_INT(pll_utree_spr, (pll_unode_t * p, pll_unode_t * r, pll_utree_rb_t * rb, double * b, unsigned int * m))
-NI_INT(pll_utree_spr_safe, (pll_unode_t * p, pll_unode_t * r, pll_utree_rb_t * rb, double * b, unsigned int * m))
-NI_INT(pll_utree_nni, (pll_unode_t * p, int t, pll_utree_rb_t * rb))
-NI_INT(pll_utree_rollback, (pll_utree_rb_t * rb, double * b, unsigned int * m))
