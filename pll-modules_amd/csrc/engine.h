@@ -110,7 +110,10 @@ struct Engine
 
   // reductions
   double * d_partials = nullptr;      // [3 * REDUCE_BLOCKS]
-  double * h_partials = nullptr;      // pinned mirror
+  double * h_partials = nullptr;      // pinned mirror (unused by the kernels that finish on device)
+  unsigned * d_counter = nullptr;     // arrival ticket of the grid-wide reductions
+  double * h_result = nullptr;        // pinned + device-mapped: final sums land here
+  double * d_result = nullptr;        // device pointer of h_result
   double * d_persite = nullptr;       // [N], allocated on first per-site request
 
   // caller-keyed device sumtables (pointer value is the key)

@@ -61,6 +61,67 @@ __device__ inline double block_sum_256(double v, double * scratch)
   return t;
 }
 
+// Grid-wide sums that end in host-visible memory without a device->host copy:
+// every block stores its total; a second, single-block kernel (k_final_sum, the
+// kernel boundary gives the visibility) adds the block totals in a FIXED order
+// and writes the result into pinned, device-mapped host memory.  Bit-reproducible
+// run to run.  (An in-kernel "last block finishes" variant with agent-scope
+// fences was measured 3x slower here: thousands of release fences from short
+// streaming blocks serialise on the XCD L2 write-back.)
+struct ReduceOut
+{
+  double * block_out;     // [quantities][gridDim.x] device scratch
+  unsigned * counter;     // zero before the launch; reset by the last block
+  double * host_result;   // device pointer of pinned host memory, [quantities]
+};
+
+inline ReduceOut reduce_out(const Engine * e)
+{
+  ReduceOut ro;
+  ro.block_out = e->d_partials;
+  ro.counter = e->d_counter;
+  ro.host_result = e->d_result;
+  return ro;
+}
+
+template <int Q>
+__device__ inline void grid_reduce_finish(const double (&tot)[Q], const ReduceOut & ro,
+                                          double * scratch)
+{
+  (void)scratch;
+  if (threadIdx.x == 0)
+  {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) ro.block_out[(size_t)q * gridDim.x + blockIdx.x] = tot[q];
+  }
+}
+
+// block_out[q][nblocks] -> host_result[q]; one block of 256 threads
+__global__ __launch_bounds__(256) void k_final_sum(const double * block_out, unsigned nblocks,
+                                                   unsigned nq, double * host_result)
+{
+  __shared__ double scratch[4];
+  for (unsigned q = 0; q < nq; ++q)
+  {
+    double a = 0.0;
+    for (unsigned b = threadIdx.x; b < nblocks; b += 256) a += block_out[(size_t)q * nblocks + b];
+    const double t = block_sum_256(a, scratch);
+    if (threadIdx.x == 0) host_result[q] = t;
+  }
+}
+
+__device__ inline void grid_reduce_finish1(double a, const ReduceOut & ro, double * scratch)
+{
+  const double t[1] = {a};
+  grid_reduce_finish<1>(t, ro, scratch);
+}
+
+__device__ inline void grid_reduce_finish2(double a, double b, const ReduceOut & ro, double * scratch)
+{
+  const double t[2] = {a, b};
+  grid_reduce_finish<2>(t, ro, scratch);
+}
+
 // log of the site likelihood.  x is the likelihood carrying `cnt` scaling
 // steps (true value x * 2^(-256 cnt)); inv is the unscaled invariant-site
 // term.  Same case split as the oracle (oracle/orc_kernels.c site_loglh).

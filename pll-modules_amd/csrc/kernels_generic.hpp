@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_edge_lnl_generic(ModelView mv, ParamIdx
                                                           const int * invariant,
                                                           const unsigned long long * tipmap,
                                                           unsigned N, unsigned R,
-                                                          double * persite, double * block_out)
+                                                          double * persite, ReduceOut block_out)
 {
   __shared__ double scratch[4];
   const unsigned S = mv.S, Sp = mv.Sp;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void k_edge_lnl_generic(ModelView mv, ParamIdx
     acc += l * (double)weights[n];
   }
   const double tot = block_sum_256(acc, scratch);
-  if (threadIdx.x == 0) block_out[blockIdx.x] = tot;
+  grid_reduce_finish1(tot, block_out, scratch);
 }
 
 // ---------------------------------------------------------------------------
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void k_derivatives_generic(ModelView mv, Param
                                                              const unsigned * weights,
                                                              const int * invariant,
                                                              unsigned N, unsigned R,
-                                                             double * block_out)
+                                                             ReduceOut block_out)
 {
   extern __shared__ double lds[];          // e0 | e1 | e2, each R*S
   __shared__ double scratch[4];
@@ -342,11 +342,7 @@ __global__ __launch_bounds__(256) void k_derivatives_generic(ModelView mv, Param
   }
   const double tdf = block_sum_256(df, scratch);
   const double tddf = block_sum_256(ddf, scratch);
-  if (threadIdx.x == 0)
-  {
-    block_out[blockIdx.x] = tdf;
-    block_out[gridDim.x + blockIdx.x] = tddf;
-  }
+  grid_reduce_finish2(tdf, tddf, block_out, scratch);
 }
 
 // ---------------------------------------------------------------------------
@@ -426,7 +422,7 @@ static int launch_edge_lnl_generic(Engine * e, const ModelView & mv, const Param
 {
   hipLaunchKernelGGL(k_edge_lnl_generic, dim3(nblocks), dim3(256), 0, e->stream,
                      mv, fidx, parent, child, pm, lut, e->lut_codes, ps, cs,
-                     e->d_weights, e->d_invariant, e->d_tipmap, e->N, e->R, persite, e->d_partials);
+                     e->d_weights, e->d_invariant, e->d_tipmap, e->N, e->R, persite, reduce_out(e));
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }
@@ -450,7 +446,7 @@ static int launch_derivatives_generic(Engine * e, const ModelView & mv, const Pa
   const size_t lds = sizeof(double) * 3 * e->R * e->S;
   hipLaunchKernelGGL(k_derivatives_generic, dim3(nblocks), dim3(256), lds, e->stream,
                      mv, params, t, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->R,
-                     e->d_partials);
+                     reduce_out(e));
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

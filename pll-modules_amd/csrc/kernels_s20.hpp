@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_lnl_s20(ModelView mv, ParamIdx 
                                                          const unsigned * weights, const int * invariant,
                                                          const unsigned long long * tipmap,
                                                          unsigned N, unsigned nblk, unsigned R,
-                                                         double * persite, double * block_out)
+                                                         double * persite, ReduceOut block_out)
 {
   extern __shared__ double frag[];
   __shared__ double scratch[4];
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_lnl_s20(ModelView mv, ParamIdx 
     }
   }
   const double tot = block_sum_256(acc, scratch);
-  if (threadIdx.x == 0) block_out[blockIdx.x] = tot;
+  grid_reduce_finish1(tot, block_out, scratch);
 }
 
 // ---------------------------------------------------------------------------
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void k_derivatives_s20(ModelView mv, ParamIdx 
                                                          const unsigned * ps, const unsigned * cs,
                                                          const unsigned * weights, const int * invariant,
                                                          unsigned N, unsigned nblk, unsigned R,
-                                                         double * block_out)
+                                                         ReduceOut block_out)
 {
   extern __shared__ double coef[];        // e0 | e1 | e2, each [R][20]
   __shared__ double scratch[4];
@@ -447,11 +447,7 @@ __global__ __launch_bounds__(256) void k_derivatives_s20(ModelView mv, ParamIdx 
   }
   const double tdf = block_sum_256(df, scratch);
   const double tddf = block_sum_256(ddf, scratch);
-  if (threadIdx.x == 0)
-  {
-    block_out[blockIdx.x] = tdf;
-    block_out[gridDim.x + blockIdx.x] = tddf;
-  }
+  grid_reduce_finish2(tdf, tddf, block_out, scratch);
 }
 
 // ---------------------------------------------------------------------------
@@ -520,7 +516,7 @@ static int launch_edge_lnl_s20(Engine * e, const ModelView & mv, const ParamIdx 
   hipLaunchKernelGGL(k_edge_lnl_s20, dim3(nblocks), dim3(256), lds, e->stream,
                      mv, fidx, parent, child, pm, lut, e->lut_codes, ps, cs,
                      e->d_weights, e->d_invariant, e->d_tipmap, e->N, e->nblk, e->R,
-                     persite, e->d_partials);
+                     persite, reduce_out(e));
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }
@@ -562,7 +558,7 @@ static int launch_derivatives_s20(Engine * e, const ModelView & mv, const ParamI
   const size_t lds = sizeof(double) * 3 * e->R * 20;
   hipLaunchKernelGGL(k_derivatives_s20, dim3(nblocks), dim3(256), lds, e->stream,
                      mv, params, t, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R,
-                     e->d_partials);
+                     reduce_out(e));
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

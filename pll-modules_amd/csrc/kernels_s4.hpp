@@ -3,12 +3,16 @@
 // Roofline: a 4-state site-update moves 24*4 + 12/R bytes and needs 68 flops
 // (AI 0.69 flop/B): purely HBM-bound, so the design goal is nothing but
 // perfectly streaming access:
-//   * one lane per (site, rate) column; consecutive lanes = consecutive 32-byte
-//     CLV vectors, so a wave reads and writes contiguous 2 KiB runs;
-//   * the lane's rate is invariant under the grid stride (stride is a multiple
-//     of R), so its two 4x4 P-matrices stay in 64 VGPRs for the whole kernel;
-//   * the per-site scaling vote and the sum over rates are R-lane butterfly
-//     shuffles (R is a power of two <= 16 in this family);
+//   * partials: two lanes per (site, rate) column, 16 bytes each, so every wave
+//     load/store is one contiguous 1 KiB run; the halves meet through one xor-1
+//     lane exchange per output (k_partials_s4);
+//   * reductions (edge lnL, derivatives): one lane per column, four grid-stride
+//     steps per trip so that 8 loads per lane are in flight;
+//   * a lane's rate (and half) is invariant under the grid stride, so its
+//     P-matrix entries stay in VGPRs for the whole kernel;
+//   * the per-site scaling vote and the sum over rates are butterfly shuffles
+//     over the lanes of a site (R is a power of two <= 16 in this family, so
+//     all index arithmetic is shifts and masks);
 //   * coded tips cost 1 byte per site: the child term is a 32-byte gather from
 //     the 2 KiB per-matrix lookup table (L1/L2 resident).
 #pragma once
@@ -55,69 +59,102 @@ __device__ inline d4 tip_value4(unsigned long long mask)
             (double)((mask >> 2) & 1ULL), (double)((mask >> 3) & 1ULL)};
 }
 
-// grid = (gx, ops), block = 256.  total columns = N*R; gx*256 is a multiple of R.
+// Partials, lane-pair mapping: two lanes per (site, rate) column, each owning
+// two of the four states.  Lane g loads and stores the 16-byte half-vector at
+// byte g*16 of the CLV, so every wave instruction moves one contiguous 1 KiB run.
+//   own_a = sum_b P[2h+a][2h+b] c[2h+b]        (this lane's outputs, own inputs)
+//   oth_a = sum_b P[2(1-h)+a][2h+b] c[2h+b]    (partner's outputs, own inputs)
+//   out_a = own_a + partner's oth_a            (one xor-1 lane exchange per value)
+// The lane's half h and rate r are invariant under the grid stride (a multiple of
+// 2R), so its 16 P-matrix entries stay in 32 VGPRs.
+// grid = (gx, ops), block = 256.
+struct HalfP { double own[4], oth[4]; };   // [a*2+b]
+
+__device__ inline HalfP s4_load_half_p(const double * pmat, unsigned r, unsigned h)
+{
+  HalfP q;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+    {
+      q.own[a * 2 + b] = pmat[r * 16 + (2 * h + a) * 4 + 2 * h + b];
+      q.oth[a * 2 + b] = pmat[r * 16 + (2 * (1 - h) + a) * 4 + 2 * h + b];
+    }
+  return q;
+}
+
+__device__ inline double2 s4_half_matvec(const HalfP & q, const double2 c)
+{
+  const double own0 = q.own[0] * c.x + q.own[1] * c.y, own1 = q.own[2] * c.x + q.own[3] * c.y;
+  const double oth0 = q.oth[0] * c.x + q.oth[1] * c.y, oth1 = q.oth[2] * c.x + q.oth[3] * c.y;
+  return make_double2(own0 + __shfl_xor(oth0, 1, 64), own1 + __shfl_xor(oth1, 1, 64));
+}
+
 __global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, unsigned R,
                                                      unsigned lut_codes)
 {
   const OpDesc & op = batch.op[blockIdx.y];
-  const unsigned long long total = (unsigned long long)N * R;
+  const unsigned long long total = 2ULL * N * R;              // half-columns
   const unsigned long long stride = (unsigned long long)gridDim.x * 256ULL;
   unsigned long long g = (unsigned long long)blockIdx.x * 256ULL + threadIdx.x;
-  const unsigned r = (unsigned)(g % R);
+  const unsigned h = (unsigned)(g & 1ULL), r = (unsigned)((g >> 1) & (R - 1));
+  const unsigned group = 2 * R;                               // lanes per site
+  const unsigned rs = (unsigned)__ffs((int)R) - 1;           // R is a power of two in this family
 
-  double P1[16], P2[16];
-  if (!op.codes1)
-  {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) P1[q] = op.pmat1[r * 16 + q];
-  }
-  if (!op.codes2)
-  {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) P2[q] = op.pmat2[r * 16 + q];
-  }
+  HalfP p1 = {}, p2 = {};
+  if (!op.codes1) p1 = s4_load_half_p(op.pmat1, r, h);
+  if (!op.codes2) p2 = s4_load_half_p(op.pmat2, r, h);
 
-  // whole waves iterate together so that the shuffles below see full groups
+  // whole waves iterate together (shuffles); two grid-stride steps per trip
   const unsigned long long limit = (total + 63ULL) & ~63ULL;
-  for (; g < limit; g += stride)
+  for (; g < limit; g += 2 * stride)
   {
-    const bool live = g < total;
-    const unsigned long long n = g / R;
-    d4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-    if (live)
+    double2 in1[2], in2[2];
+    unsigned long long nn[2];
+    bool live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
     {
-      if (op.codes1)
-        a = load4(op.lut1 + ((size_t)r * lut_codes + op.codes1[n]) * 4);
-      else
+      const unsigned long long gu = g + u * stride;
+      live[u] = gu < total;
+      nn[u] = live[u] ? (gu >> 1) >> rs : 0;
+      in1[u] = in2[u] = make_double2(0.0, 0.0);
+      if (live[u])
       {
-        const d4 c = load4(op.clv1 + g * 4);
-        a = d4{dot4(P1, c), dot4(P1 + 4, c), dot4(P1 + 8, c), dot4(P1 + 12, c)};
-      }
-      if (op.codes2)
-        b = load4(op.lut2 + ((size_t)r * lut_codes + op.codes2[n]) * 4);
-      else
-      {
-        const d4 c = load4(op.clv2 + g * 4);
-        b = d4{dot4(P2, c), dot4(P2 + 4, c), dot4(P2 + 8, c), dot4(P2 + 12, c)};
+        in1[u] = op.codes1
+          ? *reinterpret_cast<const double2 *>(op.lut1 + ((size_t)r * lut_codes + op.codes1[nn[u]]) * 4 + 2 * h)
+          : *reinterpret_cast<const double2 *>(op.clv1 + gu * 2);
+        in2[u] = op.codes2
+          ? *reinterpret_cast<const double2 *>(op.lut2 + ((size_t)r * lut_codes + op.codes2[nn[u]]) * 4 + 2 * h)
+          : *reinterpret_cast<const double2 *>(op.clv2 + gu * 2);
       }
     }
-    d4 v = {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w};
-    if (op.parent_scaler)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
     {
-      int big = live && !(v.x < SCALE_THRESHOLD && v.y < SCALE_THRESHOLD &&
-                          v.z < SCALE_THRESHOLD && v.w < SCALE_THRESHOLD);
-      big = group_or(big, R);
-      if (live)
+      const unsigned long long gu = g + u * stride;
+      if (gu >= limit) break;                                 // wave-uniform
+      const double2 a = op.codes1 ? in1[u] : s4_half_matvec(p1, in1[u]);
+      const double2 b = op.codes2 ? in2[u] : s4_half_matvec(p2, in2[u]);
+      double2 v = make_double2(a.x * b.x, a.y * b.y);
+      if (op.parent_scaler)
       {
-        if (!big) { v.x *= SCALE_FACTOR; v.y *= SCALE_FACTOR; v.z *= SCALE_FACTOR; v.w *= SCALE_FACTOR; }
-        if (r == 0)
+        int big = live[u] && !(v.x < SCALE_THRESHOLD && v.y < SCALE_THRESHOLD);
+        big = group_or(big, group);
+        if (live[u])
         {
-          const unsigned cnt = (op.scaler1 ? op.scaler1[n] : 0u) + (op.scaler2 ? op.scaler2[n] : 0u);
-          op.parent_scaler[n] = cnt + (big ? 0u : 1u);
+          if (!big) { v.x *= SCALE_FACTOR; v.y *= SCALE_FACTOR; }
+          if ((gu & (group - 1)) == 0)
+          {
+            const unsigned long long n = nn[u];
+            const unsigned cnt = (op.scaler1 ? op.scaler1[n] : 0u) + (op.scaler2 ? op.scaler2[n] : 0u);
+            op.parent_scaler[n] = cnt + (big ? 0u : 1u);
+          }
         }
       }
+      if (live[u]) *reinterpret_cast<double2 *>(op.parent + gu * 2) = v;
     }
-    if (live) store4(op.parent + g * 4, v);
   }
 }
 
@@ -130,13 +167,14 @@ __global__ __launch_bounds__(256) void k_edge_lnl_s4(ModelView mv, ParamIdx fidx
                                                      const unsigned * weights, const int * invariant,
                                                      const unsigned long long * tipmap,
                                                      unsigned N, unsigned R,
-                                                     double * persite, double * block_out)
+                                                     double * persite, ReduceOut block_out)
 {
   __shared__ double scratch[4];
   const unsigned long long total = (unsigned long long)N * R;
   const unsigned long long stride = (unsigned long long)gridDim.x * 256ULL;
   unsigned long long g = (unsigned long long)blockIdx.x * 256ULL + threadIdx.x;
-  const unsigned r = (unsigned)(g % R);
+  const unsigned r = (unsigned)(g & (R - 1));
+  const unsigned rs = (unsigned)__ffs((int)R) - 1;
   const unsigned fi = fidx.v[r];
   const double * pi = mv.freqs(fi);
   const d4 f = {pi[0], pi[1], pi[2], pi[3]};
@@ -161,7 +199,7 @@ __global__ __launch_bounds__(256) void k_edge_lnl_s4(ModelView mv, ParamIdx fidx
     {
       const unsigned long long gu = g + u * stride;
       live[u] = gu < total;
-      nn[u] = live[u] ? gu / R : 0;
+      nn[u] = live[u] ? gu >> rs : 0;
       cv[u] = d4{0, 0, 0, 0};
       pv[u] = d4{0, 0, 0, 0};
       if (live[u])
@@ -197,7 +235,7 @@ __global__ __launch_bounds__(256) void k_edge_lnl_s4(ModelView mv, ParamIdx fidx
     }
   }
   const double tot = block_sum_256(acc, scratch);
-  if (threadIdx.x == 0) block_out[blockIdx.x] = tot;
+  grid_reduce_finish1(tot, block_out, scratch);
 }
 
 // sumtable: lane = (site, rate)
@@ -209,7 +247,8 @@ __global__ __launch_bounds__(256) void k_sumtable_s4(ModelView mv, ParamIdx para
   const unsigned long long total = (unsigned long long)N * R;
   const unsigned long long stride = (unsigned long long)gridDim.x * 256ULL;
   unsigned long long g = (unsigned long long)blockIdx.x * 256ULL + threadIdx.x;
-  const unsigned r = (unsigned)(g % R);
+  const unsigned r = (unsigned)(g & (R - 1));
+  const unsigned rs = (unsigned)__ffs((int)R) - 1;
   const unsigned pi_ = params.v[r];
   const double * pi = mv.freqs(pi_), * V = mv.evecs(pi_), * Vi = mv.ievecs(pi_);
   double L[16], Rm[16];        // L[k][i] = pi_i V[i][k];  Rm[k][j] = Vinv[k][j]
@@ -223,7 +262,7 @@ __global__ __launch_bounds__(256) void k_sumtable_s4(ModelView mv, ParamIdx para
     }
   for (; g < total; g += stride)
   {
-    const unsigned long long n = g / R;
+    const unsigned long long n = g >> rs;
     const d4 pv = parent.codes ? tip_value4(tipmap[parent.codes[n]]) : load4(parent.clv + g * 4);
     const d4 cv = child.codes ? tip_value4(tipmap[child.codes[n]]) : load4(child.clv + g * 4);
     const d4 out = {dot4(L, pv) * dot4(Rm, cv), dot4(L + 4, pv) * dot4(Rm + 4, cv),
@@ -237,13 +276,14 @@ __global__ __launch_bounds__(256) void k_derivatives_s4(ModelView mv, ParamIdx p
                                                         const double * sumtable,
                                                         const unsigned * ps, const unsigned * cs,
                                                         const unsigned * weights, const int * invariant,
-                                                        unsigned N, unsigned R, double * block_out)
+                                                        unsigned N, unsigned R, ReduceOut block_out)
 {
   __shared__ double scratch[4];
   const unsigned long long total = (unsigned long long)N * R;
   const unsigned long long stride = (unsigned long long)gridDim.x * 256ULL;
   unsigned long long g = (unsigned long long)blockIdx.x * 256ULL + threadIdx.x;
-  const unsigned r = (unsigned)(g % R);
+  const unsigned r = (unsigned)(g & (R - 1));
+  const unsigned rs = (unsigned)__ffs((int)R) - 1;
   const unsigned pi_ = params.v[r];
   const double pinv = mv.pinv()[pi_];
   const double rho = mv.rates()[r] / (1.0 - pinv);
@@ -277,7 +317,7 @@ __global__ __launch_bounds__(256) void k_derivatives_s4(ModelView mv, ParamIdx p
     {
       const unsigned long long gu = g + u * stride;
       if (gu >= limit) break;                        // wave-uniform
-      const unsigned long long n = live[u] ? gu / R : 0;
+      const unsigned long long n = live[u] ? gu >> rs : 0;
       double A = dot4(e0, sv[u]), B = dot4(e1, sv[u]), C = dot4(e2, sv[u]), inv = 0.0;
       if (live[u] && winv > 0.0 && invariant && invariant[n] >= 0)
         inv = winv * mv.freqs(pi_)[invariant[n]];
@@ -300,11 +340,7 @@ __global__ __launch_bounds__(256) void k_derivatives_s4(ModelView mv, ParamIdx p
   }
   const double tdf = block_sum_256(df, scratch);
   const double tddf = block_sum_256(ddf, scratch);
-  if (threadIdx.x == 0)
-  {
-    block_out[blockIdx.x] = tdf;
-    block_out[gridDim.x + blockIdx.x] = tddf;
-  }
+  grid_reduce_finish2(tdf, tddf, block_out, scratch);
 }
 
 // --- launchers -------------------------------------------------------------
@@ -318,8 +354,10 @@ static unsigned s4_grid(const Engine * e, unsigned cap_blocks)
 
 static int launch_partials_s4(Engine * e, const OpBatch & batch, unsigned nops)
 {
-  // 256 threads is a multiple of every admissible R, so stride % R == 0
-  const unsigned gx = s4_grid(e, e->cu_count * 16u);
+  // two lanes per column; 256 threads is a multiple of 2R for every admissible R
+  const unsigned long long need = (2ULL * e->N * e->R + 511ULL) / 512ULL;   // 2 steps per trip
+  const unsigned gx = (unsigned)std::max<unsigned long long>(
+      1ULL, std::min<unsigned long long>(need, (unsigned long long)e->cu_count * 16ULL));
   hipLaunchKernelGGL(k_partials_s4, dim3(gx, nops), dim3(256), 0, e->stream,
                      batch, e->N, e->R, e->lut_codes);
   PLLHIP_TRY(hipGetLastError());
@@ -334,7 +372,7 @@ static int launch_edge_lnl_s4(Engine * e, const ModelView & mv, const ParamIdx &
 {
   hipLaunchKernelGGL(k_edge_lnl_s4, dim3(nblocks), dim3(256), 0, e->stream,
                      mv, fidx, parent, child, pm, lut, e->lut_codes, ps, cs,
-                     e->d_weights, e->d_invariant, e->d_tipmap, e->N, e->R, persite, e->d_partials);
+                     e->d_weights, e->d_invariant, e->d_tipmap, e->N, e->R, persite, reduce_out(e));
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }
@@ -355,7 +393,7 @@ static int launch_derivatives_s4(Engine * e, const ModelView & mv, const ParamId
 {
   hipLaunchKernelGGL(k_derivatives_s4, dim3(nblocks), dim3(256), 0, e->stream,
                      mv, params, t, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->R,
-                     e->d_partials);
+                     reduce_out(e));
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

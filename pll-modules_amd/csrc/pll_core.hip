@@ -156,6 +156,12 @@ Engine * engine_create(pll_partition_t * p)
   ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void **>(&e->h_partials),
                                   3 * REDUCE_BLOCKS * sizeof(double), hipHostMallocDefault),
                     "hipHostMalloc");
+  ok = ok && dev_alloc(&e->d_counter, (size_t)4, "reduction ticket");
+  ok = ok && hip_ok(hipMemsetAsync(e->d_counter, 0, 4 * sizeof(unsigned), e->stream), "memset ticket");
+  ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void **>(&e->h_result), 8 * sizeof(double),
+                                  hipHostMallocMapped), "hipHostMalloc result");
+  ok = ok && hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->d_result), e->h_result, 0),
+                    "hipHostGetDevicePointer");
   e->pmat_brlen.assign(e->nmat, std::numeric_limits<double>::quiet_NaN());
   e->pmat_params.assign(e->nmat, std::vector<unsigned>());
 
@@ -206,6 +212,8 @@ void engine_destroy(Engine * e)
   (void)hipFree(e->d_persite);
   (void)hipFree(e->d_sum_scratch);
   if (e->h_partials) (void)hipHostFree(e->h_partials);
+  if (e->h_result) (void)hipHostFree(e->h_result);
+  (void)hipFree(e->d_counter);
   for (auto & ev : e->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -462,18 +470,15 @@ static unsigned reduce_grid(const Engine * e)
   return (unsigned)std::max<unsigned long long>(1ULL, std::min<unsigned long long>(need, REDUCE_BLOCKS));
 }
 
-// finish a reduction: copy `n_quant` rows of `nblocks` partials, sum on host
+// finish a reduction: a single-block kernel adds the block totals in a fixed
+// order straight into pinned host memory; then wait for the stream
 static int finish_reduction(Engine * e, unsigned nblocks, unsigned n_quant, double * out)
 {
-  PLLHIP_TRY(hipMemcpyAsync(e->h_partials, e->d_partials, sizeof(double) * nblocks * n_quant,
-                            hipMemcpyDeviceToHost, e->stream));
+  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, e->stream,
+                     e->d_partials, nblocks, n_quant, e->d_result);
+  PLLHIP_TRY(hipGetLastError());
   PLLHIP_TRY(hipStreamSynchronize(e->stream));
-  for (unsigned q = 0; q < n_quant; ++q)
-  {
-    double s = 0.0;
-    for (unsigned b = 0; b < nblocks; ++b) s += e->h_partials[(size_t)q * nblocks + b];
-    out[q] = s;
-  }
+  for (unsigned q = 0; q < n_quant; ++q) out[q] = e->h_result[q];
   return PLL_SUCCESS;
 }
 

@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Secondary workloads of SURVEY.md section 8d on one GPU, driven through the C ABI:
+
+  W2  Newton-Raphson inner loop: 1 pll_update_sumtable + 16
+      pll_compute_likelihood_derivatives on one branch
+      (src/optimize/pll_optimize.c:1468, 1249)
+  W3  SPR-like scoring: 1000 x {2 pll_update_prob_matrices, a 1-3 op
+      pll_update_partials, 1 pll_compute_edge_loglikelihood}
+      (src/algorithm/algo_search.c:786-790)
+  C4  multi-partition mixed DNA + protein (2 x 250k DNA + 2 x 125k AA sites,
+      100 taxa, linked branch lengths): one full evaluation = loop over the
+      partitions + sum, as treeinfo_compute_loglh does (src/tree/treeinfo.c:1024-1067)
+
+Every call goes through ctypes, i.e. ~2-5 us of Python per call sit inside the
+W3 timings; a C caller pays less.
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pll-modules_amd"))
+import numpy as np  # noqa: E402
+import pllhip_ctypes as pc  # noqa: E402
+
+NONE = pc.PLL_SCALE_BUFFER_NONE
+
+
+def w2(lib, cfg, out):
+    S, R, ntips, N = pc.CONFIGS[cfg]
+    ntips = min(ntips, 16)
+    inst = pc.build_instance(lib, states=S, rate_cats=R, ntips=ntips, nsites=N, coded=True)
+    with inst:
+        pc.full_traversal(inst)
+        t = inst.tree
+        # an inner-inner branch near the root
+        op = next(o for o in reversed(t.ops) if o[2] >= ntips and o[5] >= ntips)
+        p_clv, c_clv = op[0], op[2]
+        st = inst.alloc_sumtable()
+        args = (p_clv, c_clv, t.scaler_of(p_clv), t.scaler_of(c_clv))
+        brl = np.geomspace(1e-3, 2.0, 16)
+
+        def once():
+            inst.update_sumtable(*args, st)
+            for b in brl:
+                inst.derivatives(args[2], args[3], float(b), st)
+        once()
+        lib.lib.pllhip_synchronize(inst.p)
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            once()
+        dt = (time.perf_counter() - t0) / reps
+        nbytes = N * R * 8 * S * (3 + 16)
+        out[f"W2_{cfg}"] = {"ms": dt * 1e3, "us_per_derivative_call": (dt * 1e6) / 17,
+                            "algorithmic_GBps": nbytes / dt / 1e9,
+                            "what": "1 sumtable + 16 derivative evaluations, host sync per derivative"}
+        inst.free_sumtable(st)
+
+
+def w3(lib, cfg, out, nsites=None):
+    S, R, ntips, N = pc.CONFIGS[cfg]
+    N = nsites or N
+    inst = pc.build_instance(lib, states=S, rate_cats=R, ntips=ntips, nsites=N, coded=True)
+    with inst:
+        pc.full_traversal(inst)
+        t = inst.tree
+        rnd = pc.splitmix64(77, 4000)
+        tail = t.ops[-3:]
+        sa, sb = t.scaler_of(t.root_a), t.scaler_of(t.root_b)
+        arrs = {k: inst.make_ops(tail[-k:]) for k in (1, 2, 3)}
+        mi = np.zeros(2, dtype=np.uint32)
+        bl = np.zeros(2)
+        mi_p, bl_p = mi.ctypes.data_as(pc.c_uint_p), bl.ctypes.data_as(pc.c_double_p)
+        L = lib.lib
+
+        def run(n):
+            updates = 0
+            for i in range(n):
+                k = 1 + int(rnd[3 * i] % np.uint64(3))
+                ops = tail[-k:]
+                mi[0], mi[1] = ops[0][3], ops[0][6]
+                bl[0] = 0.01 + float(rnd[3 * i + 1] % np.uint64(1000)) * 2e-4
+                bl[1] = 0.01 + float(rnd[3 * i + 2] % np.uint64(1000)) * 2e-4
+                L.pll_update_prob_matrices(inst.p, inst.params_p, mi_p, bl_p, 2)
+                inst.update_partials(arrs[k], k)
+                inst.edge_lnl(t.root_a, sa, t.root_b, sb, t.root_matrix)
+                updates += k
+            return updates
+        run(20)
+        L.pllhip_synchronize(inst.p)
+        t0 = time.perf_counter()
+        upd = run(1000)
+        dt = time.perf_counter() - t0
+        out[f"W3_{cfg}_{N}"] = {"ms_total": dt * 1e3, "us_per_iteration": dt * 1e3,
+                                "site_updates_per_s": upd * N * R / dt,
+                                "what": "1000 x {2 P-matrix updates, 1-3 partial ops, 1 edge lnL}"}
+
+
+def c4(lib, out):
+    tree = pc.Tree(100)
+    parts = [pc.build_instance(lib, states=4, rate_cats=4, ntips=100, nsites=250_000, coded=True, tree=tree, seed_shift=s)
+             for s in (0, 1)]
+    parts += [pc.build_instance(lib, states=20, rate_cats=4, ntips=100, nsites=125_000, coded=True, tree=tree, seed_shift=s)
+              for s in (2, 3)]
+    for p in parts:
+        p.tree = tree
+
+    def evaluate():
+        return sum(pc.full_traversal(p, one_by_one_pmatrices=True) for p in parts)
+    lnl = evaluate()
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lnl = evaluate()
+    dt = (time.perf_counter() - t0) / reps
+    upd = sum(len(tree.ops) * p.N * p.R for p in parts)
+    out["C4_1gpu"] = {"ms_per_evaluation": dt * 1e3, "site_updates_per_s": upd / dt, "lnl": lnl,
+                      "what": "2 x 250k-site DNA + 2 x 125k-site protein partitions, 100 taxa, linked "
+                              "branch lengths, per-branch P-matrix calls, partitions evaluated in turn"}
+    for p in parts:
+        p.close()
+
+
+def main():
+    lib = pc.PllLib(pc.PRODUCT_LIB)
+    out = {}
+    which = sys.argv[1:] or ["w2", "w3", "c4"]
+    if "w2" in which:
+        w2(lib, "c3", out)
+        w2(lib, "c2", out)
+    if "w3" in which:
+        w3(lib, "c3", out)
+        w3(lib, "c2", out)
+        w3(lib, "c3", out, nsites=125_000)
+    if "c4" in which:
+        c4(lib, out)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
