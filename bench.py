@@ -3,10 +3,12 @@
 
 One "step" = one full likelihood evaluation of the synthetic partition
 (workload W1 of SURVEY.md section 8d, the call pattern of
-treeinfo_compute_loglh, src/tree/treeinfo.c:946-1079): all 2n-3 P-matrices,
-the n-2 partial-likelihood operations of a full post-order traversal, one edge
+treeinfo_compute_loglh, src/tree/treeinfo.c:946-1079): all 2n-3 P-matrices (one
+pll_update_prob_matrices call per branch, as treeinfo issues them), the n-2
+partial-likelihood operations of a full post-order traversal, one edge
 log-likelihood and -- with more than one rank -- the all-reduce of the summed
-lnL through the reference's reduce-callback interface (RCCL over xGMI).
+lnL through the reference's reduce-callback interface (RCCL over xGMI).  The
+step loop runs in C (include/pllhip_eval.h); Python only starts and times it.
 
 Default workload: BASELINE.json's target configuration C3 (20 states, Gamma4,
 200 taxa, 1M sites; the "LG-shaped" seeded model because the real LG table is
@@ -28,10 +30,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pll-modules_amd"))
 
-import numpy as np  # noqa: E402
+import numpy as np  # noqa: E402,F401
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-FP64_PEAK_TFLOPS = 78.6
 
 
 def parse_args():
@@ -51,36 +52,51 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(pc, states, rate_cats, ntips, nsites_gpu, cpu_sites):
+def model_of(pc, states):
+    if states == 4:
+        return pc.DNA_GTR_RATES, pc.DNA_FREQS, 0.841
+    if states == 20:
+        r, f = pc.protein_model()
+        return r, f, 0.5
+    r, f = pc.codon_model()
+    return r, f, 0.5
+
+
+def make_evaluation(pc, lib, tree, states, rate_cats, nsites, seed, per_branch):
+    ev = pc.Evaluation(lib, tree.newick(), flags=1 if per_branch else 0, nparts=1)
+    subst, freqs, alpha = model_of(pc, states)
+    codes = pc.random_codes(tree.ntips, nsites, states, seed)
+    inst = ev.add_partition(0, states, nsites, rate_cats, codes, subst, freqs, alpha, coded=True)
+    return ev, inst
+
+
+def cpu_baseline(pc, tree, states, rate_cats, nsites_gpu, cpu_sites, per_branch):
     """the oracle (a from-scratch CPU port, NOT libpll) timed on the host cores
-    on a bounded sample of the same workload: same tree, model and tip
-    generator, fewer sites, scaled to ~10-30 s of CPU work"""
+    on a bounded sample of the same workload: same tree, model, tip generator and
+    C driver, fewer sites, sized for ~10-30 s of CPU work"""
     threads = min(os.cpu_count() or 1, 16)      # the 1-GPU box share of host cores
     os.environ.setdefault("OMP_NUM_THREADS", str(threads))
     os.environ.setdefault("OMP_PROC_BIND", "close")
-    oracle_path = os.path.join(ROOT, "oracle", "_build", "libpll_oracle.so")
-    oracle = pc.PllLib(oracle_path)
-    # per-site-update cost on one core is ~ (4 S^2 + S) flops at ~1-2 GFLOP/s scalar
+    oracle = pc.PllLib(os.path.join(ROOT, "oracle", "_build", "libpll_oracle.so"))
+    ntips = tree.ntips
     if not cpu_sites:
-        per_update = (4.0 * states * states + states) / 1.5e9
-        budget = 15.0 * threads
-        cpu_sites = int(budget / (per_update * rate_cats * (ntips - 2)))
+        per_update = (4.0 * states * states + states) / 1.5e9      # ~scalar flop rate of one core
+        cpu_sites = int(15.0 * threads / (per_update * rate_cats * (ntips - 2)))
         cpu_sites = max(1000, min(nsites_gpu, cpu_sites // 1000 * 1000))
-    inst = pc.build_instance(oracle, states=states, rate_cats=rate_cats, ntips=ntips,
-                             nsites=cpu_sites, coded=True)
-    with inst:
-        pc.full_traversal(inst)                       # warm-up
+    ev, _ = make_evaluation(pc, oracle, tree, states, rate_cats, cpu_sites, 44, per_branch)
+    with ev:
+        ev.loglh()                                  # warm-up
         t0 = time.perf_counter()
         reps = 0
         while True:
-            lnl = pc.full_traversal(inst)
+            lnl = ev.loglh()
             reps += 1
             if time.perf_counter() - t0 > 10.0 or reps >= 5:
                 break
         dt = time.perf_counter() - t0
     updates = reps * (ntips - 2) * cpu_sites * rate_cats
     return {"value": updates / dt, "unit": "CLV site-updates/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} full traversals of the same tree/model with {cpu_sites} sites "
+            "sample": f"{reps} full evaluations of the same tree/model with {cpu_sites} sites "
                       f"(oracle/, plain C + OpenMP over sites, {threads} threads); lnL/site "
                       f"{lnl / cpu_sites:.6f}"}
 
@@ -114,16 +130,22 @@ def main():
     if args.taxa:
         ntips = args.taxa
     if args.scaling == "strong" and world > 1:
-        lo = nsites * rank // world
-        hi = nsites * (rank + 1) // world
-        local_sites = hi - lo
+        local_sites = nsites * (rank + 1) // world - nsites * rank // world
         total_sites = nsites
     else:
         local_sites = nsites
         total_sites = nsites * world
+    per_branch = args.pmatrix_calls == "per-branch"
+
+    tree = pc.Tree(ntips, 42, 43)
+    # every rank owns a different slice of the alignment (different tip seed)
+    ev, inst = make_evaluation(pc, product, tree, states, rate_cats, local_sites, 44 + 7919 * rank,
+                               per_branch)
 
     if world > 1:
-        # the native reduce callback (RCCL in C) gets its unique id through torch's store
+        # the native reduce callback (RCCL in C, behind the reference's parallel_reduce_cb
+        # signature) gets its unique id through torch's store; the driver calls it after
+        # every edge log-likelihood, exactly where treeinfo does (src/tree/treeinfo.c:1061)
         idbuf = C.create_string_buffer(128)
         if rank == 0 and not product.lib.pllhip_comm_get_unique_id(idbuf):
             raise SystemExit(product.errmsg)
@@ -132,25 +154,10 @@ def main():
         comm = product.lib.pllhip_comm_create(obj[0], rank, world, local_rank)
         if not comm:
             raise SystemExit(product.errmsg)
+        cb = C.cast(product.lib.pllhip_reduce_cb, C.c_void_p)
+        product.lib.pllhip_eval_set_parallel_context(ev.ev, comm, cb)
 
-    # each rank owns a different slice of the alignment (different tip seed)
-    inst = pc.build_instance(product, states=states, rate_cats=rate_cats, ntips=ntips,
-                             nsites=local_sites, coded=True, seed_shift=0)
-    if world > 1 and rank > 0:
-        cmap = pc.state_charmap(states)
-        codes = pc.random_codes(ntips, local_sites, states, 44 + 7919 * rank)
-        for t in range(ntips):
-            inst.set_tip_states(t, cmap, (codes[t] + 48).tobytes())
-    tree = inst.tree
-    nops = len(tree.ops)
-    lnl_buf = np.zeros(1)
-    per_branch = args.pmatrix_calls == "per-branch"
-
-    def step():
-        lnl_buf[0] = pc.full_traversal(inst, one_by_one_pmatrices=per_branch)
-        if comm:
-            product.lib.pllhip_reduce_cb(comm, lnl_buf.ctypes.data_as(pc.c_double_p), 1, 0)
-        return lnl_buf[0]
+    nops = ntips - 2
 
     def barrier():
         product.lib.pllhip_synchronize(inst.p)
@@ -161,18 +168,19 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        ev.loglh()
     product.lib.pllhip_profile_partials(inst.p, 1)
     barrier()
     t0 = time.perf_counter()
     lnl = 0.0
     for _ in range(args.steps):
-        lnl = step()
+        lnl = ev.loglh()
     barrier()
     elapsed = time.perf_counter() - t0
     prof = pc.Profile()
     product.lib.pllhip_profile_read(inst.p, C.byref(prof))
     product.lib.pllhip_profile_partials(inst.p, 0)
+    counters = inst.counters()
 
     if dist is not None:
         import torch
@@ -205,9 +213,9 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(pc, states, rate_cats, ntips, local_sites, args.cpu_sites)
+        cpu = cpu_baseline(pc, tree, states, rate_cats, local_sites, args.cpu_sites, per_branch)
 
-    inst.close()
+    ev.close()
     if comm:
         product.lib.pllhip_comm_destroy(comm)
     if dist is not None:
@@ -217,6 +225,7 @@ def main():
     if rank == 0:
         names = {"c2": "C2 DNA GTR+G4", "c3": "C3 protein 'LG-shaped' GTR20+G4 (real LG table unavailable offline)",
                  "c5": "C5 codon GY94-shaped+G4"}
+        evals = max(1, args.steps + args.warmup)
         out = {
             "metric": "CLV site-updates/sec (sites x rates x edges)",
             "value": value, "unit": "CLV site-updates/s",
@@ -232,6 +241,8 @@ def main():
                 "sites_total": total_sites, "sites_per_gpu": local_sites, "ops_per_step": nops,
                 "tips": "1-byte codes", "scalers": "per-site, one per inner node",
                 "pmatrix_calls": args.pmatrix_calls,
+                "pmatrix_launches_per_step": counters.pmatrix_launches // evals,
+                "partial_launches_per_step": counters.partial_launches // evals,
             },
             "lnl": lnl, "lnl_per_site": lnl / total_sites,
             "roofline": roofline,

@@ -1,0 +1,470 @@
+/*
+ * pllhip_eval.c -- evaluation driver on top of include/pll.h (see
+ * include/pllhip_eval.h for scope and the reference functions it mirrors).
+ * Plain C, no device code: everything below is calls into the libpll-style
+ * interface, so the same file serves the HIP library and the CPU oracle.
+ */
+#include "pllhip_eval.h"
+#include <stdarg.h>
+
+struct pllhip_eval
+{
+  pll_utree_t * tree;
+  pll_unode_t * root;
+  unsigned int tips, inner, records, edges, nparts, flags;
+  pll_partition_t ** parts;
+  unsigned int ** params;         /* [partition][rate_cats] */
+  double ** sumtables;            /* [partition], allocated on first use */
+  char * clv_valid;               /* by node_index */
+  char * pmat_valid;              /* by pmatrix_index */
+  pll_unode_t ** trav;
+  pll_operation_t * ops;
+  double * brlens;
+  unsigned int * midx;
+  double * part_lnl;
+  void * ctx;
+  pllhip_reduce_fn reduce_cb;
+  unsigned long n_ops, n_pmat, n_deriv;
+};
+
+static __thread pllhip_eval_t * cb_self;   /* pll_utree_traverse callbacks carry no user pointer */
+
+static void eval_error(int code, const char * fmt, ...)
+{
+  va_list ap;
+  pll_errno = code;
+  va_start(ap, fmt);
+  vsnprintf(pll_errmsg, 200, fmt, ap);
+  va_end(ap);
+}
+
+pllhip_eval_t * pllhip_eval_create(pll_utree_t * tree, unsigned int partition_count, unsigned int flags)
+{
+  unsigned int i;
+  if (!tree || !tree->binary || !partition_count)
+  {
+    eval_error(PLL_ERROR_PARAM_INVALID, "pllhip_eval_create needs a binary tree and >= 1 partition");
+    return NULL;
+  }
+  pllhip_eval_t * ev = (pllhip_eval_t *)calloc(1, sizeof(*ev));
+  if (!ev) goto nomem;
+  ev->tree = tree;
+  ev->tips = tree->tip_count;
+  ev->inner = tree->inner_count;
+  ev->records = ev->tips + 3 * ev->inner;
+  ev->edges = tree->edge_count;
+  ev->nparts = partition_count;
+  ev->flags = flags;
+  ev->parts = (pll_partition_t **)calloc(partition_count, sizeof(*ev->parts));
+  ev->params = (unsigned int **)calloc(partition_count, sizeof(*ev->params));
+  ev->sumtables = (double **)calloc(partition_count, sizeof(*ev->sumtables));
+  ev->part_lnl = (double *)calloc(partition_count, sizeof(double));
+  ev->clv_valid = (char *)calloc(ev->records, 1);
+  ev->pmat_valid = (char *)calloc(ev->edges, 1);
+  ev->trav = (pll_unode_t **)calloc(ev->tips + ev->inner, sizeof(*ev->trav));
+  ev->ops = (pll_operation_t *)calloc(ev->inner, sizeof(*ev->ops));
+  ev->brlens = (double *)calloc(ev->edges, sizeof(double));
+  ev->midx = (unsigned int *)calloc(ev->edges, sizeof(unsigned int));
+  if (!ev->parts || !ev->params || !ev->sumtables || !ev->part_lnl || !ev->clv_valid ||
+      !ev->pmat_valid || !ev->trav || !ev->ops || !ev->brlens || !ev->midx)
+    goto nomem;
+  /* indices must address the flag arrays */
+  for (i = 0; i < ev->tips + ev->inner; ++i)
+  {
+    pll_unode_t * n = tree->nodes[i], * s = n;
+    do
+    {
+      if (s->node_index >= ev->records || s->pmatrix_index >= ev->edges)
+      {
+        eval_error(PLL_ERROR_PARAM_INVALID, "node/pmatrix index out of range in tree record");
+        pllhip_eval_destroy(ev);
+        return NULL;
+      }
+      s = s->next;
+    } while (s && s != n);
+  }
+  ev->root = tree->vroot->next ? tree->vroot : tree->vroot->back;
+  return ev;
+nomem:
+  eval_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate evaluator");
+  pllhip_eval_destroy(ev);
+  return NULL;
+}
+
+void pllhip_eval_destroy(pllhip_eval_t * ev)
+{
+  unsigned int p;
+  if (!ev) return;
+  for (p = 0; p < ev->nparts; ++p)
+  {
+    if (ev->params) free(ev->params[p]);
+    if (ev->sumtables) free(ev->sumtables[p]);   /* pll_aligned_alloc memory is free()-able */
+  }
+  free(ev->parts); free(ev->params); free(ev->sumtables); free(ev->part_lnl);
+  free(ev->clv_valid); free(ev->pmat_valid); free(ev->trav); free(ev->ops);
+  free(ev->brlens); free(ev->midx);
+  free(ev);
+}
+
+int pllhip_eval_set_partition(pllhip_eval_t * ev, unsigned int index, pll_partition_t * partition,
+                              const unsigned int * params_indices)
+{
+  unsigned int r;
+  if (index >= ev->nparts)
+  {
+    eval_error(PLL_ERROR_PARAM_INVALID, "partition index %u out of range", index);
+    return PLL_FAILURE;
+  }
+  if (partition)
+  {
+    if (partition->tips != ev->tips || partition->clv_buffers < ev->inner ||
+        partition->prob_matrices < ev->edges)
+    {
+      eval_error(PLL_ERROR_PARAM_INVALID, "partition %u does not fit the tree", index);
+      return PLL_FAILURE;
+    }
+    free(ev->params[index]);
+    ev->params[index] = (unsigned int *)calloc(partition->rate_cats, sizeof(unsigned int));
+    if (!ev->params[index])
+    {
+      eval_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate params indices");
+      return PLL_FAILURE;
+    }
+    for (r = 0; params_indices && r < partition->rate_cats; ++r) ev->params[index][r] = params_indices[r];
+  }
+  ev->parts[index] = partition;
+  pllhip_eval_invalidate_all(ev);
+  return PLL_SUCCESS;
+}
+
+void pllhip_eval_set_parallel_context(pllhip_eval_t * ev, void * ctx, pllhip_reduce_fn reduce_cb)
+{
+  ev->ctx = ctx;
+  ev->reduce_cb = reduce_cb;
+}
+
+int pllhip_eval_set_root(pllhip_eval_t * ev, pll_unode_t * root)
+{
+  if (!root || !root->next)
+  {
+    eval_error(PLL_ERROR_PARAM_INVALID, "the root must be an inner node record");
+    return PLL_FAILURE;
+  }
+  ev->root = root;
+  return PLL_SUCCESS;
+}
+
+pll_unode_t * pllhip_eval_root(const pllhip_eval_t * ev) { return ev->root; }
+
+void pllhip_eval_invalidate_all(pllhip_eval_t * ev)
+{
+  memset(ev->clv_valid, 0, ev->records);
+  memset(ev->pmat_valid, 0, ev->edges);
+}
+
+void pllhip_eval_invalidate_pmatrix(pllhip_eval_t * ev, const pll_unode_t * edge)
+{
+  ev->pmat_valid[edge->pmatrix_index] = 0;
+}
+
+void pllhip_eval_invalidate_clv(pllhip_eval_t * ev, const pll_unode_t * node)
+{
+  ev->clv_valid[node->node_index] = 0;
+}
+
+void pllhip_eval_set_branch_length(pllhip_eval_t * ev, pll_unode_t * edge, double length)
+{
+  edge->length = edge->back->length = length;
+  ev->pmat_valid[edge->pmatrix_index] = 0;
+  /* every CLV that looks across this edge depends on it: all records on the far
+     side pointing this way.  Conservative and cheap: drop all CLV flags. */
+  memset(ev->clv_valid, 0, ev->records);
+}
+
+/* the CLV slot of an inner node is shared by its three records */
+static void mark_clv_valid(pllhip_eval_t * ev, const pll_unode_t * node)
+{
+  ev->clv_valid[node->node_index] = 1;
+  ev->clv_valid[node->next->node_index] = 0;
+  ev->clv_valid[node->next->next->node_index] = 0;
+}
+
+static int cb_all(pll_unode_t * node) { (void)node; return 1; }
+
+static int cb_invalid_only(pll_unode_t * node)
+{
+  if (!node->next) return 0;
+  return !cb_self->clv_valid[node->node_index];
+}
+
+static int update_pmatrices(pllhip_eval_t * ev)
+{
+  unsigned int n = 0, i, k = 0, p;
+  if (!pll_utree_traverse(ev->root, PLL_TREE_TRAVERSE_POSTORDER, cb_all, ev->trav, &n)) return PLL_FAILURE;
+  for (i = 0; i < n; ++i)
+  {
+    const pll_unode_t * node = ev->trav[i];
+    if (ev->pmat_valid[node->pmatrix_index]) continue;
+    ev->pmat_valid[node->pmatrix_index] = 1;
+    ev->midx[k] = node->pmatrix_index;
+    ev->brlens[k++] = node->length;
+  }
+  if (!k) return PLL_SUCCESS;
+  for (p = 0; p < ev->nparts; ++p)
+  {
+    if (!ev->parts[p]) continue;
+    if (ev->flags & PLLHIP_EVAL_PMATRIX_PER_BRANCH)
+    {
+      for (i = 0; i < k; ++i)
+        if (!pll_update_prob_matrices(ev->parts[p], ev->params[p], &ev->midx[i], &ev->brlens[i], 1))
+          return PLL_FAILURE;
+    }
+    else if (!pll_update_prob_matrices(ev->parts[p], ev->params[p], ev->midx, ev->brlens, k))
+      return PLL_FAILURE;
+  }
+  ev->n_pmat += k;
+  return PLL_SUCCESS;
+}
+
+static double edge_loglh(pllhip_eval_t * ev, const pll_unode_t * e)
+{
+  unsigned int p;
+  double total = 0.0;
+  for (p = 0; p < ev->nparts; ++p)
+  {
+    ev->part_lnl[p] = 0.0;
+    if (!ev->parts[p]) continue;
+    ev->part_lnl[p] = pll_compute_edge_loglikelihood(ev->parts[p], e->clv_index, e->scaler_index,
+                                                     e->back->clv_index, e->back->scaler_index,
+                                                     e->pmatrix_index, ev->params[p], NULL);
+  }
+  if (ev->reduce_cb) ev->reduce_cb(ev->ctx, ev->part_lnl, ev->nparts, 0 /* SUM */);
+  for (p = 0; p < ev->nparts; ++p) total += ev->part_lnl[p];
+  return total;
+}
+
+double pllhip_eval_loglh(pllhip_eval_t * ev, int incremental)
+{
+  unsigned int n = 0, nops = 0, i, p;
+  if (!incremental) pllhip_eval_invalidate_all(ev);
+  pll_errno = 0;
+  if (!update_pmatrices(ev)) return NAN;
+
+  cb_self = ev;
+  if (!pll_utree_traverse(ev->root, PLL_TREE_TRAVERSE_POSTORDER, cb_invalid_only, ev->trav, &n))
+    return NAN;
+  pll_utree_create_operations(ev->trav, n, NULL, NULL, ev->ops, NULL, &nops);
+  if (nops)
+  {
+    for (p = 0; p < ev->nparts; ++p)
+      if (ev->parts[p]) pll_update_partials(ev->parts[p], ev->ops, nops);
+    if (pll_errno) return NAN;
+    for (i = 0; i < n; ++i)
+      if (ev->trav[i]->next) mark_clv_valid(ev, ev->trav[i]);
+    ev->n_ops += nops;
+  }
+  return edge_loglh(ev, ev->root);
+}
+
+/* ---------------------------------------------------------------------- */
+/* Newton-Raphson branch-length optimisation, linked branch lengths        */
+/* ---------------------------------------------------------------------- */
+
+typedef struct
+{
+  pllhip_eval_t * ev;
+  double bl_min, bl_max, tolerance;
+  unsigned int max_newton;
+} blo_t;
+
+static int ensure_sumtables(pllhip_eval_t * ev)
+{
+  unsigned int p;
+  for (p = 0; p < ev->nparts; ++p)
+  {
+    const pll_partition_t * part = ev->parts[p];
+    if (!part || ev->sumtables[p]) continue;
+    /* sized and aligned exactly as the reference does it (src/tree/treeinfo.c:333-340) */
+    size_t len = (size_t)part->sites * part->rate_cats * part->states_padded;
+    ev->sumtables[p] = (double *)pll_aligned_alloc((len ? len : 1) * sizeof(double), part->alignment);
+    if (!ev->sumtables[p])
+    {
+      eval_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate sumtable");
+      return PLL_FAILURE;
+    }
+  }
+  return PLL_SUCCESS;
+}
+
+/* first and second derivative of -lnL over all partitions at branch length t */
+static int derivatives(pllhip_eval_t * ev, const pll_unode_t * e, double t, double * f, double * df)
+{
+  unsigned int p;
+  double v[2] = {0.0, 0.0};
+  for (p = 0; p < ev->nparts; ++p)
+  {
+    double a, b;
+    if (!ev->parts[p]) continue;
+    if (!pll_compute_likelihood_derivatives(ev->parts[p], e->scaler_index, e->back->scaler_index, t,
+                                            ev->params[p], ev->sumtables[p], &a, &b))
+      return PLL_FAILURE;
+    v[0] += a;
+    v[1] += b;
+  }
+  ev->n_deriv++;
+  if (ev->reduce_cb) ev->reduce_cb(ev->ctx, v, 2, 0 /* SUM */);
+  *f = v[0];
+  *df = v[1];
+  return PLL_SUCCESS;
+}
+
+/* one-dimensional Newton-Raphson with bracketing: step rule of the reference's
+   multi-function minimiser for a single function (opt_algorithms.c:133-261) */
+static int newton(const blo_t * b, const pll_unode_t * e, double * x)
+{
+  pllhip_eval_t * ev = b->ev;
+  const double dxmax = b->bl_max / b->max_newton;
+  double xl = b->bl_min, xh = b->bl_max, f, df, dx;
+  unsigned int iter = 0;
+  *x = PLL_MAX(PLL_MIN(*x, b->bl_max), b->bl_min);
+  for (;;)
+  {
+    if (iter++ > b->max_newton)
+    {
+      eval_error(PLLHIP_EVAL_ERROR_NEWTON_LIMIT, "Exceeded maximum number of iterations");
+      return PLL_FAILURE;
+    }
+    if (!derivatives(ev, e, *x, &f, &df)) return PLL_FAILURE;
+    if (!isfinite(f) || !isfinite(df))
+    {
+      eval_error(PLLHIP_EVAL_ERROR_NEWTON_DERIV, "Wrong likelihood derivatives");
+      return PLL_FAILURE;
+    }
+    if (df > 0.0)
+    {
+      if (fabs(f) < b->tolerance) return PLL_SUCCESS;
+      if (f < 0.0) xl = *x; else xh = *x;
+      dx = -f / df;
+    }
+    else
+      dx = -f / fabs(df);
+    dx = PLL_MAX(PLL_MIN(dx, dxmax), -dxmax);
+    if (*x + dx < xl) dx = xl - *x;
+    if (*x + dx > xh) dx = xh - *x;
+    if (fabs(dx) < b->tolerance) return PLL_SUCCESS;
+    *x += dx;
+    *x = PLL_MAX(PLL_MIN(*x, b->bl_max), b->bl_min);
+  }
+}
+
+/* recompute the CLV at `parent` from the far ends of c1 and c2
+   (update_partials_and_scalers, src/optimize/pll_optimize.c:748-775) */
+static int reorient(pllhip_eval_t * ev, const pll_unode_t * parent, const pll_unode_t * c1,
+                    const pll_unode_t * c2)
+{
+  pll_operation_t op;
+  unsigned int p;
+  op.parent_clv_index = parent->clv_index;
+  op.parent_scaler_index = parent->scaler_index;
+  op.child1_clv_index = c1->back->clv_index;
+  op.child1_matrix_index = c1->back->pmatrix_index;
+  op.child1_scaler_index = c1->back->scaler_index;
+  op.child2_clv_index = c2->back->clv_index;
+  op.child2_matrix_index = c2->back->pmatrix_index;
+  op.child2_scaler_index = c2->back->scaler_index;
+  for (p = 0; p < ev->nparts; ++p)
+    if (ev->parts[p]) pll_update_partials(ev->parts[p], &op, 1);
+  ev->n_ops++;
+  return pll_errno ? PLL_FAILURE : PLL_SUCCESS;
+}
+
+static int optimise_around(const blo_t * b, pll_unode_t * p_edge, int radius)
+{
+  pllhip_eval_t * ev = b->ev;
+  pll_unode_t * q = p_edge->next, * z = q ? q->next : NULL;
+  const double xorig = p_edge->length;
+  double x = xorig;
+  unsigned int p;
+
+  for (p = 0; p < ev->nparts; ++p)
+    if (ev->parts[p] &&
+        !pll_update_sumtable(ev->parts[p], p_edge->clv_index, p_edge->back->clv_index,
+                             p_edge->scaler_index, p_edge->back->scaler_index, ev->params[p],
+                             ev->sumtables[p]))
+      return PLL_FAILURE;
+
+  if (!newton(b, p_edge, &x))
+  {
+    if (pll_errno != PLLHIP_EVAL_ERROR_NEWTON_LIMIT) return PLL_FAILURE;
+    x = xorig;                    /* no convergence, no lnL check: keep the old length */
+    pll_errno = 0;
+  }
+  if (fabs(x - xorig) >= 1e-10)
+  {
+    p_edge->length = p_edge->back->length = x;
+    for (p = 0; p < ev->nparts; ++p)
+      if (ev->parts[p] &&
+          !pll_update_prob_matrices(ev->parts[p], ev->params[p], &p_edge->pmatrix_index, &x, 1))
+        return PLL_FAILURE;
+    ev->n_pmat++;
+  }
+  if (radius && q && z)
+  {
+    if (!reorient(ev, q, p_edge, z) || !optimise_around(b, q->back, radius - 1)) return PLL_FAILURE;
+    if (!reorient(ev, z, q, p_edge) || !optimise_around(b, z->back, radius - 1)) return PLL_FAILURE;
+    if (!reorient(ev, p_edge, z, q)) return PLL_FAILURE;
+  }
+  return PLL_SUCCESS;
+}
+
+double pllhip_eval_optimize_branches(pllhip_eval_t * ev, double min_brlen, double max_brlen,
+                                     double lh_epsilon, int max_iters, int radius)
+{
+  blo_t b;
+  double lnl, new_lnl;
+  int iters = max_iters;
+  pll_unode_t * root = ev->root;
+  if (radius < PLLHIP_EVAL_RADIUS_ALL)
+  {
+    eval_error(PLL_ERROR_PARAM_INVALID, "Invalid radius for branch length optimization");
+    return 0.0;
+  }
+  b.ev = ev;
+  b.bl_min = (min_brlen > 0) ? min_brlen : 1e-6;
+  b.bl_max = (max_brlen > 0) ? max_brlen : 100.0;
+  b.tolerance = (min_brlen > 0) ? min_brlen / 10.0 : 1e-4;
+  b.max_newton = 30;
+  if (!ensure_sumtables(ev)) return 0.0;
+
+  /* precondition of the reference: CLVs valid towards the root, P-matrices current */
+  lnl = pllhip_eval_loglh(ev, 1);
+  if (isnan(lnl)) return 0.0;
+
+  while (iters)
+  {
+    if (!optimise_around(&b, root, radius)) return 0.0;
+    if (radius && !optimise_around(&b, root->back, radius - 1)) return 0.0;
+    new_lnl = edge_loglh(ev, root->back);
+    if (new_lnl - lnl > new_lnl * 1e-13)
+    {
+      iters--;
+      if (fabs(new_lnl - lnl) < lh_epsilon) iters = 0;
+      lnl = new_lnl;
+    }
+    else
+    {
+      eval_error(PLLHIP_EVAL_ERROR_NEWTON_WORSE,
+                 "BL opt converged to a worse likelihood score by %.15f units", new_lnl - lnl);
+      lnl = new_lnl;
+      break;
+    }
+  }
+  /* P-matrices are current for every branch; CLVs were last refreshed at
+     different moments of the sweep: let the next evaluation rebuild them */
+  memset(ev->clv_valid, 0, ev->records);
+  return -lnl;
+}
+
+unsigned long pllhip_eval_ops(const pllhip_eval_t * ev) { return ev->n_ops; }
+unsigned long pllhip_eval_pmatrix_updates(const pllhip_eval_t * ev) { return ev->n_pmat; }
+unsigned long pllhip_eval_derivative_calls(const pllhip_eval_t * ev) { return ev->n_deriv; }

@@ -43,6 +43,25 @@ constexpr unsigned S20_UNIT = 20 * S20_BS;   // doubles per (block, rate) unit
 constexpr unsigned S20_FRAGS = 10 * 64;      // A-fragment doubles per (child, rate)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// streaming accesses: CLV data is touched once per operation, so it can bypass
+// the cache allocation policy (flags bit 0: loads, bit 1: stores)
+__device__ inline double2 s20_ld(const double * p, bool nt)
+{
+  const v2d v = nt ? __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p))
+                   : *reinterpret_cast<const v2d *>(p);
+  return make_double2(v.x, v.y);
+}
+
+__device__ inline void s20_st(double * p, const double2 & t, bool nt)
+{
+  v2d v;
+  v.x = t.x;
+  v.y = t.y;
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<v2d *>(p));
+  else *reinterpret_cast<v2d *>(p) = v;
+}
 
 __device__ inline v4d mfma_f64(double a, double b, v4d c)
 {
@@ -67,13 +86,13 @@ __device__ inline void s20_fill_frags(double * frag, const double * mats, unsign
 
 // child term in D layout: t[k] = {even site, odd site} for row s20_row(k, q)
 __device__ inline void s20_child_inner(const double * unit, const double * frag_r, unsigned lane,
-                                       double2 t[5])
+                                       double2 t[5], bool nt = false)
 {
   const unsigned off = lane * 2;            // doubles: (q*32 + 2n)
   double2 b[5];
 #pragma unroll
   for (int ks = 0; ks < 5; ++ks)
-    b[ks] = *reinterpret_cast<const double2 *>(unit + ks * 128 + off);
+    b[ks] = s20_ld(unit + ks * 128 + off, nt);
   v4d a0e = {0, 0, 0, 0}, a0o = {0, 0, 0, 0}, a1e = {0, 0, 0, 0}, a1o = {0, 0, 0, 0};
 #pragma unroll
   for (int ks = 0; ks < 5; ++ks)
@@ -113,12 +132,12 @@ __device__ inline void s20_load_d(const double * unit, unsigned lane, double2 t[
     t[k] = *reinterpret_cast<const double2 *>(unit + k * 128 + off);
 }
 
-__device__ inline void s20_store_d(double * unit, unsigned lane, const double2 t[5])
+__device__ inline void s20_store_d(double * unit, unsigned lane, const double2 t[5], bool nt = false)
 {
   const unsigned off = lane * 2;
 #pragma unroll
   for (int k = 0; k < 5; ++k)
-    *reinterpret_cast<double2 *>(unit + k * 128 + off) = t[k];
+    s20_st(unit + k * 128 + off, t[k], nt);
 }
 
 __device__ inline void s20_tip_d(unsigned long long mask_e, unsigned long long mask_o, unsigned q,
@@ -152,15 +171,26 @@ __device__ inline double s20_sum_q(double v)
 // the P-matrices).   grid = (gx, ops), block = 256 (4 independent waves)
 // dynamic LDS = 2 * R * S20_FRAGS doubles
 // ---------------------------------------------------------------------------
-template <unsigned RT>   // RT > 0: rate count known at compile time (rate loop unrolled)
+template <unsigned RT>   // RT > 0: rate count known at compile time (register-resident block)
 __global__ __launch_bounds__(256, 2) void k_partials_s20(OpBatch batch, unsigned nblk, unsigned Rrt,
-                                                         unsigned lut_codes)
+                                                         unsigned lut_codes, unsigned flags)
 {
+  const bool nt_ld = flags & 1u, nt_st = flags & 2u;
   extern __shared__ double frag[];
   const unsigned R = RT ? RT : Rrt;
   const OpDesc & op = batch.op[blockIdx.y];
+  // each child owns R * S20_FRAGS doubles of LDS: the A fragments of its P-matrix,
+  // or -- for a coded tip -- its lookup table (fits while lut_codes <= 32); LUT
+  // gathers then hit LDS banks instead of the L1 address pipeline, which is what
+  // bounds tip x tip operations otherwise
+  const bool lut_lds = lut_codes <= 32;
+  double * const frag2 = frag + R * S20_FRAGS;
   if (!op.codes1) s20_fill_frags(frag, op.pmat1, R);
-  if (!op.codes2) s20_fill_frags(frag + R * S20_FRAGS, op.pmat2, R);
+  else if (lut_lds)
+    for (unsigned e = threadIdx.x; e < R * lut_codes * 20; e += blockDim.x) frag[e] = op.lut1[e];
+  if (!op.codes2) s20_fill_frags(frag2, op.pmat2, R);
+  else if (lut_lds)
+    for (unsigned e = threadIdx.x; e < R * lut_codes * 20; e += blockDim.x) frag2[e] = op.lut2[e];
   __syncthreads();
 
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -176,15 +206,67 @@ __global__ __launch_bounds__(256, 2) void k_partials_s20(OpBatch batch, unsigned
     if (op.codes2) { c2e = op.codes2[site0]; c2o = op.codes2[site0 + 1]; }
     int small_e = 1, small_o = 1;
 
+    if constexpr (RT > 0)
+    {
+      // compile-time rate count: all RT units of the block stay in registers
+      // until the scaling vote is known, so nothing is written twice
+      double2 out[RT][5];
 #pragma unroll
+      for (unsigned r = 0; r < RT; ++r)
+      {
+        const size_t ubase = ((size_t)blk * RT + r) * S20_UNIT;
+        double2 t2[5];
+        if (!op.codes1) s20_child_inner(op.clv1 + ubase, frag + r * S20_FRAGS, lane, out[r], nt_ld);
+        else if (lut_lds) s20_child_tip(frag + r * lut_codes * 20, c1e, c1o, q, out[r]);
+        else s20_child_tip(op.lut1 + (size_t)r * lut_codes * 20, c1e, c1o, q, out[r]);
+        if (!op.codes2) s20_child_inner(op.clv2 + ubase, frag2 + r * S20_FRAGS, lane, t2, nt_ld);
+        else if (lut_lds) s20_child_tip(frag2 + r * lut_codes * 20, c2e, c2o, q, t2);
+        else s20_child_tip(op.lut2 + (size_t)r * lut_codes * 20, c2e, c2o, q, t2);
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+        {
+          out[r][k].x *= t2[k].x;
+          out[r][k].y *= t2[k].y;
+          small_e &= (out[r][k].x < SCALE_THRESHOLD);
+          small_o &= (out[r][k].y < SCALE_THRESHOLD);
+        }
+      }
+      double fe = 1.0, fo = 1.0;
+      if (scaling)
+      {
+        small_e = s20_and_q(small_e);
+        small_o = s20_and_q(small_o);
+        fe = small_e ? SCALE_FACTOR : 1.0;
+        fo = small_o ? SCALE_FACTOR : 1.0;
+      }
+#pragma unroll
+      for (unsigned r = 0; r < RT; ++r)
+      {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { out[r][k].x *= fe; out[r][k].y *= fo; }
+        s20_store_d(op.parent + ((size_t)blk * RT + r) * S20_UNIT, lane, out[r], nt_st);
+      }
+      if (scaling && q == 0)
+      {
+        unsigned ce = small_e ? 1u : 0u, co = small_o ? 1u : 0u;
+        if (op.scaler1) { ce += op.scaler1[site0]; co += op.scaler1[site0 + 1]; }
+        if (op.scaler2) { ce += op.scaler2[site0]; co += op.scaler2[site0 + 1]; }
+        op.parent_scaler[site0] = ce;
+        op.parent_scaler[site0 + 1] = co;
+      }
+      continue;
+    }
+
     for (unsigned r = 0; r < R; ++r)
     {
       const size_t ubase = ((size_t)blk * R + r) * S20_UNIT;
       double2 t1[5], t2[5];
-      if (op.codes1) s20_child_tip(op.lut1 + (size_t)r * lut_codes * 20, c1e, c1o, q, t1);
-      else s20_child_inner(op.clv1 + ubase, frag + r * S20_FRAGS, lane, t1);
-      if (op.codes2) s20_child_tip(op.lut2 + (size_t)r * lut_codes * 20, c2e, c2o, q, t2);
-      else s20_child_inner(op.clv2 + ubase, frag + (R + r) * S20_FRAGS, lane, t2);
+      if (!op.codes1) s20_child_inner(op.clv1 + ubase, frag + r * S20_FRAGS, lane, t1, nt_ld);
+      else if (lut_lds) s20_child_tip(frag + r * lut_codes * 20, c1e, c1o, q, t1);
+      else s20_child_tip(op.lut1 + (size_t)r * lut_codes * 20, c1e, c1o, q, t1);
+      if (!op.codes2) s20_child_inner(op.clv2 + ubase, frag2 + r * S20_FRAGS, lane, t2, nt_ld);
+      else if (lut_lds) s20_child_tip(frag2 + r * lut_codes * 20, c2e, c2o, q, t2);
+      else s20_child_tip(op.lut2 + (size_t)r * lut_codes * 20, c2e, c2o, q, t2);
 #pragma unroll
       for (int k = 0; k < 5; ++k)
       {
@@ -193,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void k_partials_s20(OpBatch batch, unsigned
         small_e &= (t1[k].x < SCALE_THRESHOLD);
         small_o &= (t1[k].y < SCALE_THRESHOLD);
       }
-      s20_store_d(op.parent + ubase, lane, t1);
+      s20_store_d(op.parent + ubase, lane, t1, nt_st);
     }
 
     if (scaling)
@@ -495,13 +577,14 @@ static unsigned s20_grid(const Engine * e, unsigned blocks_per_cu)
 static int launch_partials_s20(Engine * e, const OpBatch & batch, unsigned nops)
 {
   const size_t lds = sizeof(double) * 2 * e->R * S20_FRAGS;
-  static const int no_unroll = getenv("PLLHIP_S20_NOUNROLL") ? atoi(getenv("PLLHIP_S20_NOUNROLL")) : 0;
-  if (e->R == 4 && !no_unroll)
+  static const int unroll = getenv("PLLHIP_S20_UNROLL") ? atoi(getenv("PLLHIP_S20_UNROLL")) : 0;
+  static const unsigned flags = getenv("PLLHIP_S20_NT") ? (unsigned)atoi(getenv("PLLHIP_S20_NT")) : 0u;
+  if (e->R == 4 && !unroll)    // PLLHIP_S20_UNROLL=1 selects the runtime-R variant for A/B runs
     hipLaunchKernelGGL(k_partials_s20<4>, dim3(s20_grid(e, 4), nops), dim3(256), lds, e->stream,
-                       batch, e->nblk, e->R, e->lut_codes);
+                       batch, e->nblk, e->R, e->lut_codes, flags);
   else
     hipLaunchKernelGGL(k_partials_s20<0>, dim3(s20_grid(e, 4), nops), dim3(256), lds, e->stream,
-                       batch, e->nblk, e->R, e->lut_codes);
+                       batch, e->nblk, e->R, e->lut_codes, flags);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

@@ -91,69 +91,102 @@ __device__ inline double2 s4_half_matvec(const HalfP & q, const double2 c)
   return make_double2(own0 + __shfl_xor(oth0, 1, 64), own1 + __shfl_xor(oth1, 1, 64));
 }
 
+template <unsigned U>    // iterations issued per batch (loads first, arithmetic after)
 __global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, unsigned R,
                                                      unsigned lut_codes)
 {
   const OpDesc & op = batch.op[blockIdx.y];
-  const unsigned long long total = 2ULL * N * R;              // half-columns
-  const unsigned long long stride = (unsigned long long)gridDim.x * 256ULL;
-  unsigned long long g = (unsigned long long)blockIdx.x * 256ULL + threadIdx.x;
-  const unsigned h = (unsigned)(g & 1ULL), r = (unsigned)((g >> 1) & (R - 1));
-  const unsigned group = 2 * R;                               // lanes per site
-  const unsigned rs = (unsigned)__ffs((int)R) - 1;           // R is a power of two in this family
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned h = lane & 1u, r = (lane >> 1) & (R - 1);
+  const unsigned group = 2 * R;                      // lanes per site
+  const unsigned spi = 64 / group;                   // sites per wave iteration
+  const unsigned rs = (unsigned)__ffs((int)R) - 1;   // R is a power of two in this family
+  const unsigned long long total = 2ULL * N * R;     // half-columns
 
   HalfP p1 = {}, p2 = {};
   if (!op.codes1) p1 = s4_load_half_p(op.pmat1, r, h);
   if (!op.codes2) p2 = s4_load_half_p(op.pmat2, r, h);
 
-  // whole waves iterate together (shuffles); two grid-stride steps per trip
-  const unsigned long long limit = (total + 63ULL) & ~63ULL;
-  for (; g < limit; g += 2 * stride)
+  // tip lookup tables (R x 16 codes x 4 doubles each) are staged in LDS: the
+  // per-site gathers then cost LDS bank cycles instead of L1 address cycles
+  __shared__ double lut_s[2][16 * 16 * 4];
+  const bool lut_lds = lut_codes == 16;              // always true for DNA tip codes
+  if (lut_lds)
   {
-    double2 in1[2], in2[2];
-    unsigned long long nn[2];
-    bool live[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
+    if (op.codes1) for (unsigned e = threadIdx.x; e < R * 64; e += 256) lut_s[0][e] = op.lut1[e];
+    if (op.codes2) for (unsigned e = threadIdx.x; e < R * 64; e += 256) lut_s[1][e] = op.lut2[e];
+    __syncthreads();
+  }
+
+  // A wave owns chunks of 64 consecutive sites = `group` iterations of 64
+  // half-columns (1 KiB per child each).  The scaling vote of an iteration is
+  // known inside the iteration (values are scaled before they are stored); the
+  // 64 scaler counts of the chunk are written once, coalesced, at the end.
+  const unsigned nchunks = (N + 63) / 64;
+  const unsigned wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = gridDim.x * 4;
+  for (unsigned chunk = wave; chunk < nchunks; chunk += nwaves)
+  {
+    const unsigned long long hc0 = (unsigned long long)chunk * 64ULL * group + lane;
+    unsigned scaled_mask = 0;                        // bit k: iteration k rescaled (same in a lane group)
+    for (unsigned k0 = 0; k0 < group; k0 += U)
     {
-      const unsigned long long gu = g + u * stride;
-      live[u] = gu < total;
-      nn[u] = live[u] ? (gu >> 1) >> rs : 0;
-      in1[u] = in2[u] = make_double2(0.0, 0.0);
-      if (live[u])
-      {
-        in1[u] = op.codes1
-          ? *reinterpret_cast<const double2 *>(op.lut1 + ((size_t)r * lut_codes + op.codes1[nn[u]]) * 4 + 2 * h)
-          : *reinterpret_cast<const double2 *>(op.clv1 + gu * 2);
-        in2[u] = op.codes2
-          ? *reinterpret_cast<const double2 *>(op.lut2 + ((size_t)r * lut_codes + op.codes2[nn[u]]) * 4 + 2 * h)
-          : *reinterpret_cast<const double2 *>(op.clv2 + gu * 2);
-      }
-    }
+      double2 in1[U], in2[U];
+      bool live[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-    {
-      const unsigned long long gu = g + u * stride;
-      if (gu >= limit) break;                                 // wave-uniform
-      const double2 a = op.codes1 ? in1[u] : s4_half_matvec(p1, in1[u]);
-      const double2 b = op.codes2 ? in2[u] : s4_half_matvec(p2, in2[u]);
-      double2 v = make_double2(a.x * b.x, a.y * b.y);
-      if (op.parent_scaler)
+      for (unsigned u = 0; u < U; ++u)
       {
-        int big = live[u] && !(v.x < SCALE_THRESHOLD && v.y < SCALE_THRESHOLD);
-        big = group_or(big, group);
+        const unsigned long long gu = hc0 + (unsigned long long)(k0 + u) * 64ULL;
+        live[u] = (k0 + u < group) && gu < total;
+        in1[u] = in2[u] = make_double2(0.0, 0.0);
         if (live[u])
         {
-          if (!big) { v.x *= SCALE_FACTOR; v.y *= SCALE_FACTOR; }
-          if ((gu & (group - 1)) == 0)
-          {
-            const unsigned long long n = nn[u];
-            const unsigned cnt = (op.scaler1 ? op.scaler1[n] : 0u) + (op.scaler2 ? op.scaler2[n] : 0u);
-            op.parent_scaler[n] = cnt + (big ? 0u : 1u);
-          }
+          const unsigned long long n = (gu >> 1) >> rs;
+          if (!op.codes1) in1[u] = *reinterpret_cast<const double2 *>(op.clv1 + gu * 2);
+          else if (lut_lds)
+            in1[u] = *reinterpret_cast<const double2 *>(&lut_s[0][(r * 16 + op.codes1[n]) * 4 + 2 * h]);
+          else
+            in1[u] = *reinterpret_cast<const double2 *>(op.lut1 + ((size_t)r * lut_codes + op.codes1[n]) * 4 + 2 * h);
+          if (!op.codes2) in2[u] = *reinterpret_cast<const double2 *>(op.clv2 + gu * 2);
+          else if (lut_lds)
+            in2[u] = *reinterpret_cast<const double2 *>(&lut_s[1][(r * 16 + op.codes2[n]) * 4 + 2 * h]);
+          else
+            in2[u] = *reinterpret_cast<const double2 *>(op.lut2 + ((size_t)r * lut_codes + op.codes2[n]) * 4 + 2 * h);
         }
       }
-      if (live[u]) *reinterpret_cast<double2 *>(op.parent + gu * 2) = v;
+#pragma unroll
+      for (unsigned u = 0; u < U; ++u)
+      {
+        if (k0 + u >= group) break;                  // wave-uniform
+        const unsigned long long gu = hc0 + (unsigned long long)(k0 + u) * 64ULL;
+        const double2 a = op.codes1 ? in1[u] : s4_half_matvec(p1, in1[u]);
+        const double2 b = op.codes2 ? in2[u] : s4_half_matvec(p2, in2[u]);
+        double2 v = make_double2(a.x * b.x, a.y * b.y);
+        if (op.parent_scaler)
+        {
+          int big = live[u] && !(v.x < SCALE_THRESHOLD && v.y < SCALE_THRESHOLD);
+          big = group_or(big, group);
+          if (!big)
+          {
+            v.x *= SCALE_FACTOR;
+            v.y *= SCALE_FACTOR;
+            scaled_mask |= 1u << (k0 + u);
+          }
+        }
+        if (live[u]) *reinterpret_cast<double2 *>(op.parent + gu * 2) = v;
+      }
+    }
+    if (op.parent_scaler)
+    {
+      // lane l finishes site chunk*64 + l: it was handled in iteration l / spi by
+      // lane group l % spi
+      const unsigned src = (lane % spi) * group;
+      const unsigned m = (unsigned)__shfl((int)scaled_mask, (int)src, 64);
+      const unsigned long long n = (unsigned long long)chunk * 64ULL + lane;
+      if (n < N)
+      {
+        const unsigned cnt = (op.scaler1 ? op.scaler1[n] : 0u) + (op.scaler2 ? op.scaler2[n] : 0u);
+        op.parent_scaler[n] = cnt + ((m >> (lane / spi)) & 1u);
+      }
     }
   }
 }
@@ -354,12 +387,15 @@ static unsigned s4_grid(const Engine * e, unsigned cap_blocks)
 
 static int launch_partials_s4(Engine * e, const OpBatch & batch, unsigned nops)
 {
-  // two lanes per column; 256 threads is a multiple of 2R for every admissible R
-  const unsigned long long need = (2ULL * e->N * e->R + 511ULL) / 512ULL;   // 2 steps per trip
-  const unsigned gx = (unsigned)std::max<unsigned long long>(
-      1ULL, std::min<unsigned long long>(need, (unsigned long long)e->cu_count * 16ULL));
-  hipLaunchKernelGGL(k_partials_s4, dim3(gx, nops), dim3(256), 0, e->stream,
-                     batch, e->N, e->R, e->lut_codes);
+  // one wave per 64-site chunk (grid-stride over chunks), 4 waves per block
+  const unsigned nchunks = (e->N + 63) / 64;
+  const unsigned gx = std::max(1u, std::min((nchunks + 3) / 4, e->cu_count * 16u));
+  if (e->R >= 2)
+    hipLaunchKernelGGL(k_partials_s4<4>, dim3(gx, nops), dim3(256), 0, e->stream,
+                       batch, e->N, e->R, e->lut_codes);
+  else
+    hipLaunchKernelGGL(k_partials_s4<2>, dim3(gx, nops), dim3(256), 0, e->stream,
+                       batch, e->N, e->R, e->lut_codes);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

@@ -115,6 +115,12 @@ pll_utree_parse_newick_unroot pll_utree_parse_newick_string
 pll_utree_parse_newick_string_unroot pll_utree_export_newick pll_utree_show_ascii
 pll_random_create pll_random_getint pll_random_destroy""".split()
 
+PLLHIP_EVAL_H_FUNCTIONS = """pllhip_eval_create pllhip_eval_destroy pllhip_eval_set_partition
+pllhip_eval_set_parallel_context pllhip_eval_set_root pllhip_eval_root pllhip_eval_invalidate_all
+pllhip_eval_invalidate_pmatrix pllhip_eval_invalidate_clv pllhip_eval_loglh
+pllhip_eval_set_branch_length pllhip_eval_optimize_branches pllhip_eval_ops
+pllhip_eval_pmatrix_updates pllhip_eval_derivative_calls""".split()
+
 PLLHIP_H_FUNCTIONS = """pllhip_device_count pllhip_set_device pllhip_get_device
 pllhip_device_arch pllhip_eigen_decompose pllhip_sync_to_host pllhip_get_clv
 pllhip_get_scaler pllhip_get_sumtable pllhip_set_clv pllhip_set_scaler pllhip_synchronize
@@ -186,6 +192,27 @@ class PllLib:
                                                   C.POINTER(Operation), c_uint_p, c_uint_p]
         L.pll_utree_export_newick.restype = C.c_void_p
         L.pll_utree_export_newick.argtypes = [up, C.c_void_p]
+        if hasattr(L, "pllhip_eval_create"):
+            L.pllhip_eval_create.restype = C.c_void_p
+            L.pllhip_eval_create.argtypes = [tp, C.c_uint, C.c_uint]
+            L.pllhip_eval_destroy.argtypes = [C.c_void_p]
+            L.pllhip_eval_set_partition.argtypes = [C.c_void_p, C.c_uint, pp, c_uint_p]
+            L.pllhip_eval_set_parallel_context.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            L.pllhip_eval_set_root.argtypes = [C.c_void_p, up]
+            L.pllhip_eval_root.restype = up
+            L.pllhip_eval_root.argtypes = [C.c_void_p]
+            L.pllhip_eval_invalidate_all.argtypes = [C.c_void_p]
+            L.pllhip_eval_invalidate_pmatrix.argtypes = [C.c_void_p, up]
+            L.pllhip_eval_invalidate_clv.argtypes = [C.c_void_p, up]
+            L.pllhip_eval_loglh.restype = C.c_double
+            L.pllhip_eval_loglh.argtypes = [C.c_void_p, C.c_int]
+            L.pllhip_eval_set_branch_length.argtypes = [C.c_void_p, up, C.c_double]
+            L.pllhip_eval_optimize_branches.restype = C.c_double
+            L.pllhip_eval_optimize_branches.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                                        C.c_int, C.c_int]
+            for fn in ("pllhip_eval_ops", "pllhip_eval_pmatrix_updates", "pllhip_eval_derivative_calls"):
+                getattr(L, fn).restype = C.c_ulong
+                getattr(L, fn).argtypes = [C.c_void_p]
         if self.is_product:
             L.pllhip_device_count.restype = C.c_int
             L.pllhip_set_device.argtypes = [C.c_int]
@@ -499,7 +526,7 @@ class Tree:
                 s = labels[nd] if labels else f"t{nd}"
             else:
                 s = "(" + ",".join(rec(v, nd, kk) for (v, kk) in self.adj[nd] if v != par) + ")"
-            return s + (f":{self.brlens[k]:.6f}" if k is not None else "")
+            return s + (f":{self.brlens[k]:.17g}" if k is not None else "")
         root = self.ntips
         return "(" + ",".join(rec(v, root, kk) for (v, kk) in self.adj[root]) + ");"
 
@@ -564,6 +591,77 @@ def state_charmap(nstates):
         m[48 + i] = np.uint64(1) << np.uint64(i)
     m[ord("-")] = (np.uint64(1) << np.uint64(nstates)) - np.uint64(1) if nstates < 64 else _M64
     return m
+
+
+class Evaluation:
+    """pll_utree_t + partitions + pllhip_eval driver (include/pllhip_eval.h).
+
+    The tree comes from a newick string; tips are matched to alignment rows by
+    their labels "t<k>" (the parser numbers tips in order of appearance)."""
+
+    def __init__(self, lib, newick, flags=0, nparts=1):
+        self.lib, self.L = lib, lib.lib
+        self.utree = self.L.pll_utree_parse_newick_string(newick.encode())
+        if not self.utree:
+            raise RuntimeError(lib.errmsg)
+        tr = self.utree.contents
+        self.ntips = tr.tip_count
+        # row k of an alignment belongs to the tip labelled t<k>
+        self.tip_clv = {}
+        for i in range(self.ntips):
+            nd = tr.nodes[i].contents
+            self.tip_clv[int(nd.label.decode()[1:])] = nd.clv_index
+        self.ev = self.L.pllhip_eval_create(self.utree, nparts, flags)
+        if not self.ev:
+            raise RuntimeError(lib.errmsg)
+        self.parts = []
+
+    def add_partition(self, index, states, nsites, rate_cats, codes, subst, freqs, alpha, coded=True):
+        inst = Instance(self.lib, self.ntips, states, nsites, rate_cats,
+                        attributes=PLL_ATTRIB_PATTERN_TIP if coded else 0)
+        rates = self.lib.gamma_cats(alpha, rate_cats) if rate_cats > 1 else np.ones(1)
+        inst.set_model(subst, freqs, rates)
+        cmap = state_charmap(states)
+        for k in range(self.ntips):
+            inst.set_tip_states(self.tip_clv[k], cmap, (codes[k] + 48).tobytes())
+        if not self.L.pllhip_eval_set_partition(self.ev, index, inst.p, inst.params_p):
+            raise RuntimeError(self.lib.errmsg)
+        self.parts.append(inst)
+        return inst
+
+    def loglh(self, incremental=False):
+        v = self.L.pllhip_eval_loglh(self.ev, 1 if incremental else 0)
+        if v != v:
+            raise RuntimeError(self.lib.errmsg)
+        return v
+
+    def optimize_branches(self, bl_min=1e-4, bl_max=10.0, eps=0.01, iters=8, radius=-1):
+        self.lib.errno = 0
+        v = self.L.pllhip_eval_optimize_branches(self.ev, bl_min, bl_max, eps, iters, radius)
+        if v == 0.0 or self.lib.errno:
+            raise RuntimeError(f"[{self.lib.errno}] {self.lib.errmsg}")
+        return -v
+
+    def counters(self):
+        return (self.L.pllhip_eval_ops(self.ev), self.L.pllhip_eval_pmatrix_updates(self.ev),
+                self.L.pllhip_eval_derivative_calls(self.ev))
+
+    def close(self):
+        if self.ev:
+            self.L.pllhip_eval_destroy(self.ev)
+            self.ev = None
+        for p in self.parts:
+            p.close()
+        self.parts = []
+        if self.utree:
+            self.L.pll_utree_destroy(self.utree, None)
+            self.utree = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 CONFIGS = {

@@ -15,6 +15,7 @@
 #include "pll_tree.h"
 #include "pll_optimize.h"
 #include "pllmod_algorithm.h"
+#include "pllhip_eval.h"
 #include <stdio.h>
 
 #define TAXA 12
@@ -126,6 +127,24 @@ int main(int argc, char ** argv)
   { fprintf(stderr, "init_partition: %s\n", pll_errmsg); return 1; }
 
   printf("direct lnL:          %.6f\n", direct_lnl(tree, parts, 2));
+
+  /* this repository's own driver (include/pllhip_eval.h) on a clone of the tree,
+     same partitions, same optimiser settings as the reference call below */
+  {
+    pll_utree_t * copy = pll_utree_clone(tree);
+    pllhip_eval_t * ev = pllhip_eval_create(copy, 2, 0);
+    if (!ev || !pllhip_eval_set_partition(ev, 0, parts[0], params_indices) ||
+        !pllhip_eval_set_partition(ev, 1, parts[1], params_indices))
+    { fprintf(stderr, "eval: %s\n", pll_errmsg); return 1; }
+    printf("driver full lnL:     %.6f\n", pllhip_eval_loglh(ev, 0));
+    pllhip_eval_invalidate_clv(ev, pllhip_eval_root(ev)->next->back);
+    printf("driver incremental:  %.6f\n", pllhip_eval_loglh(ev, 1));
+    double l = -pllhip_eval_optimize_branches(ev, 1e-4, 10.0, 0.01, 8, PLLHIP_EVAL_RADIUS_ALL);
+    if (pll_errno) { fprintf(stderr, "driver BLO: [%d] %s\n", pll_errno, pll_errmsg); return 1; }
+    printf("driver after BLO:    %.6f\n", l);
+    pllhip_eval_destroy(ev);
+    pll_utree_destroy(copy, NULL);
+  }
   double l_full = pllmod_treeinfo_compute_loglh(ti, 0);
   printf("full lnL:            %.6f\n", l_full);
 

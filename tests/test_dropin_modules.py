@@ -54,8 +54,13 @@ def driver(oracle, tmp_path_factory):
 def test_reference_treeinfo_blo_and_spr_round_run_on_this_library(driver, args):
     out = subprocess.run([driver, *args], check=True, capture_output=True, text=True, timeout=600).stdout
     v = {k.strip(): float(x) for k, x in re.findall(r"^(.*?):\s+(-?[0-9.]+)$", out, re.M)}
-    assert set(v) == {"direct lnL", "full lnL", "incremental lnL", "after BLO", "after SPR round",
-                      "full recomputation"}
+    assert set(v) == {"direct lnL", "driver full lnL", "driver incremental", "driver after BLO",
+                      "full lnL", "incremental lnL", "after BLO", "after SPR round", "full recomputation"}
+    # this repository's evaluation driver (include/pllhip_eval.h) against the
+    # reference's treeinfo + Newton-Raphson optimiser on the same data and settings
+    assert abs(v["driver full lnL"] - v["full lnL"]) < 1e-6
+    assert abs(v["driver incremental"] - v["full lnL"]) < 1e-6
+    assert abs(v["driver after BLO"] - v["after BLO"]) < 1e-4
     assert abs(v["direct lnL"] - v["full lnL"]) < 1e-6          # raw pll_* calls == treeinfo
     assert abs(v["incremental lnL"] - v["full lnL"]) < 1e-6
     assert v["after BLO"] > v["full lnL"] + 1.0

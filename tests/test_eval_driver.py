@@ -1,0 +1,161 @@
+"""The C evaluation driver (include/pllhip_eval.h): treeinfo-style incremental
+likelihood and Newton-Raphson branch-length optimisation over several
+partitions.  CPU tests run it on the oracle; GPU tests run it on the HIP engine
+and compare with the oracle (same C code, different library underneath).
+tests/test_dropin_modules.py additionally checks it against the reference's own
+treeinfo / optimiser on identical data."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import pllhip_ctypes as pc
+
+
+def build(lib, ntips=14, flags=0, sizes=(400, 150), coded=True):
+    t = pc.Tree(ntips, 42, 43)
+    ev = pc.Evaluation(lib, t.newick(), flags=flags, nparts=2)
+    ev.add_partition(0, 4, sizes[0], 4, pc.random_codes(ntips, sizes[0], 4), pc.DNA_GTR_RATES,
+                     pc.DNA_FREQS, 0.7, coded=coded)
+    r, f = pc.protein_model()
+    ev.add_partition(1, 20, sizes[1], 4, pc.random_codes(ntips, sizes[1], 20, seed=99), r, f, 0.5,
+                     coded=coded)
+    ev.pytree = t
+    return ev
+
+
+def reference_lnl(lib, ev):
+    """the same two partitions evaluated without the driver (plain op lists)"""
+    t = ev.pytree
+    total = 0.0
+    for states, n, seed, (subst, freqs), alpha in ((4, ev.parts[0].N, 44, (pc.DNA_GTR_RATES, pc.DNA_FREQS), 0.7),
+                                                   (20, ev.parts[1].N, 99, pc.protein_model(), 0.5)):
+        inst = pc.Instance(lib, t.ntips, states, n, 4, attributes=pc.PLL_ATTRIB_PATTERN_TIP)
+        inst.set_model(subst, freqs, lib.gamma_cats(alpha, 4))
+        codes = pc.random_codes(t.ntips, n, states, seed=seed)
+        cmap = pc.state_charmap(states)
+        for k in range(t.ntips):
+            inst.set_tip_states(k, cmap, (codes[k] + 48).tobytes())
+        inst.tree = t
+        total += pc.full_traversal(inst)
+        inst.close()
+    return total
+
+
+def _walk_records(ev):
+    tr = ev.utree.contents
+    for i in range(tr.tip_count + tr.inner_count):
+        n = tr.nodes[i]
+        s = n
+        while True:
+            yield s
+            if not s.contents.next:
+                break
+            s = s.contents.next
+            if C.addressof(s.contents) == C.addressof(n.contents):
+                break
+
+
+def check_driver(lib, other=None):
+    with build(lib) as ev:
+        full = ev.loglh()
+        assert abs(full - reference_lnl(lib, ev)) < 1e-8 * abs(full)
+        ops0, pm0, _ = ev.counters()
+        assert (ops0, pm0) == (12, 25)                       # n-2 ops, 2n-3 matrices
+        # nothing invalid: an incremental evaluation does no work
+        assert ev.loglh(True) == full and ev.counters()[:2] == (ops0, pm0)
+        # invalidate an inner CLV and the root above it (as in the reference, a valid
+        # CLV shields everything below it: src/tree/treeinfo.c:38-61): only those
+        # two operations are redone
+        root = lib.lib.pllhip_eval_root(ev.ev)
+        victim = root.contents.next.contents.back
+        if not victim.contents.next:
+            victim = root.contents.next.contents.next.contents.back
+        lib.lib.pllhip_eval_invalidate_clv(ev.ev, victim)
+        assert ev.loglh(True) == full and ev.counters()[0] == ops0      # shielded by the valid root
+        lib.lib.pllhip_eval_invalidate_clv(ev.ev, root)
+        assert abs(ev.loglh(True) - full) < 1e-9 * abs(full)
+        assert ev.counters()[0] - ops0 == 2
+        # re-rooting at every inner record gives the same likelihood, incrementally
+        for rec in _walk_records(ev):
+            if rec.contents.next:
+                assert lib.lib.pllhip_eval_set_root(ev.ev, rec)
+                assert abs(ev.loglh(True) - full) < 1e-9 * abs(full)
+        # a branch-length change is picked up
+        lib.lib.pllhip_eval_set_branch_length(ev.ev, lib.lib.pllhip_eval_root(ev.ev), 0.7)
+        changed = ev.loglh(True)
+        assert abs(changed - full) > 1e-3
+        assert abs(changed - ev.loglh(False)) < 1e-9 * abs(changed)
+        # Newton-Raphson over all branches: improves, and the result is consistent
+        # with a fresh full evaluation
+        opt = ev.optimize_branches(1e-4, 10.0, 0.01, 8, -1)
+        assert opt > changed + 1.0
+        assert abs(ev.loglh(False) - opt) < 1e-6 * abs(opt)
+        assert ev.counters()[2] > 25
+        return full, changed, opt
+
+
+def test_driver_on_oracle(oracle):
+    check_driver(oracle)
+
+
+def test_per_branch_pmatrix_flag_gives_identical_results(oracle):
+    with build(oracle) as a, build(oracle, flags=1) as b:
+        assert a.loglh() == b.loglh()
+        assert a.optimize_branches() == b.optimize_branches()
+
+
+def test_remote_partitions_and_reduce_callback(oracle):
+    """two 'workers' in one process: each owns one partition (the other slot is
+    NULL, src/tree/treeinfo.c:1024-1029) and a reduce callback adds the other
+    worker's share; both must see the full-alignment likelihood"""
+    with build(oracle) as whole:
+        want = whole.loglh()
+        per_part = [p for p in whole.lib.lib.pllhip_eval_loglh.argtypes]  # noqa: F841 (keep lib alive)
+    t = pc.Tree(14, 42, 43)
+    shares = {}
+
+    def make(owner):
+        ev = pc.Evaluation(oracle, t.newick(), nparts=2)
+        if owner == 0:
+            ev.add_partition(0, 4, 400, 4, pc.random_codes(14, 400, 4), pc.DNA_GTR_RATES, pc.DNA_FREQS, 0.7)
+            oracle.lib.pllhip_eval_set_partition(ev.ev, 1, None, None)
+        else:
+            r, f = pc.protein_model()
+            oracle.lib.pllhip_eval_set_partition(ev.ev, 0, None, None)
+            ev.add_partition(1, 20, 150, 4, pc.random_codes(14, 150, 20, seed=99), r, f, 0.5)
+        return ev
+    a, b = make(0), make(1)
+    # first pass without a callback: each worker sees only its own share
+    shares[0], shares[1] = a.loglh(), b.loglh()
+    assert abs(shares[0] + shares[1] - want) < 1e-9 * abs(want)
+
+    def cb_for(other_share, slot):
+        def cb(ctx, data, n, op):
+            assert n == 2 and op == 0
+            data[slot] += other_share
+        return pc.REDUCE_CB(cb)
+    cba, cbb = cb_for(shares[1], 1), cb_for(shares[0], 0)
+    oracle.lib.pllhip_eval_set_parallel_context(a.ev, None, C.cast(cba, C.c_void_p))
+    oracle.lib.pllhip_eval_set_parallel_context(b.ev, None, C.cast(cbb, C.c_void_p))
+    assert abs(a.loglh() - want) < 1e-9 * abs(want)
+    assert abs(b.loglh() - want) < 1e-9 * abs(want)
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
+def test_driver_on_gpu_matches_oracle(product, oracle):
+    g = check_driver(product)
+    c = check_driver(oracle)
+    for x, y in zip(g, c):
+        assert abs(x - y) < 1e-7 * abs(y)
+
+
+@pytest.mark.gpu
+def test_driver_counters_reach_the_engine(product):
+    with build(product, flags=1) as ev:
+        ev.loglh()
+        c = ev.parts[1].counters()
+        assert c.pmatrix_updates == 25 and c.pmatrix_launches == 1   # 25 calls, one launch
+        assert c.partial_ops == 12 and c.partial_launches < 12       # level-scheduled
