@@ -23,8 +23,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "profiles")
 
 
+def newest(pattern):
+    """gpurun merges every run into gpurun_out/: keep the most recent file only"""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
 def pmc_per_kernel(directory, counter):
-    files = glob.glob(os.path.join(directory, "*", "*_counter_collection.csv"))
+    files = newest(os.path.join(directory, "*", "*_counter_collection.csv"))
     acc = {}
     for f in files:
         for row in csv.DictReader(open(f)):
@@ -42,7 +48,7 @@ def main():
     kernel_key = sys.argv[3] if len(sys.argv) > 3 else None
     os.makedirs(OUT, exist_ok=True)
     g = os.path.join(ROOT, "gpurun_out")
-    stats = glob.glob(os.path.join(g, f"prof_{cfg}", "*", "*_kernel_stats.csv"))
+    stats = newest(os.path.join(g, f"prof_{cfg}", "*", "*_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(OUT, f"{rnd}_{cfg}_kernel_stats.csv"))
     bench = os.path.join(g, f"bench_{cfg}.json")
