@@ -113,6 +113,7 @@ typedef struct pllhip_profile
   unsigned long long ops;
   double kernel_ms;
   double algorithmic_bytes;
+  double algorithmic_flops;   /* 2*S*S per non-tip child matvec + S products, per site-update */
 } pllhip_profile_t;
 
 PLL_EXPORT int pllhip_profile_partials(pll_partition_t * partition, int enable);

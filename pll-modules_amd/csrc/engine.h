@@ -55,7 +55,7 @@ struct OpBatch
   OpDesc op[MAX_OPS_PER_LAUNCH];
 };
 
-enum class KernelFamily { Generic, S4, S20 };
+enum class KernelFamily { Generic, S4, S20, S61 };
 
 struct Engine
 {
@@ -129,6 +129,7 @@ struct Engine
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;  // pool, reused
   size_t prof_used = 0;
   double prof_bytes = 0.0;        // algorithmic bytes of the recorded launches
+  double prof_flops = 0.0;        // algorithmic flops of the recorded launches
   unsigned long long prof_ops = 0;
 };
 

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void k_invariant(const double * const * tip_cl
         for (unsigned j = 0; j < S; ++j)
         {
           // rate 0 of site n: API layout, or the 32-site blocked layout of kernels_s20.hpp
-          const double v = blocked32 ? tip_clv[t][(((n >> 5) * R) * S + j) * 32 + (n & 31)]
+          const double v = blocked32 ? tip_clv[t][(((n >> 5) * R) * Sp + j) * 32 + (n & 31)]
                                      : tip_clv[t][n * R * Sp + j];
           if (v > 0.0) m |= (1ULL << j);
         }

@@ -536,31 +536,34 @@ __global__ __launch_bounds__(256) void k_derivatives_s20(ModelView mv, ParamIdx 
 // layout converters between the API layout [site][rate][20] and the blocked
 // device layout (host materialisation, tip CLV upload, checkpoint restore)
 // ---------------------------------------------------------------------------
+// (shared by the 61-state family: `rows` = states_padded = rows per unit)
 __global__ __launch_bounds__(256) void k_s20_to_blocked(const double * api, double * blocked,
-                                                        unsigned N, unsigned nblk, unsigned R)
+                                                        unsigned N, unsigned nblk, unsigned R,
+                                                        unsigned rows)
 {
-  const unsigned long long total = (unsigned long long)nblk * R * S20_UNIT;
+  const unsigned unit = rows * S20_BS;
+  const unsigned long long total = (unsigned long long)nblk * R * unit;
   for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (unsigned long long)gridDim.x * blockDim.x)
   {
-    const unsigned s = e % S20_BS, j = (e / S20_BS) % 20;
-    const unsigned long long br = e / S20_UNIT;
+    const unsigned s = e % S20_BS, j = (e / S20_BS) % rows;
+    const unsigned long long br = e / unit;
     const unsigned r = br % R;
     const unsigned long long n = (br / R) * S20_BS + s;
-    blocked[e] = (n < N) ? api[(n * R + r) * 20 + j] : 0.0;
+    blocked[e] = (n < N) ? api[(n * R + r) * rows + j] : 0.0;
   }
 }
 
 __global__ __launch_bounds__(256) void k_s20_from_blocked(const double * blocked, double * api,
-                                                          unsigned N, unsigned R)
+                                                          unsigned N, unsigned R, unsigned rows)
 {
-  const unsigned long long total = (unsigned long long)N * R * 20;
+  const unsigned long long total = (unsigned long long)N * R * rows;
   for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (unsigned long long)gridDim.x * blockDim.x)
   {
-    const unsigned j = e % 20, r = (e / 20) % R;
-    const unsigned long long n = e / 20 / R;
-    api[e] = blocked[(((n / S20_BS) * R + r) * 20 + j) * S20_BS + (n % S20_BS)];
+    const unsigned j = e % rows, r = (e / rows) % R;
+    const unsigned long long n = e / rows / R;
+    api[e] = blocked[(((n / S20_BS) * R + r) * rows + j) * S20_BS + (n % S20_BS)];
   }
 }
 

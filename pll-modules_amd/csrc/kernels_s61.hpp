@@ -1,0 +1,531 @@
+// kernels_s61.hpp -- 61-state (codon) kernel family on the fp64 matrix cores.
+//
+// Same blocked device layout and lane mapping as the 20-state family
+// (kernels_s20.hpp): clv[site_block][rate][state row][32 sites], a (block, rate)
+// unit is a 64 x 32 fp64 matrix (16 KiB; rows 61..63 are zero padding), lane
+// l = 16q + n holds sites 2n, 2n+1, and slot k of a lane is row 4k + q -- for
+// the MFMA B operand (k-step k) and for the MFMA D result (register k%4 of
+// M-tile k/4) alike.  Every CLV load/store is a fully coalesced 1 KiB wave
+// instruction.
+//
+// What differs from 20 states is the balance: a site-update moves 1 467 B for
+// 14 945 flops (AI 10.2 flop/B), i.e. the kernel sits on the ridge
+// between HBM and the FP64 matrix pipe (256 MFMA = 16 384 SIMD cycles per unit
+// against ~4 700 CU cycles of HBM time per unit).  The A fragments of ONE rate
+// (both children: 2 x 4 M-tiles x 16 k-steps x 512 B = 64 KiB) fill the LDS, so a
+// workgroup walks the rates together: fill fragments of rate r, barrier, every
+// wave processes its NB site blocks for that rate, barrier, next rate.  Results
+// are stored unscaled; the per-site scaling vote (all R*61 entries) is known
+// after the last rate and the rare rescale is a fix-up pass over the units just
+// written (L2-hot).
+#pragma once
+
+#include "kernels_common.hpp"
+#include "kernels_s20.hpp"
+#include "engine.h"
+
+namespace pllhip {
+
+constexpr unsigned S61_S = 61;
+constexpr unsigned S61_SP = 64;
+constexpr unsigned S61_KS = 16;                      // k-steps = slots per lane
+constexpr unsigned S61_MT = 4;                       // 16-row M tiles
+constexpr unsigned S61_UNIT = S61_SP * S20_BS;       // doubles per (block, rate) unit
+constexpr unsigned S61_FRAGS = S61_MT * S61_KS * 64; // A-fragment doubles per (child, rate)
+constexpr unsigned S61_NB = 2;                       // site blocks per wave per tile
+
+// A fragments of rate r of a [R][61][64] row-major matrix set:
+//   frag[(mt*16 + ks)*64 + lane] = M[r][(lane&15) + 16*mt][4*ks + (lane>>4)]   (0 beyond row/col 60)
+__device__ inline void s61_fill_frags(double * frag, const double * mats, unsigned r)
+{
+  const double * M = mats + (size_t)r * S61_S * S61_SP;
+  for (unsigned e = threadIdx.x; e < S61_FRAGS; e += blockDim.x)
+  {
+    const unsigned lane = e & 63, f = e >> 6, ks = f & 15, mt = f >> 4;
+    const unsigned i = (lane & 15) + 16 * mt, j = 4 * ks + (lane >> 4);
+    frag[e] = (i < S61_S && j < S61_S) ? M[(size_t)i * S61_SP + j] : 0.0;
+  }
+}
+
+// child term in D layout: t[k] = {even site, odd site} for row 4k + q
+__device__ inline void s61_child_inner(const double * unit, const double * frag, unsigned lane,
+                                       double2 t[S61_KS])
+{
+  const unsigned off = lane * 2;
+  v4d acc[S61_MT][2];
+#pragma unroll
+  for (unsigned mt = 0; mt < S61_MT; ++mt)
+  {
+    acc[mt][0] = v4d{0, 0, 0, 0};
+    acc[mt][1] = v4d{0, 0, 0, 0};
+  }
+#pragma unroll
+  for (unsigned half = 0; half < 2; ++half)
+  {
+    double2 b[8];
+#pragma unroll
+    for (unsigned k = 0; k < 8; ++k)
+      b[k] = *reinterpret_cast<const double2 *>(unit + (half * 8 + k) * 128 + off);
+#pragma unroll
+    for (unsigned k = 0; k < 8; ++k)
+    {
+      const unsigned ks = half * 8 + k;
+#pragma unroll
+      for (unsigned mt = 0; mt < S61_MT; ++mt)
+      {
+        const double a = frag[(mt * S61_KS + ks) * 64 + lane];
+        acc[mt][0] = mfma_f64(a, b[k].x, acc[mt][0]);
+        acc[mt][1] = mfma_f64(a, b[k].y, acc[mt][1]);
+      }
+    }
+  }
+#pragma unroll
+  for (unsigned mt = 0; mt < S61_MT; ++mt)
+#pragma unroll
+    for (unsigned v = 0; v < 4; ++v)
+      t[mt * 4 + v] = make_double2(acc[mt][0][v], acc[mt][1][v]);
+}
+
+// LUT row layout [code][61]
+__device__ inline void s61_child_tip(const double * lut_r, unsigned code_e, unsigned code_o,
+                                     unsigned q, double2 t[S61_KS])
+{
+  const double * le = lut_r + code_e * S61_S, * lo = lut_r + code_o * S61_S;
+#pragma unroll
+  for (unsigned k = 0; k < S61_KS; ++k)
+  {
+    const unsigned i = 4 * k + q;
+    t[k] = (i < S61_S) ? make_double2(le[i], lo[i]) : make_double2(0.0, 0.0);
+  }
+}
+
+__device__ inline void s61_load_d(const double * unit, unsigned lane, double2 t[S61_KS])
+{
+#pragma unroll
+  for (unsigned k = 0; k < S61_KS; ++k)
+    t[k] = *reinterpret_cast<const double2 *>(unit + k * 128 + lane * 2);
+}
+
+__device__ inline void s61_store_d(double * unit, unsigned lane, const double2 t[S61_KS])
+{
+#pragma unroll
+  for (unsigned k = 0; k < S61_KS; ++k)
+    *reinterpret_cast<double2 *>(unit + k * 128 + lane * 2) = t[k];
+}
+
+__device__ inline void s61_tip_d(unsigned long long mask_e, unsigned long long mask_o, unsigned q,
+                                 double2 t[S61_KS])
+{
+#pragma unroll
+  for (unsigned k = 0; k < S61_KS; ++k)
+  {
+    const unsigned i = 4 * k + q;
+    t[k] = (i < S61_S) ? make_double2((double)((mask_e >> i) & 1ULL), (double)((mask_o >> i) & 1ULL))
+                       : make_double2(0.0, 0.0);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// partials (also the sumtable, with eigen-basis matrices).
+// grid = (tiles capped, ops), block = 256; a tile = 4 waves x S61_NB site blocks
+// dynamic LDS = 2 * S61_FRAGS doubles (64 KiB): A fragments -- or the tip lookup
+// table of the current rate when it fits (codes * 61 <= 4096) -- per child
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_partials_s61(OpBatch batch, unsigned nblk, unsigned R,
+                                                         unsigned lut_codes)
+{
+  extern __shared__ double frag[];
+  double * const frag2 = frag + S61_FRAGS;
+  const OpDesc & op = batch.op[blockIdx.y];
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, n = lane & 15;
+  const bool scaling = op.parent_scaler != nullptr;
+  const bool lut_lds = lut_codes * S61_S <= S61_FRAGS;
+  const unsigned ntiles = (nblk + 4 * S61_NB - 1) / (4 * S61_NB);
+
+  for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+  {
+    unsigned blk[S61_NB], c1e[S61_NB], c1o[S61_NB], c2e[S61_NB], c2o[S61_NB];
+    int small_e[S61_NB], small_o[S61_NB];
+#pragma unroll
+    for (unsigned b = 0; b < S61_NB; ++b)
+    {
+      blk[b] = (tile * 4 + wave) * S61_NB + b;
+      small_e[b] = small_o[b] = 1;
+      c1e[b] = c1o[b] = c2e[b] = c2o[b] = 0;
+      if (blk[b] < nblk)
+      {
+        const size_t site0 = (size_t)blk[b] * S20_BS + 2 * n;
+        if (op.codes1) { c1e[b] = op.codes1[site0]; c1o[b] = op.codes1[site0 + 1]; }
+        if (op.codes2) { c2e[b] = op.codes2[site0]; c2o[b] = op.codes2[site0 + 1]; }
+      }
+    }
+
+    for (unsigned r = 0; r < R; ++r)
+    {
+      __syncthreads();            // every wave is done reading the previous rate's fragments
+      if (!op.codes1) s61_fill_frags(frag, op.pmat1, r);
+      else if (lut_lds)
+        for (unsigned e = threadIdx.x; e < lut_codes * S61_S; e += blockDim.x)
+          frag[e] = op.lut1[(size_t)r * lut_codes * S61_S + e];
+      if (!op.codes2) s61_fill_frags(frag2, op.pmat2, r);
+      else if (lut_lds)
+        for (unsigned e = threadIdx.x; e < lut_codes * S61_S; e += blockDim.x)
+          frag2[e] = op.lut2[(size_t)r * lut_codes * S61_S + e];
+      __syncthreads();
+
+#pragma unroll
+      for (unsigned b = 0; b < S61_NB; ++b)
+      {
+        if (blk[b] >= nblk) continue;
+        const size_t ubase = ((size_t)blk[b] * R + r) * S61_UNIT;
+        double2 t1[S61_KS], t2[S61_KS];
+        if (!op.codes1) s61_child_inner(op.clv1 + ubase, frag, lane, t1);
+        else if (lut_lds) s61_child_tip(frag, c1e[b], c1o[b], q, t1);
+        else s61_child_tip(op.lut1 + (size_t)r * lut_codes * S61_S, c1e[b], c1o[b], q, t1);
+        if (!op.codes2) s61_child_inner(op.clv2 + ubase, frag2, lane, t2);
+        else if (lut_lds) s61_child_tip(frag2, c2e[b], c2o[b], q, t2);
+        else s61_child_tip(op.lut2 + (size_t)r * lut_codes * S61_S, c2e[b], c2o[b], q, t2);
+#pragma unroll
+        for (unsigned k = 0; k < S61_KS; ++k)
+        {
+          t1[k].x *= t2[k].x;
+          t1[k].y *= t2[k].y;
+          if (4 * k + q < S61_S)
+          {
+            small_e[b] &= (t1[k].x < SCALE_THRESHOLD);
+            small_o[b] &= (t1[k].y < SCALE_THRESHOLD);
+          }
+        }
+        s61_store_d(op.parent + ubase, lane, t1);
+      }
+    }
+
+    if (scaling)
+    {
+#pragma unroll
+      for (unsigned b = 0; b < S61_NB; ++b)
+      {
+        if (blk[b] >= nblk) continue;
+        const int se = s20_and_q(small_e[b]), so = s20_and_q(small_o[b]);
+        if (__any(se | so))
+        {
+          const double fe = se ? SCALE_FACTOR : 1.0, fo = so ? SCALE_FACTOR : 1.0;
+          for (unsigned r = 0; r < R; ++r)
+          {
+            double * unit = op.parent + ((size_t)blk[b] * R + r) * S61_UNIT;
+            double2 t[S61_KS];
+            s61_load_d(unit, lane, t);
+#pragma unroll
+            for (unsigned k = 0; k < S61_KS; ++k) { t[k].x *= fe; t[k].y *= fo; }
+            s61_store_d(unit, lane, t);
+          }
+        }
+        if (q == 0)
+        {
+          const size_t site0 = (size_t)blk[b] * S20_BS + 2 * n;
+          unsigned ce = se ? 1u : 0u, co = so ? 1u : 0u;
+          if (op.scaler1) { ce += op.scaler1[site0]; co += op.scaler1[site0 + 1]; }
+          if (op.scaler2) { ce += op.scaler2[site0]; co += op.scaler2[site0 + 1]; }
+          op.parent_scaler[site0] = ce;
+          op.parent_scaler[site0 + 1] = co;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// edge / root log-likelihood.  grid <= REDUCE_BLOCKS tiles-strided, block = 256
+// dynamic LDS = S61_FRAGS doubles
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_edge_lnl_s61(ModelView mv, ParamIdx fidx,
+                                                         NodeRef parent, NodeRef child,
+                                                         const double * pmat, const double * lut,
+                                                         unsigned lut_codes,
+                                                         const unsigned * ps, const unsigned * cs,
+                                                         const unsigned * weights, const int * invariant,
+                                                         const unsigned long long * tipmap,
+                                                         unsigned N, unsigned nblk, unsigned R,
+                                                         double * persite, ReduceOut block_out)
+{
+  extern __shared__ double frag[];
+  __shared__ double scratch[4];
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, n = lane & 15;
+  const unsigned ntiles = (nblk + 3) / 4;
+  double acc = 0.0;
+
+  for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+  {
+    const unsigned blk = tile * 4 + wave;
+    const bool live = blk < nblk;
+    const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+    unsigned cce = 0, cco = 0;
+    unsigned long long pme = 0, pmo = 0;
+    int inv_e = -1, inv_o = -1;
+    if (live)
+    {
+      if (child.codes) { cce = child.codes[site0]; cco = child.codes[site0 + 1]; }
+      if (parent.codes) { pme = tipmap[parent.codes[site0]]; pmo = tipmap[parent.codes[site0 + 1]]; }
+      if (invariant)
+      {
+        inv_e = (site0 < N) ? invariant[site0] : -1;
+        inv_o = (site0 + 1 < N) ? invariant[site0 + 1] : -1;
+      }
+    }
+    double site_e = 0.0, site_o = 0.0, ie = 0.0, io = 0.0;
+    for (unsigned r = 0; r < R; ++r)
+    {
+      __syncthreads();
+      if (pmat && !child.codes) s61_fill_frags(frag, pmat, r);
+      __syncthreads();
+      if (!live) continue;
+      const size_t ubase = ((size_t)blk * R + r) * S61_UNIT;
+      const unsigned fi = fidx.v[r];
+      const double * pi = mv.freqs(fi);
+      double2 t[S61_KS], pv[S61_KS];
+      if (!pmat)
+      {
+#pragma unroll
+        for (unsigned k = 0; k < S61_KS; ++k) t[k] = make_double2(1.0, 1.0);
+      }
+      else if (child.codes) s61_child_tip(lut + (size_t)r * lut_codes * S61_S, cce, cco, q, t);
+      else s61_child_inner(child.clv + ubase, frag, lane, t);
+      if (parent.codes) s61_tip_d(pme, pmo, q, pv);
+      else s61_load_d(parent.clv + ubase, lane, pv);
+      double le = 0.0, lo = 0.0;
+#pragma unroll
+      for (unsigned k = 0; k < S61_KS; ++k)
+      {
+        const unsigned i = 4 * k + q;
+        const double f = (i < S61_S) ? pi[i] : 0.0;
+        le += f * pv[k].x * t[k].x;
+        lo += f * pv[k].y * t[k].y;
+      }
+      le = s20_sum_q(le);
+      lo = s20_sum_q(lo);
+      const double pinv = mv.pinv()[fi], w = mv.weights()[r];
+      if (pinv > 0.0)
+      {
+        site_e += w * (1.0 - pinv) * le;
+        site_o += w * (1.0 - pinv) * lo;
+        if (inv_e >= 0) ie += w * pinv * pi[inv_e];
+        if (inv_o >= 0) io += w * pinv * pi[inv_o];
+      }
+      else
+      {
+        site_e += w * le;
+        site_o += w * lo;
+      }
+    }
+    if (live && q == 0)
+    {
+      if (site0 < N)
+      {
+        const unsigned cnt = (ps ? ps[site0] : 0u) + (cs ? cs[site0] : 0u);
+        const double l = site_loglh(site_e, cnt, ie);
+        if (persite) persite[site0] = l;
+        acc += l * (double)weights[site0];
+      }
+      if (site0 + 1 < N)
+      {
+        const unsigned cnt = (ps ? ps[site0 + 1] : 0u) + (cs ? cs[site0 + 1] : 0u);
+        const double l = site_loglh(site_o, cnt, io);
+        if (persite) persite[site0 + 1] = l;
+        acc += l * (double)weights[site0 + 1];
+      }
+    }
+  }
+  const double tot = block_sum_256(acc, scratch);
+  grid_reduce_finish1(tot, block_out, scratch);
+}
+
+// sumtable preparation: Lm[r][k][i] = pi_i V[i][k], Rm[r][k][j] = V^-1[k][j] in
+// [r][61][64] row-major form, plus tip lookup tables [r][code][61]
+__global__ __launch_bounds__(256) void k_sumtable_prep_s61(ModelView mv, ParamIdx params,
+                                                           const unsigned long long * tipmap,
+                                                           unsigned lut_codes, bool want_lut,
+                                                           double * Lm, double * Rm,
+                                                           double * lutL, double * lutR)
+{
+  const unsigned r = blockIdx.x, pi_ = params.v[r];
+  const double * pi = mv.freqs(pi_), * V = mv.evecs(pi_), * Vi = mv.ievecs(pi_);
+  double * L = Lm + (size_t)r * S61_S * S61_SP, * Rr = Rm + (size_t)r * S61_S * S61_SP;
+  for (unsigned e = threadIdx.x; e < S61_S * S61_SP; e += blockDim.x)
+  {
+    const unsigned k = e / S61_SP, i = e % S61_SP;
+    L[e] = (i < S61_S) ? pi[i] * V[i * S61_SP + k] : 0.0;
+    Rr[e] = (i < S61_S) ? Vi[k * S61_SP + i] : 0.0;
+  }
+  if (!want_lut) return;
+  for (unsigned e = threadIdx.x; e < lut_codes * S61_S; e += blockDim.x)
+  {
+    const unsigned c = e / S61_S, k = e % S61_S;
+    const unsigned long long mask = tipmap[c];
+    double a = 0.0, b = 0.0;
+    for (unsigned i = 0; i < S61_S; ++i)
+      if ((mask >> i) & 1ULL) { a += pi[i] * V[i * S61_SP + k]; b += Vi[k * S61_SP + i]; }
+    lutL[((size_t)r * lut_codes + c) * S61_S + k] = a;
+    lutR[((size_t)r * lut_codes + c) * S61_S + k] = b;
+  }
+}
+
+// derivatives of -lnL from a blocked sumtable; dynamic LDS = 3 * R * 64 doubles
+__global__ __launch_bounds__(256) void k_derivatives_s61(ModelView mv, ParamIdx params, double t,
+                                                         const double * sumtable,
+                                                         const unsigned * ps, const unsigned * cs,
+                                                         const unsigned * weights, const int * invariant,
+                                                         unsigned N, unsigned nblk, unsigned R,
+                                                         ReduceOut block_out)
+{
+  extern __shared__ double coef[];        // e0 | e1 | e2, each [R][64]
+  __shared__ double scratch[4];
+  double * e0 = coef, * e1 = coef + R * S61_SP, * e2 = coef + 2 * R * S61_SP;
+  for (unsigned x = threadIdx.x; x < R * S61_SP; x += blockDim.x)
+  {
+    const unsigned r = x / S61_SP, k = x % S61_SP, pi_ = params.v[r];
+    double a = 0.0, b = 0.0, c = 0.0;
+    if (k < S61_S)
+    {
+      const double pinv = mv.pinv()[pi_];
+      const double lam = mv.evals(pi_)[k] * mv.rates()[r] / (1.0 - pinv);
+      const double wr = mv.weights()[r] * ((pinv > 0.0) ? (1.0 - pinv) : 1.0);
+      const double ex = exp(lam * t);
+      a = wr * ex; b = wr * ex * lam; c = wr * ex * lam * lam;
+    }
+    e0[x] = a; e1[x] = b; e2[x] = c;
+  }
+  __syncthreads();
+
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, n = lane & 15;
+  const unsigned wstride = gridDim.x * 4;
+  double df = 0.0, ddf = 0.0;
+  for (unsigned blk = blockIdx.x * 4 + wave; blk < nblk; blk += wstride)
+  {
+    const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+    double Ae = 0, Be = 0, Ce = 0, Ao = 0, Bo = 0, Co = 0, inv_e = 0, inv_o = 0;
+    for (unsigned r = 0; r < R; ++r)
+    {
+      double2 s[S61_KS];
+      s61_load_d(sumtable + ((size_t)blk * R + r) * S61_UNIT, lane, s);
+#pragma unroll
+      for (unsigned k = 0; k < S61_KS; ++k)
+      {
+        const unsigned row = r * S61_SP + 4 * k + q;
+        Ae += s[k].x * e0[row]; Be += s[k].x * e1[row]; Ce += s[k].x * e2[row];
+        Ao += s[k].y * e0[row]; Bo += s[k].y * e1[row]; Co += s[k].y * e2[row];
+      }
+      const unsigned pi_ = params.v[r];
+      const double pinv = mv.pinv()[pi_];
+      if (pinv > 0.0 && invariant)
+      {
+        const double w = mv.weights()[r] * pinv;
+        if (site0 < N && invariant[site0] >= 0) inv_e += w * mv.freqs(pi_)[invariant[site0]];
+        if (site0 + 1 < N && invariant[site0 + 1] >= 0) inv_o += w * mv.freqs(pi_)[invariant[site0 + 1]];
+      }
+    }
+    Ae = s20_sum_q(Ae); Be = s20_sum_q(Be); Ce = s20_sum_q(Ce);
+    Ao = s20_sum_q(Ao); Bo = s20_sum_q(Bo); Co = s20_sum_q(Co);
+    if (q == 0)
+    {
+      if (site0 < N)
+      {
+        if (inv_e > 0.0)
+        {
+          const unsigned cnt = (ps ? ps[site0] : 0u) + (cs ? cs[site0] : 0u);
+          Ae += (cnt <= 3) ? ldexp(inv_e, 256 * (int)cnt) : INFINITY;
+        }
+        const double w = (double)weights[site0], ba = Be / Ae, ca = Ce / Ae;
+        df -= w * ba;
+        ddf += w * (ba * ba - ca);
+      }
+      if (site0 + 1 < N)
+      {
+        if (inv_o > 0.0)
+        {
+          const unsigned cnt = (ps ? ps[site0 + 1] : 0u) + (cs ? cs[site0 + 1] : 0u);
+          Ao += (cnt <= 3) ? ldexp(inv_o, 256 * (int)cnt) : INFINITY;
+        }
+        const double w = (double)weights[site0 + 1], ba = Bo / Ao, ca = Co / Ao;
+        df -= w * ba;
+        ddf += w * (ba * ba - ca);
+      }
+    }
+  }
+  const double tdf = block_sum_256(df, scratch);
+  const double tddf = block_sum_256(ddf, scratch);
+  grid_reduce_finish2(tdf, tddf, block_out, scratch);
+}
+
+// --- launchers -------------------------------------------------------------
+
+static int launch_partials_s61(Engine * e, const OpBatch & batch, unsigned nops)
+{
+  const size_t lds = sizeof(double) * 2 * S61_FRAGS;
+  const unsigned ntiles = (e->nblk + 4 * S61_NB - 1) / (4 * S61_NB);
+  const unsigned gx = std::max(1u, std::min(ntiles, e->cu_count * 2u));
+  hipLaunchKernelGGL(k_partials_s61, dim3(gx, nops), dim3(256), lds, e->stream,
+                     batch, e->nblk, e->R, e->lut_codes);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+static int launch_edge_lnl_s61(Engine * e, const ModelView & mv, const ParamIdx & fidx,
+                               const NodeRef & parent, const NodeRef & child,
+                               const double * pm, const double * lut,
+                               const unsigned * ps, const unsigned * cs,
+                               double * persite, unsigned nblocks)
+{
+  const size_t lds = sizeof(double) * S61_FRAGS;
+  hipLaunchKernelGGL(k_edge_lnl_s61, dim3(nblocks), dim3(256), lds, e->stream,
+                     mv, fidx, parent, child, pm, lut, e->lut_codes, ps, cs,
+                     e->d_weights, e->d_invariant, e->d_tipmap, e->N, e->nblk, e->R,
+                     persite, reduce_out(e));
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+static int launch_sumtable_s61(Engine * e, const ModelView & mv, const ParamIdx & params,
+                               const NodeRef & parent, const NodeRef & child, double * d_sum)
+{
+  const size_t mats = (size_t)e->R * S61_S * S61_SP, luts = (size_t)e->R * std::max(1u, e->lut_codes) * S61_S;
+  if (!e->d_sum_scratch)
+  {
+    hipError_t err = hipMalloc(reinterpret_cast<void **>(&e->d_sum_scratch),
+                               sizeof(double) * 2 * (mats + (size_t)e->R * PLL_ASCII_SIZE * S61_S));
+    if (err != hipSuccess)
+    {
+      set_error(PLL_ERROR_MEM_ALLOC, "hipMalloc for sumtable scratch failed");
+      return PLL_FAILURE;
+    }
+  }
+  double * Lm = e->d_sum_scratch, * Rm = Lm + mats, * lutL = Rm + mats, * lutR = lutL + luts;
+  const bool want_lut = parent.codes || child.codes;
+  hipLaunchKernelGGL(k_sumtable_prep_s61, dim3(e->R), dim3(256), 0, e->stream,
+                     mv, params, e->d_tipmap, e->lut_codes, want_lut, Lm, Rm, lutL, lutR);
+  PLLHIP_TRY(hipGetLastError());
+  OpBatch batch;
+  OpDesc & d = batch.op[0];
+  d.clv1 = parent.clv; d.codes1 = parent.codes; d.pmat1 = Lm; d.lut1 = lutL;
+  d.clv2 = child.clv;  d.codes2 = child.codes;  d.pmat2 = Rm; d.lut2 = lutR;
+  d.scaler1 = d.scaler2 = nullptr;
+  d.parent = d_sum;
+  d.parent_scaler = nullptr;
+  return launch_partials_s61(e, batch, 1);
+}
+
+static int launch_derivatives_s61(Engine * e, const ModelView & mv, const ParamIdx & params, double t,
+                                  const double * d_sum, const unsigned * ps, const unsigned * cs,
+                                  unsigned nblocks)
+{
+  const size_t lds = sizeof(double) * 3 * e->R * S61_SP;
+  hipLaunchKernelGGL(k_derivatives_s61, dim3(nblocks), dim3(256), lds, e->stream,
+                     mv, params, t, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R,
+                     reduce_out(e));
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+} // namespace pllhip

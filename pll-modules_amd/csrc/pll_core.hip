@@ -22,6 +22,7 @@
 #include "kernels_generic.hpp"
 #include "kernels_s4.hpp"
 #include "kernels_s20.hpp"
+#include "kernels_s61.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -120,13 +121,14 @@ Engine * engine_create(pll_partition_t * p)
   if (force && atoi(force)) e->family = KernelFamily::Generic;
   else if (e->S == 4 && (e->R & (e->R - 1)) == 0) e->family = KernelFamily::S4;
   else if (e->S == 20 && e->R <= 8) e->family = KernelFamily::S20;
+  else if (e->S == 61) e->family = KernelFamily::S61;
   else e->family = KernelFamily::Generic;
-  e->blocked = (e->family == KernelFamily::S20);
+  e->blocked = (e->family == KernelFamily::S20 || e->family == KernelFamily::S61);
   e->nblk = (e->N + S20_BS - 1) / S20_BS;
   e->Nalloc = e->blocked ? e->nblk * S20_BS : e->N;
 
   bool ok = hip_ok(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate");
-  const size_t clv_len = e->blocked ? (size_t)e->nblk * e->R * S20_UNIT : (size_t)e->N * e->R * e->Sp;
+  const size_t clv_len = e->blocked ? (size_t)e->nblk * e->R * e->Sp * S20_BS : (size_t)e->N * e->R * e->Sp;
   e->clv_len = clv_len;
   e->d_clv.assign(e->nodes, nullptr);
   e->d_codes.assign(e->tips, nullptr);
@@ -266,7 +268,7 @@ static int store_clv(Engine * e, double * d_dst, const double * host_clv)
   if (!dev_alloc(&tmp, len, "layout staging")) return PLL_FAILURE;
   PLLHIP_TRY(hipMemcpyAsync(tmp, host_clv, len * sizeof(double), hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(k_s20_to_blocked, dim3(e->cu_count * 8), dim3(256), 0, e->stream,
-                     tmp, d_dst, e->N, e->nblk, e->R);
+                     tmp, d_dst, e->N, e->nblk, e->R, e->Sp);
   PLLHIP_TRY(hipGetLastError());
   PLLHIP_TRY(hipStreamSynchronize(e->stream));
   (void)hipFree(tmp);
@@ -287,7 +289,7 @@ static int fetch_clv(Engine * e, const double * d_src, double * host_out)
   double * tmp = nullptr;
   if (!dev_alloc(&tmp, len, "layout staging")) return PLL_FAILURE;
   hipLaunchKernelGGL(k_s20_from_blocked, dim3(e->cu_count * 8), dim3(256), 0, e->stream,
-                     d_src, tmp, e->N, e->R);
+                     d_src, tmp, e->N, e->R, e->Sp);
   PLLHIP_TRY(hipGetLastError());
   PLLHIP_TRY(hipMemcpyAsync(host_out, tmp, len * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   PLLHIP_TRY(hipStreamSynchronize(e->stream));
@@ -535,6 +537,8 @@ static int launch_partials(Engine * e, const OpBatch & batch, unsigned nops)
       return launch_partials_s4(e, batch, nops);
     case KernelFamily::S20:
       return launch_partials_s20(e, batch, nops);
+    case KernelFamily::S61:
+      return launch_partials_s61(e, batch, nops);
     default:
       break;
   }
@@ -600,7 +604,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
   {
     OpBatch batch;
     unsigned nb = 0;
-    double batch_bytes = 0.0;
+    double batch_bytes = 0.0, batch_flops = 0.0;
     for (unsigned k = 0; k <= count; ++k)
     {
       if (k < count && level[k] == l)
@@ -630,6 +634,8 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
         batch_bytes += (double)e->N * 4.0 * ((d.scaler1 ? 1 : 0) + (d.scaler2 ? 1 : 0) + (d.parent_scaler ? 1 : 0));
         batch_bytes += 8.0 * e->R * e->S * ((t1 ? (double)e->lut_codes : (double)e->Sp) +
                                             (t2 ? (double)e->lut_codes : (double)e->Sp));
+        // algorithmic flops: a 2*S*S matvec per non-tip child + S products
+        batch_flops += nr * (2.0 * e->S * e->S * ((t1 ? 0.0 : 1.0) + (t2 ? 0.0 : 1.0)) + e->S);
       }
       if (nb == MAX_OPS_PER_LAUNCH || (k == count && nb))
       {
@@ -653,11 +659,13 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
         {
           PLLHIP_TRY(hipEventRecord(ev1, e->stream));
           e->prof_bytes += batch_bytes;
+          e->prof_flops += batch_flops;
           e->prof_ops += nb;
         }
         e->counters.partial_launches++;
         nb = 0;
         batch_bytes = 0.0;
+        batch_flops = 0.0;
       }
     }
   }
@@ -759,6 +767,9 @@ static double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsi
   else if (e->family == KernelFamily::S20)
     rc = launch_edge_lnl_s20(e, mv, fidx, parent, child, pm, lut, scaler_ptr(e, psc), scaler_ptr(e, csc),
                              persite_lnl ? e->d_persite : nullptr, nblocks);
+  else if (e->family == KernelFamily::S61)
+    rc = launch_edge_lnl_s61(e, mv, fidx, parent, child, pm, lut, scaler_ptr(e, psc), scaler_ptr(e, csc),
+                             persite_lnl ? e->d_persite : nullptr, nblocks);
   else
     rc = launch_edge_lnl_generic(e, mv, fidx, parent, child, pm, lut, scaler_ptr(e, psc),
                                  (matrix_index >= 0) ? scaler_ptr(e, csc) : nullptr,
@@ -819,6 +830,8 @@ int pll_update_sumtable(pll_partition_t * p,
     rc = launch_sumtable_s4(e, mv, params, parent, child, d_sum);
   else if (e->family == KernelFamily::S20)
     rc = launch_sumtable_s20(e, mv, params, parent, child, d_sum);
+  else if (e->family == KernelFamily::S61)
+    rc = launch_sumtable_s61(e, mv, params, parent, child, d_sum);
   else
     rc = launch_sumtable_generic(e, mv, params, parent, child, d_sum);
   e->counters.sumtable_calls++;
@@ -852,6 +865,9 @@ int pll_compute_likelihood_derivatives(pll_partition_t * p,
                                scaler_ptr(e, child_scaler_index), nblocks);
   else if (e->family == KernelFamily::S20)
     rc = launch_derivatives_s20(e, mv, params, branch_length, d_sum, scaler_ptr(e, parent_scaler_index),
+                                scaler_ptr(e, child_scaler_index), nblocks);
+  else if (e->family == KernelFamily::S61)
+    rc = launch_derivatives_s61(e, mv, params, branch_length, d_sum, scaler_ptr(e, parent_scaler_index),
                                 scaler_ptr(e, child_scaler_index), nblocks);
   else
     rc = launch_derivatives_generic(e, mv, params, branch_length, d_sum,
@@ -1073,6 +1089,7 @@ int pllhip_profile_partials(pll_partition_t * p, int enable)
   e->profiling = enable != 0;
   e->prof_used = 0;
   e->prof_bytes = 0.0;
+  e->prof_flops = 0.0;
   e->prof_ops = 0;
   return PLL_SUCCESS;
 }
@@ -1093,8 +1110,10 @@ int pllhip_profile_read(pll_partition_t * p, pllhip_profile_t * out)
   out->ops = e->prof_ops;
   out->kernel_ms = ms;
   out->algorithmic_bytes = e->prof_bytes;
+  out->algorithmic_flops = e->prof_flops;
   e->prof_used = 0;
   e->prof_bytes = 0.0;
+  e->prof_flops = 0.0;
   e->prof_ops = 0;
   return PLL_SUCCESS;
 }
@@ -1105,6 +1124,7 @@ const char * pllhip_partials_kernel_name(const pll_partition_t * p)
   {
     case KernelFamily::S4: return "s4-valu";
     case KernelFamily::S20: return "s20-mfma";
+    case KernelFamily::S61: return "s61-mfma";
     default: return "generic";
   }
 }

