@@ -32,7 +32,6 @@ constexpr unsigned S61_KS = 16;                      // k-steps = slots per lane
 constexpr unsigned S61_MT = 4;                       // 16-row M tiles
 constexpr unsigned S61_UNIT = S61_SP * S20_BS;       // doubles per (block, rate) unit
 constexpr unsigned S61_FRAGS = S61_MT * S61_KS * 64; // A-fragment doubles per (child, rate)
-constexpr unsigned S61_NB = 2;                       // site blocks per wave per tile
 
 // A fragments of rate r of a [R][61][64] row-major matrix set:
 //   frag[(mt*16 + ks)*64 + lane] = M[r][(lane&15) + 16*mt][4*ks + (lane>>4)]   (0 beyond row/col 60)
@@ -131,6 +130,7 @@ __device__ inline void s61_tip_d(unsigned long long mask_e, unsigned long long m
 // dynamic LDS = 2 * S61_FRAGS doubles (64 KiB): A fragments -- or the tip lookup
 // table of the current rate when it fits (codes * 61 <= 4096) -- per child
 // ---------------------------------------------------------------------------
+template <unsigned S61_NB>    // site blocks per wave per tile (amortises the per-rate fragment fill)
 __global__ __launch_bounds__(256, 2) void k_partials_s61(OpBatch batch, unsigned nblk, unsigned R,
                                                          unsigned lut_codes)
 {
@@ -463,11 +463,20 @@ __global__ __launch_bounds__(256) void k_derivatives_s61(ModelView mv, ParamIdx 
 
 static int launch_partials_s61(Engine * e, const OpBatch & batch, unsigned nops)
 {
+  static const int env_nb = getenv("PLLHIP_S61_NB") ? atoi(getenv("PLLHIP_S61_NB")) : 0;
   const size_t lds = sizeof(double) * 2 * S61_FRAGS;
-  const unsigned ntiles = (e->nblk + 4 * S61_NB - 1) / (4 * S61_NB);
+  const unsigned nb = env_nb ? (unsigned)env_nb : 4u;
+  const unsigned ntiles = (e->nblk + 4 * nb - 1) / (4 * nb);
   const unsigned gx = std::max(1u, std::min(ntiles, e->cu_count * 2u));
-  hipLaunchKernelGGL(k_partials_s61, dim3(gx, nops), dim3(256), lds, e->stream,
-                     batch, e->nblk, e->R, e->lut_codes);
+  if (nb == 1)
+    hipLaunchKernelGGL(k_partials_s61<1>, dim3(gx, nops), dim3(256), lds, e->stream,
+                       batch, e->nblk, e->R, e->lut_codes);
+  else if (nb == 4)
+    hipLaunchKernelGGL(k_partials_s61<4>, dim3(gx, nops), dim3(256), lds, e->stream,
+                       batch, e->nblk, e->R, e->lut_codes);
+  else
+    hipLaunchKernelGGL(k_partials_s61<2>, dim3(gx, nops), dim3(256), lds, e->stream,
+                       batch, e->nblk, e->R, e->lut_codes);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }
