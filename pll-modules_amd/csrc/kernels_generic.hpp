@@ -383,6 +383,49 @@ __global__ __launch_bounds__(256) void k_invariant(const double * const * tip_cl
   }
 }
 
+// ---------------------------------------------------------------------------
+// marginal ancestral state probabilities at a node (src/tree/treeinfo.c:1698):
+//   anc[n][i] ~ sum_r w_r pi_i node[n,r,i] * sum_j P[r,i,j] other[n,r,j], normalised
+// one thread per site; works on the API layout and on the 32-site blocked layout
+// (element (n, r, j) at ((n/32 * R + r) * Sp + j) * 32 + n%32)
+// ---------------------------------------------------------------------------
+__device__ inline double clv_elem(const NodeRef & nd, const unsigned long long * tipmap, bool blocked32,
+                                  unsigned long long n, unsigned r, unsigned j, unsigned R, unsigned Sp)
+{
+  if (nd.codes) return (double)((tipmap[nd.codes[n]] >> j) & 1ULL);
+  return blocked32 ? nd.clv[(((n >> 5) * R + r) * Sp + j) * 32 + (n & 31)]
+                   : nd.clv[(n * R + r) * Sp + j];
+}
+
+__global__ __launch_bounds__(256) void k_node_ancestral(ModelView mv, ParamIdx fidx, NodeRef node,
+                                                        NodeRef other, const double * pmat,
+                                                        const unsigned long long * tipmap, bool blocked32,
+                                                        unsigned N, unsigned R, double * out)
+{
+  const unsigned S = mv.S, Sp = mv.Sp;
+  for (unsigned long long n = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; n < N;
+       n += (unsigned long long)gridDim.x * blockDim.x)
+  {
+    double * o = out + n * S;
+    double sum = 0.0;
+    for (unsigned i = 0; i < S; ++i)
+    {
+      double v = 0.0;
+      for (unsigned r = 0; r < R; ++r)
+      {
+        const double * row = pmat + ((size_t)r * S + i) * Sp;
+        double a = 0.0;
+        for (unsigned j = 0; j < S; ++j) a += row[j] * clv_elem(other, tipmap, blocked32, n, r, j, R, Sp);
+        v += mv.weights()[r] * mv.freqs(fidx.v[r])[i] * clv_elem(node, tipmap, blocked32, n, r, i, R, Sp) * a;
+      }
+      o[i] = v;
+      sum += v;
+    }
+    if (sum > 0.0)
+      for (unsigned i = 0; i < S; ++i) o[i] /= sum;
+  }
+}
+
 // expand a coded tip into a 0/1 CLV (host materialisation path)
 __global__ __launch_bounds__(256) void k_expand_codes(const uint8_t * codes,
                                                       const unsigned long long * tipmap,

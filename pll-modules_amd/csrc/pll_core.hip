@@ -918,12 +918,37 @@ int pll_update_invariant_sites(pll_partition_t * p)
   return PLL_SUCCESS;
 }
 
-int pll_compute_node_ancestral(pll_partition_t *, unsigned int, int, unsigned int, int,
-                               unsigned int, const unsigned int *, double *)
+int pll_compute_node_ancestral(pll_partition_t * p, unsigned int node_clv_index, int node_scaler_index,
+                               unsigned int other_clv_index, int other_scaler_index,
+                               unsigned int matrix_index, const unsigned int * freqs_indices,
+                               double * ancestral)
 {
-  set_error(PLL_ERROR_NOT_IMPLEMENTED,
-            "pll_compute_node_ancestral is not implemented by the HIP engine yet");
-  return PLL_FAILURE;
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  if (!check_clv_index(e, node_clv_index, "node") || !check_clv_index(e, other_clv_index, "other") ||
+      !check_scaler_index(e, node_scaler_index) || !check_scaler_index(e, other_scaler_index))
+    return PLL_FAILURE;
+  if (matrix_index >= e->nmat)
+  {
+    set_error(PLL_ERROR_PARAM_INVALID, "matrix index out of range");
+    return PLL_FAILURE;
+  }
+  if (!sync_model(p) || !flush_pmatrices(p) || !ensure_luts(p)) return PLL_FAILURE;
+  if (!e->N) return PLL_SUCCESS;
+  // the result is normalised per site, so scaler counts cancel
+  double * d_out = nullptr;
+  if (!dev_alloc(&d_out, (size_t)e->N * e->S, "ancestral states")) return PLL_FAILURE;
+  const unsigned gx = (unsigned)std::min<unsigned long long>(((unsigned long long)e->N + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_node_ancestral, dim3(gx), dim3(256), 0, e->stream,
+                     model_view(e), make_params(p, freqs_indices), node_ref(e, node_clv_index),
+                     node_ref(e, other_clv_index),
+                     e->d_pmat + (size_t)matrix_index * e->R * e->S * e->Sp, e->d_tipmap, e->blocked,
+                     e->N, e->R, d_out);
+  PLLHIP_TRY(hipGetLastError());
+  PLLHIP_TRY(hipMemcpyAsync(ancestral, d_out, sizeof(double) * e->N * e->S, hipMemcpyDeviceToHost, e->stream));
+  PLLHIP_TRY(hipStreamSynchronize(e->stream));
+  (void)hipFree(d_out);
+  return PLL_SUCCESS;
 }
 
 // ===========================================================================

@@ -176,6 +176,8 @@ class PllLib:
         L.pll_update_sumtable.argtypes = [pp, C.c_uint, C.c_uint, C.c_int, C.c_int, c_uint_p, c_double_p]
         L.pll_compute_likelihood_derivatives.argtypes = [pp, C.c_int, C.c_int, C.c_double, c_uint_p,
                                                          c_double_p, c_double_p, c_double_p]
+        L.pll_compute_node_ancestral.argtypes = [pp, C.c_uint, C.c_int, C.c_uint, C.c_int, C.c_uint,
+                                                 c_uint_p, c_double_p]
         L.pll_aligned_alloc.restype = C.c_void_p
         L.pll_aligned_alloc.argtypes = [C.c_size_t, C.c_size_t]
         L.pll_aligned_free.argtypes = [C.c_void_p]
@@ -370,6 +372,13 @@ class Instance:
         v = self.L.pll_compute_root_loglikelihood(
             self.p, clv, sc, self.params_p, buf.ctypes.data_as(c_double_p) if persite else None)
         return (v, buf) if persite else v
+
+    def node_ancestral(self, node, node_sc, other, other_sc, matrix):
+        out = np.zeros(self.N * self.S)
+        if not self.L.pll_compute_node_ancestral(self.p, node, node_sc, other, other_sc, matrix,
+                                                 self.params_p, out.ctypes.data_as(c_double_p)):
+            raise RuntimeError(self.lib.errmsg)
+        return out.reshape(self.N, self.S)
 
     def alloc_sumtable(self):
         """caller-owned buffer exactly as src/tree/treeinfo.c:336-340 allocates it"""

@@ -247,6 +247,21 @@ def test_invariant_sites(product, oracle, states):
         a.free_sumtable(sa_); b.free_sumtable(sb_)
 
 
+@pytest.mark.parametrize("states", [4, 20, 5, 61])
+def test_node_ancestral_states(product, oracle, states):
+    """marginal ancestral state probabilities (src/tree/treeinfo.c:1698)"""
+    a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=7, nsites=77, coded=True)
+    with a, b:
+        if states > 20:
+            share_eigen(a, b)
+        pc.full_traversal(a); pc.full_traversal(b)
+        t = a.tree
+        args = (t.root_a, t.scaler_of(t.root_a), t.root_b, t.scaler_of(t.root_b), t.root_matrix)
+        pa, pb = a.node_ancestral(*args), b.node_ancestral(*args)
+        assert np.allclose(pa.sum(axis=1), 1.0, atol=1e-12)
+        assert np.allclose(pa, pb, rtol=1e-9 if states <= 20 else 1e-5, atol=1e-12)
+
+
 def test_host_model_arrays_are_source_of_truth(product, oracle):
     """pll-modules writes partition->rates / frequencies / subst_params directly and
     flips eigen_decomp_valid (src/algorithm/algo_callback.c:44-68): the engine must
