@@ -172,13 +172,11 @@ __device__ inline double s20_sum_q(double v)
 // dynamic LDS = 2 * R * S20_FRAGS doubles
 // ---------------------------------------------------------------------------
 template <unsigned RT>   // RT > 0: rate count known at compile time (register-resident block)
-__global__ __launch_bounds__(256, 2) void k_partials_s20(OpBatch batch, unsigned nblk, unsigned Rrt,
-                                                         unsigned lut_codes, unsigned flags)
+__device__ inline void s20_op_body(const OpDesc & op, unsigned nblk, unsigned Rrt,
+                                   unsigned lut_codes, unsigned flags, double * frag)
 {
   const bool nt_ld = flags & 1u, nt_st = flags & 2u;
-  extern __shared__ double frag[];
   const unsigned R = RT ? RT : Rrt;
-  const OpDesc & op = batch.op[blockIdx.y];
   // each child owns R * S20_FRAGS doubles of LDS: the A fragments of its P-matrix,
   // or -- for a coded tip -- its lookup table (fits while lut_codes <= 32); LUT
   // gathers then hit LDS banks instead of the L1 address pipeline, which is what
@@ -305,6 +303,34 @@ __global__ __launch_bounds__(256, 2) void k_partials_s20(OpBatch batch, unsigned
         op.parent_scaler[site0 + 1] = co;
       }
     }
+  }
+}
+
+// one launch per dependency level: grid = (gx, ops of the level)
+template <unsigned RT>
+__global__ __launch_bounds__(256, 2) void k_partials_s20(OpBatch batch, unsigned nblk, unsigned Rrt,
+                                                         unsigned lut_codes, unsigned flags)
+{
+  extern __shared__ double frag[];
+  s20_op_body<RT>(batch.op[blockIdx.y], nblk, Rrt, lut_codes, flags, frag);
+}
+
+// Whole operation list in ONE launch.  Operations only couple the same sites, and
+// a wave owns the same site blocks (blk = wave id + k * #waves) for every
+// operation, so walking the post-order list inside the kernel needs no
+// inter-workgroup synchronisation at all: a parent block is read back by the
+// wave that wrote it, in program order.  The two workgroup barriers per
+// operation only protect the LDS fragments.  grid = gx, block = 256.
+template <unsigned RT>
+__global__ __launch_bounds__(256, 2) void k_traverse_s20(const OpDesc * ops, unsigned nops,
+                                                         unsigned nblk, unsigned Rrt,
+                                                         unsigned lut_codes, unsigned flags)
+{
+  extern __shared__ double frag[];
+  for (unsigned i = 0; i < nops; ++i)
+  {
+    __syncthreads();          // every wave is done with the previous operation's fragments
+    s20_op_body<RT>(ops[i], nblk, Rrt, lut_codes, flags, frag);
   }
 }
 
@@ -588,6 +614,21 @@ static int launch_partials_s20(Engine * e, const OpBatch & batch, unsigned nops)
   else
     hipLaunchKernelGGL(k_partials_s20<0>, dim3(s20_grid(e, 4), nops), dim3(256), lds, e->stream,
                        batch, e->nblk, e->R, e->lut_codes, flags);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+static int launch_traverse_s20(Engine * e, const OpDesc * d_ops, unsigned nops)
+{
+  const size_t lds = sizeof(double) * 2 * e->R * S20_FRAGS;
+  static const unsigned flags = getenv("PLLHIP_S20_NT") ? (unsigned)atoi(getenv("PLLHIP_S20_NT")) : 0u;
+  const unsigned gx = s20_grid(e, 2);
+  if (e->R == 4)
+    hipLaunchKernelGGL(k_traverse_s20<4>, dim3(gx), dim3(256), lds, e->stream,
+                       d_ops, nops, e->nblk, e->R, e->lut_codes, flags);
+  else
+    hipLaunchKernelGGL(k_traverse_s20<0>, dim3(gx), dim3(256), lds, e->stream,
+                       d_ops, nops, e->nblk, e->R, e->lut_codes, flags);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

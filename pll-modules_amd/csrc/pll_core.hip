@@ -213,6 +213,7 @@ void engine_destroy(Engine * e)
   (void)hipFree(e->d_partials);
   (void)hipFree(e->d_persite);
   (void)hipFree(e->d_sum_scratch);
+  (void)hipFree(e->d_ops);
   if (e->h_partials) (void)hipHostFree(e->h_partials);
   if (e->h_result) (void)hipHostFree(e->h_result);
   (void)hipFree(e->d_counter);
@@ -600,6 +601,93 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
 
   const size_t pm_stride = (size_t)e->R * e->S * e->Sp;
   const size_t lut_stride = (size_t)e->R * e->lut_codes * e->S;
+  // resolve one operation to device pointers and add its algorithmic bytes
+  // (child vectors in -- 8*S per (site, rate), a coded tip is 1 byte
+  // per site --, parent vector out, scalers, the two P-matrices or lookup tables
+  // once per op) and flops (a 2*S*S matvec per non-tip child + S products)
+  auto fill_desc = [&](const pll_operation_t & op, OpDesc & d, double & bytes, double & flops)
+  {
+    const bool t1 = e->coded_tips && op.child1_clv_index < e->tips;
+    const bool t2 = e->coded_tips && op.child2_clv_index < e->tips;
+    d.clv1 = t1 ? nullptr : e->d_clv[op.child1_clv_index];
+    d.codes1 = t1 ? e->d_codes[op.child1_clv_index] : nullptr;
+    d.pmat1 = e->d_pmat + pm_stride * op.child1_matrix_index;
+    d.lut1 = t1 ? e->d_lut + lut_stride * op.child1_matrix_index : nullptr;
+    d.clv2 = t2 ? nullptr : e->d_clv[op.child2_clv_index];
+    d.codes2 = t2 ? e->d_codes[op.child2_clv_index] : nullptr;
+    d.pmat2 = e->d_pmat + pm_stride * op.child2_matrix_index;
+    d.lut2 = t2 ? e->d_lut + lut_stride * op.child2_matrix_index : nullptr;
+    d.scaler1 = scaler_ptr(e, op.child1_scaler_index);
+    d.scaler2 = scaler_ptr(e, op.child2_scaler_index);
+    d.parent = e->d_clv[op.parent_clv_index];
+    d.parent_scaler = const_cast<unsigned *>(scaler_ptr(e, op.parent_scaler_index));
+    const double nr = (double)e->N * e->R;
+    bytes += nr * 8.0 * e->S * (1.0 + (t1 ? 0.0 : 1.0) + (t2 ? 0.0 : 1.0));
+    bytes += (double)e->N * ((t1 ? 1.0 : 0.0) + (t2 ? 1.0 : 0.0));
+    bytes += (double)e->N * 4.0 * ((d.scaler1 ? 1 : 0) + (d.scaler2 ? 1 : 0) + (d.parent_scaler ? 1 : 0));
+    bytes += 8.0 * e->R * e->S * ((t1 ? (double)e->lut_codes : (double)e->Sp) +
+                                  (t2 ? (double)e->lut_codes : (double)e->Sp));
+    flops += nr * (2.0 * e->S * e->S * ((t1 ? 0.0 : 1.0) + (t2 ? 0.0 : 1.0)) + e->S);
+  };
+  auto prof_begin = [&](hipEvent_t & ev1) -> int
+  {
+    ev1 = nullptr;
+    if (!e->profiling) return PLL_SUCCESS;
+    if (e->prof_used == e->prof_events.size())
+    {
+      hipEvent_t x, y;
+      PLLHIP_TRY(hipEventCreate(&x));
+      PLLHIP_TRY(hipEventCreate(&y));
+      e->prof_events.emplace_back(x, y);
+    }
+    hipEvent_t ev0 = e->prof_events[e->prof_used].first;
+    ev1 = e->prof_events[e->prof_used].second;
+    e->prof_used++;
+    PLLHIP_TRY(hipEventRecord(ev0, e->stream));
+    return PLL_SUCCESS;
+  };
+  auto prof_end = [&](hipEvent_t ev1, double bytes, double flops, unsigned nops) -> int
+  {
+    if (!e->profiling) return PLL_SUCCESS;
+    PLLHIP_TRY(hipEventRecord(ev1, e->stream));
+    e->prof_bytes += bytes;
+    e->prof_flops += flops;
+    e->prof_ops += nops;
+    return PLL_SUCCESS;
+  };
+
+  // Whole list in one launch (families that own fixed site blocks per wave):
+  // operations only couple the same sites, so the kernel can walk the list itself.
+  // Opt-in (PLLHIP_TRAVERSE=1): measured on C3 it is 7 % SLOWER than the
+  // level-batched launches at 1 M sites (all workgroups march through the same
+  // operation type in phase -- e.g. everybody write-only during a tip x tip
+  // operation -- and two barriers per operation couple the four waves of a block)
+  // and only 1 % faster at 125 k sites, so level batching stays the default.
+  static const int no_traverse = getenv("PLLHIP_TRAVERSE") ? !atoi(getenv("PLLHIP_TRAVERSE")) : 1;
+  if (count >= 3 && !no_traverse && e->family == KernelFamily::S20)
+  {
+    std::vector<OpDesc> h(count);
+    double bytes = 0.0, flops = 0.0;
+    for (unsigned k = 0; k < count; ++k) fill_desc(ops[k], h[k], bytes, flops);
+    if (e->d_ops_cap < count)
+    {
+      if (e->d_ops) { PLLHIP_TRY(hipStreamSynchronize(e->stream)); (void)hipFree(e->d_ops); e->d_ops = nullptr; }
+      if (!dev_alloc(&e->d_ops, (size_t)count + 64, "operation list")) return PLL_FAILURE;
+      e->d_ops_cap = count + 64;
+    }
+    // pageable source: staged by the runtime before the call returns, `h` may die;
+    // stream order keeps a previous traversal's reads ahead of this overwrite
+    PLLHIP_TRY(hipMemcpyAsync(e->d_ops, h.data(), sizeof(OpDesc) * count, hipMemcpyHostToDevice, e->stream));
+    hipEvent_t ev1;
+    if (!prof_begin(ev1)) return PLL_FAILURE;
+    if (!launch_traverse_s20(e, e->d_ops, count)) return PLL_FAILURE;
+    if (!prof_end(ev1, bytes, flops, count)) return PLL_FAILURE;
+    e->counters.partial_launches++;
+    e->counters.partial_ops += count;
+    e->counters.site_updates += (unsigned long long)count * e->N * e->R;
+    return PLL_SUCCESS;
+  }
+
   for (int l = 0; l <= max_level; ++l)
   {
     OpBatch batch;
@@ -607,61 +695,13 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     double batch_bytes = 0.0, batch_flops = 0.0;
     for (unsigned k = 0; k <= count; ++k)
     {
-      if (k < count && level[k] == l)
-      {
-        const pll_operation_t & op = ops[k];
-        OpDesc & d = batch.op[nb++];
-        const bool t1 = e->coded_tips && op.child1_clv_index < e->tips;
-        const bool t2 = e->coded_tips && op.child2_clv_index < e->tips;
-        d.clv1 = t1 ? nullptr : e->d_clv[op.child1_clv_index];
-        d.codes1 = t1 ? e->d_codes[op.child1_clv_index] : nullptr;
-        d.pmat1 = e->d_pmat + pm_stride * op.child1_matrix_index;
-        d.lut1 = t1 ? e->d_lut + lut_stride * op.child1_matrix_index : nullptr;
-        d.clv2 = t2 ? nullptr : e->d_clv[op.child2_clv_index];
-        d.codes2 = t2 ? e->d_codes[op.child2_clv_index] : nullptr;
-        d.pmat2 = e->d_pmat + pm_stride * op.child2_matrix_index;
-        d.lut2 = t2 ? e->d_lut + lut_stride * op.child2_matrix_index : nullptr;
-        d.scaler1 = scaler_ptr(e, op.child1_scaler_index);
-        d.scaler2 = scaler_ptr(e, op.child2_scaler_index);
-        d.parent = e->d_clv[op.parent_clv_index];
-        d.parent_scaler = const_cast<unsigned *>(scaler_ptr(e, op.parent_scaler_index));
-        // algorithmic bytes of this op: child vectors in (8*S per
-        // (site,rate); a coded tip is 1 byte per site), parent vector out, scalers,
-        // the two P-matrices (or lookup tables) once per op
-        const double nr = (double)e->N * e->R;
-        batch_bytes += nr * 8.0 * e->S * (1.0 + (t1 ? 0.0 : 1.0) + (t2 ? 0.0 : 1.0));
-        batch_bytes += (double)e->N * ((t1 ? 1.0 : 0.0) + (t2 ? 1.0 : 0.0));
-        batch_bytes += (double)e->N * 4.0 * ((d.scaler1 ? 1 : 0) + (d.scaler2 ? 1 : 0) + (d.parent_scaler ? 1 : 0));
-        batch_bytes += 8.0 * e->R * e->S * ((t1 ? (double)e->lut_codes : (double)e->Sp) +
-                                            (t2 ? (double)e->lut_codes : (double)e->Sp));
-        // algorithmic flops: a 2*S*S matvec per non-tip child + S products
-        batch_flops += nr * (2.0 * e->S * e->S * ((t1 ? 0.0 : 1.0) + (t2 ? 0.0 : 1.0)) + e->S);
-      }
+      if (k < count && level[k] == l) fill_desc(ops[k], batch.op[nb++], batch_bytes, batch_flops);
       if (nb == MAX_OPS_PER_LAUNCH || (k == count && nb))
       {
-        hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        if (e->profiling)
-        {
-          if (e->prof_used == e->prof_events.size())
-          {
-            hipEvent_t a, b;
-            PLLHIP_TRY(hipEventCreate(&a));
-            PLLHIP_TRY(hipEventCreate(&b));
-            e->prof_events.emplace_back(a, b);
-          }
-          ev0 = e->prof_events[e->prof_used].first;
-          ev1 = e->prof_events[e->prof_used].second;
-          e->prof_used++;
-          PLLHIP_TRY(hipEventRecord(ev0, e->stream));
-        }
+        hipEvent_t ev1;
+        if (!prof_begin(ev1)) return PLL_FAILURE;
         if (!launch_partials(e, batch, nb)) return PLL_FAILURE;
-        if (e->profiling)
-        {
-          PLLHIP_TRY(hipEventRecord(ev1, e->stream));
-          e->prof_bytes += batch_bytes;
-          e->prof_flops += batch_flops;
-          e->prof_ops += nb;
-        }
+        if (!prof_end(ev1, batch_bytes, batch_flops, nb)) return PLL_FAILURE;
         e->counters.partial_launches++;
         nb = 0;
         batch_bytes = 0.0;
