@@ -680,6 +680,7 @@ CONFIGS = {
     "c1": (4, 1, 10, 1000),
     "c2": (4, 4, 100, 1_000_000),
     "c3": (20, 4, 200, 1_000_000),
+    "c4": (20, 4, 100, 1_000_000),     # site count split 25/25/12.5/12.5 % over 2 DNA + 2 protein partitions
     "c5": (61, 4, 50, 200_000),
 }
 
