@@ -123,10 +123,43 @@ def c4(lib, out):
         p.close()
 
 
+def blo(lib, cfg, out, nsites=None):
+    """one smoothing pass of Newton-Raphson branch-length optimisation over ALL branches
+    through the C driver (pllhip_eval_optimize_branches = the reference's
+    pllmod_opt_optimize_branch_lengths_local_multi pattern: per branch 1 sumtable,
+    a few derivative scans, 1 P-matrix, up to 3 single-op CLV updates)"""
+    S, R, ntips, N = pc.CONFIGS[cfg]
+    N = nsites or N
+    t = pc.Tree(ntips, 42, 43)
+    ev = pc.Evaluation(lib, t.newick(), nparts=1)
+    if S == 4:
+        subst, freqs, alpha = pc.DNA_GTR_RATES, pc.DNA_FREQS, 0.841
+    else:
+        (subst, freqs), alpha = pc.protein_model(), 0.5
+    inst = ev.add_partition(0, S, N, R, pc.random_codes(ntips, N, S), subst, freqs, alpha)
+    with ev:
+        l0 = ev.loglh()
+        lib.lib.pllhip_synchronize(inst.p)
+        ops0, pm0, d0 = ev.counters()
+        t0 = time.perf_counter()
+        l1 = ev.optimize_branches(1e-4, 10.0, 0.01, 1, -1)
+        dt = time.perf_counter() - t0
+        ops1, pm1, d1 = ev.counters()
+        out[f"BLO_{cfg}_{N}"] = {"s_per_smoothing_pass": dt, "lnl_before": l0, "lnl_after": l1,
+                                 "derivative_calls": d1 - d0, "single_op_updates": ops1 - ops0,
+                                 "pmatrix_updates": pm1 - pm0, "branches": t.nedges,
+                                 "us_per_derivative_call_incl_everything": dt / max(1, d1 - d0) * 1e6,
+                                 "what": "pllhip_eval_optimize_branches(iters=1, radius=ALL), C driver"}
+
+
 def main():
     lib = pc.PllLib(pc.PRODUCT_LIB)
     out = {}
-    which = sys.argv[1:] or ["w2", "w3", "c4"]
+    which = sys.argv[1:] or ["w2", "w3", "c4", "blo"]
+    if "blo" in which:
+        blo(lib, "c3", out)
+        blo(lib, "c2", out)
+        blo(lib, "c3", out, nsites=125_000)
     if "w2" in which:
         w2(lib, "c3", out)
         w2(lib, "c2", out)
