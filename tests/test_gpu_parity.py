@@ -91,8 +91,9 @@ def test_golden_fixtures_on_gpu(product, name, coded):
     common.check_golden(expected, got)
 
 
-@pytest.mark.parametrize("states,rate_cats", [(4, 4), (4, 1), (4, 2), (20, 4), (20, 1), (5, 4),
-                                              (2, 3), (7, 4), (61, 2)])
+@pytest.mark.parametrize("states,rate_cats", [(4, 4), (4, 1), (4, 2), (4, 8), (4, 16), (4, 3),
+                                              (20, 4), (20, 1), (20, 2), (20, 8), (20, 12),
+                                              (5, 4), (2, 3), (7, 4), (61, 2), (61, 4)])
 @pytest.mark.parametrize("coded", [True, False])
 def test_full_traversal_parity(product, oracle, states, rate_cats, coded):
     ntips, nsites = (9, 257) if states > 20 else (14, 1031)
@@ -108,6 +109,48 @@ def test_ragged_site_counts(product, oracle, states, nsites):
     a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=6, nsites=nsites, coded=True)
     with a, b:
         _compare_full(a, b)
+
+
+@pytest.mark.parametrize("states,ncodes", [(20, 45), (4, 15), (61, 70), (7, 40)])
+def test_many_ambiguity_codes(product, oracle, states, ncodes):
+    """tip alphabets with many ambiguity codes: beyond 32 (20 states) / 67 (61 states)
+    codes the lookup tables no longer fit the LDS staging area and are gathered from
+    global memory instead; code tables also grow after P-matrices exist (LUT rebuild)"""
+    ntips, nsites = 9, 333
+    rng = pc.splitmix64(1234 + states, ncodes * 3)
+    cmap = np.zeros(256, dtype=np.uint64)
+    full = (1 << states) - 1
+    for c in range(ncodes):
+        if c < states:
+            m = 1 << c
+        else:
+            m = (1 << int(rng[3 * c] % np.uint64(states))) | (1 << int(rng[3 * c + 1] % np.uint64(states))) | \
+                (1 << int(rng[3 * c + 2] % np.uint64(states)))
+        cmap[48 + c] = m & full
+    masks = {int(cmap[48 + c]) for c in range(ncodes)}
+    seqs = (pc.splitmix64(77, ntips * nsites) % np.uint64(ncodes)).astype(np.uint8).reshape(ntips, nsites)
+    insts = []
+    for lib in (product, oracle):
+        inst = pc.build_instance(lib, states=states, rate_cats=4, ntips=ntips, nsites=nsites, coded=True)
+        l_plain = pc.full_traversal(inst)           # P-matrices + LUTs exist for the plain alphabet
+        for t in range(ntips):
+            inst.set_tip_states(t, cmap, (seqs[t] + 48).tobytes())
+        insts.append((inst, l_plain))
+    (a, la0), (b, lb0) = insts
+    with a, b:
+        if states > 20:
+            share_eigen(a, b)
+        assert a.p.contents.maxstates == b.p.contents.maxstates >= min(len(masks), ncodes) - 1
+        la, lb = pc.full_traversal(a), pc.full_traversal(b)
+        assert lnl_close(la, lb, nsites), (la, lb)
+        assert abs(la - la0) > 1.0                   # the ambiguous alignment really is different
+        t = a.tree
+        sa, sb = a.alloc_sumtable(), b.alloc_sumtable()
+        args = (t.root_a, t.root_b, t.scaler_of(t.root_a), t.scaler_of(t.root_b))
+        a.update_sumtable(*args, sa); b.update_sumtable(*args, sb)
+        assert np.allclose(a.derivatives(args[2], args[3], 0.2, sa), b.derivatives(args[2], args[3], 0.2, sb),
+                           rtol=1e-8 if states <= 20 else 2e-6)
+        a.free_sumtable(sa); b.free_sumtable(sb)
 
 
 def test_empty_partition(product):
