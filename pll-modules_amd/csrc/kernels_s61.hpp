@@ -236,6 +236,335 @@ __global__ __launch_bounds__(256, 2) void k_partials_s61(OpBatch batch, unsigned
 }
 
 // ---------------------------------------------------------------------------
+// partials, range-walking variant ("v3").  Two measured costs of k_partials_s61
+// are removed: (1) the per-tile fragment fill -- every workgroup now owns ONE
+// contiguous range of site blocks and walks it once per rate, so the fragments of
+// a rate are filled once per workgroup; (2) exposed HBM latency -- the B operands
+// are fetched half a child (8 KiB per wave) ahead of the MFMAs that consume them,
+// into two alternating register sets, so a wave always has loads in flight while
+// it (or the other wave of its SIMD) feeds the matrix pipe.
+// Fragment layout (pairs of M tiles, one ds_read_b128 feeds four MFMAs):
+//   frag[((ks*2 + mp)*64 + lane)*2 + h] = M[r][(lane&15) + 16*(2*mp + h)][4*ks + (lane>>4)]
+// grid = (<= 2 x CUs, ops), block = 256, dynamic LDS = 64 KiB.
+// ---------------------------------------------------------------------------
+constexpr unsigned S61_CHUNK = 128;      // blocks per workgroup pass: 4 waves x 32 flag bits
+
+__device__ inline void s61_fill_frags_v3(double * frag, const double * mats, unsigned r)
+{
+  const double * M = mats + (size_t)r * S61_S * S61_SP;
+  for (unsigned e = threadIdx.x; e < S61_FRAGS; e += blockDim.x)
+  {
+    const unsigned h = e & 1, lane = (e >> 1) & 63, f = e >> 7, mp = f & 1, ks = f >> 1;
+    const unsigned i = (lane & 15) + 16 * (2 * mp + h), j = 4 * ks + (lane >> 4);
+    frag[e] = (i < S61_S && j < S61_S) ? M[(size_t)i * S61_SP + j] : 0.0;
+  }
+}
+
+#define S61_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <unsigned HALF>
+__device__ inline void s61_issue_half(const double * unit, unsigned lane, double2 b[8])
+{
+#pragma unroll
+  for (unsigned k = 0; k < 8; ++k)
+    b[k] = *reinterpret_cast<const double2 *>(unit + (HALF * 8 + k) * 128 + lane * 2);
+}
+
+template <unsigned HALF>
+__device__ inline void s61_mfma_half(const double2 b[8], const double2 * fragv, unsigned lane,
+                                     v4d acc[S61_MT][2])
+{
+#pragma unroll
+  for (unsigned k = 0; k < 8; ++k)
+  {
+    const unsigned ks = HALF * 8 + k;
+#pragma unroll
+    for (unsigned mp = 0; mp < 2; ++mp)
+    {
+      const double2 a = fragv[(ks * 2 + mp) * 64 + lane];
+      acc[2 * mp][0] = mfma_f64(a.x, b[k].x, acc[2 * mp][0]);
+      acc[2 * mp][1] = mfma_f64(a.x, b[k].y, acc[2 * mp][1]);
+      acc[2 * mp + 1][0] = mfma_f64(a.y, b[k].x, acc[2 * mp + 1][0]);
+      acc[2 * mp + 1][1] = mfma_f64(a.y, b[k].y, acc[2 * mp + 1][1]);
+    }
+  }
+}
+
+__device__ inline void s61_acc_zero(v4d acc[S61_MT][2])
+{
+#pragma unroll
+  for (unsigned mt = 0; mt < S61_MT; ++mt)
+  {
+    acc[mt][0] = v4d{0, 0, 0, 0};
+    acc[mt][1] = v4d{0, 0, 0, 0};
+  }
+}
+
+// product of the two child terms, scaling vote, store: t1 * acc -> parent unit
+__device__ inline void s61_finish_unit(double * dst, unsigned lane, unsigned q, double2 t1[S61_KS],
+                                       const double2 t2[S61_KS], unsigned bit, unsigned & small_e,
+                                       unsigned & small_o)
+{
+  int se = 1, so = 1;
+#pragma unroll
+  for (unsigned k = 0; k < S61_KS; ++k)
+  {
+    t1[k].x *= t2[k].x;
+    t1[k].y *= t2[k].y;
+    if (4 * k + q < S61_S)
+    {
+      se &= (t1[k].x < SCALE_THRESHOLD);
+      so &= (t1[k].y < SCALE_THRESHOLD);
+    }
+  }
+  if (!se) small_e &= ~bit;
+  if (!so) small_o &= ~bit;
+  s61_store_d(dst, lane, t1);
+}
+
+__device__ inline void s61_acc_to_t(const v4d acc[S61_MT][2], double2 t[S61_KS])
+{
+#pragma unroll
+  for (unsigned mt = 0; mt < S61_MT; ++mt)
+#pragma unroll
+    for (unsigned v = 0; v < 4; ++v)
+      t[mt * 4 + v] = make_double2(acc[mt][0][v], acc[mt][1][v]);
+}
+
+// one rate of a wave's blocks (first, first + 4, ...: nb of them), both children inner
+__device__ inline void s61_rate_ii(const OpDesc & op, const double * frag, const double * frag2,
+                                   unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
+                                   unsigned & small_e, unsigned & small_o)
+{
+  const double2 * f1 = reinterpret_cast<const double2 *>(frag);
+  const double2 * f2 = reinterpret_cast<const double2 *>(frag2);
+  const unsigned q = lane >> 4;
+  double2 bA[8], bB[8];
+  s61_issue_half<0>(op.clv1 + ((size_t)first * R + r) * S61_UNIT, lane, bA);
+  for (unsigned i = 0; i < nb; ++i)
+  {
+    const size_t ub = ((size_t)(first + 4 * i) * R + r) * S61_UNIT;
+    const size_t ubn = ((size_t)(first + 4 * (i + 1 < nb ? i + 1 : i)) * R + r) * S61_UNIT;
+    v4d acc[S61_MT][2];
+    double2 t1[S61_KS], t2[S61_KS];
+    s61_acc_zero(acc);
+    s61_issue_half<1>(op.clv1 + ub, lane, bB);
+    S61_SCHED_FENCE();
+    s61_mfma_half<0>(bA, f1, lane, acc);
+    S61_SCHED_FENCE();
+    s61_issue_half<0>(op.clv2 + ub, lane, bA);
+    S61_SCHED_FENCE();
+    s61_mfma_half<1>(bB, f1, lane, acc);
+    S61_SCHED_FENCE();
+    s61_acc_to_t(acc, t1);
+    s61_acc_zero(acc);
+    s61_issue_half<1>(op.clv2 + ub, lane, bB);
+    S61_SCHED_FENCE();
+    s61_mfma_half<0>(bA, f2, lane, acc);
+    S61_SCHED_FENCE();
+    s61_issue_half<0>(op.clv1 + ubn, lane, bA);      // next block (the last one re-reads itself)
+    S61_SCHED_FENCE();
+    s61_mfma_half<1>(bB, f2, lane, acc);
+    S61_SCHED_FENCE();
+    s61_acc_to_t(acc, t2);
+    s61_finish_unit(op.parent + ub, lane, q, t1, t2, 1u << i, small_e, small_o);
+  }
+}
+
+// one inner child (clv, fragments) and one tip child (codes, per-rate table in LDS or global)
+__device__ inline void s61_rate_ti(const OpDesc & op, const double * clv, const double * fragi,
+                                   const unsigned char * codes, const double * lut_r,
+                                   unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
+                                   unsigned & small_e, unsigned & small_o)
+{
+  const double2 * f1 = reinterpret_cast<const double2 *>(fragi);
+  const unsigned q = lane >> 4, n = lane & 15;
+  double2 bA[8], bB[8];
+  s61_issue_half<0>(clv + ((size_t)first * R + r) * S61_UNIT, lane, bA);
+  for (unsigned i = 0; i < nb; ++i)
+  {
+    const unsigned blk = first + 4 * i;
+    const size_t ub = ((size_t)blk * R + r) * S61_UNIT;
+    const size_t ubn = ((size_t)(first + 4 * (i + 1 < nb ? i + 1 : i)) * R + r) * S61_UNIT;
+    const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+    const unsigned ce = codes[site0], co = codes[site0 + 1];
+    v4d acc[S61_MT][2];
+    double2 t1[S61_KS], t2[S61_KS];
+    s61_acc_zero(acc);
+    s61_issue_half<1>(clv + ub, lane, bB);
+    S61_SCHED_FENCE();
+    s61_mfma_half<0>(bA, f1, lane, acc);
+    S61_SCHED_FENCE();
+    s61_issue_half<0>(clv + ubn, lane, bA);
+    S61_SCHED_FENCE();
+    s61_mfma_half<1>(bB, f1, lane, acc);
+    S61_SCHED_FENCE();
+    s61_acc_to_t(acc, t1);
+    s61_child_tip(lut_r, ce, co, q, t2);
+    s61_finish_unit(op.parent + ub, lane, q, t1, t2, 1u << i, small_e, small_o);
+  }
+}
+
+__device__ inline void s61_rate_tt(const OpDesc & op, const double * lut1_r, const double * lut2_r,
+                                   unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
+                                   unsigned & small_e, unsigned & small_o)
+{
+  const unsigned q = lane >> 4, n = lane & 15;
+  // the tip codes of block i+1 are fetched while block i is looked up and stored
+  size_t site0 = (size_t)first * S20_BS + 2 * n;
+  unsigned c1e = op.codes1[site0], c1o = op.codes1[site0 + 1];
+  unsigned c2e = op.codes2[site0], c2o = op.codes2[site0 + 1];
+  for (unsigned i = 0; i < nb; ++i)
+  {
+    const unsigned blk = first + 4 * i;
+    const size_t siten = (size_t)(first + 4 * (i + 1 < nb ? i + 1 : i)) * S20_BS + 2 * n;
+    const unsigned n1e = op.codes1[siten], n1o = op.codes1[siten + 1];
+    const unsigned n2e = op.codes2[siten], n2o = op.codes2[siten + 1];
+    double2 t1[S61_KS], t2[S61_KS];
+    s61_child_tip(lut1_r, c1e, c1o, q, t1);
+    s61_child_tip(lut2_r, c2e, c2o, q, t2);
+    s61_finish_unit(op.parent + ((size_t)blk * R + r) * S61_UNIT, lane, q, t1, t2, 1u << i,
+                    small_e, small_o);
+    c1e = n1e; c1o = n1o; c2e = n2e; c2o = n2o;
+  }
+}
+
+// Rate-parallel launches (gridDim.z = R, used when a GPU has few blocks per wave):
+// a workgroup handles ONE rate, writes its per-site "all entries small" vote to
+// votes[(op*R + r)*Nalloc + site], and k_s61_scale_fixup combines the votes.
+__global__ __launch_bounds__(256, 2) void k_partials_s61v3(OpBatch batch, unsigned nblk, unsigned R,
+                                                           unsigned lut_codes, uint8_t * votes)
+{
+  extern __shared__ double frag[];
+  double * const frag2 = frag + S61_FRAGS;
+  const OpDesc & op = batch.op[blockIdx.y];
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, n = lane & 15;
+  const bool scaling = op.parent_scaler != nullptr;
+  const bool lut_lds = lut_codes * S61_S <= S61_FRAGS;
+  const bool tip1 = op.codes1 != nullptr, tip2 = op.codes2 != nullptr;
+  const unsigned beg = (unsigned)(((unsigned long long)nblk * blockIdx.x) / gridDim.x);
+  const unsigned end = (unsigned)(((unsigned long long)nblk * (blockIdx.x + 1)) / gridDim.x);
+  const bool rate_parallel = gridDim.z > 1;
+  const unsigned r_begin = rate_parallel ? blockIdx.z : 0, r_end = rate_parallel ? blockIdx.z + 1 : R;
+
+  for (unsigned c0 = beg; c0 < end; c0 += S61_CHUNK)
+  {
+    const unsigned c1 = min(end, c0 + S61_CHUNK);
+    const unsigned first = c0 + wave;
+    const unsigned nb = first < c1 ? (c1 - first + 3) / 4 : 0;     // blocks first, first+4, ...
+    unsigned small_e = ~0u, small_o = ~0u;                          // bit i: block i all-small so far
+
+    for (unsigned r = r_begin; r < r_end; ++r)
+    {
+      __syncthreads();            // every wave is done reading the previous rate's fragments
+      if (!tip1) s61_fill_frags_v3(frag, op.pmat1, r);
+      else if (lut_lds)
+        for (unsigned e = threadIdx.x; e < lut_codes * S61_S; e += blockDim.x)
+          frag[e] = op.lut1[(size_t)r * lut_codes * S61_S + e];
+      if (!tip2) s61_fill_frags_v3(frag2, op.pmat2, r);
+      else if (lut_lds)
+        for (unsigned e = threadIdx.x; e < lut_codes * S61_S; e += blockDim.x)
+          frag2[e] = op.lut2[(size_t)r * lut_codes * S61_S + e];
+      __syncthreads();
+      if (nb == 0) continue;
+      const double * l1 = lut_lds ? frag : op.lut1 + (size_t)r * lut_codes * S61_S;
+      const double * l2 = lut_lds ? frag2 : op.lut2 + (size_t)r * lut_codes * S61_S;
+      if (!tip1 && !tip2) s61_rate_ii(op, frag, frag2, r, R, first, nb, lane, small_e, small_o);
+      else if (tip1 && tip2) s61_rate_tt(op, l1, l2, r, R, first, nb, lane, small_e, small_o);
+      else if (tip1) s61_rate_ti(op, op.clv2, frag2, op.codes1, l1, r, R, first, nb, lane, small_e, small_o);
+      else s61_rate_ti(op, op.clv1, frag, op.codes2, l2, r, R, first, nb, lane, small_e, small_o);
+    }
+
+    if (scaling && rate_parallel)
+    {
+      uint8_t * v = votes + ((size_t)blockIdx.y * R + r_begin) * ((size_t)nblk * S20_BS);
+      for (unsigned i = 0; i < nb; ++i)
+      {
+        const int se = s20_and_q((int)((small_e >> i) & 1u)), so = s20_and_q((int)((small_o >> i) & 1u));
+        if (q == 0)
+        {
+          const size_t site0 = (size_t)(first + 4 * i) * S20_BS + 2 * n;
+          v[site0] = (uint8_t)se;
+          v[site0 + 1] = (uint8_t)so;
+        }
+      }
+    }
+    else if (scaling)
+    {
+      for (unsigned i = 0; i < nb; ++i)
+      {
+        const unsigned blk = first + 4 * i;
+        const int se = s20_and_q((int)((small_e >> i) & 1u)), so = s20_and_q((int)((small_o >> i) & 1u));
+        if (__any(se | so))
+        {
+          const double fe = se ? SCALE_FACTOR : 1.0, fo = so ? SCALE_FACTOR : 1.0;
+          for (unsigned r = 0; r < R; ++r)
+          {
+            double * unit = op.parent + ((size_t)blk * R + r) * S61_UNIT;
+            double2 t[S61_KS];
+            s61_load_d(unit, lane, t);
+#pragma unroll
+            for (unsigned k = 0; k < S61_KS; ++k) { t[k].x *= fe; t[k].y *= fo; }
+            s61_store_d(unit, lane, t);
+          }
+        }
+        if (q == 0)
+        {
+          const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+          unsigned ce = se ? 1u : 0u, co = so ? 1u : 0u;
+          if (op.scaler1) { ce += op.scaler1[site0]; co += op.scaler1[site0 + 1]; }
+          if (op.scaler2) { ce += op.scaler2[site0]; co += op.scaler2[site0 + 1]; }
+          op.parent_scaler[site0] = ce;
+          op.parent_scaler[site0 + 1] = co;
+        }
+      }
+    }
+  }
+}
+
+// second half of a rate-parallel launch: combine the R votes of every site, rescale
+// the (rare) all-small sites, write the parent scalers.  One wave per (block, rate):
+// grid = (blocks/4, ops, R), block = 256
+__global__ __launch_bounds__(256) void k_s61_scale_fixup(OpBatch batch, unsigned nblk, unsigned R,
+                                                         const uint8_t * votes)
+{
+  const OpDesc & op = batch.op[blockIdx.y];
+  if (!op.parent_scaler) return;
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, n = lane & 15;
+  const unsigned blk = blockIdx.x * 4 + wave;
+  if (blk >= nblk) return;
+  const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+  const size_t nsite = (size_t)nblk * S20_BS;
+  int se = 1, so = 1;
+  for (unsigned r = 0; r < R; ++r)
+  {
+    const uint8_t * v = votes + ((size_t)blockIdx.y * R + r) * nsite;
+    se &= v[site0];
+    so &= v[site0 + 1];
+  }
+  if (__any(se | so))
+  {
+    const double fe = se ? SCALE_FACTOR : 1.0, fo = so ? SCALE_FACTOR : 1.0;
+    double * unit = op.parent + ((size_t)blk * R + blockIdx.z) * S61_UNIT;
+    double2 t[S61_KS];
+    s61_load_d(unit, lane, t);
+#pragma unroll
+    for (unsigned k = 0; k < S61_KS; ++k) { t[k].x *= fe; t[k].y *= fo; }
+    s61_store_d(unit, lane, t);
+  }
+  if (q == 0 && blockIdx.z == 0)
+  {
+    unsigned ce = se ? 1u : 0u, co = so ? 1u : 0u;
+    if (op.scaler1) { ce += op.scaler1[site0]; co += op.scaler1[site0 + 1]; }
+    if (op.scaler2) { ce += op.scaler2[site0]; co += op.scaler2[site0 + 1]; }
+    op.parent_scaler[site0] = ce;
+    op.parent_scaler[site0 + 1] = co;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // edge / root log-likelihood.  grid <= REDUCE_BLOCKS tiles-strided, block = 256
 // dynamic LDS = S61_FRAGS doubles
 // ---------------------------------------------------------------------------
@@ -464,18 +793,52 @@ __global__ __launch_bounds__(256) void k_derivatives_s61(ModelView mv, ParamIdx 
 static int launch_partials_s61(Engine * e, const OpBatch & batch, unsigned nops)
 {
   static const int env_nb = getenv("PLLHIP_S61_NB") ? atoi(getenv("PLLHIP_S61_NB")) : 0;
+  static const int v3 = getenv("PLLHIP_S61_V3") ? atoi(getenv("PLLHIP_S61_V3")) : 1;
   const size_t lds = sizeof(double) * 2 * S61_FRAGS;
+  if (v3)
+  {
+    // few blocks per wave: one workgroup per (range, rate) balances the matrix pipes better and
+    // quarters the critical path of small slices; the scaling votes then meet in a second kernel
+    static const int env_rp = getenv("PLLHIP_S61_RATEPAR") ? atoi(getenv("PLLHIP_S61_RATEPAR")) : -1;
+    const unsigned slots = e->cu_count * 2u;
+    const bool rate_parallel = e->R > 1 && (env_rp >= 0 ? env_rp != 0 : e->nblk < slots * 4u * 8u);
+    if (!rate_parallel)
+    {
+      const unsigned gx = std::max(1u, std::min((e->nblk + 3) / 4, slots));
+      hipLaunchKernelGGL(k_partials_s61v3, dim3(gx, nops), dim3(256), lds, e->stream,
+                         batch, e->nblk, e->R, e->lut_codes, (uint8_t *)nullptr);
+      PLLHIP_TRY(hipGetLastError());
+      return PLL_SUCCESS;
+    }
+    bool scaling = false;
+    for (unsigned i = 0; i < nops; ++i) scaling |= batch.op[i].parent_scaler != nullptr;
+    if (scaling && !e->d_s61_votes)
+      PLLHIP_TRY(hipMalloc((void **)&e->d_s61_votes,
+                           (size_t)MAX_OPS_PER_LAUNCH * e->R * e->nblk * S20_BS));
+    const unsigned per_rate = std::max(1u, slots / e->R);
+    const unsigned gx = std::max(1u, std::min((e->nblk + 3) / 4, per_rate));
+    hipLaunchKernelGGL(k_partials_s61v3, dim3(gx, nops, e->R), dim3(256), lds, e->stream,
+                       batch, e->nblk, e->R, e->lut_codes, e->d_s61_votes);
+    PLLHIP_TRY(hipGetLastError());
+    if (scaling)
+    {
+      hipLaunchKernelGGL(k_s61_scale_fixup, dim3((e->nblk + 3) / 4, nops, e->R), dim3(256), 0, e->stream,
+                         batch, e->nblk, e->R, (const uint8_t *)e->d_s61_votes);
+      PLLHIP_TRY(hipGetLastError());
+    }
+    return PLL_SUCCESS;
+  }
   const unsigned nb = env_nb ? (unsigned)env_nb : 4u;
   const unsigned ntiles = (e->nblk + 4 * nb - 1) / (4 * nb);
   const unsigned gx = std::max(1u, std::min(ntiles, e->cu_count * 2u));
   if (nb == 1)
     hipLaunchKernelGGL(k_partials_s61<1>, dim3(gx, nops), dim3(256), lds, e->stream,
                        batch, e->nblk, e->R, e->lut_codes);
-  else if (nb == 4)
-    hipLaunchKernelGGL(k_partials_s61<4>, dim3(gx, nops), dim3(256), lds, e->stream,
+  else if (nb == 2)
+    hipLaunchKernelGGL(k_partials_s61<2>, dim3(gx, nops), dim3(256), lds, e->stream,
                        batch, e->nblk, e->R, e->lut_codes);
   else
-    hipLaunchKernelGGL(k_partials_s61<2>, dim3(gx, nops), dim3(256), lds, e->stream,
+    hipLaunchKernelGGL(k_partials_s61<4>, dim3(gx, nops), dim3(256), lds, e->stream,
                        batch, e->nblk, e->R, e->lut_codes);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;

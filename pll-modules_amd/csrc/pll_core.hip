@@ -206,6 +206,7 @@ void engine_destroy(Engine * e)
   (void)hipFree(e->d_scalers);
   (void)hipFree(e->d_pmat);
   (void)hipFree(e->d_lut);
+  (void)hipFree(e->d_s61_votes);
   (void)hipFree(e->d_weights);
   (void)hipFree(e->d_invariant);
   (void)hipFree(e->d_tipmap);
@@ -417,7 +418,10 @@ static int ensure_luts(pll_partition_t * p)
   if (!e->d_lut || e->lut_codes < want)
   {
     // grow with head-room so that a few late codes do not re-allocate
-    const unsigned cap = std::min<unsigned>(PLL_ASCII_SIZE, std::max(want, (e->S == 4) ? 16u : want + 8u));
+    // (but never past the size the 20-/61-state kernels can stage in LDS: 32 / 67 codes)
+    unsigned cap = std::min<unsigned>(PLL_ASCII_SIZE, std::max(want, (e->S == 4) ? 16u : want + 8u));
+    if (e->family == KernelFamily::S61 && want <= 67u) cap = std::min(cap, 67u);
+    if (e->family == KernelFamily::S20 && want <= 32u) cap = std::min(cap, 32u);
     if (e->d_lut) { PLLHIP_TRY(hipStreamSynchronize(e->stream)); (void)hipFree(e->d_lut); e->d_lut = nullptr; }
     if (!dev_alloc(&e->d_lut, (size_t)e->nmat * e->R * cap * e->S, "tip lookup tables")) return PLL_FAILURE;
     e->lut_codes = cap;
