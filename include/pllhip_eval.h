@@ -19,6 +19,7 @@
  *                                  src/optimize/pll_optimize.c:1395-1951; Newton-Raphson
  *                                  step rule of pllmod_opt_minimize_newton_multi,
  *                                  src/optimize/opt_algorithms.c:133-261
+ *   pllhip_eval_spr_round          pllmod_algo_spr_round, src/algorithm/algo_search.c:1052-1484
  * One deliberate difference: P-matrix updates of an evaluation go out in one
  * pll_update_prob_matrices call per partition (count = number of invalid
  * branches) unless PLLHIP_EVAL_PMATRIX_PER_BRANCH is set, which reproduces the
@@ -81,6 +82,68 @@ PLL_EXPORT double pllhip_eval_optimize_branches(pllhip_eval_t * ev, double min_b
                                                 double lh_epsilon, int max_iters, int radius);
 
 /* work counters: operations and P-matrices handed to libpll so far */
+/* ---------------------------------------------------------------------------
+ * One SPR round: the counterpart of pllmod_algo_spr_round
+ * (src/algorithm/algo_search.c:1052-1484, linked branch lengths, no topological
+ * constraint, incremental CLV updates) on this driver, for machines where
+ * pll-modules cannot go.  Same decision procedure, so the same moves on the same
+ * data:
+ *   scan   every inner record p, in the reference's post-order (algo_search.c:94-121),
+ *          is pruned and scored at every branch within [radius_min, radius_max]
+ *          of the pruning point (breadth-first, descent stopped by the lnL cutoff;
+ *          algo_search.c:603-899).  A placement that beats the current best by
+ *          more than 1e-6 is applied at once and remembered for undo; otherwise
+ *          it competes for the list of the ntopol_keep (x3 in fast mode) best
+ *          placements (algo_search.c:905-1050).
+ *   rescore all branches are optimised (smoothings/4 passes), then every
+ *          remembered topology -- applied moves undone one by one, listed
+ *          placements re-applied -- gets the same optimisation; the best one
+ *          (by more than 0.01 lnL units) is restored (algo_search.c:1233-1445).
+ * The reference's second, "thorough" scan of the listed nodes in fast mode is
+ * unreachable there (its guard reads a counter that is never advanced,
+ * algo_search.c:1193) and is therefore not built.
+ * Returns the final log-likelihood (checked against a full re-evaluation to 1e-6,
+ * algo_search.c:1453-1457); 0 on error (pll_errno set).
+ * ------------------------------------------------------------------------- */
+typedef struct pllhip_spr_params
+{
+  unsigned int radius_min;          /* >= 1 */
+  unsigned int radius_max;
+  unsigned int ntopol_keep;
+  int thorough;                     /* optimise the three branches at every insertion */
+  double bl_min, bl_max;
+  int smoothings;
+  double epsilon;                   /* lnL epsilon of the whole-tree optimisations */
+  double subtree_cutoff;            /* multiplier of the average lnL loss -> next round's cutoff */
+  double lh_epsilon_brlen_triplet;
+} pllhip_spr_params_t;
+
+/* carried from round to round (cutoff_info_t, src/algorithm/pllmod_algorithm.h:41-47) */
+typedef struct pllhip_spr_cutoff
+{
+  double lh_start;
+  double lh_cutoff;
+  double lh_dec_sum;
+  int lh_dec_count;
+} pllhip_spr_cutoff_t;
+
+#define PLLHIP_SPR_LOG_MAX 256
+
+typedef struct pllhip_spr_stats
+{
+  unsigned long prunings;           /* subtrees pruned and scanned */
+  unsigned long insertions;         /* placements scored */
+  unsigned long moves_applied;      /* improving moves applied during the scan */
+  unsigned long rescored;           /* topologies that got a whole-tree optimisation */
+  double lnl_start, lnl_scan, lnl_final;
+  unsigned int log_count;           /* applied moves, in order: node_index of p and of r */
+  unsigned int log_prune[PLLHIP_SPR_LOG_MAX];
+  unsigned int log_regraft[PLLHIP_SPR_LOG_MAX];
+} pllhip_spr_stats_t;
+
+PLL_EXPORT double pllhip_eval_spr_round(pllhip_eval_t * ev, const pllhip_spr_params_t * params,
+                                        pllhip_spr_cutoff_t * cutoff, pllhip_spr_stats_t * stats);
+
 PLL_EXPORT unsigned long pllhip_eval_ops(const pllhip_eval_t * ev);
 PLL_EXPORT unsigned long pllhip_eval_pmatrix_updates(const pllhip_eval_t * ev);
 PLL_EXPORT unsigned long pllhip_eval_derivative_calls(const pllhip_eval_t * ev);

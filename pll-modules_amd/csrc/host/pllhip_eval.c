@@ -4,32 +4,12 @@
  * Plain C, no device code: everything below is calls into the libpll-style
  * interface, so the same file serves the HIP library and the CPU oracle.
  */
-#include "pllhip_eval.h"
+#include "pllhip_eval_internal.h"
 #include <stdarg.h>
-
-struct pllhip_eval
-{
-  pll_utree_t * tree;
-  pll_unode_t * root;
-  unsigned int tips, inner, records, edges, nparts, flags;
-  pll_partition_t ** parts;
-  unsigned int ** params;         /* [partition][rate_cats] */
-  double ** sumtables;            /* [partition], allocated on first use */
-  char * clv_valid;               /* by node_index */
-  char * pmat_valid;              /* by pmatrix_index */
-  pll_unode_t ** trav;
-  pll_operation_t * ops;
-  double * brlens;
-  unsigned int * midx;
-  double * part_lnl;
-  void * ctx;
-  pllhip_reduce_fn reduce_cb;
-  unsigned long n_ops, n_pmat, n_deriv;
-};
 
 static __thread pllhip_eval_t * cb_self;   /* pll_utree_traverse callbacks carry no user pointer */
 
-static void eval_error(int code, const char * fmt, ...)
+void pllhip_eval_error(int code, const char * fmt, ...)
 {
   va_list ap;
   pll_errno = code;
@@ -43,7 +23,7 @@ pllhip_eval_t * pllhip_eval_create(pll_utree_t * tree, unsigned int partition_co
   unsigned int i;
   if (!tree || !tree->binary || !partition_count)
   {
-    eval_error(PLL_ERROR_PARAM_INVALID, "pllhip_eval_create needs a binary tree and >= 1 partition");
+    pllhip_eval_error(PLL_ERROR_PARAM_INVALID, "pllhip_eval_create needs a binary tree and >= 1 partition");
     return NULL;
   }
   pllhip_eval_t * ev = (pllhip_eval_t *)calloc(1, sizeof(*ev));
@@ -76,7 +56,7 @@ pllhip_eval_t * pllhip_eval_create(pll_utree_t * tree, unsigned int partition_co
     {
       if (s->node_index >= ev->records || s->pmatrix_index >= ev->edges)
       {
-        eval_error(PLL_ERROR_PARAM_INVALID, "node/pmatrix index out of range in tree record");
+        pllhip_eval_error(PLL_ERROR_PARAM_INVALID, "node/pmatrix index out of range in tree record");
         pllhip_eval_destroy(ev);
         return NULL;
       }
@@ -86,7 +66,7 @@ pllhip_eval_t * pllhip_eval_create(pll_utree_t * tree, unsigned int partition_co
   ev->root = tree->vroot->next ? tree->vroot : tree->vroot->back;
   return ev;
 nomem:
-  eval_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate evaluator");
+  pllhip_eval_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate evaluator");
   pllhip_eval_destroy(ev);
   return NULL;
 }
@@ -112,7 +92,7 @@ int pllhip_eval_set_partition(pllhip_eval_t * ev, unsigned int index, pll_partit
   unsigned int r;
   if (index >= ev->nparts)
   {
-    eval_error(PLL_ERROR_PARAM_INVALID, "partition index %u out of range", index);
+    pllhip_eval_error(PLL_ERROR_PARAM_INVALID, "partition index %u out of range", index);
     return PLL_FAILURE;
   }
   if (partition)
@@ -120,14 +100,14 @@ int pllhip_eval_set_partition(pllhip_eval_t * ev, unsigned int index, pll_partit
     if (partition->tips != ev->tips || partition->clv_buffers < ev->inner ||
         partition->prob_matrices < ev->edges)
     {
-      eval_error(PLL_ERROR_PARAM_INVALID, "partition %u does not fit the tree", index);
+      pllhip_eval_error(PLL_ERROR_PARAM_INVALID, "partition %u does not fit the tree", index);
       return PLL_FAILURE;
     }
     free(ev->params[index]);
     ev->params[index] = (unsigned int *)calloc(partition->rate_cats, sizeof(unsigned int));
     if (!ev->params[index])
     {
-      eval_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate params indices");
+      pllhip_eval_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate params indices");
       return PLL_FAILURE;
     }
     for (r = 0; params_indices && r < partition->rate_cats; ++r) ev->params[index][r] = params_indices[r];
@@ -147,7 +127,7 @@ int pllhip_eval_set_root(pllhip_eval_t * ev, pll_unode_t * root)
 {
   if (!root || !root->next)
   {
-    eval_error(PLL_ERROR_PARAM_INVALID, "the root must be an inner node record");
+    pllhip_eval_error(PLL_ERROR_PARAM_INVALID, "the root must be an inner node record");
     return PLL_FAILURE;
   }
   ev->root = root;
@@ -289,7 +269,7 @@ static int ensure_sumtables(pllhip_eval_t * ev)
     ev->sumtables[p] = (double *)pll_aligned_alloc((len ? len : 1) * sizeof(double), part->alignment);
     if (!ev->sumtables[p])
     {
-      eval_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate sumtable");
+      pllhip_eval_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate sumtable");
       return PLL_FAILURE;
     }
   }
@@ -331,13 +311,13 @@ static int newton(const blo_t * b, const pll_unode_t * e, double * x)
   {
     if (iter++ > b->max_newton)
     {
-      eval_error(PLLHIP_EVAL_ERROR_NEWTON_LIMIT, "Exceeded maximum number of iterations");
+      pllhip_eval_error(PLLHIP_EVAL_ERROR_NEWTON_LIMIT, "Exceeded maximum number of iterations");
       return PLL_FAILURE;
     }
     if (!derivatives(ev, e, *x, &f, &df)) return PLL_FAILURE;
     if (!isfinite(f) || !isfinite(df))
     {
-      eval_error(PLLHIP_EVAL_ERROR_NEWTON_DERIV, "Wrong likelihood derivatives");
+      pllhip_eval_error(PLLHIP_EVAL_ERROR_NEWTON_DERIV, "Wrong likelihood derivatives");
       return PLL_FAILURE;
     }
     if (df > 0.0)
@@ -420,13 +400,21 @@ static int optimise_around(const blo_t * b, pll_unode_t * p_edge, int radius)
 double pllhip_eval_optimize_branches(pllhip_eval_t * ev, double min_brlen, double max_brlen,
                                      double lh_epsilon, int max_iters, int radius)
 {
+  return pllhip_eval_optimize_impl(ev, min_brlen, max_brlen, lh_epsilon, max_iters, radius, 0);
+}
+
+/* keep_flags: the caller tracks validity itself (the SPR scan optimises the three
+   branches around an insertion point and restores them afterwards) */
+double pllhip_eval_optimize_impl(pllhip_eval_t * ev, double min_brlen, double max_brlen,
+                                 double lh_epsilon, int max_iters, int radius, int keep_flags)
+{
   blo_t b;
   double lnl, new_lnl;
   int iters = max_iters;
   pll_unode_t * root = ev->root;
   if (radius < PLLHIP_EVAL_RADIUS_ALL)
   {
-    eval_error(PLL_ERROR_PARAM_INVALID, "Invalid radius for branch length optimization");
+    pllhip_eval_error(PLL_ERROR_PARAM_INVALID, "Invalid radius for branch length optimization");
     return 0.0;
   }
   b.ev = ev;
@@ -453,7 +441,7 @@ double pllhip_eval_optimize_branches(pllhip_eval_t * ev, double min_brlen, doubl
     }
     else
     {
-      eval_error(PLLHIP_EVAL_ERROR_NEWTON_WORSE,
+      pllhip_eval_error(PLLHIP_EVAL_ERROR_NEWTON_WORSE,
                  "BL opt converged to a worse likelihood score by %.15f units", new_lnl - lnl);
       lnl = new_lnl;
       break;
@@ -461,7 +449,7 @@ double pllhip_eval_optimize_branches(pllhip_eval_t * ev, double min_brlen, doubl
   }
   /* P-matrices are current for every branch; CLVs were last refreshed at
      different moments of the sweep: let the next evaluation rebuild them */
-  memset(ev->clv_valid, 0, ev->records);
+  if (!keep_flags) memset(ev->clv_valid, 0, ev->records);
   return -lnl;
 }
 

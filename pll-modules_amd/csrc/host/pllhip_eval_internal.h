@@ -1,0 +1,35 @@
+/*
+ * pllhip_eval_internal.h -- shared between the evaluation driver
+ * (pllhip_eval.c) and the topology search built on it (pllhip_search.c).
+ * Not installed; the public interface is include/pllhip_eval.h.
+ */
+#ifndef PLLHIP_EVAL_INTERNAL_H_INCLUDED
+#define PLLHIP_EVAL_INTERNAL_H_INCLUDED
+
+#include "pllhip_eval.h"
+
+struct pllhip_eval
+{
+  pll_utree_t * tree;
+  pll_unode_t * root;
+  unsigned int tips, inner, records, edges, nparts, flags;
+  pll_partition_t ** parts;
+  unsigned int ** params;         /* [partition][rate_cats] */
+  double ** sumtables;            /* [partition], allocated on first use */
+  char * clv_valid;               /* by node_index */
+  char * pmat_valid;              /* by pmatrix_index */
+  pll_unode_t ** trav;
+  pll_operation_t * ops;
+  double * brlens;
+  unsigned int * midx;
+  double * part_lnl;
+  void * ctx;
+  pllhip_reduce_fn reduce_cb;
+  unsigned long n_ops, n_pmat, n_deriv;
+};
+
+void pllhip_eval_error(int code, const char * fmt, ...);
+double pllhip_eval_optimize_impl(pllhip_eval_t * ev, double min_brlen, double max_brlen,
+                                 double lh_epsilon, int max_iters, int radius, int keep_flags);
+
+#endif

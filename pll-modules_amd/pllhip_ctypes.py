@@ -120,7 +120,7 @@ PLLHIP_EVAL_H_FUNCTIONS = """pllhip_eval_create pllhip_eval_destroy pllhip_eval_
 pllhip_eval_set_parallel_context pllhip_eval_set_root pllhip_eval_root pllhip_eval_invalidate_all
 pllhip_eval_invalidate_pmatrix pllhip_eval_invalidate_clv pllhip_eval_loglh
 pllhip_eval_set_branch_length pllhip_eval_optimize_branches pllhip_eval_ops
-pllhip_eval_pmatrix_updates pllhip_eval_derivative_calls""".split()
+pllhip_eval_pmatrix_updates pllhip_eval_derivative_calls pllhip_eval_spr_round""".split()
 
 PLLHIP_H_FUNCTIONS = """pllhip_device_count pllhip_set_device pllhip_get_device
 pllhip_device_arch pllhip_eigen_decompose pllhip_sync_to_host pllhip_get_clv
@@ -214,6 +214,9 @@ class PllLib:
             L.pllhip_eval_optimize_branches.restype = C.c_double
             L.pllhip_eval_optimize_branches.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double,
                                                         C.c_int, C.c_int]
+            L.pllhip_eval_spr_round.restype = C.c_double
+            L.pllhip_eval_spr_round.argtypes = [C.c_void_p, C.POINTER(SprParams), C.POINTER(SprCutoff),
+                                                C.POINTER(SprStats)]
             for fn in ("pllhip_eval_ops", "pllhip_eval_pmatrix_updates", "pllhip_eval_derivative_calls"):
                 getattr(L, fn).restype = C.c_ulong
                 getattr(L, fn).argtypes = [C.c_void_p]
@@ -594,6 +597,31 @@ def random_codes(ntips, nsites, nstates, seed=44):
     return out
 
 
+def simulated_codes(tree, nsites, nstates, seed=45, scale=1.0):
+    """states evolved along `tree` (a Tree) from inner node `ntips` outwards:
+    equal-rates process, two site-rate classes; uint8 [tips][sites].  Gives an
+    alignment with phylogenetic signal (seed 45)."""
+    out = np.empty((tree.ntips, nsites), dtype=np.uint8)
+    S = nstates
+    rate = np.where(uniform01(seed, nsites) < 0.5, 0.4, 1.6)
+    start = (splitmix64(seed + 1, nsites) % np.uint64(S)).astype(np.int64)
+    stack = [(tree.ntips, -1, start)]
+    while stack:
+        node, parent, state = stack.pop()
+        if node < tree.ntips:
+            out[node] = state.astype(np.uint8)
+            continue
+        for child, k in tree.adj[node]:
+            if child == parent:
+                continue
+            t = tree.brlens[k] * scale
+            pchange = (S - 1.0) / S * (1.0 - np.exp(-S / (S - 1.0) * t * rate))
+            u = uniform01(seed + 7919 * (k + 1), nsites)
+            jump = 1 + (splitmix64(seed + 104729 * (k + 1), nsites) % np.uint64(S - 1)).astype(np.int64)
+            stack.append((child, node, np.where(u < pchange, (state + jump) % S, state)))
+    return out
+
+
 def state_charmap(nstates):
     """a 256-entry char -> mask map where byte value 48+i ('0'+i) means state i and
     '-' means every state (so uint8 state arrays + 48 are valid sequences)"""
@@ -602,6 +630,29 @@ def state_charmap(nstates):
         m[48 + i] = np.uint64(1) << np.uint64(i)
     m[ord("-")] = (np.uint64(1) << np.uint64(nstates)) - np.uint64(1) if nstates < 64 else _M64
     return m
+
+
+class SprParams(C.Structure):
+    """pllhip_spr_params_t, include/pllhip_eval.h"""
+    _fields_ = [("radius_min", C.c_uint), ("radius_max", C.c_uint), ("ntopol_keep", C.c_uint),
+                ("thorough", C.c_int), ("bl_min", C.c_double), ("bl_max", C.c_double),
+                ("smoothings", C.c_int), ("epsilon", C.c_double), ("subtree_cutoff", C.c_double),
+                ("lh_epsilon_brlen_triplet", C.c_double)]
+
+
+class SprCutoff(C.Structure):
+    _fields_ = [("lh_start", C.c_double), ("lh_cutoff", C.c_double), ("lh_dec_sum", C.c_double),
+                ("lh_dec_count", C.c_int)]
+
+
+SPR_LOG_MAX = 256
+
+
+class SprStats(C.Structure):
+    _fields_ = [("prunings", C.c_ulong), ("insertions", C.c_ulong), ("moves_applied", C.c_ulong),
+                ("rescored", C.c_ulong), ("lnl_start", C.c_double), ("lnl_scan", C.c_double),
+                ("lnl_final", C.c_double), ("log_count", C.c_uint),
+                ("log_prune", C.c_uint * SPR_LOG_MAX), ("log_regraft", C.c_uint * SPR_LOG_MAX)]
 
 
 class Evaluation:
@@ -652,6 +703,29 @@ class Evaluation:
         if v == 0.0 or self.lib.errno:
             raise RuntimeError(f"[{self.lib.errno}] {self.lib.errmsg}")
         return -v
+
+    def spr_round(self, radius_min=1, radius_max=5, ntopol_keep=5, thorough=False, bl_min=1e-4,
+                  bl_max=10.0, smoothings=8, epsilon=0.1, subtree_cutoff=1.0, triplet_epsilon=0.1,
+                  cutoff=None):
+        """one SPR round; returns (lnL, SprStats); `cutoff` (SprCutoff) is carried between rounds"""
+        prm = SprParams(radius_min, radius_max, ntopol_keep, int(thorough), bl_min, bl_max, smoothings,
+                        epsilon, subtree_cutoff, triplet_epsilon)
+        st = SprStats()
+        self.lib.errno = 0
+        v = self.L.pllhip_eval_spr_round(self.ev, C.byref(prm), C.byref(cutoff) if cutoff is not None else None,
+                                         C.byref(st))
+        if v == 0.0:
+            raise RuntimeError(f"[{self.lib.errno}] {self.lib.errmsg}")
+        return v, st
+
+    def newick(self):
+        root = self.L.pllhip_eval_root(self.ev)
+        ptr = self.L.pll_utree_export_newick(root, None)
+        text = C.string_at(ptr).decode()
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        libc.free(ptr)
+        return text
 
     def counters(self):
         return (self.L.pllhip_eval_ops(self.ev), self.L.pllhip_eval_pmatrix_updates(self.ev),

@@ -72,3 +72,122 @@ def test_tip_pattern_mode_gives_the_same_numbers(driver):
     a = subprocess.run([driver], check=True, capture_output=True, text=True).stdout
     b = subprocess.run([driver, "tv"], check=True, capture_output=True, text=True).stdout
     assert a == b       # the reference's own cross-backend criterion (test/runtest.py:45-51)
+
+
+# ---------------------------------------------------------------------------
+# SPR round: the reference's pllmod_algo_spr_round against this repository's
+# counterpart (pllhip_eval_spr_round) from the same starting tree
+# ---------------------------------------------------------------------------
+def _simulate(ntaxa, nsites, seed):
+    """sequences evolved along a random tree (JC-like, two rate classes) and a
+    scrambled starting tree over the same labels"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+
+    def random_tree(order):
+        items = [f"t{i}" for i in order]
+        while len(items) > 3:
+            i, j = sorted(rng.choice(len(items), 2, replace=False))
+            b = items.pop(j)
+            a = items.pop(i)
+            items.append((a, b))
+        return tuple(items)
+
+    true = random_tree(range(ntaxa))
+    seqs = {}
+
+    def evolve(node, state, rate):
+        if isinstance(node, str):
+            seqs[node] = state
+            return
+        for child in node:
+            t = rng.uniform(0.02, 0.25)
+            p = 0.75 * (1.0 - np.exp(-4.0 / 3.0 * t * rate))
+            change = rng.random(state.size) < p
+            new = np.where(change, (state + rng.integers(1, 4, state.size)) % 4, state)
+            evolve(child, new, rate)
+
+    rate = np.where(rng.random(nsites) < 0.5, 0.3, 1.7)
+    root = rng.integers(0, 4, nsites)
+    for child in true:
+        evolve(child, root if False else np.where(rng.random(nsites) < 0.05, (root + 1) % 4, root), rate)
+
+    def newick(node):
+        if isinstance(node, str):
+            return f"{node}:{rng.uniform(0.03, 0.2):.6f}"
+        return "(" + ",".join(newick(c) for c in node) + f"):{rng.uniform(0.03, 0.2):.6f}"
+
+    start = random_tree(rng.permutation(ntaxa))
+    nwk = "(" + ",".join(newick(c) for c in start) + ");"
+    aln = "\n".join(f"{k} {''.join('acgt'[x] for x in v)}" for k, v in sorted(seqs.items())) + "\n"
+    return nwk, aln
+
+
+def _splits(nwk):
+    """set of bipartitions (as frozensets of tip labels on the side without t0)"""
+    labels = set(re.findall(r"t\d+", nwk))
+    out, stack = set(), []
+    for tok in re.findall(r"\(|\)|t\d+", nwk):
+        if tok == "(":
+            stack.append(set())
+        elif tok == ")":
+            s = stack.pop()
+            if stack:
+                stack[-1] |= s
+            side = frozenset(s if "t0" not in s else labels - s)
+            if 1 < len(side) < len(labels) - 1:
+                out.add(side)
+        else:
+            if stack:
+                stack[-1].add(tok)
+    return out
+
+
+def _brlens(nwk):
+    return sorted(float(x) for x in re.findall(r":([0-9.eE+-]+)", nwk))
+
+
+@pytest.fixture(scope="module")
+def spr_driver(oracle, tmp_path_factory):
+    if not os.path.isdir(REF):
+        pytest.skip("reference tree not present on this box")
+    exe = tmp_path_factory.mktemp("dropin_spr") / "spr_driver"
+    src = [os.path.join(ROOT, "tests", "dropin", "spr_driver.c")]
+    src += [os.path.join(REF, m) for m in MODULES] + sorted(glob.glob(f"{REF}/src/optimize/lbfgsb/*.c"))
+    inc = sum((["-I", d] for d in [f"{ROOT}/include", f"{REF}/src", f"{REF}/src/optimize", f"{REF}/src/tree",
+                                   f"{REF}/src/algorithm", f"{REF}/src/util"]), [])
+    libdir = os.path.dirname(ORACLE_LIB)
+    subprocess.run(["gcc", "-std=gnu99", "-D_GNU_SOURCE", "-O2", "-w", *inc, "-o", str(exe), *src,
+                    "-L", libdir, "-lpll_oracle", "-lm", f"-Wl,-rpath,{libdir}"], check=True)
+    return str(exe)
+
+
+@pytest.mark.parametrize("mode,ntaxa,radius,rounds,ntopol,seed", [
+    ("fast", 14, 5, 2, 5, 1),
+    ("thorough", 12, 4, 1, 3, 2),
+    ("fast", 20, 7, 2, 8, 3),
+    ("thorough", 16, 3, 2, 4, 4),
+])
+def test_own_spr_round_makes_the_reference_s_moves(spr_driver, tmp_path, mode, ntaxa, radius, rounds,
+                                                   ntopol, seed):
+    nwk, aln = _simulate(ntaxa, 600, seed)
+    (tmp_path / "start.nwk").write_text(nwk)
+    (tmp_path / "aln.txt").write_text(aln)
+    out = subprocess.run([spr_driver, str(tmp_path / "start.nwk"), str(tmp_path / "aln.txt"), mode,
+                          str(radius), str(rounds), str(ntopol)],
+                         check=True, capture_output=True, text=True, timeout=900).stdout
+    ref_tree = re.search(r"^ref tree: (.*)$", out, re.M).group(1)
+    own_tree = re.search(r"^own tree: (.*)$", out, re.M).group(1)
+    assert _splits(ref_tree) != _splits(nwk), "the round should have changed the starting topology"
+    assert _splits(own_tree) == _splits(ref_tree)
+    for a, b in zip(_brlens(own_tree), _brlens(ref_tree)):
+        assert abs(a - b) < 1e-5
+    for r in range(rounds):
+        ref = float(re.search(rf"^ref round {r} lnL: (\S+)$", out, re.M).group(1))
+        own = float(re.search(rf"^own round {r} lnL: (\S+)$", out, re.M).group(1))
+        assert abs(ref - own) < 1e-5
+        # the cutoff statistics accumulate over EVERY placement scored in the scan
+        rc = re.search(rf"^ref round {r} cutoff: (\S+) (\S+) (\S+)$", out, re.M).groups()
+        oc = re.search(rf"^own round {r} cutoff: (\S+) (\S+) (\S+)$", out, re.M).groups()
+        assert rc[0] == oc[0]
+        assert abs(float(rc[1]) - float(oc[1])) < 1e-5 * max(1.0, abs(float(rc[1])))

@@ -159,3 +159,63 @@ def test_driver_counters_reach_the_engine(product):
         c = ev.parts[1].counters()
         assert c.pmatrix_updates == 25 and c.pmatrix_launches == 1   # 25 calls, one launch
         assert c.partial_ops == 12 and c.partial_launches < 12       # level-scheduled
+
+
+# ---------------------------------------------------------------------------
+# SPR round (pllhip_eval_spr_round; tests/test_dropin_modules.py pins it against
+# the reference's pllmod_algo_spr_round where the reference is present)
+# ---------------------------------------------------------------------------
+def build_search(lib, states, ntips=12, nsites=300, true_seed=7, start_seed=11, model=None):
+    """alignment simulated on one tree, evaluation started on another"""
+    truth = pc.Tree(ntips, true_seed, true_seed + 1, brlen_range=(0.03, 0.25))
+    start = pc.Tree(ntips, start_seed, start_seed + 1, brlen_range=(0.05, 0.15))
+    ev = pc.Evaluation(lib, start.newick(), nparts=1)
+    if model is None:
+        model = {4: (pc.DNA_GTR_RATES, pc.DNA_FREQS), 20: pc.protein_model(), 61: pc.codon_model()}[states]
+    ev.add_partition(0, states, nsites, 4, pc.simulated_codes(truth, nsites, states), model[0], model[1], 0.8)
+    return ev
+
+
+def run_rounds(lib, states, thorough, rounds=2, **kw):
+    with build_search(lib, states, **kw) as ev:
+        cut = pc.SprCutoff(0.0, 1e30, 0.0, 0)
+        first = ev.loglh()
+        trace = []
+        for _ in range(rounds):
+            lnl, st = ev.spr_round(radius_max=4, ntopol_keep=4, thorough=thorough, cutoff=cut)
+            assert st.lnl_start <= lnl + 1e-9
+            assert abs(ev.loglh() - lnl) < 1e-6                 # restored tree re-evaluates to the result
+            trace.append((lnl, st.prunings, st.insertions, st.moves_applied, st.rescored,
+                          tuple(st.log_prune[:st.log_count]), tuple(st.log_regraft[:st.log_count]),
+                          cut.lh_dec_count, cut.lh_dec_sum))
+        return first, trace, ev.newick()
+
+
+@pytest.mark.parametrize("states,thorough", [(4, False), (4, True), (20, False)])
+def test_spr_round_improves_and_is_deterministic(oracle, states, thorough):
+    first, trace, nwk = run_rounds(oracle, states, thorough)
+    assert trace[0][0] > first + 1.0                            # the scrambled start is far from optimal
+    assert trace[0][3] > 0 and trace[0][2] > trace[0][1]        # moves applied; several insertions per pruning
+    assert trace[1][0] >= trace[0][0] - 1e-6
+    again = run_rounds(oracle, states, thorough)
+    assert again == (first, trace, nwk)                         # bit-identical rerun (algo_search.c:1453)
+
+
+def test_spr_round_rejects_bad_parameters(oracle):
+    with build_search(oracle, 4) as ev:
+        with pytest.raises(RuntimeError):
+            ev.spr_round(radius_min=0)
+        with pytest.raises(RuntimeError):
+            ev.spr_round(radius_min=3, radius_max=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("states,thorough", [(4, False), (20, False), (20, True), (61, False)])
+def test_spr_round_on_gpu_makes_the_oracle_s_moves(product, oracle, states, thorough):
+    kw = dict(ntips=10, nsites=200) if states == 61 else {}
+    g = run_rounds(product, states, thorough, **kw)
+    c = run_rounds(oracle, states, thorough, **kw)
+    assert abs(g[0] - c[0]) < 1e-8 * abs(c[0])
+    for a, b in zip(g[1], c[1]):
+        assert a[1:8] == b[1:8]                                 # same scan, same accepted moves, in order
+        assert abs(a[0] - b[0]) < 1e-6 and abs(a[8] - b[8]) < 1e-6 * max(1.0, abs(b[8]))

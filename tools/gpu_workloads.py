@@ -11,6 +11,10 @@
       100 taxa, linked branch lengths): one full evaluation = loop over the
       partitions + sum, as treeinfo_compute_loglh does (src/tree/treeinfo.c:1024-1067)
 
+  SPR one pllhip_eval_spr_round (the counterpart of pllmod_algo_spr_round,
+      src/algorithm/algo_search.c:1052-1484) on the codon configuration C5: the
+      whole round runs in the C driver, one ctypes call
+
 Every call goes through ctypes, i.e. ~2-5 us of Python per call sit inside the
 W3 timings; a C caller pays less.
 """
@@ -152,6 +156,34 @@ def blo(lib, cfg, out, nsites=None):
                                  "what": "pllhip_eval_optimize_branches(iters=1, radius=ALL), C driver"}
 
 
+def spr(lib, out, nsites=None, ntips=None, radius_max=5, thorough=False):
+    """BASELINE config 5: codon GY94-like + G4, 50 taxa, one SPR round from a scrambled start"""
+    S, R, taxa, N = pc.CONFIGS["c5"]
+    N = nsites or N
+    taxa = ntips or taxa
+    truth = pc.Tree(taxa, 7, 8, brlen_range=(0.03, 0.25))
+    start = pc.Tree(taxa, 11, 12, brlen_range=(0.05, 0.15))
+    ev = pc.Evaluation(lib, start.newick(), nparts=1)
+    subst, freqs = pc.codon_model()
+    inst = ev.add_partition(0, S, N, R, pc.simulated_codes(truth, N, S), subst, freqs, 0.8)
+    with ev:
+        l0 = ev.loglh()
+        lib.lib.pllhip_synchronize(inst.p)
+        ops0, pm0, d0 = ev.counters()
+        t0 = time.perf_counter()
+        l1, st = ev.spr_round(radius_max=radius_max, ntopol_keep=5, thorough=thorough)
+        dt = time.perf_counter() - t0
+        ops1, pm1, d1 = ev.counters()
+        out[f"SPR_c5_{taxa}x{N}_{'thorough' if thorough else 'fast'}"] = {
+            "s_per_round": dt, "lnl_before": l0, "lnl_after": l1, "prunings": st.prunings,
+            "insertions": st.insertions, "moves_applied": st.moves_applied, "rescored": st.rescored,
+            "clv_ops": ops1 - ops0, "pmatrix_updates": pm1 - pm0, "derivative_calls": d1 - d0,
+            "insertions_per_s": st.insertions / dt,
+            "clv_site_updates_per_s": (ops1 - ops0) * N * R / dt,
+            "what": f"pllhip_eval_spr_round(radius 1..{radius_max}, ntopol_keep 5), whole round incl. "
+                    "branch-length optimisation of the remembered topologies"}
+
+
 def main():
     lib = pc.PllLib(pc.PRODUCT_LIB)
     out = {}
@@ -169,6 +201,9 @@ def main():
         w3(lib, "c3", out, nsites=125_000)
     if "c4" in which:
         c4(lib, out)
+    if "spr" in which:
+        spr(lib, out)
+        spr(lib, out, nsites=25_000)
     print(json.dumps(out, indent=1))
 
 
