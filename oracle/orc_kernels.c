@@ -139,7 +139,7 @@ void pll_update_partials(pll_partition_t * p, const pll_operation_t * ops,
 
     long n;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((size_t)p->sites * R * S * S > 4000000)
 #endif
     for (n = 0; n < (long)p->sites; ++n)
     {

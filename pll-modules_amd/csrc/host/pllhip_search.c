@@ -19,6 +19,16 @@
  * subtree, wherever that subtree is attached at the time.
  */
 #include "pllhip_eval_internal.h"
+#include <stdio.h>
+
+/* PLLHIP_SPR_TRACE=1: one line per scan / applied move / re-scored topology on stderr */
+static int trace_on(void)
+{
+  static int on = -1;
+  if (on < 0) { const char * e = getenv("PLLHIP_SPR_TRACE"); on = (e && atoi(e)) ? 1 : 0; }
+  return on;
+}
+#define TRACE(...) do { if (trace_on()) fprintf(stderr, "[spr] " __VA_ARGS__); } while (0)
 
 typedef struct
 {
@@ -294,6 +304,8 @@ static int scan_placements(search_t * s, placement_t * entry)
     }
   }
 
+  TRACE("scan p=%u: %u candidates, best lh %.6f at r=%d\n", p->node_index, j, entry->lh,
+        entry->r ? (int)entry->r->node_index : -1);
   /* back home, original lengths, everything looks at p again */
   attach(p, home);
   set_len(p, z1); set_len(p->next, z2); set_len(p->next->next, z3);
@@ -362,6 +374,8 @@ static double scan_nodes(search_t * s, pll_unode_t ** nodes, unsigned int count)
       pllhip_eval_invalidate_clv(ev, p);       /* the root is at p already */
       lh = pllhip_eval_loglh(ev, 1);
       if (isnan(lh)) return 0.0;
+      TRACE("applied p=%u -> r=%u: lh %.6f (re-evaluated %.6f)\n", p->node_index, r->node_index,
+            entry.lh, lh);
       best_lh = entry.lh;
     }
     else
@@ -430,8 +444,10 @@ double pllhip_eval_spr_round(pllhip_eval_t * ev, const pllhip_spr_params_t * prm
   if (st) st->lnl_scan = lh;
 
   root_at(&s, initial_root);
+  TRACE("scan done: lh %.6f\n", lh);
   best_lh = optimise_all(&s, prm->epsilon, 0.25);
   if (!best_lh) goto done;
+  TRACE("after whole-tree optimisation: lh %.6f\n", best_lh);
   save_topology(&s, best_topol, &best_root);
 
   /* walk the history backwards: at every point in time first the placements that
@@ -485,6 +501,7 @@ double pllhip_eval_spr_round(pllhip_eval_t * ev, const pllhip_spr_params_t * prm
     lh = optimise_all(&s, prm->epsilon, 0.25);
     if (!lh) goto done;
     if (st) st->rescored++;
+    TRACE("rescored (%s, history %zu): lh %.6f, best %.6f\n", applied_listed ? "listed" : "undo", pos, lh, best_lh);
     if (lh - best_lh > 0.01)
     {
       save_topology(&s, best_topol, NULL);
