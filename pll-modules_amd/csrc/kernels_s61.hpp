@@ -11,13 +11,12 @@
 // What differs from 20 states is the balance: a site-update moves 1 467 B for
 // 14 945 flops (AI 10.2 flop/B), i.e. the kernel sits on the ridge
 // between HBM and the FP64 matrix pipe (256 MFMA = 16 384 SIMD cycles per unit
-// against ~4 700 CU cycles of HBM time per unit).  The A fragments of ONE rate
-// (both children: 2 x 4 M-tiles x 16 k-steps x 512 B = 64 KiB) fill the LDS, so a
-// workgroup walks the rates together: fill fragments of rate r, barrier, every
-// wave processes its NB site blocks for that rate, barrier, next rate.  Results
-// are stored unscaled; the per-site scaling vote (all R*61 entries) is known
-// after the last rate and the rare rescale is a fix-up pass over the units just
-// written (L2-hot).
+// against ~4 700 CU cycles of HBM time per unit), and has to keep both busy at
+// once.  The A fragments of ONE rate (both children: 2 x 4 M-tiles x 16 k-steps x
+// 512 B = 64 KiB) fill the LDS, so a workgroup walks the rates one after the other
+// over its range of site blocks.  Results are stored unscaled; the per-site scaling
+// vote (all R*61 entries) is known after the last rate and the rare rescale is a
+// fix-up pass over the units just written.
 #pragma once
 
 #include "kernels_common.hpp"
@@ -125,124 +124,16 @@ __device__ inline void s61_tip_d(unsigned long long mask_e, unsigned long long m
 }
 
 // ---------------------------------------------------------------------------
-// partials (also the sumtable, with eigen-basis matrices).
-// grid = (tiles capped, ops), block = 256; a tile = 4 waves x S61_NB site blocks
-// dynamic LDS = 2 * S61_FRAGS doubles (64 KiB): A fragments -- or the tip lookup
-// table of the current rate when it fits (codes * 61 <= 4096) -- per child
-// ---------------------------------------------------------------------------
-template <unsigned S61_NB>    // site blocks per wave per tile (amortises the per-rate fragment fill)
-__global__ __launch_bounds__(256, 2) void k_partials_s61(OpBatch batch, unsigned nblk, unsigned R,
-                                                         unsigned lut_codes)
-{
-  extern __shared__ double frag[];
-  double * const frag2 = frag + S61_FRAGS;
-  const OpDesc & op = batch.op[blockIdx.y];
-  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned q = lane >> 4, n = lane & 15;
-  const bool scaling = op.parent_scaler != nullptr;
-  const bool lut_lds = lut_codes * S61_S <= S61_FRAGS;
-  const unsigned ntiles = (nblk + 4 * S61_NB - 1) / (4 * S61_NB);
-
-  for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
-  {
-    unsigned blk[S61_NB], c1e[S61_NB], c1o[S61_NB], c2e[S61_NB], c2o[S61_NB];
-    int small_e[S61_NB], small_o[S61_NB];
-#pragma unroll
-    for (unsigned b = 0; b < S61_NB; ++b)
-    {
-      blk[b] = (tile * 4 + wave) * S61_NB + b;
-      small_e[b] = small_o[b] = 1;
-      c1e[b] = c1o[b] = c2e[b] = c2o[b] = 0;
-      if (blk[b] < nblk)
-      {
-        const size_t site0 = (size_t)blk[b] * S20_BS + 2 * n;
-        if (op.codes1) { c1e[b] = op.codes1[site0]; c1o[b] = op.codes1[site0 + 1]; }
-        if (op.codes2) { c2e[b] = op.codes2[site0]; c2o[b] = op.codes2[site0 + 1]; }
-      }
-    }
-
-    for (unsigned r = 0; r < R; ++r)
-    {
-      __syncthreads();            // every wave is done reading the previous rate's fragments
-      if (!op.codes1) s61_fill_frags(frag, op.pmat1, r);
-      else if (lut_lds)
-        for (unsigned e = threadIdx.x; e < lut_codes * S61_S; e += blockDim.x)
-          frag[e] = op.lut1[(size_t)r * lut_codes * S61_S + e];
-      if (!op.codes2) s61_fill_frags(frag2, op.pmat2, r);
-      else if (lut_lds)
-        for (unsigned e = threadIdx.x; e < lut_codes * S61_S; e += blockDim.x)
-          frag2[e] = op.lut2[(size_t)r * lut_codes * S61_S + e];
-      __syncthreads();
-
-#pragma unroll
-      for (unsigned b = 0; b < S61_NB; ++b)
-      {
-        if (blk[b] >= nblk) continue;
-        const size_t ubase = ((size_t)blk[b] * R + r) * S61_UNIT;
-        double2 t1[S61_KS], t2[S61_KS];
-        if (!op.codes1) s61_child_inner(op.clv1 + ubase, frag, lane, t1);
-        else if (lut_lds) s61_child_tip(frag, c1e[b], c1o[b], q, t1);
-        else s61_child_tip(op.lut1 + (size_t)r * lut_codes * S61_S, c1e[b], c1o[b], q, t1);
-        if (!op.codes2) s61_child_inner(op.clv2 + ubase, frag2, lane, t2);
-        else if (lut_lds) s61_child_tip(frag2, c2e[b], c2o[b], q, t2);
-        else s61_child_tip(op.lut2 + (size_t)r * lut_codes * S61_S, c2e[b], c2o[b], q, t2);
-#pragma unroll
-        for (unsigned k = 0; k < S61_KS; ++k)
-        {
-          t1[k].x *= t2[k].x;
-          t1[k].y *= t2[k].y;
-          if (4 * k + q < S61_S)
-          {
-            small_e[b] &= (t1[k].x < SCALE_THRESHOLD);
-            small_o[b] &= (t1[k].y < SCALE_THRESHOLD);
-          }
-        }
-        s61_store_d(op.parent + ubase, lane, t1);
-      }
-    }
-
-    if (scaling)
-    {
-#pragma unroll
-      for (unsigned b = 0; b < S61_NB; ++b)
-      {
-        if (blk[b] >= nblk) continue;
-        const int se = s20_and_q(small_e[b]), so = s20_and_q(small_o[b]);
-        if (__any(se | so))
-        {
-          const double fe = se ? SCALE_FACTOR : 1.0, fo = so ? SCALE_FACTOR : 1.0;
-          for (unsigned r = 0; r < R; ++r)
-          {
-            double * unit = op.parent + ((size_t)blk[b] * R + r) * S61_UNIT;
-            double2 t[S61_KS];
-            s61_load_d(unit, lane, t);
-#pragma unroll
-            for (unsigned k = 0; k < S61_KS; ++k) { t[k].x *= fe; t[k].y *= fo; }
-            s61_store_d(unit, lane, t);
-          }
-        }
-        if (q == 0)
-        {
-          const size_t site0 = (size_t)blk[b] * S20_BS + 2 * n;
-          unsigned ce = se ? 1u : 0u, co = so ? 1u : 0u;
-          if (op.scaler1) { ce += op.scaler1[site0]; co += op.scaler1[site0 + 1]; }
-          if (op.scaler2) { ce += op.scaler2[site0]; co += op.scaler2[site0 + 1]; }
-          op.parent_scaler[site0] = ce;
-          op.parent_scaler[site0 + 1] = co;
-        }
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// partials, range-walking variant ("v3").  Two measured costs of k_partials_s61
-// are removed: (1) the per-tile fragment fill -- every workgroup now owns ONE
-// contiguous range of site blocks and walks it once per rate, so the fragments of
-// a rate are filled once per workgroup; (2) exposed HBM latency -- the B operands
-// are fetched half a child (8 KiB per wave) ahead of the MFMAs that consume them,
-// into two alternating register sets, so a wave always has loads in flight while
-// it (or the other wave of its SIMD) feeds the matrix pipe.
+// partials (also the sumtable, with eigen-basis matrices).  Every workgroup owns ONE
+// contiguous range of site blocks and walks it once per rate, so the A fragments of a
+// rate (both children: 64 KiB of LDS, or the tip lookup table of the rate when it fits:
+// codes * 61 <= 4096) are filled once per workgroup and rate.  The B operands are
+// fetched half a child (8 KiB per wave) ahead of the MFMAs that consume them, into two
+// alternating register sets, so a wave always has loads in flight while it (or the
+// other wave of its SIMD) feeds the matrix pipe.  (Measured against the first version
+// of this kernel -- per-tile fragment fill, loads issued right before their MFMAs --
+// this is 1.2x faster at 200k sites and 2.7x at 25k; one wave per SIMD with whole-unit
+// prefetch was tried and is no faster.)
 // Fragment layout (pairs of M tiles, one ds_read_b128 feeds four MFMAs):
 //   frag[((ks*2 + mp)*64 + lane)*2 + h] = M[r][(lane&15) + 16*(2*mp + h)][4*ks + (lane>>4)]
 // grid = (<= 2 x CUs, ops), block = 256, dynamic LDS = 64 KiB.
@@ -470,8 +361,8 @@ __global__ __launch_bounds__(256, 2) void k_partials_s61v3(OpBatch batch, unsign
       if (nb == 0) continue;
       const double * l1 = lut_lds ? frag : op.lut1 + (size_t)r * lut_codes * S61_S;
       const double * l2 = lut_lds ? frag2 : op.lut2 + (size_t)r * lut_codes * S61_S;
-      if (!tip1 && !tip2) s61_rate_ii(op, frag, frag2, r, R, first, nb, lane, small_e, small_o);
-      else if (tip1 && tip2) s61_rate_tt(op, l1, l2, r, R, first, nb, lane, small_e, small_o);
+      if (tip1 && tip2) s61_rate_tt(op, l1, l2, r, R, first, nb, lane, small_e, small_o);
+      else if (!tip1 && !tip2) s61_rate_ii(op, frag, frag2, r, R, first, nb, lane, small_e, small_o);
       else if (tip1) s61_rate_ti(op, op.clv2, frag2, op.codes1, l1, r, R, first, nb, lane, small_e, small_o);
       else s61_rate_ti(op, op.clv1, frag, op.codes2, l2, r, R, first, nb, lane, small_e, small_o);
     }
@@ -670,6 +561,130 @@ __global__ __launch_bounds__(256, 2) void k_edge_lnl_s61(ModelView mv, ParamIdx 
   grid_reduce_finish1(tot, block_out, scratch);
 }
 
+// edge log-likelihood, inner child, R <= 4: the A fragments of ALL rates stay in LDS
+// (R x 32 KiB), so a workgroup fills them once and every wave then streams its site
+// blocks without a barrier; child operands are fetched half a unit ahead of the MFMAs
+// (as in k_partials_s61v3), the parent unit of a rate during that rate's MFMAs.
+// grid <= #CUs (one workgroup per CU, one wave per SIMD with the whole register file), dynamic LDS = (R * S61_FRAGS + R * 64) doubles.
+// Block totals go to block_out[0 .. nreduce); slots beyond the grid are zeroed.
+__global__ __launch_bounds__(256, 1) void k_edge_lnl_s61_r4(ModelView mv, ParamIdx fidx,
+                                                            NodeRef parent, const double * child_clv,
+                                                            const double * pmat,
+                                                            const unsigned * ps, const unsigned * cs,
+                                                            const unsigned * weights, const int * invariant,
+                                                            const unsigned long long * tipmap,
+                                                            unsigned N, unsigned nblk, unsigned R,
+                                                            double * persite, ReduceOut block_out,
+                                                            unsigned nreduce)
+{
+  extern __shared__ double frag[];
+  __shared__ double scratch[4];
+  double * const fq = frag + (size_t)R * S61_FRAGS;          // [R][64] frequencies, zero padded
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, n = lane & 15;
+  const unsigned beg = (unsigned)(((unsigned long long)nblk * blockIdx.x) / gridDim.x);
+  const unsigned end = (unsigned)(((unsigned long long)nblk * (blockIdx.x + 1)) / gridDim.x);
+
+  for (unsigned r = 0; r < R; ++r) s61_fill_frags_v3(frag + (size_t)r * S61_FRAGS, pmat, r);
+  for (unsigned e = threadIdx.x; e < R * 64; e += blockDim.x)
+    fq[e] = ((e & 63) < S61_S) ? mv.freqs(fidx.v[e >> 6])[e & 63] : 0.0;
+  __syncthreads();
+
+  double acc_lnl = 0.0;
+  const unsigned first = beg + wave;
+  const unsigned nb = first < end ? (end - first + 3) / 4 : 0;
+  double2 bA[8], bB[8];
+  if (nb) s61_issue_half<0>(child_clv + (size_t)first * R * S61_UNIT, lane, bA);
+
+  for (unsigned i = 0; i < nb; ++i)
+  {
+    const unsigned blk = first + 4 * i;
+    const unsigned blkn = first + 4 * (i + 1 < nb ? i + 1 : i);
+    const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+    unsigned long long pme = 0, pmo = 0;
+    int inv_e = -1, inv_o = -1;
+    if (parent.codes) { pme = tipmap[parent.codes[site0]]; pmo = tipmap[parent.codes[site0 + 1]]; }
+    if (invariant)
+    {
+      inv_e = (site0 < N) ? invariant[site0] : -1;
+      inv_o = (site0 + 1 < N) ? invariant[site0 + 1] : -1;
+    }
+    double site_e = 0.0, site_o = 0.0, ie = 0.0, io = 0.0;
+    for (unsigned r = 0; r < R; ++r)
+    {
+      const size_t ub = ((size_t)blk * R + r) * S61_UNIT;
+      const size_t ubn = (r + 1 < R) ? ub + S61_UNIT : (size_t)blkn * R * S61_UNIT;
+      const double2 * fr = reinterpret_cast<const double2 *>(frag + (size_t)r * S61_FRAGS);
+      v4d acc[S61_MT][2];
+      double2 pv[S61_KS];
+      s61_acc_zero(acc);
+      s61_issue_half<1>(child_clv + ub, lane, bB);
+      if (parent.codes) s61_tip_d(pme, pmo, q, pv);
+      else s61_load_d(parent.clv + ub, lane, pv);
+      S61_SCHED_FENCE();
+      s61_mfma_half<0>(bA, fr, lane, acc);
+      S61_SCHED_FENCE();
+      s61_issue_half<0>(child_clv + ubn, lane, bA);      // next rate / next block (the last re-reads)
+      S61_SCHED_FENCE();
+      s61_mfma_half<1>(bB, fr, lane, acc);
+      S61_SCHED_FENCE();
+      double le = 0.0, lo = 0.0;
+#pragma unroll
+      for (unsigned mt = 0; mt < S61_MT; ++mt)
+#pragma unroll
+        for (unsigned v = 0; v < 4; ++v)
+        {
+          const unsigned k = mt * 4 + v;
+          const double f = fq[r * 64 + 4 * k + q];
+          le += f * pv[k].x * acc[mt][0][v];
+          lo += f * pv[k].y * acc[mt][1][v];
+        }
+      le = s20_sum_q(le);
+      lo = s20_sum_q(lo);
+      const unsigned fi = fidx.v[r];
+      const double pinv = mv.pinv()[fi], w = mv.weights()[r];
+      if (pinv > 0.0)
+      {
+        site_e += w * (1.0 - pinv) * le;
+        site_o += w * (1.0 - pinv) * lo;
+        if (inv_e >= 0) ie += w * pinv * fq[r * 64 + inv_e];
+        if (inv_o >= 0) io += w * pinv * fq[r * 64 + inv_o];
+      }
+      else
+      {
+        site_e += w * le;
+        site_o += w * lo;
+      }
+    }
+    if (q == 0)
+    {
+      if (site0 < N)
+      {
+        const unsigned cnt = (ps ? ps[site0] : 0u) + (cs ? cs[site0] : 0u);
+        const double l = site_loglh(site_e, cnt, ie);
+        if (persite) persite[site0] = l;
+        acc_lnl += l * (double)weights[site0];
+      }
+      if (site0 + 1 < N)
+      {
+        const unsigned cnt = (ps ? ps[site0 + 1] : 0u) + (cs ? cs[site0 + 1] : 0u);
+        const double l = site_loglh(site_o, cnt, io);
+        if (persite) persite[site0 + 1] = l;
+        acc_lnl += l * (double)weights[site0 + 1];
+      }
+    }
+  }
+  // 4 waves -> one total, fixed order
+  acc_lnl = wave_sum(acc_lnl);
+  if (lane == 0) scratch[wave] = acc_lnl;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    block_out.block_out[blockIdx.x] = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    for (unsigned b = blockIdx.x + gridDim.x; b < nreduce; b += gridDim.x) block_out.block_out[b] = 0.0;
+  }
+}
+
 // sumtable preparation: Lm[r][k][i] = pi_i V[i][k], Rm[r][k][j] = V^-1[k][j] in
 // [r][61][64] row-major form, plus tip lookup tables [r][code][61]
 __global__ __launch_bounds__(256) void k_sumtable_prep_s61(ModelView mv, ParamIdx params,
@@ -792,55 +807,28 @@ __global__ __launch_bounds__(256) void k_derivatives_s61(ModelView mv, ParamIdx 
 
 static int launch_partials_s61(Engine * e, const OpBatch & batch, unsigned nops)
 {
-  static const int env_nb = getenv("PLLHIP_S61_NB") ? atoi(getenv("PLLHIP_S61_NB")) : 0;
-  static const int v3 = getenv("PLLHIP_S61_V3") ? atoi(getenv("PLLHIP_S61_V3")) : 1;
+  // few blocks per wave: one workgroup per (range, rate) balances the matrix pipes better and
+  // quarters the critical path of small slices; the scaling votes then meet in a second kernel
+  static const int env_rp = getenv("PLLHIP_S61_RATEPAR") ? atoi(getenv("PLLHIP_S61_RATEPAR")) : -1;
   const size_t lds = sizeof(double) * 2 * S61_FRAGS;
-  if (v3)
-  {
-    // few blocks per wave: one workgroup per (range, rate) balances the matrix pipes better and
-    // quarters the critical path of small slices; the scaling votes then meet in a second kernel
-    static const int env_rp = getenv("PLLHIP_S61_RATEPAR") ? atoi(getenv("PLLHIP_S61_RATEPAR")) : -1;
-    const unsigned slots = e->cu_count * 2u;
-    const bool rate_parallel = e->R > 1 && (env_rp >= 0 ? env_rp != 0 : e->nblk < slots * 4u * 8u);
-    if (!rate_parallel)
-    {
-      const unsigned gx = std::max(1u, std::min((e->nblk + 3) / 4, slots));
-      hipLaunchKernelGGL(k_partials_s61v3, dim3(gx, nops), dim3(256), lds, e->stream,
-                         batch, e->nblk, e->R, e->lut_codes, (uint8_t *)nullptr);
-      PLLHIP_TRY(hipGetLastError());
-      return PLL_SUCCESS;
-    }
-    bool scaling = false;
-    for (unsigned i = 0; i < nops; ++i) scaling |= batch.op[i].parent_scaler != nullptr;
-    if (scaling && !e->d_s61_votes)
-      PLLHIP_TRY(hipMalloc((void **)&e->d_s61_votes,
-                           (size_t)MAX_OPS_PER_LAUNCH * e->R * e->nblk * S20_BS));
-    const unsigned per_rate = std::max(1u, slots / e->R);
-    const unsigned gx = std::max(1u, std::min((e->nblk + 3) / 4, per_rate));
-    hipLaunchKernelGGL(k_partials_s61v3, dim3(gx, nops, e->R), dim3(256), lds, e->stream,
-                       batch, e->nblk, e->R, e->lut_codes, e->d_s61_votes);
-    PLLHIP_TRY(hipGetLastError());
-    if (scaling)
-    {
-      hipLaunchKernelGGL(k_s61_scale_fixup, dim3((e->nblk + 3) / 4, nops, e->R), dim3(256), 0, e->stream,
-                         batch, e->nblk, e->R, (const uint8_t *)e->d_s61_votes);
-      PLLHIP_TRY(hipGetLastError());
-    }
-    return PLL_SUCCESS;
-  }
-  const unsigned nb = env_nb ? (unsigned)env_nb : 4u;
-  const unsigned ntiles = (e->nblk + 4 * nb - 1) / (4 * nb);
-  const unsigned gx = std::max(1u, std::min(ntiles, e->cu_count * 2u));
-  if (nb == 1)
-    hipLaunchKernelGGL(k_partials_s61<1>, dim3(gx, nops), dim3(256), lds, e->stream,
-                       batch, e->nblk, e->R, e->lut_codes);
-  else if (nb == 2)
-    hipLaunchKernelGGL(k_partials_s61<2>, dim3(gx, nops), dim3(256), lds, e->stream,
-                       batch, e->nblk, e->R, e->lut_codes);
-  else
-    hipLaunchKernelGGL(k_partials_s61<4>, dim3(gx, nops), dim3(256), lds, e->stream,
-                       batch, e->nblk, e->R, e->lut_codes);
+  const unsigned slots = e->cu_count * 2u;
+  const bool rate_parallel = e->R > 1 && (env_rp >= 0 ? env_rp != 0 : e->nblk < slots * 4u * 8u);
+  bool scaling = false;
+  for (unsigned i = 0; i < nops; ++i) scaling |= batch.op[i].parent_scaler != nullptr;
+  if (rate_parallel && scaling && !e->d_s61_votes)
+    PLLHIP_TRY(hipMalloc((void **)&e->d_s61_votes,
+                         (size_t)MAX_OPS_PER_LAUNCH * e->R * e->nblk * S20_BS));
+  const unsigned per = rate_parallel ? std::max(1u, slots / e->R) : slots;
+  const unsigned gx = std::max(1u, std::min((e->nblk + 3) / 4, per));
+  hipLaunchKernelGGL(k_partials_s61v3, dim3(gx, nops, rate_parallel ? e->R : 1u), dim3(256), lds, e->stream,
+                     batch, e->nblk, e->R, e->lut_codes, rate_parallel ? e->d_s61_votes : (uint8_t *)nullptr);
   PLLHIP_TRY(hipGetLastError());
+  if (rate_parallel && scaling)
+  {
+    hipLaunchKernelGGL(k_s61_scale_fixup, dim3((e->nblk + 3) / 4, nops, e->R), dim3(256), 0, e->stream,
+                       batch, e->nblk, e->R, (const uint8_t *)e->d_s61_votes);
+    PLLHIP_TRY(hipGetLastError());
+  }
   return PLL_SUCCESS;
 }
 
@@ -850,6 +838,25 @@ static int launch_edge_lnl_s61(Engine * e, const ModelView & mv, const ParamIdx 
                                const unsigned * ps, const unsigned * cs,
                                double * persite, unsigned nblocks)
 {
+  static const int env_r4 = getenv("PLLHIP_S61_LNL_R4") ? atoi(getenv("PLLHIP_S61_LNL_R4")) : 1;
+  if (env_r4 && pm && !child.codes && e->R <= 4 && e->nblk)
+  {
+    const size_t lds = sizeof(double) * ((size_t)e->R * S61_FRAGS + (size_t)e->R * 64);
+    static bool attr_set = false;
+    if (!attr_set)
+    {
+      PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_lnl_s61_r4),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (S61_FRAGS + 64) * 8));
+      attr_set = true;
+    }
+    const unsigned gx = std::max(1u, std::min({nblocks, e->cu_count, (e->nblk + 3) / 4}));
+    hipLaunchKernelGGL(k_edge_lnl_s61_r4, dim3(gx), dim3(256), lds, e->stream,
+                       mv, fidx, parent, child.clv, pm, ps, cs,
+                       e->d_weights, e->d_invariant, e->d_tipmap, e->N, e->nblk, e->R,
+                       persite, reduce_out(e), nblocks);
+    PLLHIP_TRY(hipGetLastError());
+    return PLL_SUCCESS;
+  }
   const size_t lds = sizeof(double) * S61_FRAGS;
   hipLaunchKernelGGL(k_edge_lnl_s61, dim3(nblocks), dim3(256), lds, e->stream,
                      mv, fidx, parent, child, pm, lut, e->lut_codes, ps, cs,

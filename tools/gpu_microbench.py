@@ -63,6 +63,9 @@ def main():
     dt = timed(lambda: inst.edge_lnl(t.root_a, sa, t.root_b, sb, t.root_matrix))
     nb = N * R * 8 * S * (2 if t.root_b >= 8 else 1)
     print(f"S={S} edge lnL (sync each call)      {dt * 1e6:9.1f} us  {nb / dt / 1e9:8.1f} GB/s alg")
+    if ii:    # an inner-inner branch (timing only: the parent CLV looks the other way)
+        dt = timed(lambda: inst.edge_lnl(ii[0], t.scaler_of(ii[0]), ii[2], t.scaler_of(ii[2]), ii[3]))
+        print(f"S={S} edge lnL inner-inner (sync)      {dt * 1e6:9.1f} us  {N * R * 16 * S / dt / 1e9:8.1f} GB/s alg")
     st = inst.alloc_sumtable()
     dt = timed(lambda: inst.update_sumtable(t.root_a, t.root_b, sa, sb, st))
     print(f"S={S} sumtable                       {dt * 1e6:9.1f} us  {(nb + N * R * 8 * S) / dt / 1e9:8.1f} GB/s alg")
