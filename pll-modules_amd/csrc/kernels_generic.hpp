@@ -28,35 +28,70 @@ struct PmatBatch
 __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, PmatBatch batch,
                                                  unsigned R, double * pmat, double * lut,
                                                  unsigned lut_codes,
-                                                 const unsigned long long * tipmap)
+                                                 const unsigned long long * tipmap, int staged)
 {
-  extern __shared__ double lds[];            // expk[S] | P[S*Sp]
+  // staged (S*Sp <= 4096):  A[S*Sp] = V diag(exp(lambda rho t)) | B[S*Sp] = V^-1; P overwrites A
+  // otherwise:              expk[Sp] | P[S*Sp], operands read from global memory
+  extern __shared__ double lds[];
   const unsigned S = mv.S, Sp = mv.Sp;
-  double * expk = lds;
-  double * Pl = lds + Sp;
   const unsigned m = batch.midx[blockIdx.x], r = blockIdx.y;
   const double t = batch.t[blockIdx.x];
   const unsigned pi_ = params.v[r];
   const double * V = mv.evecs(pi_), * Vi = mv.ievecs(pi_), * L = mv.evals(pi_);
   double * P = pmat + ((size_t)m * R + r) * S * Sp;
+  double * Pl = staged ? lds : lds + Sp;
 
   if (t == 0.0)
   {
     for (unsigned e = threadIdx.x; e < S * Sp; e += blockDim.x)
       Pl[e] = (e / Sp == e % Sp) ? 1.0 : 0.0;
   }
+  else if (staged)
+  {
+    const double rt = mv.rates()[r] * t / (1.0 - mv.pinv()[pi_]);
+    double * A = lds, * B = lds + S * Sp;
+    for (unsigned e = threadIdx.x; e < S * Sp; e += blockDim.x)
+    {
+      const unsigned k = e % Sp;
+      A[e] = (k < S) ? V[e] * exp(L[k] * rt) : 0.0;
+      B[e] = Vi[e];
+    }
+    __syncthreads();
+    double res[16];
+#pragma unroll
+    for (unsigned u = 0; u < 16; ++u)
+    {
+      const unsigned e = threadIdx.x + u * 256;
+      double acc = 0.0;
+      if (e < S * Sp)
+      {
+        const unsigned i = e / Sp, j = e % Sp;
+        if (j < S)
+          for (unsigned k = 0; k < S; ++k) acc += A[i * Sp + k] * B[k * Sp + j];
+      }
+      res[u] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (unsigned u = 0; u < 16; ++u)
+    {
+      const unsigned e = threadIdx.x + u * 256;
+      if (e < S * Sp) Pl[e] = res[u];
+    }
+  }
   else
   {
+    double * expk = lds;
     const double rt = mv.rates()[r] * t / (1.0 - mv.pinv()[pi_]);
     for (unsigned k = threadIdx.x; k < S; k += blockDim.x) expk[k] = exp(L[k] * rt);
     __syncthreads();
     for (unsigned e = threadIdx.x; e < S * Sp; e += blockDim.x)
     {
       const unsigned i = e / Sp, j = e % Sp;
-      double s = 0.0;
+      double acc = 0.0;
       if (j < S)
-        for (unsigned k = 0; k < S; ++k) s += V[i * Sp + k] * expk[k] * Vi[k * Sp + j];
-      Pl[e] = s;
+        for (unsigned k = 0; k < S; ++k) acc += V[i * Sp + k] * expk[k] * Vi[k * Sp + j];
+      Pl[e] = acc;
     }
   }
   __syncthreads();
@@ -68,10 +103,13 @@ __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, 
     {
       const unsigned c = e / S, i = e % S;
       const unsigned long long mask = tipmap[c];
-      double s = 0.0;
-      for (unsigned j = 0; j < S; ++j)
-        if ((mask >> j) & 1ULL) s += Pl[i * Sp + j];
-      T[e] = s;
+      double acc = 0.0;
+      if (mask && !(mask & (mask - 1)))               // one state: a column of P
+        acc = Pl[i * Sp + (unsigned)__ffsll((long long)mask) - 1];
+      else
+        for (unsigned j = 0; j < S; ++j)
+          if ((mask >> j) & 1ULL) acc += Pl[i * Sp + j];
+      T[e] = acc;
     }
   }
 }

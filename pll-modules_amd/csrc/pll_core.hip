@@ -360,7 +360,10 @@ int flush_pmatrices(pll_partition_t * p)
     if (stale && !ensure_luts(p)) return PLL_FAILURE;
   }
   const ModelView mv = model_view(e);
-  const size_t lds = sizeof(double) * ((size_t)e->Sp + (size_t)e->S * e->Sp);
+  // operands staged in LDS when two S x Sp matrices fit the kernel's register tiling (S <= 64)
+  const int staged = (size_t)e->S * e->Sp <= 4096;
+  const size_t lds = staged ? sizeof(double) * 2 * (size_t)e->S * e->Sp
+                            : sizeof(double) * ((size_t)e->Sp + (size_t)e->S * e->Sp);
   const unsigned count = (unsigned)e->pend_midx.size();
   for (unsigned base = 0; base < count; base += MAX_PMAT_PER_LAUNCH)
   {
@@ -374,7 +377,7 @@ int flush_pmatrices(pll_partition_t * p)
     }
     hipLaunchKernelGGL(k_pmatrix, dim3(nb, e->R), dim3(256), lds, e->stream,
                        mv, e->pend_params, batch, e->R, e->d_pmat,
-                       e->coded_tips ? e->d_lut : nullptr, e->lut_codes, e->d_tipmap);
+                       e->coded_tips ? e->d_lut : nullptr, e->lut_codes, e->d_tipmap, staged);
     PLLHIP_TRY(hipGetLastError());
     e->counters.pmatrix_launches++;
   }

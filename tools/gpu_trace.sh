@@ -1,17 +1,15 @@
 #!/bin/bash
-# rocprofv3 kernel trace of an arbitrary python tool: tools/gpu_trace.sh <name> <script> [args...]
-mkdir -p gpurun_out
+# rocprofv3 kernel-trace summary of an arbitrary python tool: tools/gpu_trace.sh <name> <script> [args...]
+NAME=$1; shift
 R=$GRAFT_REPO_ROOT
-name=$1; shift
+mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trace_$name -- python3 $R/"$@" > $R/gpurun_out/trace_$name.log 2>&1
-python3 - <<PY
-import csv, glob, collections
-f = glob.glob("$R/gpurun_out/trace_$name/*/*_kernel_trace.csv")[0]
-d = collections.defaultdict(list)
-for r in csv.DictReader(open(f)):
-    d[r["Kernel_Name"].split("(")[0]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
-    v.sort()
-    print(f"{k:45s} n={len(v):5d} avg={sum(v)/len(v)/1e3:9.1f} us  med={v[len(v)//2]/1e3:9.1f}  min={v[0]/1e3:8.1f} max={v[-1]/1e3:9.1f}")
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trace_$NAME -- python3 "$@" > $R/gpurun_out/trace_$NAME.log 2>&1
+f=$(ls -t $R/gpurun_out/trace_$NAME/*/*_kernel_stats.csv | head -1)
+cut -c1-60 --complement $f > /dev/null 2>&1
+python3 - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows[:14]:
+    print(f"{r['Name'].split('(')[0][:44]:44s} calls={int(r['Calls']):7d} total_ms={int(r['TotalDurationNs'])/1e6:10.2f} avg_us={float(r['AverageNs'])/1e3:9.1f} pct={r['Percentage']}")
 PY

@@ -201,8 +201,9 @@ def main():
         w3(lib, "c3", out, nsites=125_000)
     if "c4" in which:
         c4(lib, out)
-    if "spr" in which:
+    if "spr" in which or "spr200" in which:
         spr(lib, out)
+    if "spr" in which or "spr25" in which:
         spr(lib, out, nsites=25_000)
     print(json.dumps(out, indent=1))
 
