@@ -84,11 +84,27 @@ __device__ inline HalfP s4_load_half_p(const double * pmat, unsigned r, unsigned
   return q;
 }
 
+// value of the partner lane (lane ^ 1): a DPP quad permute, no LDS round trip
+__device__ inline double swap_pair(double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ inline double2 s4_half_matvec(const HalfP & q, const double2 c)
 {
   const double own0 = q.own[0] * c.x + q.own[1] * c.y, own1 = q.own[2] * c.x + q.own[3] * c.y;
   const double oth0 = q.oth[0] * c.x + q.oth[1] * c.y, oth1 = q.oth[2] * c.x + q.oth[3] * c.y;
-  return make_double2(own0 + __shfl_xor(oth0, 1, 64), own1 + __shfl_xor(oth1, 1, 64));
+  return make_double2(own0 + swap_pair(oth0), own1 + swap_pair(oth1));
+}
+
+// 1 if any of the `group` lanes (aligned, power of two <= 32) of this lane's site votes 1
+__device__ inline int group_any(int vote, unsigned lane, unsigned group)
+{
+  const unsigned long long b = __ballot(vote);
+  const unsigned long long m = (group >= 64) ? ~0ULL : ((1ULL << group) - 1ULL);
+  return ((b >> (lane & ~(group - 1u))) & m) != 0ULL;
 }
 
 template <unsigned U>    // iterations issued per batch (loads first, arithmetic after)
@@ -103,20 +119,22 @@ __global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, 
   const unsigned rs = (unsigned)__ffs((int)R) - 1;   // R is a power of two in this family
   const unsigned long long total = 2ULL * N * R;     // half-columns
 
-  HalfP p1 = {}, p2 = {};
-  if (!op.codes1) p1 = s4_load_half_p(op.pmat1, r, h);
-  if (!op.codes2) p2 = s4_load_half_p(op.pmat2, r, h);
-
   // tip lookup tables (R x 16 codes x 4 doubles each) are staged in LDS: the
-  // per-site gathers then cost LDS bank cycles instead of L1 address cycles
+  // per-site gathers then cost LDS bank cycles instead of L1 address cycles.
+  // Inner children stage their R 4x4 matrices the same way (one global load per
+  // thread instead of sixteen scattered ones per lane: the prologue of a workgroup
+  // that lives for a few chunks only).
   __shared__ double lut_s[2][16 * 16 * 4];
+  __shared__ double pm_s[2][16 * 16];
   const bool lut_lds = lut_codes == 16;              // always true for DNA tip codes
-  if (lut_lds)
-  {
-    if (op.codes1) for (unsigned e = threadIdx.x; e < R * 64; e += 256) lut_s[0][e] = op.lut1[e];
-    if (op.codes2) for (unsigned e = threadIdx.x; e < R * 64; e += 256) lut_s[1][e] = op.lut2[e];
-    __syncthreads();
-  }
+  if (op.codes1) { if (lut_lds) for (unsigned e = threadIdx.x; e < R * 64; e += 256) lut_s[0][e] = op.lut1[e]; }
+  else for (unsigned e = threadIdx.x; e < R * 16; e += 256) pm_s[0][e] = op.pmat1[e];
+  if (op.codes2) { if (lut_lds) for (unsigned e = threadIdx.x; e < R * 64; e += 256) lut_s[1][e] = op.lut2[e]; }
+  else for (unsigned e = threadIdx.x; e < R * 16; e += 256) pm_s[1][e] = op.pmat2[e];
+  __syncthreads();
+  HalfP p1 = {}, p2 = {};
+  if (!op.codes1) p1 = s4_load_half_p(pm_s[0], r, h);
+  if (!op.codes2) p2 = s4_load_half_p(pm_s[1], r, h);
 
   // A wave owns chunks of 64 consecutive sites = `group` iterations of 64
   // half-columns (1 KiB per child each).  The scaling vote of an iteration is
@@ -128,6 +146,11 @@ __global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, 
   {
     const unsigned long long hc0 = (unsigned long long)chunk * 64ULL * group + lane;
     unsigned scaled_mask = 0;                        // bit k: iteration k rescaled (same in a lane group)
+    // the children's scaler counts of this lane's site: fetched now, needed after the chunk
+    const unsigned long long nsc = (unsigned long long)chunk * 64ULL + lane;
+    unsigned child_cnt = 0;
+    if (op.parent_scaler && nsc < N)
+      child_cnt = (op.scaler1 ? op.scaler1[nsc] : 0u) + (op.scaler2 ? op.scaler2[nsc] : 0u);
     for (unsigned k0 = 0; k0 < group; k0 += U)
     {
       double2 in1[U], in2[U];
@@ -163,8 +186,7 @@ __global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, 
         double2 v = make_double2(a.x * b.x, a.y * b.y);
         if (op.parent_scaler)
         {
-          int big = live[u] && !(v.x < SCALE_THRESHOLD && v.y < SCALE_THRESHOLD);
-          big = group_or(big, group);
+          const int big = group_any(live[u] && !(v.x < SCALE_THRESHOLD && v.y < SCALE_THRESHOLD), lane, group);
           if (!big)
           {
             v.x *= SCALE_FACTOR;
@@ -181,12 +203,7 @@ __global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, 
       // lane group l % spi
       const unsigned src = (lane % spi) * group;
       const unsigned m = (unsigned)__shfl((int)scaled_mask, (int)src, 64);
-      const unsigned long long n = (unsigned long long)chunk * 64ULL + lane;
-      if (n < N)
-      {
-        const unsigned cnt = (op.scaler1 ? op.scaler1[n] : 0u) + (op.scaler2 ? op.scaler2[n] : 0u);
-        op.parent_scaler[n] = cnt + ((m >> (lane / spi)) & 1u);
-      }
+      if (nsc < N) op.parent_scaler[nsc] = child_cnt + ((m >> (lane / spi)) & 1u);
     }
   }
 }
