@@ -55,6 +55,18 @@ struct OpBatch
   OpDesc op[MAX_OPS_PER_LAUNCH];
 };
 
+// Operation chains (20-state family): consecutive operations along one root-ward
+// path of the tree, run by ONE launch; the parent vector of a link is handed to the
+// next operation in registers, so that operation never reads it back from HBM.
+struct ChainBatch
+{
+  OpDesc op[MAX_OPS_PER_LAUNCH];                 // chains back to back
+  unsigned char first[MAX_OPS_PER_LAUNCH];       // per chain: index of its first op
+  unsigned char len[MAX_OPS_PER_LAUNCH];         // per chain: number of ops
+  unsigned char carried[MAX_OPS_PER_LAUNCH];     // per op: 0 = both children from memory,
+                                                 // 1 / 2 = child 1 / 2 is the previous op's parent
+};
+
 enum class KernelFamily { Generic, S4, S20, S61 };
 
 struct Engine

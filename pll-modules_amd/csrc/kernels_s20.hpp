@@ -335,6 +335,165 @@ __global__ __launch_bounds__(256, 2) void k_traverse_s20(const OpDesc * ops, uns
 }
 
 // ---------------------------------------------------------------------------
+// Operation chains.  A chain is a run of operations in which each one consumes the
+// parent vector of the one before (the path from a node towards the root).  Because
+// the MFMA D layout of a result IS the B layout of an operand (slot k = state row
+// s20_row(k, q) in both), a wave keeps the block it has just computed in registers
+// and multiplies it straight into the next operation: the carried child is never
+// re-read, which removes one of the three HBM streams of an inner x inner operation.
+// Every vector is still stored (later partial traversals need it), bit-identical to
+// what k_partials_s20 stores.  A workgroup walks the chain in lockstep (the LDS
+// fragments are per operation); every wave owns one site block per pass.
+// grid = (gx, chains), block = 256, dynamic LDS = 2 * RT * S20_FRAGS doubles.
+// ---------------------------------------------------------------------------
+__device__ inline void s20_child_regs(const double2 b[5], const double * frag_r, unsigned lane,
+                                      double2 t[5])
+{
+  v4d a0e = {0, 0, 0, 0}, a0o = {0, 0, 0, 0}, a1e = {0, 0, 0, 0}, a1o = {0, 0, 0, 0};
+#pragma unroll
+  for (int ks = 0; ks < 5; ++ks)
+  {
+    const double f0 = frag_r[ks * 64 + lane];
+    const double f1 = frag_r[(5 + ks) * 64 + lane];
+    a0e = mfma_f64(f0, b[ks].x, a0e);
+    a0o = mfma_f64(f0, b[ks].y, a0o);
+    a1e = mfma_f64(f1, b[ks].x, a1e);
+    a1o = mfma_f64(f1, b[ks].y, a1o);
+  }
+  t[0] = make_double2(a0e[0], a0o[0]);
+  t[1] = make_double2(a0e[1], a0o[1]);
+  t[2] = make_double2(a0e[2], a0o[2]);
+  t[3] = make_double2(a0e[3], a0o[3]);
+  t[4] = make_double2(a1e[0], a1o[0]);
+}
+
+// one operation for one site block; X holds the handed-over operand on entry (when
+// carried != 0) and the result on exit
+template <unsigned RT>
+__device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2 X[RT][5],
+                                    const double * frag, unsigned lut_codes, bool lut_lds,
+                                    unsigned blk, unsigned lane, bool nt_ld, bool nt_st,
+                                    unsigned & xe, unsigned & xo)
+{
+  const double * frag2 = frag + RT * S20_FRAGS;
+  const unsigned q = lane >> 4, n = lane & 15;
+  const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+  unsigned c1e = 0, c1o = 0, c2e = 0, c2o = 0;
+  if (op.codes1) { c1e = op.codes1[site0]; c1o = op.codes1[site0 + 1]; }
+  if (op.codes2) { c2e = op.codes2[site0]; c2o = op.codes2[site0 + 1]; }
+  const bool scaling = op.parent_scaler != nullptr;
+  int small_e = 1, small_o = 1;
+#pragma unroll
+  for (unsigned r = 0; r < RT; ++r)
+  {
+    const size_t ubase = ((size_t)blk * RT + r) * S20_UNIT;
+    double2 t1[5], t2[5];
+    if (carried == 1) s20_child_regs(X[r], frag + r * S20_FRAGS, lane, t1);
+    else if (!op.codes1) s20_child_inner(op.clv1 + ubase, frag + r * S20_FRAGS, lane, t1, nt_ld);
+    else if (lut_lds) s20_child_tip(frag + r * lut_codes * 20, c1e, c1o, q, t1);
+    else s20_child_tip(op.lut1 + (size_t)r * lut_codes * 20, c1e, c1o, q, t1);
+    if (carried == 2) s20_child_regs(X[r], frag2 + r * S20_FRAGS, lane, t2);
+    else if (!op.codes2) s20_child_inner(op.clv2 + ubase, frag2 + r * S20_FRAGS, lane, t2, nt_ld);
+    else if (lut_lds) s20_child_tip(frag2 + r * lut_codes * 20, c2e, c2o, q, t2);
+    else s20_child_tip(op.lut2 + (size_t)r * lut_codes * 20, c2e, c2o, q, t2);
+    // X[r] has been consumed (if it was an operand at all): it now takes the result
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+    {
+      X[r][k].x = t1[k].x * t2[k].x;
+      X[r][k].y = t1[k].y * t2[k].y;
+      small_e &= (X[r][k].x < SCALE_THRESHOLD);
+      small_o &= (X[r][k].y < SCALE_THRESHOLD);
+    }
+  }
+  double fe = 1.0, fo = 1.0;
+  if (scaling)
+  {
+    small_e = s20_and_q(small_e);
+    small_o = s20_and_q(small_o);
+    fe = small_e ? SCALE_FACTOR : 1.0;
+    fo = small_o ? SCALE_FACTOR : 1.0;
+  }
+#pragma unroll
+  for (unsigned r = 0; r < RT; ++r)
+  {
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+    {
+      X[r][k].x *= fe;
+      X[r][k].y *= fo;
+    }
+    s20_store_d(op.parent + ((size_t)blk * RT + r) * S20_UNIT, lane, X[r], nt_st);
+  }
+  unsigned ce = 0, co = 0;
+  if (scaling && q == 0)
+  {
+    ce = small_e ? 1u : 0u;
+    co = small_o ? 1u : 0u;
+    if (op.scaler1)
+    {
+      if (carried == 1) { ce += xe; co += xo; }
+      else { ce += op.scaler1[site0]; co += op.scaler1[site0 + 1]; }
+    }
+    if (op.scaler2)
+    {
+      if (carried == 2) { ce += xe; co += xo; }
+      else { ce += op.scaler2[site0]; co += op.scaler2[site0 + 1]; }
+    }
+    op.parent_scaler[site0] = ce;
+    op.parent_scaler[site0 + 1] = co;
+  }
+  xe = ce;
+  xo = co;
+}
+
+__device__ inline void s20_fill_op(double * frag, const OpDesc & op, unsigned R, unsigned lut_codes, bool lut_lds)
+{
+  double * const frag2 = frag + R * S20_FRAGS;
+  if (!op.codes1) s20_fill_frags(frag, op.pmat1, R);
+  else if (lut_lds)
+    for (unsigned e = threadIdx.x; e < R * lut_codes * 20; e += blockDim.x) frag[e] = op.lut1[e];
+  if (!op.codes2) s20_fill_frags(frag2, op.pmat2, R);
+  else if (lut_lds)
+    for (unsigned e = threadIdx.x; e < R * lut_codes * 20; e += blockDim.x) frag2[e] = op.lut2[e];
+}
+
+// Chains of at most S20_CHAIN_MAX operations: the fragments of ALL of them stay in LDS
+// (40 KiB each), so -- exactly like k_partials_s20 -- a workgroup fills LDS once and its
+// waves then stream site blocks independently, without any barrier; per block a wave
+// runs the chain bottom-up with the intermediate vector in registers.  One 512-thread
+// workgroup per CU (eight waves share the fragments: same occupancy as two 256-thread
+// workgroups, half the LDS).
+// grid = (gx, chains), block = 512, dynamic LDS = S20_CHAIN_MAX * 2 * RT * S20_FRAGS doubles.
+constexpr unsigned S20_CHAIN_MAX = 4;
+constexpr unsigned S20_CHAIN_WAVES = 8;
+
+template <unsigned RT>
+__global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_chain_s20(ChainBatch batch, unsigned nblk,
+                                                                        unsigned lut_codes, unsigned flags)
+{
+  extern __shared__ double lds[];
+  const bool nt_ld = flags & 1u, nt_st = flags & 2u;
+  const bool lut_lds = lut_codes <= 32;
+  const unsigned first = batch.first[blockIdx.y], len = batch.len[blockIdx.y];
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (unsigned i = 0; i < len; ++i)
+    s20_fill_op(lds + i * 2 * RT * S20_FRAGS, batch.op[first + i], RT, lut_codes, lut_lds);
+  __syncthreads();
+
+  const unsigned wstride = gridDim.x * S20_CHAIN_WAVES;
+  for (unsigned blk = blockIdx.x * S20_CHAIN_WAVES + wave; blk < nblk; blk += wstride)
+  {
+    double2 X[RT][5];
+    unsigned xe = 0, xo = 0;
+#pragma unroll 1
+    for (unsigned i = 0; i < len; ++i)
+      s20_chain_op<RT>(batch.op[first + i], i ? batch.carried[first + i] : 0u, X,
+                       lds + i * 2 * RT * S20_FRAGS, lut_codes, lut_lds, blk, lane, nt_ld, nt_st, xe, xo);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // edge / root log-likelihood.  grid = nblocks (<= REDUCE_BLOCKS), block = 256
 // dynamic LDS = R * S20_FRAGS doubles (unused for the root form)
 // ---------------------------------------------------------------------------
@@ -614,6 +773,30 @@ static int launch_partials_s20(Engine * e, const OpBatch & batch, unsigned nops)
   else
     hipLaunchKernelGGL(k_partials_s20<0>, dim3(s20_grid(e, 4), nops), dim3(256), lds, e->stream,
                        batch, e->nblk, e->R, e->lut_codes, flags);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+static bool chains_supported_s20(const Engine * e) { return e->R == 4; }
+
+static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned nchains)
+{
+  const size_t lds = sizeof(double) * S20_CHAIN_MAX * 2 * e->R * S20_FRAGS;
+  static const unsigned flags = getenv("PLLHIP_S20_NT") ? (unsigned)atoi(getenv("PLLHIP_S20_NT")) : 0u;
+  static bool attr_set = false;
+  if (!attr_set)
+  {
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_s20<4>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(sizeof(double) * S20_CHAIN_MAX * 8 * S20_FRAGS)));
+    attr_set = true;
+  }
+  // one workgroup per CU per chain (measured: 1 beats 2 and 4 per CU)
+  static const int env_bpc = getenv("PLLHIP_S20_CHAIN_BPC") ? atoi(getenv("PLLHIP_S20_CHAIN_BPC")) : 1;
+  const unsigned need = (e->nblk + S20_CHAIN_WAVES - 1) / S20_CHAIN_WAVES;
+  const unsigned gx = std::max(1u, std::min(need, e->cu_count * (unsigned)std::max(1, env_bpc)));
+  hipLaunchKernelGGL(k_chain_s20<4>, dim3(gx, nchains), dim3(64 * S20_CHAIN_WAVES), lds, e->stream,
+                     batch, e->nblk, e->lut_codes, flags);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

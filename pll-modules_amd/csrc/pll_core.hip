@@ -553,6 +553,85 @@ static int launch_partials(Engine * e, const OpBatch & batch, unsigned nops)
   return launch_partials_generic(e, batch, nops);
 }
 
+// Chain schedule of an operation list (see ChainBatch, engine.h).  Accepted only for
+// lists with the shape of a tree traversal -- every vector written once, read by at
+// most one later operation, nothing overwritten after it was read, child scalers
+// being the ones the producers wrote -- anything else keeps the level schedule.
+struct ChainPlan
+{
+  std::vector<std::vector<unsigned>> chains;     // op indices, bottom to top
+  std::vector<int> launch;                       // per chain: launch round
+  std::vector<unsigned char> carried;            // per op
+  int rounds = 0;
+};
+
+static bool plan_chains(const Engine * e, const pll_operation_t * ops, unsigned count, unsigned max_len,
+                        ChainPlan & plan)
+{
+  std::vector<int> producer(e->nodes, -1), sc_writer(e->nscalers, -1), chain_of(count, -1);
+  std::vector<char> read_ext(e->nodes, 0), sc_read_ext(e->nscalers, 0);
+  std::vector<unsigned> size(count, 1), consumers(count, 0);
+  plan.carried.assign(count, 0);
+  for (unsigned k = 0; k < count; ++k)
+  {
+    const pll_operation_t & op = ops[k];
+    const unsigned child[2] = {op.child1_clv_index, op.child2_clv_index};
+    const int child_sc[2] = {op.child1_scaler_index, op.child2_scaler_index};
+    if (child[0] == child[1] || op.parent_clv_index == child[0] || op.parent_clv_index == child[1]) return false;
+    int pr[2];
+    for (int c = 0; c < 2; ++c)
+    {
+      pr[c] = producer[child[c]];
+      if (pr[c] < 0)
+      {
+        read_ext[child[c]] = 1;
+        if (child_sc[c] >= 0)
+        {
+          if (sc_writer[child_sc[c]] >= 0) return false;
+          sc_read_ext[child_sc[c]] = 1;
+        }
+      }
+      else
+      {
+        if (++consumers[pr[c]] > 1) return false;
+        if (child_sc[c] != ops[pr[c]].parent_scaler_index) return false;
+      }
+    }
+    if (producer[op.parent_clv_index] >= 0 || read_ext[op.parent_clv_index]) return false;
+    producer[op.parent_clv_index] = (int)k;
+    if (op.parent_scaler_index >= 0)
+    {
+      if (sc_writer[op.parent_scaler_index] >= 0 || sc_read_ext[op.parent_scaler_index]) return false;
+      sc_writer[op.parent_scaler_index] = (int)k;
+    }
+
+    size[k] = 1 + (pr[0] >= 0 ? size[pr[0]] : 0) + (pr[1] >= 0 ? size[pr[1]] : 0);
+    int heavy = -1;                               // which child (0 / 1) continues a chain
+    if (pr[0] >= 0 && (pr[1] < 0 || size[pr[0]] >= size[pr[1]])) heavy = 0;
+    else if (pr[1] >= 0) heavy = 1;
+    if (heavy >= 0 && plan.chains[chain_of[pr[heavy]]].size() >= max_len) heavy = -1;
+    int round = 0;
+    for (int c = 0; c < 2; ++c)
+      if (pr[c] >= 0 && c != heavy) round = std::max(round, plan.launch[chain_of[pr[c]]] + 1);
+    if (heavy >= 0)
+    {
+      const int ch = chain_of[pr[heavy]];
+      plan.chains[ch].push_back(k);
+      plan.launch[ch] = std::max(plan.launch[ch], round);
+      plan.carried[k] = (unsigned char)(heavy + 1);
+      chain_of[k] = ch;
+    }
+    else
+    {
+      chain_of[k] = (int)plan.chains.size();
+      plan.chains.push_back(std::vector<unsigned>(1, k));
+      plan.launch.push_back(round);
+    }
+    plan.rounds = std::max(plan.rounds, plan.launch[chain_of[k]] + 1);
+  }
+  return true;
+}
+
 static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops, unsigned count)
 {
   Engine * e = engine_of(p);
@@ -693,6 +772,61 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     e->counters.partial_ops += count;
     e->counters.site_updates += (unsigned long long)count * e->N * e->R;
     return PLL_SUCCESS;
+  }
+
+  // chain schedule (20-state family): one launch per round of chains, the vector of a
+  // link stays in registers.  PLLHIP_CHAINS=0 keeps the plain level schedule.
+  static const int use_chains = getenv("PLLHIP_CHAINS") ? atoi(getenv("PLLHIP_CHAINS")) : 1;
+  if (use_chains && count >= 2 && e->family == KernelFamily::S20 && chains_supported_s20(e))
+  {
+    ChainPlan plan;
+    if (plan_chains(e, ops, count, S20_CHAIN_MAX, plan))
+    {
+      for (int round = 0; round < plan.rounds; ++round)
+      {
+        ChainBatch cb;
+        unsigned nops = 0, nchains = 0, longest = 0;
+        double bytes = 0.0, flops = 0.0;
+        auto flush = [&]() -> int
+        {
+          if (!nchains) return PLL_SUCCESS;
+          hipEvent_t ev1;
+          if (!prof_begin(ev1)) return PLL_FAILURE;
+          if (longest == 1)
+          {
+            OpBatch ob;                       // nothing to hand over: the plain kernel
+            for (unsigned i = 0; i < nops; ++i) ob.op[i] = cb.op[i];
+            if (!launch_partials(e, ob, nops)) return PLL_FAILURE;
+          }
+          else if (!launch_chains_s20(e, cb, nchains)) return PLL_FAILURE;
+          if (!prof_end(ev1, bytes, flops, nops)) return PLL_FAILURE;
+          e->counters.partial_launches++;
+          nops = nchains = longest = 0;
+          bytes = flops = 0.0;
+          return PLL_SUCCESS;
+        };
+        for (size_t c = 0; c < plan.chains.size(); ++c)
+        {
+          if (plan.launch[c] != round) continue;
+          const std::vector<unsigned> & ch = plan.chains[c];
+          if (nops + ch.size() > MAX_OPS_PER_LAUNCH && !flush()) return PLL_FAILURE;
+          cb.first[nchains] = (unsigned char)nops;
+          cb.len[nchains] = (unsigned char)ch.size();
+          for (size_t i = 0; i < ch.size(); ++i)
+          {
+            fill_desc(ops[ch[i]], cb.op[nops], bytes, flops);
+            cb.carried[nops] = i ? plan.carried[ch[i]] : 0;
+            ++nops;
+          }
+          ++nchains;
+          longest = std::max<unsigned>(longest, (unsigned)ch.size());
+        }
+        if (!flush()) return PLL_FAILURE;
+      }
+      e->counters.partial_ops += count;
+      e->counters.site_updates += (unsigned long long)count * e->N * e->R;
+      return PLL_SUCCESS;
+    }
   }
 
   for (int l = 0; l <= max_level; ++l)
