@@ -208,6 +208,118 @@ __global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, 
   }
 }
 
+// Operation chains (ChainBatch, engine.h), four rate categories: a wave keeps the 64-site
+// chunk it has just computed in registers (8 half-columns per lane) and feeds it to the
+// next operation of the chain, so the carried child is not read back from HBM.  The
+// lookup tables / matrices of ALL operations of the chain are staged in LDS up front
+// (5 KiB per operation); the waves of a workgroup never synchronise afterwards.  Values
+// are scaled before they are handed on, i.e. exactly what k_partials_s4 stores and the
+// next launch would have loaded.  grid = (gx, chains), block = 256,
+// dynamic LDS = chain length x S4_CHAIN_OP_LDS doubles.
+constexpr unsigned S4_CHAIN_MAX = 8;
+constexpr unsigned S4_CHAIN_OP_LDS = 2 * 256 + 2 * 64;     // two tables [4][16][4], two matrix sets [4][16]
+
+template <unsigned U>
+__global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
+{
+  constexpr unsigned R = 4, group = 8, spi = 8, rs = 2;
+  extern __shared__ double lds[];
+  const unsigned first = batch.first[blockIdx.y], len = batch.len[blockIdx.y];
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned h = lane & 1u, r = (lane >> 1) & (R - 1);
+  const unsigned long long total = 2ULL * N * R;
+
+  for (unsigned i = 0; i < len; ++i)
+  {
+    const OpDesc & op = batch.op[first + i];
+    double * base = lds + i * S4_CHAIN_OP_LDS;
+    if (op.codes1) base[threadIdx.x] = op.lut1[threadIdx.x];
+    else if (threadIdx.x < 64) base[512 + threadIdx.x] = op.pmat1[threadIdx.x];
+    if (op.codes2) base[256 + threadIdx.x] = op.lut2[threadIdx.x];
+    else if (threadIdx.x < 64) base[576 + threadIdx.x] = op.pmat2[threadIdx.x];
+  }
+  __syncthreads();
+
+  const unsigned nchunks = (N + 63) / 64;
+  const unsigned wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = gridDim.x * 4;
+  for (unsigned chunk = wave; chunk < nchunks; chunk += nwaves)
+  {
+    const unsigned long long hc0 = (unsigned long long)chunk * 64ULL * group + lane;
+    const unsigned long long nsc = (unsigned long long)chunk * 64ULL + lane;   // this lane's site for scalers
+    double2 X[group];
+    unsigned xcnt = 0;                                 // scaler count that goes with X
+#pragma unroll 1
+    for (unsigned i = 0; i < len; ++i)
+    {
+      const OpDesc & op = batch.op[first + i];
+      const unsigned carried = i ? batch.carried[first + i] : 0u;
+      const double * base = lds + i * S4_CHAIN_OP_LDS;
+      HalfP p1 = {}, p2 = {};
+      if (!op.codes1) p1 = s4_load_half_p(base + 512, r, h);
+      if (!op.codes2) p2 = s4_load_half_p(base + 576, r, h);
+      unsigned child_cnt = 0;
+      if (op.parent_scaler && nsc < N)
+      {
+        if (op.scaler1) child_cnt += (carried == 1) ? xcnt : op.scaler1[nsc];
+        if (op.scaler2) child_cnt += (carried == 2) ? xcnt : op.scaler2[nsc];
+      }
+      unsigned scaled_mask = 0;
+#pragma unroll
+      for (unsigned k0 = 0; k0 < group; k0 += U)
+      {
+        double2 in1[U], in2[U];
+        bool live[U];
+#pragma unroll
+        for (unsigned u = 0; u < U; ++u)
+        {
+          const unsigned long long gu = hc0 + (unsigned long long)(k0 + u) * 64ULL;
+          live[u] = gu < total;
+          in1[u] = in2[u] = make_double2(0.0, 0.0);
+          if (live[u])
+          {
+            const unsigned long long n = (gu >> 1) >> rs;
+            if (op.codes1)
+              in1[u] = *reinterpret_cast<const double2 *>(&base[(r * 16 + op.codes1[n]) * 4 + 2 * h]);
+            else if (carried != 1) in1[u] = *reinterpret_cast<const double2 *>(op.clv1 + gu * 2);
+            if (op.codes2)
+              in2[u] = *reinterpret_cast<const double2 *>(&base[256 + (r * 16 + op.codes2[n]) * 4 + 2 * h]);
+            else if (carried != 2) in2[u] = *reinterpret_cast<const double2 *>(op.clv2 + gu * 2);
+          }
+        }
+#pragma unroll
+        for (unsigned u = 0; u < U; ++u)
+        {
+          const unsigned k = k0 + u;
+          const unsigned long long gu = hc0 + (unsigned long long)k * 64ULL;
+          const double2 a = op.codes1 ? in1[u] : s4_half_matvec(p1, carried == 1 ? X[k] : in1[u]);
+          const double2 b = op.codes2 ? in2[u] : s4_half_matvec(p2, carried == 2 ? X[k] : in2[u]);
+          double2 v = make_double2(a.x * b.x, a.y * b.y);
+          if (op.parent_scaler)
+          {
+            const int big = group_any(live[u] && !(v.x < SCALE_THRESHOLD && v.y < SCALE_THRESHOLD), lane, group);
+            if (!big)
+            {
+              v.x *= SCALE_FACTOR;
+              v.y *= SCALE_FACTOR;
+              scaled_mask |= 1u << k;
+            }
+          }
+          X[k] = v;
+          if (live[u]) *reinterpret_cast<double2 *>(op.parent + gu * 2) = v;
+        }
+      }
+      if (op.parent_scaler)
+      {
+        const unsigned src = (lane % spi) * group;
+        const unsigned m = (unsigned)__shfl((int)scaled_mask, (int)src, 64);
+        xcnt = child_cnt + ((m >> (lane / spi)) & 1u);
+        if (nsc < N) op.parent_scaler[nsc] = xcnt;
+      }
+      else xcnt = 0;
+    }
+  }
+}
+
 // edge log-likelihood: lane = (site, rate).  grid = nblocks (<= REDUCE_BLOCKS)
 __global__ __launch_bounds__(256) void k_edge_lnl_s4(ModelView mv, ParamIdx fidx,
                                                      NodeRef parent, NodeRef child,
@@ -413,6 +525,18 @@ static int launch_partials_s4(Engine * e, const OpBatch & batch, unsigned nops)
   else
     hipLaunchKernelGGL(k_partials_s4<2>, dim3(gx, nops), dim3(256), 0, e->stream,
                        batch, e->N, e->R, e->lut_codes);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+static bool chains_supported_s4(const Engine * e) { return e->R == 4 && e->lut_codes == 16; }
+
+static int launch_chains_s4(Engine * e, const ChainBatch & batch, unsigned nchains, unsigned longest)
+{
+  const unsigned nchunks = (e->N + 63) / 64;
+  const unsigned gx = std::max(1u, std::min((nchunks + 3) / 4, e->cu_count * 16u));
+  const size_t lds = sizeof(double) * longest * S4_CHAIN_OP_LDS;
+  hipLaunchKernelGGL(k_chain_s4<4>, dim3(gx, nchains), dim3(256), lds, e->stream, batch, e->N);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

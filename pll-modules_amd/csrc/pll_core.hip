@@ -774,13 +774,15 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     return PLL_SUCCESS;
   }
 
-  // chain schedule (20-state family): one launch per round of chains, the vector of a
-  // link stays in registers.  PLLHIP_CHAINS=0 keeps the plain level schedule.
+  // chain schedule (4- and 20-state families, four rates): one launch per round of chains,
+  // the vector of a link stays in registers.  PLLHIP_CHAINS=0 keeps the plain level schedule.
   static const int use_chains = getenv("PLLHIP_CHAINS") ? atoi(getenv("PLLHIP_CHAINS")) : 1;
-  if (use_chains && count >= 2 && e->family == KernelFamily::S20 && chains_supported_s20(e))
+  const bool chains20 = e->family == KernelFamily::S20 && chains_supported_s20(e);
+  const bool chains4 = e->family == KernelFamily::S4 && chains_supported_s4(e);
+  if (use_chains && count >= 2 && (chains20 || chains4))
   {
     ChainPlan plan;
-    if (plan_chains(e, ops, count, S20_CHAIN_MAX, plan))
+    if (plan_chains(e, ops, count, chains20 ? S20_CHAIN_MAX : S4_CHAIN_MAX, plan))
     {
       for (int round = 0; round < plan.rounds; ++round)
       {
@@ -798,7 +800,8 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
             for (unsigned i = 0; i < nops; ++i) ob.op[i] = cb.op[i];
             if (!launch_partials(e, ob, nops)) return PLL_FAILURE;
           }
-          else if (!launch_chains_s20(e, cb, nchains)) return PLL_FAILURE;
+          else if (chains20 ? !launch_chains_s20(e, cb, nchains) : !launch_chains_s4(e, cb, nchains, longest))
+            return PLL_FAILURE;
           if (!prof_end(ev1, bytes, flops, nops)) return PLL_FAILURE;
           e->counters.partial_launches++;
           nops = nchains = longest = 0;

@@ -474,14 +474,15 @@ class Tree:
     operation list towards the root edge (root_a, root_b, root_matrix).
     """
 
-    def __init__(self, ntips, seed_topology=42, seed_brlen=43, brlen_range=(0.01, 0.2)):
+    def __init__(self, ntips, seed_topology=42, seed_brlen=43, brlen_range=(0.01, 0.2), ladder=False):
         assert ntips >= 3
         self.ntips = ntips
         rnd = splitmix64(seed_topology, ntips)
         # edges as [u, v]; start with a star on tips 0,1,2 around inner node n
         edges = [[0, ntips], [1, ntips], [2, ntips]]
         for t in range(3, ntips):
-            e = int(rnd[t] % np.uint64(len(edges)))
+            # ladder: always split the pendant edge of the tip added last (a caterpillar)
+            e = len(edges) - 1 if ladder else int(rnd[t] % np.uint64(len(edges)))
             u, v = edges[e]
             w = ntips + (t - 2)          # new inner node
             edges[e] = [u, w]

@@ -341,6 +341,34 @@ def test_one_by_one_pmatrix_calls_and_single_op_calls(product):
         assert c.partial_ops == 2 * len(t.ops)
 
 
+@pytest.mark.parametrize("states,ladder", [(4, False), (4, True), (20, True)])
+def test_chained_launches_store_what_single_operations_store(product, oracle, states, ladder):
+    """a whole op list goes out as operation chains (the vector of a link stays in
+    registers, engine.h ChainBatch); one-op calls cannot chain.  Both must leave
+    bit-identical CLVs and scalers -- on a caterpillar tree too, whose single long path
+    is cut into several chains -- and agree with the oracle in the scaling regime."""
+    n = 400 if states == 4 else 90
+    t = pc.Tree(n, 42, 43, brlen_range=(0.05, 0.6), ladder=ladder)
+    kw = dict(states=states, rate_cats=4, ntips=n, nsites=197, coded=True, tree=t)
+    with pc.build_instance(product, **kw) as a, pc.build_instance(product, **kw) as b, \
+            pc.build_instance(oracle, **kw) as o:
+        la = pc.full_traversal(a)
+        launches = a.counters().partial_launches
+        b.update_pmatrices(np.arange(t.nedges), t.brlens)
+        for op in t.ops:
+            b.update_partials([op])
+        lb = b.edge_lnl(t.root_a, t.scaler_of(t.root_a), t.root_b, t.scaler_of(t.root_b), t.root_matrix)
+        assert la == lb
+        assert launches < len(t.ops) // 2                      # chains, not levels of single ops
+        lo = pc.full_traversal(o)
+        assert lnl_close(la, lo, a.N)
+        for op in t.ops:
+            assert np.array_equal(a.get_clv(op[0]), b.get_clv(op[0])), f"CLV {op[0]}"
+            assert np.array_equal(a.get_scaler(op[1]), b.get_scaler(op[1])), f"scaler {op[1]}"
+            assert np.array_equal(a.get_scaler(op[1]), o.get_scaler(op[1])), f"scaler {op[1]} vs oracle"
+        assert a.get_scaler(t.scaler_of(t.root_a)).max() >= 1, "test did not reach the scaling regime"
+
+
 def test_run_to_run_determinism(product):
     """SPR rounds assert reproducibility (src/algorithm/algo_search.c:1453-1457)"""
     with pc.build_instance(product, states=20, rate_cats=4, ntips=20, nsites=5000, coded=True) as a:
