@@ -248,6 +248,13 @@ def main():
         "avg_launch_ms": round(prof.kernel_ms / max(1, prof.launches), 4),
         "algorithmic_bytes_per_launch": round(prof.algorithmic_bytes / max(1, prof.launches)),
         "kernel_share_of_step": round(prof.kernel_ms * 1e-3 / elapsed, 4),
+        # HBM rate implied by the PMC traffic of the committed profile (same command): with
+        # operation chains the carried child of a link is not re-read, so the real traffic
+        # is BELOW the algorithmic bytes (SURVEY.md 8d counts every child as one read)
+        "traffic_GBps": (round(traffic / (prof.kernel_ms / max(1, prof.launches) * 1e-3) / 1e9, 1)
+                         if traffic and prof.kernel_ms > 0 and len(insts) == 1 else None),
+        "traffic_over_algorithmic": (round(traffic / (prof.algorithmic_bytes / max(1, prof.launches)), 3)
+                                     if traffic and prof.algorithmic_bytes > 0 and len(insts) == 1 else None),
         "method": ("algorithmic bytes of all partials launches / step wall time (partitions overlap on "
                    "concurrent streams)") if len(insts) > 1 else
                   "algorithmic bytes of the partials launches / their HIP-event time",

@@ -86,8 +86,6 @@ struct Engine
   size_t clv_len = 0;                 // doubles per CLV / sumtable buffer
   unsigned Nalloc = 0;                // per-site array length (N, or nblk*32)
   double * d_sum_scratch = nullptr;   // eigen-basis matrices + LUTs of the sumtable kernel
-  OpDesc * d_ops = nullptr;           // operation list of a single-launch traversal
-  unsigned d_ops_cap = 0;
 
   // --- device-resident data ---
   std::vector<double *> d_clv;        // [nodes], nullptr for coded tips

@@ -315,25 +315,6 @@ __global__ __launch_bounds__(256, 2) void k_partials_s20(OpBatch batch, unsigned
   s20_op_body<RT>(batch.op[blockIdx.y], nblk, Rrt, lut_codes, flags, frag);
 }
 
-// Whole operation list in ONE launch.  Operations only couple the same sites, and
-// a wave owns the same site blocks (blk = wave id + k * #waves) for every
-// operation, so walking the post-order list inside the kernel needs no
-// inter-workgroup synchronisation at all: a parent block is read back by the
-// wave that wrote it, in program order.  The two workgroup barriers per
-// operation only protect the LDS fragments.  grid = gx, block = 256.
-template <unsigned RT>
-__global__ __launch_bounds__(256, 2) void k_traverse_s20(const OpDesc * ops, unsigned nops,
-                                                         unsigned nblk, unsigned Rrt,
-                                                         unsigned lut_codes, unsigned flags)
-{
-  extern __shared__ double frag[];
-  for (unsigned i = 0; i < nops; ++i)
-  {
-    __syncthreads();          // every wave is done with the previous operation's fragments
-    s20_op_body<RT>(ops[i], nblk, Rrt, lut_codes, flags, frag);
-  }
-}
-
 // ---------------------------------------------------------------------------
 // Operation chains.  A chain is a run of operations in which each one consumes the
 // parent vector of the one before (the path from a node towards the root).  Because
@@ -797,21 +778,6 @@ static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned ncha
   const unsigned gx = std::max(1u, std::min(need, e->cu_count * (unsigned)std::max(1, env_bpc)));
   hipLaunchKernelGGL(k_chain_s20<4>, dim3(gx, nchains), dim3(64 * S20_CHAIN_WAVES), lds, e->stream,
                      batch, e->nblk, e->lut_codes, flags);
-  PLLHIP_TRY(hipGetLastError());
-  return PLL_SUCCESS;
-}
-
-static int launch_traverse_s20(Engine * e, const OpDesc * d_ops, unsigned nops)
-{
-  const size_t lds = sizeof(double) * 2 * e->R * S20_FRAGS;
-  static const unsigned flags = getenv("PLLHIP_S20_NT") ? (unsigned)atoi(getenv("PLLHIP_S20_NT")) : 0u;
-  const unsigned gx = s20_grid(e, 2);
-  if (e->R == 4)
-    hipLaunchKernelGGL(k_traverse_s20<4>, dim3(gx), dim3(256), lds, e->stream,
-                       d_ops, nops, e->nblk, e->R, e->lut_codes, flags);
-  else
-    hipLaunchKernelGGL(k_traverse_s20<0>, dim3(gx), dim3(256), lds, e->stream,
-                       d_ops, nops, e->nblk, e->R, e->lut_codes, flags);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

@@ -214,7 +214,6 @@ void engine_destroy(Engine * e)
   (void)hipFree(e->d_partials);
   (void)hipFree(e->d_persite);
   (void)hipFree(e->d_sum_scratch);
-  (void)hipFree(e->d_ops);
   if (e->h_partials) (void)hipHostFree(e->h_partials);
   if (e->h_result) (void)hipHostFree(e->h_result);
   (void)hipFree(e->d_counter);
@@ -741,38 +740,6 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     e->prof_ops += nops;
     return PLL_SUCCESS;
   };
-
-  // Whole list in one launch (families that own fixed site blocks per wave):
-  // operations only couple the same sites, so the kernel can walk the list itself.
-  // Opt-in (PLLHIP_TRAVERSE=1): measured on C3 it is 7 % SLOWER than the
-  // level-batched launches at 1 M sites (all workgroups march through the same
-  // operation type in phase -- e.g. everybody write-only during a tip x tip
-  // operation -- and two barriers per operation couple the four waves of a block)
-  // and only 1 % faster at 125 k sites, so level batching stays the default.
-  static const int no_traverse = getenv("PLLHIP_TRAVERSE") ? !atoi(getenv("PLLHIP_TRAVERSE")) : 1;
-  if (count >= 3 && !no_traverse && e->family == KernelFamily::S20)
-  {
-    std::vector<OpDesc> h(count);
-    double bytes = 0.0, flops = 0.0;
-    for (unsigned k = 0; k < count; ++k) fill_desc(ops[k], h[k], bytes, flops);
-    if (e->d_ops_cap < count)
-    {
-      if (e->d_ops) { PLLHIP_TRY(hipStreamSynchronize(e->stream)); (void)hipFree(e->d_ops); e->d_ops = nullptr; }
-      if (!dev_alloc(&e->d_ops, (size_t)count + 64, "operation list")) return PLL_FAILURE;
-      e->d_ops_cap = count + 64;
-    }
-    // pageable source: staged by the runtime before the call returns, `h` may die;
-    // stream order keeps a previous traversal's reads ahead of this overwrite
-    PLLHIP_TRY(hipMemcpyAsync(e->d_ops, h.data(), sizeof(OpDesc) * count, hipMemcpyHostToDevice, e->stream));
-    hipEvent_t ev1;
-    if (!prof_begin(ev1)) return PLL_FAILURE;
-    if (!launch_traverse_s20(e, e->d_ops, count)) return PLL_FAILURE;
-    if (!prof_end(ev1, bytes, flops, count)) return PLL_FAILURE;
-    e->counters.partial_launches++;
-    e->counters.partial_ops += count;
-    e->counters.site_updates += (unsigned long long)count * e->N * e->R;
-    return PLL_SUCCESS;
-  }
 
   // chain schedule (4- and 20-state families, four rates): one launch per round of chains,
   // the vector of a link stays in registers.  PLLHIP_CHAINS=0 keeps the plain level schedule.

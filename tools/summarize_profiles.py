@@ -71,7 +71,10 @@ def main():
                          "hbm_bytes_per_dispatch": rd + wr}
     json.dump(summary, open(os.path.join(OUT, f"{rnd}_{cfg}_pmc.json"), "w"), indent=1)
     if kernel_key:
-        dom = [v for k, v in summary.items() if "k_partials" in k]
+        # the dominant partials kernel of the run: chained launches (k_chain_*) where the
+        # family has them, per-operation launches (k_partials_*) otherwise
+        dom = sorted((v for k, v in summary.items() if "k_partials" in k or "k_chain" in k),
+                     key=lambda v: -v["dispatches"] * v["hbm_bytes_per_dispatch"])
         if dom:
             tpath = os.path.join(OUT, "traffic.json")
             t = json.load(open(tpath)) if os.path.exists(tpath) else {}
