@@ -774,7 +774,11 @@ static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned ncha
   }
   // one workgroup per CU per chain (measured: 1 beats 2 and 4 per CU)
   static const int env_bpc = getenv("PLLHIP_S20_CHAIN_BPC") ? atoi(getenv("PLLHIP_S20_CHAIN_BPC")) : 1;
-  const unsigned need = (e->nblk + S20_CHAIN_WAVES - 1) / S20_CHAIN_WAVES;
+  // blocks per wave a workgroup should at least get (measured at 125 k and 1 M sites: more
+  // than 1 only costs parallelism, the fragment fill is not what small slices wait for)
+  static const int env_tgt = getenv("PLLHIP_S20_CHAIN_TARGET") ? atoi(getenv("PLLHIP_S20_CHAIN_TARGET")) : 1;
+  const unsigned per_wg = S20_CHAIN_WAVES * (unsigned)std::max(1, env_tgt);
+  const unsigned need = (e->nblk + per_wg - 1) / per_wg;
   const unsigned gx = std::max(1u, std::min(need, e->cu_count * (unsigned)std::max(1, env_bpc)));
   hipLaunchKernelGGL(k_chain_s20<4>, dim3(gx, nchains), dim3(64 * S20_CHAIN_WAVES), lds, e->stream,
                      batch, e->nblk, e->lut_codes, flags);

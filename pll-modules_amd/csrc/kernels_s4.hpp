@@ -534,7 +534,8 @@ static bool chains_supported_s4(const Engine * e) { return e->R == 4 && e->lut_c
 static int launch_chains_s4(Engine * e, const ChainBatch & batch, unsigned nchains, unsigned longest)
 {
   const unsigned nchunks = (e->N + 63) / 64;
-  const unsigned gx = std::max(1u, std::min((nchunks + 3) / 4, e->cu_count * 16u));
+  static const int env_bpc = getenv("PLLHIP_S4_CHAIN_BPC") ? atoi(getenv("PLLHIP_S4_CHAIN_BPC")) : 8;
+  const unsigned gx = std::max(1u, std::min((nchunks + 3) / 4, e->cu_count * (unsigned)std::max(1, env_bpc)));
   const size_t lds = sizeof(double) * longest * S4_CHAIN_OP_LDS;
   hipLaunchKernelGGL(k_chain_s4<4>, dim3(gx, nchains), dim3(256), lds, e->stream, batch, e->N);
   PLLHIP_TRY(hipGetLastError());
