@@ -93,6 +93,7 @@ struct Engine
   unsigned * d_scalers = nullptr;     // [nscalers][N]
   double * d_pmat = nullptr;          // [nmat][R][S][Sp]
   double * d_lut = nullptr;           // [nmat][R][lut_codes][S]   (coded tips only)
+  unsigned long long result_seq = 0;  // sequence word of the mapped result buffer (finish_reduction)
   uint8_t * d_s61_votes = nullptr;    // [op in launch][R][site] scaling votes of rate-parallel S61 launches
   unsigned lut_codes = 0;             // row count the LUTs were built for
   bool lut_stale = false;             // tipmap grew since the LUTs were built

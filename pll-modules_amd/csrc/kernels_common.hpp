@@ -97,8 +97,13 @@ __device__ inline void grid_reduce_finish(const double (&tot)[Q], const ReduceOu
 }
 
 // block_out[q][nblocks] -> host_result[q]; one block of 256 threads
+// host_result[RESULT_SEQ_SLOT] takes `seq` (as an integer) once the sums are visible to the
+// host: the caller may poll it instead of paying a stream synchronisation.
+constexpr unsigned RESULT_SEQ_SLOT = 7;
+
 __global__ __launch_bounds__(256) void k_final_sum(const double * block_out, unsigned nblocks,
-                                                   unsigned nq, double * host_result)
+                                                   unsigned nq, double * host_result,
+                                                   unsigned long long seq)
 {
   __shared__ double scratch[4];
   for (unsigned q = 0; q < nq; ++q)
@@ -107,6 +112,12 @@ __global__ __launch_bounds__(256) void k_final_sum(const double * block_out, uns
     for (unsigned b = threadIdx.x; b < nblocks; b += 256) a += block_out[(size_t)q * nblocks + b];
     const double t = block_sum_256(a, scratch);
     if (threadIdx.x == 0) host_result[q] = t;
+  }
+  if (threadIdx.x == 0)
+  {
+    __threadfence_system();
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(host_result) + RESULT_SEQ_SLOT, seq,
+                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

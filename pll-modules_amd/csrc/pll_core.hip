@@ -25,6 +25,7 @@
 #include "kernels_s61.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -483,10 +484,30 @@ static unsigned reduce_grid(const Engine * e)
 // order straight into pinned host memory; then wait for the stream
 static int finish_reduction(Engine * e, unsigned nblocks, unsigned n_quant, double * out)
 {
+  const unsigned long long seq = ++e->result_seq;
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, e->stream,
-                     e->d_partials, nblocks, n_quant, e->d_result);
+                     e->d_partials, nblocks, n_quant, e->d_result, seq);
   PLLHIP_TRY(hipGetLastError());
-  PLLHIP_TRY(hipStreamSynchronize(e->stream));
+  // Scalar-returning calls are latency-bound for small slices (Newton-Raphson: a 14 us
+  // kernel per call): poll the sequence word the kernel writes into the mapped result
+  // buffer for a short while before falling back to a blocking stream synchronisation.
+  // PLLHIP_SPIN_US=0 disables the polling.
+  static const long spin_us = getenv("PLLHIP_SPIN_US") ? atol(getenv("PLLHIP_SPIN_US")) : 400;
+  const volatile unsigned long long * flag =
+      reinterpret_cast<const volatile unsigned long long *>(e->h_result) + RESULT_SEQ_SLOT;
+  bool done = false;
+  if (spin_us > 0)
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 0; !done; ++it)
+    {
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) done = true;
+      else if ((it & 63u) == 63u &&
+               std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us)
+        break;
+    }
+  }
+  if (!done) PLLHIP_TRY(hipStreamSynchronize(e->stream));
   for (unsigned q = 0; q < n_quant; ++q) out[q] = e->h_result[q];
   return PLL_SUCCESS;
 }
