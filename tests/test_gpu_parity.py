@@ -416,6 +416,49 @@ def test_tiled_alignment_scales_linearly(product):
             assert abs(lk - K * l1) < 1e-10 * abs(lk)
 
 
+@pytest.mark.parametrize("cfg,tile", [("c2", 1000), ("c3", 1000), ("c5", 500)])
+def test_baseline_sizes_through_tiling(product, oracle, cfg, tile):
+    """BASELINE.json's full configurations (C2: 100 taxa x 1 M DNA sites, C3: 200 taxa x 1 M
+    protein sites, C5: 50 taxa x 200 k codon sites) are out of the oracle's reach in
+    seconds, but an alignment made of K copies of one tile is not: the oracle evaluates
+    the tile, and size-independent properties carry that to the full size --
+    lnL(full) = K * lnL(tile), per-site lnL and scaler counts are periodic in the tile,
+    and the likelihood does not depend on the root edge."""
+    S, R, ntips, N = pc.CONFIGS[cfg]
+    K = N // tile
+    t = pc.Tree(ntips, 42, 43)
+    subst, freqs, alpha = {4: (pc.DNA_GTR_RATES, pc.DNA_FREQS, 0.841), 20: (*pc.protein_model(), 0.5),
+                           61: (*pc.codon_model(), 0.5)}[S]          # build_instance's models
+    with pc.build_instance(oracle, states=S, rate_cats=R, ntips=ntips, nsites=tile, coded=True, tree=t) as small:
+        l_tile = pc.full_traversal(small)
+        tile_codes = small.codes
+    with pc.build_instance(product, states=S, rate_cats=R, ntips=ntips, nsites=tile, coded=True, tree=t) as ref:
+        l_ref = pc.full_traversal(ref)
+    # own eigen-solver vs the oracle's on codon matrices: see _compare_full
+    tol = 2e-6 * abs(l_tile) if S > 20 else max(REL_LNL * abs(l_tile), PER_SITE * tile)
+    assert abs(l_ref - l_tile) <= tol
+    with pc.Instance(product, ntips, S, tile * K, R, attributes=pc.PLL_ATTRIB_PATTERN_TIP) as big:
+        big.set_model(subst, freqs, product.gamma_cats(alpha, R))
+        cmap = pc.state_charmap(S)
+        for k in range(ntips):
+            big.set_tip_states(k, cmap, (np.tile(tile_codes[k], K) + 48).tobytes())
+        big.tree = t
+        l_full = pc.full_traversal(big)
+        assert abs(l_full - K * l_ref) <= 1e-10 * abs(l_full)
+        assert abs(l_full - K * l_tile) <= K * tol
+        _, persite = big.edge_lnl(t.root_a, t.scaler_of(t.root_a), t.root_b, t.scaler_of(t.root_b),
+                                  t.root_matrix, persite=True)
+        assert np.array_equal(persite.reshape(K, tile), np.broadcast_to(persite[:tile], (K, tile)))
+        sc = big.get_scaler(t.scaler_of(t.root_a))
+        assert np.array_equal(sc.reshape(K, tile), np.broadcast_to(sc[:tile], (K, tile)))
+        # another root edge: same likelihood
+        t2 = pc.Tree(ntips, 42, 43)
+        t2.set_root_edge(t.nedges // 3)
+        big.tree = t2
+        l_rerooted = pc.full_traversal(big)
+        assert abs(l_rerooted - l_full) <= 1e-9 * abs(l_full)
+
+
 def test_rccl_reduce_callback_single_rank(product):
     """the native reduce callback (RCCL ncclAllReduce behind the reference's
     parallel_reduce_cb signature) on a 1-rank communicator: values come back
