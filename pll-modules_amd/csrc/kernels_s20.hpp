@@ -758,7 +758,7 @@ static int launch_partials_s20(Engine * e, const OpBatch & batch, unsigned nops)
   return PLL_SUCCESS;
 }
 
-static bool chains_supported_s20(const Engine * e) { return e->R == 4; }
+static bool chains_supported_s20(const Engine * e) { return e->R == 4 || e->R == 2 || e->R == 1; }
 
 static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned nchains)
 {
@@ -767,9 +767,13 @@ static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned ncha
   static bool attr_set = false;
   if (!attr_set)
   {
+    const int cap = (int)(sizeof(double) * S20_CHAIN_MAX * 8 * S20_FRAGS);
     PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_s20<4>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(sizeof(double) * S20_CHAIN_MAX * 8 * S20_FRAGS)));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_s20<2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, cap / 2));
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_s20<1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, cap / 4));
     attr_set = true;
   }
   // one workgroup per CU per chain (measured: 1 beats 2 and 4 per CU)
@@ -780,8 +784,13 @@ static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned ncha
   const unsigned per_wg = S20_CHAIN_WAVES * (unsigned)std::max(1, env_tgt);
   const unsigned need = (e->nblk + per_wg - 1) / per_wg;
   const unsigned gx = std::max(1u, std::min(need, e->cu_count * (unsigned)std::max(1, env_bpc)));
-  hipLaunchKernelGGL(k_chain_s20<4>, dim3(gx, nchains), dim3(64 * S20_CHAIN_WAVES), lds, e->stream,
-                     batch, e->nblk, e->lut_codes, flags);
+  const dim3 grid(gx, nchains), block(64 * S20_CHAIN_WAVES);
+  if (e->R == 4)
+    hipLaunchKernelGGL(k_chain_s20<4>, grid, block, lds, e->stream, batch, e->nblk, e->lut_codes, flags);
+  else if (e->R == 2)
+    hipLaunchKernelGGL(k_chain_s20<2>, grid, block, lds, e->stream, batch, e->nblk, e->lut_codes, flags);
+  else
+    hipLaunchKernelGGL(k_chain_s20<1>, grid, block, lds, e->stream, batch, e->nblk, e->lut_codes, flags);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

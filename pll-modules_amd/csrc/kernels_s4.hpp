@@ -217,12 +217,14 @@ __global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, 
 // next launch would have loaded.  grid = (gx, chains), block = 256,
 // dynamic LDS = chain length x S4_CHAIN_OP_LDS doubles.
 constexpr unsigned S4_CHAIN_MAX = 8;
-constexpr unsigned S4_CHAIN_OP_LDS = 2 * 256 + 2 * 64;     // two tables [4][16][4], two matrix sets [4][16]
+// LDS doubles per operation: two tables [R][16][4], two matrix sets [R][16]
+constexpr unsigned s4_chain_op_lds(unsigned R) { return 2 * R * 64 + 2 * R * 16; }
 
-template <unsigned U>
+template <unsigned U, unsigned R>      // R in {1, 2, 4}; U <= 2R loads issued per batch
 __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
 {
-  constexpr unsigned R = 4, group = 8, spi = 8, rs = 2;
+  constexpr unsigned group = 2 * R, spi = 64 / group, rs = (R == 4) ? 2 : (R == 2) ? 1 : 0;
+  constexpr unsigned S4_CHAIN_OP_LDS = s4_chain_op_lds(R), T2 = R * 64, M1 = 2 * R * 64, M2 = 2 * R * 64 + R * 16;
   extern __shared__ double lds[];
   const unsigned first = batch.first[blockIdx.y], len = batch.len[blockIdx.y];
   const unsigned lane = threadIdx.x & 63;
@@ -233,10 +235,10 @@ __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
   {
     const OpDesc & op = batch.op[first + i];
     double * base = lds + i * S4_CHAIN_OP_LDS;
-    if (op.codes1) base[threadIdx.x] = op.lut1[threadIdx.x];
-    else if (threadIdx.x < 64) base[512 + threadIdx.x] = op.pmat1[threadIdx.x];
-    if (op.codes2) base[256 + threadIdx.x] = op.lut2[threadIdx.x];
-    else if (threadIdx.x < 64) base[576 + threadIdx.x] = op.pmat2[threadIdx.x];
+    if (op.codes1) { if (threadIdx.x < R * 64) base[threadIdx.x] = op.lut1[threadIdx.x]; }
+    else if (threadIdx.x < R * 16) base[M1 + threadIdx.x] = op.pmat1[threadIdx.x];
+    if (op.codes2) { if (threadIdx.x < R * 64) base[T2 + threadIdx.x] = op.lut2[threadIdx.x]; }
+    else if (threadIdx.x < R * 16) base[M2 + threadIdx.x] = op.pmat2[threadIdx.x];
   }
   __syncthreads();
 
@@ -255,8 +257,8 @@ __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
       const unsigned carried = i ? batch.carried[first + i] : 0u;
       const double * base = lds + i * S4_CHAIN_OP_LDS;
       HalfP p1 = {}, p2 = {};
-      if (!op.codes1) p1 = s4_load_half_p(base + 512, r, h);
-      if (!op.codes2) p2 = s4_load_half_p(base + 576, r, h);
+      if (!op.codes1) p1 = s4_load_half_p(base + M1, r, h);
+      if (!op.codes2) p2 = s4_load_half_p(base + M2, r, h);
       unsigned child_cnt = 0;
       if (op.parent_scaler && nsc < N)
       {
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
               in1[u] = *reinterpret_cast<const double2 *>(&base[(r * 16 + op.codes1[n]) * 4 + 2 * h]);
             else if (carried != 1) in1[u] = *reinterpret_cast<const double2 *>(op.clv1 + gu * 2);
             if (op.codes2)
-              in2[u] = *reinterpret_cast<const double2 *>(&base[256 + (r * 16 + op.codes2[n]) * 4 + 2 * h]);
+              in2[u] = *reinterpret_cast<const double2 *>(&base[T2 + (r * 16 + op.codes2[n]) * 4 + 2 * h]);
             else if (carried != 2) in2[u] = *reinterpret_cast<const double2 *>(op.clv2 + gu * 2);
           }
         }
@@ -529,15 +531,21 @@ static int launch_partials_s4(Engine * e, const OpBatch & batch, unsigned nops)
   return PLL_SUCCESS;
 }
 
-static bool chains_supported_s4(const Engine * e) { return e->R == 4 && e->lut_codes == 16; }
+static bool chains_supported_s4(const Engine * e) { return (e->R == 4 || e->R == 2 || e->R == 1) && e->lut_codes == 16; }
 
 static int launch_chains_s4(Engine * e, const ChainBatch & batch, unsigned nchains, unsigned longest)
 {
   const unsigned nchunks = (e->N + 63) / 64;
   static const int env_bpc = getenv("PLLHIP_S4_CHAIN_BPC") ? atoi(getenv("PLLHIP_S4_CHAIN_BPC")) : 8;
   const unsigned gx = std::max(1u, std::min((nchunks + 3) / 4, e->cu_count * (unsigned)std::max(1, env_bpc)));
-  const size_t lds = sizeof(double) * longest * S4_CHAIN_OP_LDS;
-  hipLaunchKernelGGL(k_chain_s4<4>, dim3(gx, nchains), dim3(256), lds, e->stream, batch, e->N);
+  const size_t lds = sizeof(double) * longest * s4_chain_op_lds(e->R);
+  const dim3 grid(gx, nchains);
+  if (e->R == 4)
+    hipLaunchKernelGGL((k_chain_s4<4, 4>), grid, dim3(256), lds, e->stream, batch, e->N);
+  else if (e->R == 2)
+    hipLaunchKernelGGL((k_chain_s4<4, 2>), grid, dim3(256), lds, e->stream, batch, e->N);
+  else
+    hipLaunchKernelGGL((k_chain_s4<2, 1>), grid, dim3(256), lds, e->stream, batch, e->N);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

@@ -341,15 +341,16 @@ def test_one_by_one_pmatrix_calls_and_single_op_calls(product):
         assert c.partial_ops == 2 * len(t.ops)
 
 
-@pytest.mark.parametrize("states,ladder", [(4, False), (4, True), (20, True)])
-def test_chained_launches_store_what_single_operations_store(product, oracle, states, ladder):
+@pytest.mark.parametrize("states,ladder,rate_cats", [(4, False, 4), (4, True, 4), (20, True, 4), (4, False, 1),
+                                                     (4, True, 2), (20, False, 1), (20, True, 2)])
+def test_chained_launches_store_what_single_operations_store(product, oracle, states, ladder, rate_cats):
     """a whole op list goes out as operation chains (the vector of a link stays in
     registers, engine.h ChainBatch); one-op calls cannot chain.  Both must leave
     bit-identical CLVs and scalers -- on a caterpillar tree too, whose single long path
     is cut into several chains -- and agree with the oracle in the scaling regime."""
     n = 400 if states == 4 else 90
     t = pc.Tree(n, 42, 43, brlen_range=(0.05, 0.6), ladder=ladder)
-    kw = dict(states=states, rate_cats=4, ntips=n, nsites=197, coded=True, tree=t)
+    kw = dict(states=states, rate_cats=rate_cats, ntips=n, nsites=197, coded=True, tree=t)
     with pc.build_instance(product, **kw) as a, pc.build_instance(product, **kw) as b, \
             pc.build_instance(oracle, **kw) as o:
         la = pc.full_traversal(a)
