@@ -45,6 +45,16 @@ struct OpDesc
   const unsigned * scaler2;
   double * parent;
   unsigned * parent_scaler;
+  unsigned parent_index;      // CLV indices (host bookkeeping of per-vector side arrays)
+  unsigned child1_index, child2_index;
+};
+
+// 61-state rate-parallel launches: predicted per-site scaling decision of every parent
+// vector (what the last evaluation of that vector decided), and where the new one goes
+struct PredBatch
+{
+  const uint8_t * in[MAX_OPS_PER_LAUNCH];
+  uint8_t * out[MAX_OPS_PER_LAUNCH];
 };
 
 // per-rate parameter-set indices, by value in kernel arguments
@@ -94,7 +104,13 @@ struct Engine
   double * d_pmat = nullptr;          // [nmat][R][S][Sp]
   double * d_lut = nullptr;           // [nmat][R][lut_codes][S]   (coded tips only)
   unsigned long long result_seq = 0;  // sequence word of the mapped result buffer (finish_reduction)
-  uint8_t * d_s61_votes = nullptr;    // [op in launch][R][site] scaling votes of rate-parallel S61 launches
+  uint8_t * d_s61_votes = nullptr;
+  // last scaling decisions of the 61-state rate-parallel launches: per parent vector up to
+  // three orientations (an inner node's slot is computed from any two of its three
+  // neighbours), each double-buffered
+  struct PredSlot { unsigned long long key = ~0ULL; uint8_t * buf[2] = {nullptr, nullptr}; unsigned cur = 0; unsigned long long used = 0; };
+  std::vector<PredSlot> s61_pred;     // [3 * clv index + slot]
+  unsigned long long s61_pred_clock = 0;    // [op in launch][R][site] scaling votes of rate-parallel S61 launches
   unsigned lut_codes = 0;             // row count the LUTs were built for
   bool lut_stale = false;             // tipmap grew since the LUTs were built
   std::vector<double> pmat_brlen;     // last branch length per matrix (NaN = never set)

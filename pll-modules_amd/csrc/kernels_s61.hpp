@@ -192,9 +192,11 @@ __device__ inline void s61_acc_zero(v4d acc[S61_MT][2])
 }
 
 // product of the two child terms, scaling vote, store: t1 * acc -> parent unit
+// fe / fo: power-of-two factors the unit is stored with (the PREDICTED scaling of its two
+// sites in rate-parallel launches, 1 otherwise); the vote is taken on the unscaled values
 __device__ inline void s61_finish_unit(double * dst, unsigned lane, unsigned q, double2 t1[S61_KS],
                                        const double2 t2[S61_KS], unsigned bit, unsigned & small_e,
-                                       unsigned & small_o)
+                                       unsigned & small_o, double fe = 1.0, double fo = 1.0)
 {
   int se = 1, so = 1;
 #pragma unroll
@@ -207,10 +209,23 @@ __device__ inline void s61_finish_unit(double * dst, unsigned lane, unsigned q, 
       se &= (t1[k].x < SCALE_THRESHOLD);
       so &= (t1[k].y < SCALE_THRESHOLD);
     }
+    t1[k].x *= fe;
+    t1[k].y *= fo;
   }
   if (!se) small_e &= ~bit;
   if (!so) small_o &= ~bit;
   s61_store_d(dst, lane, t1);
+}
+
+__device__ inline void s61_pred_factors(const uint8_t * pred, unsigned blk, unsigned lane, double & fe, double & fo)
+{
+  fe = fo = 1.0;
+  if (pred)
+  {
+    const size_t site0 = (size_t)blk * S20_BS + 2 * (lane & 15);
+    fe = pred[site0] ? SCALE_FACTOR : 1.0;
+    fo = pred[site0 + 1] ? SCALE_FACTOR : 1.0;
+  }
 }
 
 __device__ inline void s61_acc_to_t(const v4d acc[S61_MT][2], double2 t[S61_KS])
@@ -225,7 +240,7 @@ __device__ inline void s61_acc_to_t(const v4d acc[S61_MT][2], double2 t[S61_KS])
 // one rate of a wave's blocks (first, first + 4, ...: nb of them), both children inner
 __device__ inline void s61_rate_ii(const OpDesc & op, const double * frag, const double * frag2,
                                    unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
-                                   unsigned & small_e, unsigned & small_o)
+                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred)
 {
   const double2 * f1 = reinterpret_cast<const double2 *>(frag);
   const double2 * f2 = reinterpret_cast<const double2 *>(frag2);
@@ -258,7 +273,9 @@ __device__ inline void s61_rate_ii(const OpDesc & op, const double * frag, const
     s61_mfma_half<1>(bB, f2, lane, acc);
     S61_SCHED_FENCE();
     s61_acc_to_t(acc, t2);
-    s61_finish_unit(op.parent + ub, lane, q, t1, t2, 1u << i, small_e, small_o);
+    double fe, fo;
+    s61_pred_factors(pred, first + 4 * i, lane, fe, fo);
+    s61_finish_unit(op.parent + ub, lane, q, t1, t2, 1u << i, small_e, small_o, fe, fo);
   }
 }
 
@@ -266,7 +283,7 @@ __device__ inline void s61_rate_ii(const OpDesc & op, const double * frag, const
 __device__ inline void s61_rate_ti(const OpDesc & op, const double * clv, const double * fragi,
                                    const unsigned char * codes, const double * lut_r,
                                    unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
-                                   unsigned & small_e, unsigned & small_o)
+                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred)
 {
   const double2 * f1 = reinterpret_cast<const double2 *>(fragi);
   const unsigned q = lane >> 4, n = lane & 15;
@@ -292,13 +309,15 @@ __device__ inline void s61_rate_ti(const OpDesc & op, const double * clv, const 
     S61_SCHED_FENCE();
     s61_acc_to_t(acc, t1);
     s61_child_tip(lut_r, ce, co, q, t2);
-    s61_finish_unit(op.parent + ub, lane, q, t1, t2, 1u << i, small_e, small_o);
+    double fe, fo;
+    s61_pred_factors(pred, blk, lane, fe, fo);
+    s61_finish_unit(op.parent + ub, lane, q, t1, t2, 1u << i, small_e, small_o, fe, fo);
   }
 }
 
 __device__ inline void s61_rate_tt(const OpDesc & op, const double * lut1_r, const double * lut2_r,
                                    unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
-                                   unsigned & small_e, unsigned & small_o)
+                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred)
 {
   const unsigned q = lane >> 4, n = lane & 15;
   // the tip codes of block i+1 are fetched while block i is looked up and stored
@@ -314,8 +333,10 @@ __device__ inline void s61_rate_tt(const OpDesc & op, const double * lut1_r, con
     double2 t1[S61_KS], t2[S61_KS];
     s61_child_tip(lut1_r, c1e, c1o, q, t1);
     s61_child_tip(lut2_r, c2e, c2o, q, t2);
+    double fe, fo;
+    s61_pred_factors(pred, blk, lane, fe, fo);
     s61_finish_unit(op.parent + ((size_t)blk * R + r) * S61_UNIT, lane, q, t1, t2, 1u << i,
-                    small_e, small_o);
+                    small_e, small_o, fe, fo);
     c1e = n1e; c1o = n1o; c2e = n2e; c2o = n2o;
   }
 }
@@ -324,7 +345,7 @@ __device__ inline void s61_rate_tt(const OpDesc & op, const double * lut1_r, con
 // a workgroup handles ONE rate, writes its per-site "all entries small" vote to
 // votes[(op*R + r)*Nalloc + site], and k_s61_scale_fixup combines the votes.
 __global__ __launch_bounds__(256, 2) void k_partials_s61v3(OpBatch batch, unsigned nblk, unsigned R,
-                                                           unsigned lut_codes, uint8_t * votes)
+                                                           unsigned lut_codes, uint8_t * votes, PredBatch preds)
 {
   extern __shared__ double frag[];
   double * const frag2 = frag + S61_FRAGS;
@@ -337,6 +358,9 @@ __global__ __launch_bounds__(256, 2) void k_partials_s61v3(OpBatch batch, unsign
   const unsigned beg = (unsigned)(((unsigned long long)nblk * blockIdx.x) / gridDim.x);
   const unsigned end = (unsigned)(((unsigned long long)nblk * (blockIdx.x + 1)) / gridDim.x);
   const bool rate_parallel = gridDim.z > 1;
+  // rate-parallel: units are stored with the scaling the LAST evaluation of this vector
+  // decided; k_s61_scale_fixup corrects the sites where the new vote differs (rare)
+  const uint8_t * pred = (rate_parallel && scaling) ? preds.in[blockIdx.y] : nullptr;
   const unsigned r_begin = rate_parallel ? blockIdx.z : 0, r_end = rate_parallel ? blockIdx.z + 1 : R;
 
   for (unsigned c0 = beg; c0 < end; c0 += S61_CHUNK)
@@ -361,10 +385,10 @@ __global__ __launch_bounds__(256, 2) void k_partials_s61v3(OpBatch batch, unsign
       if (nb == 0) continue;
       const double * l1 = lut_lds ? frag : op.lut1 + (size_t)r * lut_codes * S61_S;
       const double * l2 = lut_lds ? frag2 : op.lut2 + (size_t)r * lut_codes * S61_S;
-      if (tip1 && tip2) s61_rate_tt(op, l1, l2, r, R, first, nb, lane, small_e, small_o);
-      else if (!tip1 && !tip2) s61_rate_ii(op, frag, frag2, r, R, first, nb, lane, small_e, small_o);
-      else if (tip1) s61_rate_ti(op, op.clv2, frag2, op.codes1, l1, r, R, first, nb, lane, small_e, small_o);
-      else s61_rate_ti(op, op.clv1, frag, op.codes2, l2, r, R, first, nb, lane, small_e, small_o);
+      if (tip1 && tip2) s61_rate_tt(op, l1, l2, r, R, first, nb, lane, small_e, small_o, pred);
+      else if (!tip1 && !tip2) s61_rate_ii(op, frag, frag2, r, R, first, nb, lane, small_e, small_o, pred);
+      else if (tip1) s61_rate_ti(op, op.clv2, frag2, op.codes1, l1, r, R, first, nb, lane, small_e, small_o, pred);
+      else s61_rate_ti(op, op.clv1, frag, op.codes2, l2, r, R, first, nb, lane, small_e, small_o, pred);
     }
 
     if (scaling && rate_parallel)
@@ -414,11 +438,13 @@ __global__ __launch_bounds__(256, 2) void k_partials_s61v3(OpBatch batch, unsign
   }
 }
 
-// second half of a rate-parallel launch: combine the R votes of every site, rescale
-// the (rare) all-small sites, write the parent scalers.  One wave per (block, rate):
-// grid = (blocks/4, ops, R), block = 256
+// second half of a rate-parallel launch: combine the R votes of every site, correct the
+// units of the sites whose vote differs from the prediction they were stored with (a
+// vector is usually re-evaluated many times -- branch-length optimisation, SPR scoring --
+// and its scaling pattern rarely changes), write the parent scalers and the new
+// prediction.  One wave per (block, rate): grid = (blocks/4, ops, R), block = 256
 __global__ __launch_bounds__(256) void k_s61_scale_fixup(OpBatch batch, unsigned nblk, unsigned R,
-                                                         const uint8_t * votes)
+                                                         const uint8_t * votes, PredBatch preds)
 {
   const OpDesc & op = batch.op[blockIdx.y];
   if (!op.parent_scaler) return;
@@ -435,9 +461,11 @@ __global__ __launch_bounds__(256) void k_s61_scale_fixup(OpBatch batch, unsigned
     se &= v[site0];
     so &= v[site0 + 1];
   }
-  if (__any(se | so))
+  const int pe = preds.in[blockIdx.y][site0], po = preds.in[blockIdx.y][site0 + 1];
+  if (__any((se != pe) | (so != po)))
   {
-    const double fe = se ? SCALE_FACTOR : 1.0, fo = so ? SCALE_FACTOR : 1.0;
+    const double fe = (se == pe) ? 1.0 : (se ? SCALE_FACTOR : 1.0 / SCALE_FACTOR);
+    const double fo = (so == po) ? 1.0 : (so ? SCALE_FACTOR : 1.0 / SCALE_FACTOR);
     double * unit = op.parent + ((size_t)blk * R + blockIdx.z) * S61_UNIT;
     double2 t[S61_KS];
     s61_load_d(unit, lane, t);
@@ -452,6 +480,8 @@ __global__ __launch_bounds__(256) void k_s61_scale_fixup(OpBatch batch, unsigned
     if (op.scaler2) { ce += op.scaler2[site0]; co += op.scaler2[site0 + 1]; }
     op.parent_scaler[site0] = ce;
     op.parent_scaler[site0 + 1] = co;
+    preds.out[blockIdx.y][site0] = (uint8_t)se;
+    preds.out[blockIdx.y][site0 + 1] = (uint8_t)so;
   }
 }
 
@@ -818,15 +848,51 @@ static int launch_partials_s61(Engine * e, const OpBatch & batch, unsigned nops)
   if (rate_parallel && scaling && !e->d_s61_votes)
     PLLHIP_TRY(hipMalloc((void **)&e->d_s61_votes,
                          (size_t)MAX_OPS_PER_LAUNCH * e->R * e->nblk * S20_BS));
+  PredBatch preds;
+  memset(&preds, 0, sizeof(preds));
+  if (rate_parallel && scaling)
+  {
+    // last scaling decisions per parent vector, double-buffered (the fix-up kernel reads the
+    // old one in all its rate slices while one of them writes the new one)
+    if (e->s61_pred.empty()) e->s61_pred.resize(3 * (size_t)e->nodes);
+    const size_t bytes = (size_t)e->nblk * S20_BS;
+    for (unsigned i = 0; i < nops; ++i)
+    {
+      const OpDesc & d = batch.op[i];
+      if (!d.parent_scaler) continue;
+      const unsigned long long lo = std::min(d.child1_index, d.child2_index), hi = std::max(d.child1_index, d.child2_index);
+      const unsigned long long key = (hi << 32) | lo;
+      Engine::PredSlot * slot = nullptr, * victim = &e->s61_pred[3 * (size_t)d.parent_index];
+      for (int w = 0; w < 3; ++w)
+      {
+        Engine::PredSlot & c = e->s61_pred[3 * (size_t)d.parent_index + w];
+        if (c.key == key) { slot = &c; break; }
+        if (c.used < victim->used) victim = &c;
+      }
+      if (!slot)
+      {
+        slot = victim;                      // new orientation (or topology): start from "no site scales"
+        slot->key = key;
+        slot->cur = 0;
+        for (int w = 0; w < 2; ++w)
+          if (!slot->buf[w]) PLLHIP_TRY(hipMalloc((void **)&slot->buf[w], bytes));
+        PLLHIP_TRY(hipMemsetAsync(slot->buf[0], 0, bytes, e->stream));
+      }
+      slot->used = ++e->s61_pred_clock;
+      preds.in[i] = slot->buf[slot->cur];
+      preds.out[i] = slot->buf[slot->cur ^ 1u];
+      slot->cur ^= 1u;
+    }
+  }
   const unsigned per = rate_parallel ? std::max(1u, slots / e->R) : slots;
   const unsigned gx = std::max(1u, std::min((e->nblk + 3) / 4, per));
   hipLaunchKernelGGL(k_partials_s61v3, dim3(gx, nops, rate_parallel ? e->R : 1u), dim3(256), lds, e->stream,
-                     batch, e->nblk, e->R, e->lut_codes, rate_parallel ? e->d_s61_votes : (uint8_t *)nullptr);
+                     batch, e->nblk, e->R, e->lut_codes, rate_parallel ? e->d_s61_votes : (uint8_t *)nullptr, preds);
   PLLHIP_TRY(hipGetLastError());
   if (rate_parallel && scaling)
   {
     hipLaunchKernelGGL(k_s61_scale_fixup, dim3((e->nblk + 3) / 4, nops, e->R), dim3(256), 0, e->stream,
-                       batch, e->nblk, e->R, (const uint8_t *)e->d_s61_votes);
+                       batch, e->nblk, e->R, (const uint8_t *)e->d_s61_votes, preds);
     PLLHIP_TRY(hipGetLastError());
   }
   return PLL_SUCCESS;

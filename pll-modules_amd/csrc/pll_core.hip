@@ -208,6 +208,7 @@ void engine_destroy(Engine * e)
   (void)hipFree(e->d_pmat);
   (void)hipFree(e->d_lut);
   (void)hipFree(e->d_s61_votes);
+  for (auto & slot : e->s61_pred) { if (slot.buf[0]) (void)hipFree(slot.buf[0]); if (slot.buf[1]) (void)hipFree(slot.buf[1]); }
   (void)hipFree(e->d_weights);
   (void)hipFree(e->d_invariant);
   (void)hipFree(e->d_tipmap);
@@ -726,6 +727,9 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     d.scaler1 = scaler_ptr(e, op.child1_scaler_index);
     d.scaler2 = scaler_ptr(e, op.child2_scaler_index);
     d.parent = e->d_clv[op.parent_clv_index];
+    d.parent_index = op.parent_clv_index;
+    d.child1_index = op.child1_clv_index;
+    d.child2_index = op.child2_clv_index;
     d.parent_scaler = const_cast<unsigned *>(scaler_ptr(e, op.parent_scaler_index));
     const double nr = (double)e->N * e->R;
     bytes += nr * 8.0 * e->S * (1.0 + (t1 ? 0.0 : 1.0) + (t2 ? 0.0 : 1.0));
