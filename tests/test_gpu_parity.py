@@ -10,6 +10,7 @@ CLV / sumtable entries rel 1e-9 (P-matrix entries come out of an eigen sum with
 cancellation, and device exp() differs from libm by an ulp), lnL rel 1e-12 of |lnL|, derivatives rel 1e-9.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -51,7 +52,7 @@ def share_eigen(a, b):
     pa.eigen_decomp_valid[0] = 1
 
 
-def _compare_full(a, b, check_clvs=True):
+def _compare_full(a, b, check_clvs=True, codon_clv_tol=1e-5):
     if a.S > 20:
         # codon P-matrices hold entries down to ~1e-13 (three-step changes) that any
         # eigen-solver only gets to ~1e-14 ABSOLUTE (checked against scipy expm): with
@@ -70,7 +71,8 @@ def _compare_full(a, b, check_clvs=True):
             ca, cb = a.get_clv(op[0]), b.get_clv(op[0])
             # even on a shared eigen system the tiny codon P-matrix entries differ at
             # ~1e-5 relative between device exp() and libm (1 ulp on cancelling terms)
-            assert common.vec_err(ca, cb) < (REL_CLV if a.S <= 20 else 1e-5), f"CLV {op[0]}"
+            if a.S <= 20 or codon_clv_tol is not None:
+                assert common.vec_err(ca, cb) < (REL_CLV if a.S <= 20 else codon_clv_tol), f"CLV {op[0]}"
             if a.nscalers:
                 assert np.array_equal(a.get_scaler(op[1]), b.get_scaler(op[1])), f"scaler {op[1]}"
     return la, lb
@@ -93,7 +95,7 @@ def test_golden_fixtures_on_gpu(product, name, coded):
 
 @pytest.mark.parametrize("states,rate_cats", [(4, 4), (4, 1), (4, 2), (4, 8), (4, 16), (4, 3),
                                               (20, 4), (20, 1), (20, 2), (20, 8), (20, 12),
-                                              (5, 4), (2, 3), (7, 4), (61, 2), (61, 4)])
+                                              (5, 4), (2, 3), (7, 4), (61, 2), (61, 4), (61, 1)])
 @pytest.mark.parametrize("coded", [True, False])
 def test_full_traversal_parity(product, oracle, states, rate_cats, coded):
     ntips, nsites = (9, 257) if states > 20 else (14, 1031)
@@ -161,15 +163,58 @@ def test_empty_partition(product):
         assert a.edge_lnl(3, 0, 2, NONE, 2) == 0.0
 
 
-@pytest.mark.parametrize("states,ntips", [(4, 600), (20, 260)])
-def test_deep_tree_scaling_is_bit_exact(product, oracle, states, ntips):
+@pytest.mark.parametrize("states,ntips,rate_cats", [(4, 600, 4), (20, 260, 4), (61, 130, 4), (61, 130, 1)])
+def test_deep_tree_scaling_is_bit_exact(product, oracle, states, ntips, rate_cats):
     """random sequences on a deep tree drive CLVs below 2^-256: scaler counts must
     agree exactly and lnL must survive"""
-    a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=ntips, nsites=97, coded=True)
+    a, b = _pair(product, oracle, states=states, rate_cats=rate_cats, ntips=ntips, nsites=97, coded=True)
     with a, b:
-        la, lb = _compare_full(a, b)
+        # codon matrices: the ulp-level exp() differences on the tiny P-matrix entries (see
+        # _compare_full) grow with the depth in the improbable components of a vector (3.5e-4
+        # of the vector maximum after 130 levels), while lnL still agrees to 1e-12: for 61
+        # states this test checks the scaler counts (exact) and lnL, not the small components
+        la, lb = _compare_full(a, b, codon_clv_tol=None)
         root_sc = a.get_scaler(a.tree.scaler_of(a.tree.root_a))
         assert root_sc.max() >= 1, "test did not reach the scaling regime"
+
+
+def test_codon_launch_modes_agree_bitwise(product):
+    """61 states: small slices are launched one workgroup per (range, rate) with the scaling
+    votes combined -- and predicted from the previous evaluation -- by a second kernel;
+    large ones walk the rates inside one workgroup.  Same numbers either way, also on a
+    second evaluation (when the predictions are in use) and after a model change."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+import pllhip_ctypes as pc
+lib = pc.PllLib(pc.PRODUCT_LIB)
+with pc.build_instance(lib, states=61, rate_cats=4, ntips=130, nsites=97, coded=True) as a:
+    out = []
+    for rep in range(3):
+        if rep == 2:
+            subst, freqs = pc.codon_model()
+            a.set_model(subst, freqs, lib.gamma_cats(2.5, 4))
+            a.update_pmatrices(np.arange(a.tree.nedges), a.tree.brlens)
+        l = pc.full_traversal(a)
+        h = hashlib.sha256()
+        for op in a.tree.ops:
+            h.update(a.get_clv(op[0]).tobytes())
+            h.update(a.get_scaler(op[1]).tobytes())
+        out.append("%%.17g %%s" %% (l, h.hexdigest()))
+    assert a.get_scaler(a.tree.scaler_of(a.tree.root_a)).max() >= 1
+    print("\n".join(out))
+""" % os.path.dirname(pc.__file__)
+    runs = []
+    for mode in ("1", "0"):
+        env = dict(os.environ, PLLHIP_S61_RATEPAR=mode)
+        runs.append(subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True,
+                                   text=True, timeout=300).stdout)
+    assert runs[0] == runs[1] and runs[0].count("\n") == 3
+    first, second, third = runs[0].splitlines()
+    assert first == second and third != first
 
 
 def test_scaling_on_equals_scaling_off(product):
