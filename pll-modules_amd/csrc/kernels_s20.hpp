@@ -760,8 +760,15 @@ static int launch_partials_s20(Engine * e, const OpBatch & batch, unsigned nops)
 
 static bool chains_supported_s20(const Engine * e) { return e->R == 4 || e->R == 2 || e->R == 1; }
 
-static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned nchains)
+static unsigned s20_chain_max(const Engine *) { return S20_CHAIN_MAX; }
+
+// (A second geometry for small slices -- chains of two, two 256-thread workgroups per CU, so
+// that one workgroup's fragment fill overlaps the other's streaming -- was measured at
+// 125 k / 250 k / 500 k sites and is 13 % / 15 % / 0 % slower than this one: the extra
+// re-reads cost more than the overlap gains.)
+static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned nchains, unsigned longest)
 {
+  (void)longest;
   const size_t lds = sizeof(double) * S20_CHAIN_MAX * 2 * e->R * S20_FRAGS;
   static const unsigned flags = getenv("PLLHIP_S20_NT") ? (unsigned)atoi(getenv("PLLHIP_S20_NT")) : 0u;
   static bool attr_set = false;
@@ -776,13 +783,9 @@ static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned ncha
                                    hipFuncAttributeMaxDynamicSharedMemorySize, cap / 4));
     attr_set = true;
   }
-  // one workgroup per CU per chain (measured: 1 beats 2 and 4 per CU)
+  // workgroups per CU and chain (measured at 1 M sites: 1 beats 2 and 4)
   static const int env_bpc = getenv("PLLHIP_S20_CHAIN_BPC") ? atoi(getenv("PLLHIP_S20_CHAIN_BPC")) : 1;
-  // blocks per wave a workgroup should at least get (measured at 125 k and 1 M sites: more
-  // than 1 only costs parallelism, the fragment fill is not what small slices wait for)
-  static const int env_tgt = getenv("PLLHIP_S20_CHAIN_TARGET") ? atoi(getenv("PLLHIP_S20_CHAIN_TARGET")) : 1;
-  const unsigned per_wg = S20_CHAIN_WAVES * (unsigned)std::max(1, env_tgt);
-  const unsigned need = (e->nblk + per_wg - 1) / per_wg;
+  const unsigned need = (e->nblk + S20_CHAIN_WAVES - 1) / S20_CHAIN_WAVES;
   const unsigned gx = std::max(1u, std::min(need, e->cu_count * (unsigned)std::max(1, env_bpc)));
   const dim3 grid(gx, nchains), block(64 * S20_CHAIN_WAVES);
   if (e->R == 4)

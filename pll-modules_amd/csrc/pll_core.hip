@@ -774,7 +774,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
   if (use_chains && count >= 2 && (chains20 || chains4))
   {
     ChainPlan plan;
-    if (plan_chains(e, ops, count, chains20 ? S20_CHAIN_MAX : S4_CHAIN_MAX, plan))
+    if (plan_chains(e, ops, count, chains20 ? s20_chain_max(e) : S4_CHAIN_MAX, plan))
     {
       for (int round = 0; round < plan.rounds; ++round)
       {
@@ -792,7 +792,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
             for (unsigned i = 0; i < nops; ++i) ob.op[i] = cb.op[i];
             if (!launch_partials(e, ob, nops)) return PLL_FAILURE;
           }
-          else if (chains20 ? !launch_chains_s20(e, cb, nchains) : !launch_chains_s4(e, cb, nchains, longest))
+          else if (chains20 ? !launch_chains_s20(e, cb, nchains, longest) : !launch_chains_s4(e, cb, nchains, longest))
             return PLL_FAILURE;
           if (!prof_end(ev1, bytes, flops, nops)) return PLL_FAILURE;
           e->counters.partial_launches++;
@@ -800,9 +800,15 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
           bytes = flops = 0.0;
           return PLL_SUCCESS;
         };
+        // longest chains first: their workgroups are dispatched first, which keeps the tail
+        // of the launch short
+        std::vector<size_t> order;
         for (size_t c = 0; c < plan.chains.size(); ++c)
+          if (plan.launch[c] == round) order.push_back(c);
+        std::stable_sort(order.begin(), order.end(),
+                         [&](size_t a, size_t b) { return plan.chains[a].size() > plan.chains[b].size(); });
+        for (size_t c : order)
         {
-          if (plan.launch[c] != round) continue;
           const std::vector<unsigned> & ch = plan.chains[c];
           if (nops + ch.size() > MAX_OPS_PER_LAUNCH && !flush()) return PLL_FAILURE;
           cb.first[nchains] = (unsigned char)nops;
