@@ -239,7 +239,7 @@ typedef struct pll_partition
   unsigned int maxstates;         /* number of distinct tip codes           */
   unsigned char ** tipchars;      /* [tips] N codes                         */
   unsigned char * charmap;        /* [256] input char -> code               */
-  double * ttlookup;              /* unused by this engine (NULL)           */
+  double * ttlookup;              /* sized as libpll does, zero-filled: only the binary dump reads it */
   pll_state_t * tipmap;           /* [256] code -> state mask               */
 
   int asc_bias_alloc;

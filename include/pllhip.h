@@ -28,7 +28,16 @@ extern "C" {
 #define PLLHIP_SYNC_PMATRIX  (1 << 0)   /* all P-matrices -> partition->pmatrix   */
 #define PLLHIP_SYNC_CLV      (1 << 1)   /* all CLVs       -> partition->clv[i]    */
 #define PLLHIP_SYNC_SCALERS  (1 << 2)   /* all scalers    -> partition->scale_buffer[i] */
-#define PLLHIP_SYNC_ALL      7
+#define PLLHIP_SYNC_TIPS     (1 << 3)   /* pllhip_sync_to_device only: tip codes, tip map, pattern weights, invariant sites */
+#define PLLHIP_SYNC_ALL      15
+
+/* pll_partition_create attribute (above PLL_ATTRIB_MASK): allocate the host mirrors
+   partition->clv[i] / scale_buffer[i] up front, so that code which FILLS them -- the
+   reference's binary loader, src/binary/pll_binary.c:346-500 -- finds memory there;
+   pllhip_sync_to_device() then moves the contents to the GPU.  pllhip_sync_to_host()
+   sets the bit on the partition, so a dump carries it into the file and the loader
+   passes it back to pll_partition_create. */
+#define PLLHIP_ATTRIB_HOST_MIRRORS (1u << 30)
 
 /* reduce-callback operation codes (src/pllmod_common.h:29-31) */
 #define PLLHIP_REDUCE_SUM 0
@@ -59,6 +68,10 @@ PLL_EXPORT int pllhip_eigen_decompose(unsigned int states, unsigned int states_p
 /* copy device-resident arrays into the host mirrors of the partition
    (allocating partition->clv[i] / scale_buffer[i] on first use) */
 PLL_EXPORT int pllhip_sync_to_host(pll_partition_t * partition, unsigned int what);
+
+/* the opposite direction: host mirrors (filled by a checkpoint loader) -> device.
+   CLVs / scalers whose mirror is NULL are skipped. */
+PLL_EXPORT int pllhip_sync_to_device(pll_partition_t * partition, unsigned int what);
 
 /* single-array variants, caller-provided output.  Layouts are the partition's:
    CLV [site][rate][states_padded]; a tip stored as codes is expanded to 0/1. */

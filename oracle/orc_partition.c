@@ -206,7 +206,29 @@ void pll_partition_destroy(pll_partition_t * p)
   free_rows((void **)p->tipchars, p->tips);
   free(p->charmap);
   free(p->tipmap);
+  pll_aligned_free(p->ttlookup);
   free(p);
+}
+
+/* libpll keeps a tip-tip lookup table of (2^ceil(log2 maxstates))^2 * states_padded *
+   rate_cats doubles with coded tips; this engine does not use one, but the reference's
+   binary dump writes it (src/binary/binary_io_operations.c:242-250): keep a zero-filled
+   array of that size */
+static int ensure_ttlookup(pll_partition_t * p)
+{
+  unsigned int l2 = 0;
+  size_t n;
+  while ((1u << l2) < p->maxstates) ++l2;
+  n = ((size_t)1 << (2 * l2)) * p->states_padded * p->rate_cats;
+  pll_aligned_free(p->ttlookup);
+  p->ttlookup = (double *)pll_aligned_alloc(n * sizeof(double), p->alignment);
+  if (!p->ttlookup)
+  {
+    orc_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate the tip-tip lookup placeholder");
+    return PLL_FAILURE;
+  }
+  memset(p->ttlookup, 0, n * sizeof(double));
+  return PLL_SUCCESS;
 }
 
 void pll_set_subst_params(pll_partition_t * p, unsigned int idx, const double * v)
@@ -256,6 +278,7 @@ int pll_set_tip_states(pll_partition_t * p, unsigned int tip,
                        const pll_state_t * map, const char * seq)
 {
   unsigned int n, j, r;
+  const unsigned int old_codes = p->maxstates;
   if (tip >= p->tips)
   {
     orc_set_error(PLL_ERROR_PARAM_INVALID, "Invalid tip index %u", tip);
@@ -303,6 +326,8 @@ int pll_set_tip_states(pll_partition_t * p, unsigned int tip,
               (j < p->states) ? (double)((m >> j) & 1ULL) : 0.0;
     }
   }
+  if ((p->attributes & PLL_ATTRIB_PATTERN_TIP) && (!p->ttlookup || p->maxstates != old_codes))
+    return ensure_ttlookup(p);
   return PLL_SUCCESS;
 }
 

@@ -1276,6 +1276,51 @@ int pllhip_sync_to_host(pll_partition_t * p, unsigned int what)
       if (!p->scale_buffer[i]) { set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate host scaler mirror"); return PLL_FAILURE; }
       if (!pllhip_get_scaler(p, i, p->scale_buffer[i])) return PLL_FAILURE;
     }
+  // a dump of this partition tells the loader to create one with host mirrors again
+  if (what & (PLLHIP_SYNC_CLV | PLLHIP_SYNC_SCALERS)) p->attributes |= PLLHIP_ATTRIB_HOST_MIRRORS;
+  return PLL_SUCCESS;
+}
+
+int pllhip_sync_to_device(pll_partition_t * p, unsigned int what)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  if (what & PLLHIP_SYNC_TIPS)
+  {
+    if (e->coded_tips)
+    {
+      e->tipmap_codes_uploaded = ~0u;                       // the map itself may be new
+      for (unsigned t = 0; t < e->tips; ++t)
+        if (p->tipchars && p->tipchars[t] && !upload_tip_codes(p, t)) return PLL_FAILURE;
+      invalidate_luts(p);
+    }
+    p->pattern_weight_sum = 0;
+    for (unsigned i = 0; i < p->sites; ++i) p->pattern_weight_sum += p->pattern_weights[i];
+    if (!upload_weights(p)) return PLL_FAILURE;
+    e->invariant_uploaded = false;
+  }
+  if ((what & PLLHIP_SYNC_PMATRIX) && e->nmat)
+  {
+    // the host mirror is the truth now: queued requests are obsolete
+    for (unsigned m : e->pend_midx) e->pend_pos[m] = -1;
+    e->pend_midx.clear();
+    e->pend_t.clear();
+    PLLHIP_TRY(hipMemcpyAsync(e->d_pmat, p->pmatrix[0],
+                              sizeof(double) * (size_t)e->nmat * e->R * e->S * e->Sp,
+                              hipMemcpyHostToDevice, e->stream));
+    PLLHIP_TRY(hipStreamSynchronize(e->stream));
+    e->pmat_host_dirty = false;
+    invalidate_luts(p);
+  }
+  if (what & PLLHIP_SYNC_CLV)
+    for (unsigned i = 0; i < e->nodes; ++i)
+    {
+      if ((i < e->tips && e->coded_tips) || !p->clv[i]) continue;
+      if (!pllhip_set_clv(p, i, p->clv[i])) return PLL_FAILURE;
+    }
+  if (what & PLLHIP_SYNC_SCALERS)
+    for (unsigned i = 0; i < e->nscalers; ++i)
+      if (p->scale_buffer[i] && !pllhip_set_scaler(p, i, p->scale_buffer[i])) return PLL_FAILURE;
   return PLL_SUCCESS;
 }
 

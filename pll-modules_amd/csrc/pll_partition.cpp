@@ -197,6 +197,23 @@ pll_partition_t * pll_partition_create(unsigned int tips,
     pll_partition_destroy(p);
     return nullptr;
   }
+  if (attributes & PLLHIP_ATTRIB_HOST_MIRRORS)
+  {
+    // a loader is going to fill these (include/pllhip.h); calloc'ed pages cost nothing
+    // until they are written
+    const size_t len = static_cast<size_t>(sites) * rate_cats * Sp;
+    const unsigned first = (attributes & PLL_ATTRIB_PATTERN_TIP) ? tips : 0;
+    for (unsigned i = first; ok && i < p->nodes; ++i)
+      ok = (p->clv[i] = static_cast<double *>(calloc(len ? len : 1, sizeof(double)))) != nullptr;
+    for (unsigned i = 0; ok && i < scale_buffers; ++i)
+      ok = (p->scale_buffer[i] = static_cast<unsigned int *>(calloc(sites ? sites : 1, sizeof(unsigned int)))) != nullptr;
+    if (!ok)
+    {
+      set_error(PLL_ERROR_MEM_ALLOC, "Unable to allocate the host mirrors.");
+      pll_partition_destroy(p);
+      return nullptr;
+    }
+  }
   return p;
 }
 
@@ -221,7 +238,28 @@ void pll_partition_destroy(pll_partition_t * p)
   free_table(p->tipchars, p->tips);
   free(p->charmap);
   free(p->tipmap);
+  pll_aligned_free(p->ttlookup);
   free(p);
+}
+
+// libpll keeps a tip-tip lookup table of (2^ceil(log2 maxstates))^2 * states_padded *
+// rate_cats doubles with coded tips; this engine has per-matrix tables on the device
+// instead, but the reference's binary dump writes the array
+// (src/binary/binary_io_operations.c:242-250): keep a zero-filled one of that size
+static int ensure_ttlookup(pll_partition_t * p)
+{
+  unsigned l2 = 0;
+  while ((1u << l2) < p->maxstates) ++l2;
+  const size_t n = (static_cast<size_t>(1) << (2 * l2)) * p->states_padded * p->rate_cats;
+  pll_aligned_free(p->ttlookup);
+  p->ttlookup = static_cast<double *>(pll_aligned_alloc(n * sizeof(double), p->alignment));
+  if (!p->ttlookup)
+  {
+    set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate the tip-tip lookup placeholder");
+    return PLL_FAILURE;
+  }
+  memset(p->ttlookup, 0, n * sizeof(double));
+  return PLL_SUCCESS;
 }
 
 void pll_set_subst_params(pll_partition_t * p, unsigned int idx, const double * v)
@@ -338,6 +376,7 @@ int pll_set_tip_states(pll_partition_t * p, unsigned int tip,
   if (coded)
   {
     if (p->maxstates != old_codes) invalidate_luts(p);
+    if ((!p->ttlookup || p->maxstates != old_codes) && !ensure_ttlookup(p)) return PLL_FAILURE;
     rc = upload_tip_codes(p, tip);
   }
   else

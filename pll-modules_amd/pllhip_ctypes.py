@@ -24,7 +24,8 @@ PLL_SCALE_BUFFER_NONE = -1
 PLL_ATTRIB_PATTERN_TIP = 1 << 4
 PLL_GAMMA_RATES_MEAN = 0
 PLL_TREE_TRAVERSE_POSTORDER = 1
-PLLHIP_SYNC_PMATRIX, PLLHIP_SYNC_CLV, PLLHIP_SYNC_SCALERS = 1, 2, 4
+PLLHIP_SYNC_PMATRIX, PLLHIP_SYNC_CLV, PLLHIP_SYNC_SCALERS, PLLHIP_SYNC_TIPS, PLLHIP_SYNC_ALL = 1, 2, 4, 8, 15
+PLLHIP_ATTRIB_HOST_MIRRORS = 1 << 30
 
 c_double_p = C.POINTER(C.c_double)
 c_uint_p = C.POINTER(C.c_uint)
@@ -123,7 +124,7 @@ pllhip_eval_set_branch_length pllhip_eval_optimize_branches pllhip_eval_ops
 pllhip_eval_pmatrix_updates pllhip_eval_derivative_calls pllhip_eval_spr_round""".split()
 
 PLLHIP_H_FUNCTIONS = """pllhip_device_count pllhip_set_device pllhip_get_device
-pllhip_device_arch pllhip_eigen_decompose pllhip_sync_to_host pllhip_get_clv
+pllhip_device_arch pllhip_eigen_decompose pllhip_sync_to_host pllhip_sync_to_device pllhip_get_clv
 pllhip_get_scaler pllhip_get_sumtable pllhip_set_clv pllhip_set_scaler pllhip_synchronize
 pllhip_stream pllhip_get_counters pllhip_reset_counters pllhip_partials_kernel_name
 pllhip_comm_get_unique_id pllhip_comm_create pllhip_comm_destroy pllhip_reduce_cb
@@ -227,6 +228,7 @@ class PllLib:
             L.pllhip_eigen_decompose.argtypes = [C.c_uint, C.c_uint, c_double_p, c_double_p,
                                                  c_double_p, c_double_p, c_double_p]
             L.pllhip_sync_to_host.argtypes = [pp, C.c_uint]
+            L.pllhip_sync_to_device.argtypes = [pp, C.c_uint]
             L.pllhip_get_clv.argtypes = [pp, C.c_uint, c_double_p]
             L.pllhip_set_clv.argtypes = [pp, C.c_uint, c_double_p]
             L.pllhip_get_scaler.argtypes = [pp, C.c_uint, c_uint_p]

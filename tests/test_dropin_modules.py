@@ -191,3 +191,31 @@ def test_own_spr_round_makes_the_reference_s_moves(spr_driver, tmp_path, mode, n
         oc = re.search(rf"^own round {r} cutoff: (\S+) (\S+) (\S+)$", out, re.M).groups()
         assert rc[0] == oc[0]
         assert abs(float(rc[1]) - float(oc[1])) < 1e-5 * max(1.0, abs(float(rc[1])))
+
+
+# ---------------------------------------------------------------------------
+# binary checkpoint module (src/binary): dump a partition with CLVs, load it, evaluate
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["tv", "clv"])
+def test_reference_binary_module_round_trip(oracle, tmp_path, mode):
+    """the reference's checkpoint code walks the partition's arrays
+    directly (src/binary/binary_io_operations.c:161-314); compiled unchanged against
+    include/pll.h it must dump and restore a partition of this library such that the
+    edge log-likelihood is the same without recomputing anything
+    (test/src/binary/binary-sequential.c:344-354 uses 1e-7)."""
+    if not os.path.isdir(REF):
+        pytest.skip("reference tree not present on this box")
+    exe = tmp_path / "binary_driver"
+    src = [os.path.join(ROOT, "tests", "dropin", "binary_driver.c"), f"{REF}/src/pllmod_common.c"]
+    src += sorted(glob.glob(f"{REF}/src/binary/*.c"))
+    inc = sum((["-I", d] for d in [f"{ROOT}/include", f"{REF}/src", f"{REF}/src/binary", f"{REF}/src/tree"]), [])
+    libdir = os.path.dirname(ORACLE_LIB)
+    subprocess.run(["gcc", "-std=gnu99", "-D_GNU_SOURCE", "-O2", "-w", *inc, "-o", str(exe), *src,
+                    "-L", libdir, "-lpll_oracle", "-lm", f"-Wl,-rpath,{libdir}"], check=True)
+    out = subprocess.run([str(exe), str(tmp_path / "ckpt.bin"), mode], check=True, capture_output=True,
+                         text=True, timeout=120).stdout
+    v = {k.strip(): float(x) for k, x in re.findall(r"^(lnL \w+):\s+(-?[0-9.]+)$", out, re.M)}
+    assert set(v) == {"lnL before", "lnL after", "lnL redo"}
+    assert v["lnL before"] < -1000
+    assert abs(v["lnL after"] - v["lnL before"]) < 1e-7
+    assert abs(v["lnL redo"] - v["lnL before"]) < 1e-7

@@ -505,6 +505,49 @@ def test_baseline_sizes_through_tiling(product, oracle, cfg, tile):
         assert abs(l_rerooted - l_full) <= 1e-9 * abs(l_full)
 
 
+@pytest.mark.parametrize("states,coded", [(20, True), (4, False), (61, True)])
+def test_host_mirrors_round_trip(product, states, coded):
+    """what a checkpoint loader does on the GPU library (include/pllhip.h,
+    PLLHIP_ATTRIB_HOST_MIRRORS): sync_to_host on the source sets the attribute; a partition
+    created with it has host arrays a loader can fill (here: memmove, array by array as
+    src/binary/binary_io_operations.c:194-314 walks them); sync_to_device moves them to the
+    GPU, and the edge log-likelihood is there without recomputing anything."""
+    kw = dict(states=states, rate_cats=4, ntips=10, nsites=301, coded=coded)
+    with pc.build_instance(product, **kw) as a:
+        want = pc.full_traversal(a)
+        assert product.lib.pllhip_sync_to_host(a.p, pc.PLLHIP_SYNC_ALL)
+        pa = a.p.contents
+        assert pa.attributes & pc.PLLHIP_ATTRIB_HOST_MIRRORS
+        b = pc.Instance(product, 10, states, 301, 4, attributes=pa.attributes)
+        with b:
+            pb = b.p.contents
+            S, Sp, R, N = a.S, a.Sp, a.R, a.N
+            C.memmove(pb.eigen_decomp_valid, pa.eigen_decomp_valid, 4)
+            for dst, src, n in ((pb.eigenvecs[0], pa.eigenvecs[0], S * Sp), (pb.inv_eigenvecs[0], pa.inv_eigenvecs[0], S * Sp),
+                                (pb.eigenvals[0], pa.eigenvals[0], Sp), (pb.pmatrix[0], pa.pmatrix[0], pa.prob_matrices * R * S * Sp),
+                                (pb.subst_params[0], pa.subst_params[0], S * (S - 1) // 2), (pb.frequencies[0], pa.frequencies[0], Sp),
+                                (pb.rates, pa.rates, R), (pb.rate_weights, pa.rate_weights, R), (pb.prop_invar, pa.prop_invar, 1)):
+                C.memmove(dst, src, 8 * n)
+            first = 0
+            if coded:
+                for t in range(10):
+                    C.memmove(pb.tipchars[t], pa.tipchars[t], N)
+                C.memmove(pb.charmap, pa.charmap, 256)
+                C.memmove(pb.tipmap, pa.tipmap, 256 * 8)
+                pb.maxstates = pa.maxstates
+                first = 10
+            for i in range(first, pa.tips + pa.clv_buffers):
+                C.memmove(pb.clv[i], pa.clv[i], 8 * N * R * Sp)
+            for i in range(pa.scale_buffers):
+                C.memmove(pb.scale_buffer[i], pa.scale_buffer[i], 4 * N)
+            C.memmove(pb.pattern_weights, pa.pattern_weights, 4 * N)
+            assert product.lib.pllhip_sync_to_device(b.p, pc.PLLHIP_SYNC_ALL)
+            t = a.tree
+            got = b.edge_lnl(t.root_a, t.scaler_of(t.root_a), t.root_b, t.scaler_of(t.root_b), t.root_matrix)
+            assert got == want
+            assert b.counters().partial_ops == 0
+
+
 def test_rccl_reduce_callback_single_rank(product):
     """the native reduce callback (RCCL ncclAllReduce behind the reference's
     parallel_reduce_cb signature) on a 1-rank communicator: values come back

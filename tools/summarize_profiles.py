@@ -71,14 +71,17 @@ def main():
                          "hbm_bytes_per_dispatch": rd + wr}
     json.dump(summary, open(os.path.join(OUT, f"{rnd}_{cfg}_pmc.json"), "w"), indent=1)
     if kernel_key:
-        # the dominant partials kernel of the run: chained launches (k_chain_*) where the
-        # family has them, per-operation launches (k_partials_*) otherwise
-        dom = sorted((v for k, v in summary.items() if "k_partials" in k or "k_chain" in k),
-                     key=lambda v: -v["dispatches"] * v["hbm_bytes_per_dispatch"])
+        # all partials launches of the run -- chained (k_chain_*) and per-operation
+        # (k_partials_*, plus the 61-state fix-up that belongs to its launch) -- averaged per
+        # launch, the unit of bench.py's roofline.algorithmic_bytes_per_launch
+        dom = [v for k, v in summary.items() if "k_partials" in k or "k_chain" in k]
+        extra = [v for k, v in summary.items() if "k_s61_scale_fixup" in k]
         if dom:
+            total = sum(v["dispatches"] * v["hbm_bytes_per_dispatch"] for v in dom + extra)
+            launches = sum(v["dispatches"] for v in dom)
             tpath = os.path.join(OUT, "traffic.json")
             t = json.load(open(tpath)) if os.path.exists(tpath) else {}
-            t[f"{cfg}:{kernel_key}"] = round(dom[0]["hbm_bytes_per_dispatch"])
+            t[f"{cfg}:{kernel_key}"] = round(total / launches)
             json.dump(t, open(tpath, "w"), indent=1)
     for k, v in summary.items():
         print(f"{k:40s} n={v['dispatches']:4d} read={v['hbm_read_bytes_per_dispatch']/1e6:10.1f} MB "
