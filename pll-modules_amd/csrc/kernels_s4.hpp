@@ -40,13 +40,6 @@ __device__ inline double dot4(const double * row, const d4 & c)
   return row[0] * c.x + row[1] * c.y + row[2] * c.z + row[3] * c.w;
 }
 
-// OR over the R lanes of a site (R power of two, lanes aligned to R)
-__device__ inline int group_or(int v, unsigned R)
-{
-  for (unsigned off = 1; off < R; off <<= 1) v |= __shfl_xor(v, off, 64);
-  return v;
-}
-
 __device__ inline double group_sum(double v, unsigned R)
 {
   for (unsigned off = 1; off < R; off <<= 1) v += __shfl_xor(v, off, 64);
