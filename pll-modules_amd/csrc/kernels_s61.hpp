@@ -884,7 +884,8 @@ static int launch_partials_s61(Engine * e, const OpBatch & batch, unsigned nops)
       slot->cur ^= 1u;
     }
   }
-  const unsigned per = rate_parallel ? std::max(1u, slots / e->R) : slots;
+  static const int env_mul = getenv("PLLHIP_S61_GXMUL") ? atoi(getenv("PLLHIP_S61_GXMUL")) : 1;
+  const unsigned per = (rate_parallel ? std::max(1u, slots / e->R) : slots) * (unsigned)std::max(1, env_mul);
   const unsigned gx = std::max(1u, std::min((e->nblk + 3) / 4, per));
   hipLaunchKernelGGL(k_partials_s61v3, dim3(gx, nops, rate_parallel ? e->R : 1u), dim3(256), lds, e->stream,
                      batch, e->nblk, e->R, e->lut_codes, rate_parallel ? e->d_s61_votes : (uint8_t *)nullptr, preds);

@@ -219,3 +219,44 @@ def test_spr_round_on_gpu_makes_the_oracle_s_moves(product, oracle, states, thor
     for a, b in zip(g[1], c[1]):
         assert a[1:8] == b[1:8]                                 # same scan, same accepted moves, in order
         assert abs(a[0] - b[0]) < 1e-6 and abs(a[8] - b[8]) < 1e-6 * max(1.0, abs(b[8]))
+
+
+def _random_walk(lib, steps, seed, ntips=40):
+    """random re-rootings, CLV invalidations and branch-length changes, evaluated
+    incrementally: arbitrary partial operation lists reach pll_update_partials"""
+    rng = np.random.default_rng(seed)
+    out = []
+    with build(lib, ntips=ntips, sizes=(333, 97)) as ev:
+        ev.loglh()
+        recs = [r for r in _walk_records(ev)]
+        inner = [r for r in recs if r.contents.next]
+        for _ in range(steps):
+            what = rng.integers(0, 4)
+            if what == 0:
+                assert lib.lib.pllhip_eval_set_root(ev.ev, inner[rng.integers(len(inner))])
+            elif what == 1:
+                for k in rng.integers(0, len(inner), size=rng.integers(1, 6)):
+                    lib.lib.pllhip_eval_invalidate_clv(ev.ev, inner[k])
+            elif what == 2:
+                rec = recs[rng.integers(len(recs))]
+                lib.lib.pllhip_eval_set_branch_length(ev.ev, rec, float(rng.uniform(0.001, 1.5)))
+            else:
+                lib.lib.pllhip_eval_invalidate_all(ev.ev)
+            out.append(ev.loglh(True))
+        out.append(ev.loglh(False))
+    return out
+
+
+def test_random_incremental_walk_is_consistent(oracle):
+    vals = _random_walk(oracle, 40, 5, ntips=20)
+    assert abs(vals[-1] - vals[-2]) < 1e-9 * abs(vals[-1])        # incremental == full at the end
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_incremental_walk_on_gpu_matches_oracle(product, oracle, seed):
+    g = _random_walk(product, 60, seed)
+    c = _random_walk(oracle, 60, seed)
+    for x, y in zip(g, c):
+        assert abs(x - y) < 1e-9 * abs(y)
+    assert abs(g[-1] - g[-2]) < 1e-10 * abs(g[-1])
