@@ -213,6 +213,7 @@ constexpr unsigned S4_CHAIN_MAX = 8;
 // LDS doubles per operation: two tables [R][16][4], two matrix sets [R][16]
 constexpr unsigned s4_chain_op_lds(unsigned R) { return 2 * R * 64 + 2 * R * 16; }
 
+// (152 VGPRs, three waves per SIMD; forcing four costs 24 spilled registers and 25 % of the rate)
 template <unsigned U, unsigned R>      // R in {1, 2, 4}; U <= 2R loads issued per batch
 __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
 {
