@@ -34,6 +34,7 @@ import numpy as np  # noqa: E402,F401
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (= FP64 vector peak)
+FP64_MFMA_SUSTAINED_TFLOPS = 47.5    # measured, tools/micro/mfma_f64.hip (all 256 CUs busy)
 
 
 def parse_args():
@@ -248,6 +249,11 @@ def main():
         "avg_launch_ms": round(prof.kernel_ms / max(1, prof.launches), 4),
         "algorithmic_bytes_per_launch": round(prof.algorithmic_bytes / max(1, prof.launches)),
         "kernel_share_of_step": round(prof.kernel_ms * 1e-3 / elapsed, 4),
+        # tools/micro/mfma_f64.hip: v_mfma_f64_16x16x4_f64 back to back on every SIMD sustains
+        # 47.5 TFLOP/s on this chip (29.9 ns per MFMA per SIMD with <= 128 CUs busy, 44.1 ns with
+        # all 256: clocks drop under a full-chip FP64 matrix load), not the 78.6 TFLOP/s data-sheet peak
+        "mfma_sustained_measured_TFLOPs": FP64_MFMA_SUSTAINED_TFLOPS if mfma_bound else None,
+        "frac_of_sustained": round(tflops / FP64_MFMA_SUSTAINED_TFLOPS, 4) if mfma_bound else None,
         # HBM rate implied by the PMC traffic of the committed profile (same command): with
         # operation chains the carried child of a link is not re-read, so the real traffic
         # is BELOW the algorithmic bytes (SURVEY.md 8d counts every child as one read)
