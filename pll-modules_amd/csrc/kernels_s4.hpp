@@ -210,15 +210,18 @@ __global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, 
 // next launch would have loaded.  grid = (gx, chains), block = 256,
 // dynamic LDS = chain length x S4_CHAIN_OP_LDS doubles.
 constexpr unsigned S4_CHAIN_MAX = 8;
-// LDS doubles per operation: two tables [R][16][4], two matrix sets [R][16]
-constexpr unsigned s4_chain_op_lds(unsigned R) { return 2 * R * 64 + 2 * R * 16; }
+// LDS doubles per operation: two tables [R][16][4] (rate stride padded to 68 doubles: with 64
+// all rates of a code share their banks), two matrix sets [R][16]
+constexpr unsigned S4_LUT_RS = 68;
+constexpr unsigned s4_chain_op_lds(unsigned R) { return 2 * R * S4_LUT_RS + 2 * R * 16; }
 
 // (152 VGPRs, three waves per SIMD; forcing four costs 24 spilled registers and 25 % of the rate)
 template <unsigned U, unsigned R>      // R in {1, 2, 4}; U <= 2R loads issued per batch
 __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
 {
   constexpr unsigned group = 2 * R, spi = 64 / group, rs = (R == 4) ? 2 : (R == 2) ? 1 : 0;
-  constexpr unsigned S4_CHAIN_OP_LDS = s4_chain_op_lds(R), T2 = R * 64, M1 = 2 * R * 64, M2 = 2 * R * 64 + R * 16;
+  constexpr unsigned S4_CHAIN_OP_LDS = s4_chain_op_lds(R), T2 = R * S4_LUT_RS, M1 = 2 * R * S4_LUT_RS,
+                     M2 = 2 * R * S4_LUT_RS + R * 16;
   extern __shared__ double lds[];
   const unsigned first = batch.first[blockIdx.y], len = batch.len[blockIdx.y];
   const unsigned lane = threadIdx.x & 63;
@@ -229,9 +232,10 @@ __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
   {
     const OpDesc & op = batch.op[first + i];
     double * base = lds + i * S4_CHAIN_OP_LDS;
-    if (op.codes1) { if (threadIdx.x < R * 64) base[threadIdx.x] = op.lut1[threadIdx.x]; }
+    const unsigned trow = (threadIdx.x >> 6) * S4_LUT_RS + (threadIdx.x & 63);
+    if (op.codes1) { if (threadIdx.x < R * 64) base[trow] = op.lut1[threadIdx.x]; }
     else if (threadIdx.x < R * 16) base[M1 + threadIdx.x] = op.pmat1[threadIdx.x];
-    if (op.codes2) { if (threadIdx.x < R * 64) base[T2 + threadIdx.x] = op.lut2[threadIdx.x]; }
+    if (op.codes2) { if (threadIdx.x < R * 64) base[T2 + trow] = op.lut2[threadIdx.x]; }
     else if (threadIdx.x < R * 16) base[M2 + threadIdx.x] = op.pmat2[threadIdx.x];
   }
   __syncthreads();
@@ -275,10 +279,10 @@ __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
           {
             const unsigned long long n = (gu >> 1) >> rs;
             if (op.codes1)
-              in1[u] = *reinterpret_cast<const double2 *>(&base[(r * 16 + op.codes1[n]) * 4 + 2 * h]);
+              in1[u] = *reinterpret_cast<const double2 *>(&base[r * S4_LUT_RS + op.codes1[n] * 4 + 2 * h]);
             else if (carried != 1) in1[u] = *reinterpret_cast<const double2 *>(op.clv1 + gu * 2);
             if (op.codes2)
-              in2[u] = *reinterpret_cast<const double2 *>(&base[T2 + (r * 16 + op.codes2[n]) * 4 + 2 * h]);
+              in2[u] = *reinterpret_cast<const double2 *>(&base[T2 + r * S4_LUT_RS + op.codes2[n] * 4 + 2 * h]);
             else if (carried != 2) in2[u] = *reinterpret_cast<const double2 *>(op.clv2 + gu * 2);
           }
         }
