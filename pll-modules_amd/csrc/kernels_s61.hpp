@@ -442,7 +442,8 @@ __global__ __launch_bounds__(256, 2) void k_partials_s61v3(OpBatch batch, unsign
 // units of the sites whose vote differs from the prediction they were stored with (a
 // vector is usually re-evaluated many times -- branch-length optimisation, SPR scoring --
 // and its scaling pattern rarely changes), write the parent scalers and the new
-// prediction.  One wave per (block, rate): grid = (blocks/4, ops, R), block = 256
+// prediction.  One wave per block (with predictions a correction is the exception, so the
+// rates are not spread over workgroups): grid = (blocks/4, ops), block = 256
 __global__ __launch_bounds__(256) void k_s61_scale_fixup(OpBatch batch, unsigned nblk, unsigned R,
                                                          const uint8_t * votes, PredBatch preds)
 {
@@ -466,14 +467,17 @@ __global__ __launch_bounds__(256) void k_s61_scale_fixup(OpBatch batch, unsigned
   {
     const double fe = (se == pe) ? 1.0 : (se ? SCALE_FACTOR : 1.0 / SCALE_FACTOR);
     const double fo = (so == po) ? 1.0 : (so ? SCALE_FACTOR : 1.0 / SCALE_FACTOR);
-    double * unit = op.parent + ((size_t)blk * R + blockIdx.z) * S61_UNIT;
-    double2 t[S61_KS];
-    s61_load_d(unit, lane, t);
+    for (unsigned r = 0; r < R; ++r)
+    {
+      double * unit = op.parent + ((size_t)blk * R + r) * S61_UNIT;
+      double2 t[S61_KS];
+      s61_load_d(unit, lane, t);
 #pragma unroll
-    for (unsigned k = 0; k < S61_KS; ++k) { t[k].x *= fe; t[k].y *= fo; }
-    s61_store_d(unit, lane, t);
+      for (unsigned k = 0; k < S61_KS; ++k) { t[k].x *= fe; t[k].y *= fo; }
+      s61_store_d(unit, lane, t);
+    }
   }
-  if (q == 0 && blockIdx.z == 0)
+  if (q == 0)
   {
     unsigned ce = se ? 1u : 0u, co = so ? 1u : 0u;
     if (op.scaler1) { ce += op.scaler1[site0]; co += op.scaler1[site0 + 1]; }
@@ -892,7 +896,7 @@ static int launch_partials_s61(Engine * e, const OpBatch & batch, unsigned nops)
   PLLHIP_TRY(hipGetLastError());
   if (rate_parallel && scaling)
   {
-    hipLaunchKernelGGL(k_s61_scale_fixup, dim3((e->nblk + 3) / 4, nops, e->R), dim3(256), 0, e->stream,
+    hipLaunchKernelGGL(k_s61_scale_fixup, dim3((e->nblk + 3) / 4, nops), dim3(256), 0, e->stream,
                        batch, e->nblk, e->R, (const uint8_t *)e->d_s61_votes, preds);
     PLLHIP_TRY(hipGetLastError());
   }
