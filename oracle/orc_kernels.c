@@ -102,6 +102,108 @@ static double * tip_lookup(const pll_partition_t * p, const double * P)
   return lut;
 }
 
+/* ---------------------------------------------------------------------------
+ * Vectorised variant for 4 and 20 states (GCC vector extensions -> AVX2 + FMA with
+ * -march=x86-64-v3), used when ORC_FAST=1: the P-matrix is transposed once per
+ * operation and rate so that a parent vector is built as sum_j Pt[j][:] * c[j]
+ * (broadcast-multiply-accumulate over whole state vectors instead of one dot product
+ * per state).  Same arithmetic, different summation order: results agree with the
+ * scalar path to rounding (tests/test_oracle_properties.py).  It exists so that the CPU
+ * baseline bench.py reports next to the GPU numbers is not an artificially slow one;
+ * the scalar path stays the reference for the golden files.
+ * ------------------------------------------------------------------------- */
+typedef double orc_v4 __attribute__((vector_size(32), aligned(8)));
+
+static int orc_fast(void)
+{
+  static int on = -1;
+  if (on < 0) { const char * e = getenv("ORC_FAST"); on = (e && atoi(e)) ? 1 : 0; }
+  return on;
+}
+
+/* a[0..S) = sum_j Pt[j][0..S) * c[j];  S = 4 * NV */
+#define ORC_MATVEC(NV, Pt, c, a)                                        \
+  do {                                                                  \
+    unsigned int j_, v_;                                                \
+    for (v_ = 0; v_ < NV; ++v_) a[v_] = (orc_v4){0.0, 0.0, 0.0, 0.0};   \
+    for (j_ = 0; j_ < 4 * NV; ++j_)                                     \
+    {                                                                   \
+      const double cj_ = (c)[j_];                                       \
+      const orc_v4 b_ = {cj_, cj_, cj_, cj_};                           \
+      const orc_v4 * row_ = (const orc_v4 *)((Pt) + j_ * 4 * NV);       \
+      for (v_ = 0; v_ < NV; ++v_) a[v_] += row_[v_] * b_;               \
+    }                                                                   \
+  } while (0)
+
+#define ORC_FAST_BODY(NV)                                                                     \
+  for (n = 0; n < (long)p->sites; ++n)                                                        \
+  {                                                                                           \
+    double * out = parent + (size_t)n * R * Sp;                                               \
+    int all_small = 1;                                                                        \
+    unsigned int r, v;                                                                        \
+    for (r = 0; r < R; ++r)                                                                   \
+    {                                                                                         \
+      orc_v4 a[NV], b[NV];                                                                    \
+      if (tip1) memcpy(a, lut1 + ((size_t)r * nc + code1[n]) * S, sizeof(a));                 \
+      else ORC_MATVEC(NV, Pt1 + (size_t)r * S * S, c1 + ((size_t)n * R + r) * Sp, a);         \
+      if (tip2) memcpy(b, lut2 + ((size_t)r * nc + code2[n]) * S, sizeof(b));                 \
+      else ORC_MATVEC(NV, Pt2 + (size_t)r * S * S, c2 + ((size_t)n * R + r) * Sp, b);         \
+      for (v = 0; v < NV; ++v)                                                                \
+      {                                                                                       \
+        const orc_v4 x = a[v] * b[v];                                                         \
+        memcpy(out + r * Sp + 4 * v, &x, sizeof(x));                                          \
+        if (!(x[0] < PLL_SCALE_THRESHOLD && x[1] < PLL_SCALE_THRESHOLD &&                     \
+              x[2] < PLL_SCALE_THRESHOLD && x[3] < PLL_SCALE_THRESHOLD)) all_small = 0;       \
+      }                                                                                       \
+    }                                                                                         \
+    if (ps)                                                                                   \
+    {                                                                                         \
+      unsigned int cnt = (s1 ? s1[n] : 0) + (s2 ? s2[n] : 0);                                 \
+      if (all_small)                                                                          \
+      {                                                                                       \
+        unsigned int i;                                                                       \
+        for (i = 0; i < R * Sp; ++i) out[i] *= PLL_SCALE_FACTOR;                              \
+        cnt += 1;                                                                             \
+      }                                                                                       \
+      ps[n] = cnt;                                                                            \
+    }                                                                                         \
+  }
+
+static void partials_fast(pll_partition_t * p, double * parent, unsigned int * ps,
+                          const unsigned int * s1, const unsigned int * s2,
+                          const double * P1, const double * P2, int tip1, int tip2,
+                          const unsigned char * code1, const unsigned char * code2,
+                          const double * c1, const double * c2,
+                          const double * lut1, const double * lut2)
+{
+  const unsigned int S = p->states, Sp = p->states_padded, R = p->rate_cats, nc = p->maxstates;
+  double * Pt1 = (double *)malloc(sizeof(double) * 2 * R * S * S), * Pt2 = Pt1 + (size_t)R * S * S;
+  unsigned int r, i, j;
+  long n;
+  for (r = 0; r < R; ++r)
+    for (i = 0; i < S; ++i)
+      for (j = 0; j < S; ++j)
+      {
+        Pt1[((size_t)r * S + j) * S + i] = P1[((size_t)r * S + i) * Sp + j];
+        Pt2[((size_t)r * S + j) * S + i] = P2[((size_t)r * S + i) * Sp + j];
+      }
+  if (S == 20)
+  {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if ((size_t)p->sites * R * S * S > 4000000)
+#endif
+    ORC_FAST_BODY(5)
+  }
+  else
+  {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if ((size_t)p->sites * R * S * S > 4000000)
+#endif
+    ORC_FAST_BODY(1)
+  }
+  free(Pt1);
+}
+
 void pll_update_partials(pll_partition_t * p, const pll_operation_t * ops,
                          unsigned int count)
 {
@@ -135,6 +237,14 @@ void pll_update_partials(pll_partition_t * p, const pll_operation_t * ops,
       free(lut1); free(lut2);
       orc_set_error(PLL_ERROR_MEM_ALLOC, "tip lookup");
       return;
+    }
+
+    if (orc_fast() && (S == 20 || S == 4) && Sp == S)
+    {
+      partials_fast(p, parent, ps, s1, s2, P1, P2, tip1, tip2, code1, code2, c1, c2, lut1, lut2);
+      free(lut1);
+      free(lut2);
+      continue;
     }
 
     long n;

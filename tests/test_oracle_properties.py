@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import pllhip_ctypes as pc
+from conftest import ORACLE_LIB
 
 NONE = pc.PLL_SCALE_BUFFER_NONE
 
@@ -147,3 +148,34 @@ def test_error_reporting(oracle):
         with pytest.raises(RuntimeError):
             a.set_pinv(1.5)
         assert oracle.errno == 118
+
+
+def test_vectorised_partials_agree_with_the_scalar_path():
+    """ORC_FAST=1 (what bench.py's cpu_baseline times) reorders the sums of the 4- and
+    20-state partials; it must give the scalar path's numbers to rounding, scalers exactly"""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import pllhip_ctypes as pc
+lib = pc.PllLib(%r)
+for S, n in ((20, 120), (4, 300)):
+    with pc.build_instance(lib, states=S, rate_cats=4, ntips=n, nsites=61, coded=True) as a:
+        l = pc.full_traversal(a)
+        root = a.tree.root_a
+        print(repr(l), a.get_scaler(a.tree.scaler_of(root)).tolist(), repr(float(np.abs(a.get_clv(root)).sum())))
+""" % (os.path.dirname(pc.__file__), ORACLE_LIB)
+    out = []
+    for fast in ("0", "1"):
+        env = dict(os.environ, ORC_FAST=fast)
+        out.append(subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True,
+                                  text=True, timeout=300).stdout.splitlines())
+    for a, b in zip(*out):
+        la, sa, ca = a.split(" ", 1)[0], a[a.index("["):a.index("]") + 1], a.rsplit(" ", 1)[1]
+        lb, sb, cb = b.split(" ", 1)[0], b[b.index("["):b.index("]") + 1], b.rsplit(" ", 1)[1]
+        assert sa == sb and any(ch in "123456789" for ch in sa)    # same scaling decisions; scaling happened
+        assert abs(float(la) - float(lb)) < 1e-12 * abs(float(la))
+        assert abs(float(ca) - float(cb)) < 1e-11 * abs(float(ca))
