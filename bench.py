@@ -93,7 +93,7 @@ def cpu_baseline(pc, tree, config, states, rate_cats, nsites_gpu, cpu_sites, per
     threads = min(os.cpu_count() or 1, 16)      # the 1-GPU box share of host cores
     os.environ.setdefault("OMP_NUM_THREADS", str(threads))
     os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("ORC_FAST", "1")      # the oracle's AVX2-vectorised partials (4 / 20 states)
+    os.environ.setdefault("ORC_FAST", "1")      # the oracle's AVX2-vectorised partials (4 / 20 / 61 states)
     oracle = pc.PllLib(os.path.join(ROOT, "oracle", "_build", "libpll_oracle.so"))
     ntips = tree.ntips
     if not cpu_sites:
@@ -116,7 +116,7 @@ def cpu_baseline(pc, tree, config, states, rate_cats, nsites_gpu, cpu_sites, per
     updates = reps * (ntips - 2) * cpu_sites * rate_cats
     return {"value": updates / dt, "unit": "CLV site-updates/s", "cores": threads, "kind": "port",
             "sample": f"{reps} full evaluations of the same tree/model with {cpu_sites} sites "
-                      f"(oracle/, plain C + OpenMP over sites, AVX2-vectorised partials for 4 / 20 states, "
+                      f"(oracle/, plain C + OpenMP over sites, AVX2-vectorised partials, "
                       f"{threads} threads); lnL/site "
                       f"{lnl / cpu_sites:.6f}"}
 

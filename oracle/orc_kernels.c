@@ -103,7 +103,7 @@ static double * tip_lookup(const pll_partition_t * p, const double * P)
 }
 
 /* ---------------------------------------------------------------------------
- * Vectorised variant for 4 and 20 states (GCC vector extensions -> AVX2 + FMA with
+ * Vectorised variant for 4, 20 and 61 states (GCC vector extensions -> AVX2 + FMA with
  * -march=x86-64-v3), used when ORC_FAST=1: the P-matrix is transposed once per
  * operation and rate so that a parent vector is built as sum_j Pt[j][:] * c[j]
  * (broadcast-multiply-accumulate over whole state vectors instead of one dot product
@@ -121,12 +121,12 @@ static int orc_fast(void)
   return on;
 }
 
-/* a[0..S) = sum_j Pt[j][0..S) * c[j];  S = 4 * NV */
+/* a[0..4NV) = sum_{j<S} Pt[j][0..4NV) * c[j];  4 NV = S rounded up to a multiple of 4 */
 #define ORC_MATVEC(NV, Pt, c, a)                                        \
   do {                                                                  \
     unsigned int j_, v_;                                                \
     for (v_ = 0; v_ < NV; ++v_) a[v_] = (orc_v4){0.0, 0.0, 0.0, 0.0};   \
-    for (j_ = 0; j_ < 4 * NV; ++j_)                                     \
+    for (j_ = 0; j_ < S; ++j_)                                          \
     {                                                                   \
       const double cj_ = (c)[j_];                                       \
       const orc_v4 b_ = {cj_, cj_, cj_, cj_};                           \
@@ -144,14 +144,15 @@ static int orc_fast(void)
     for (r = 0; r < R; ++r)                                                                   \
     {                                                                                         \
       orc_v4 a[NV], b[NV];                                                                    \
-      if (tip1) memcpy(a, lut1 + ((size_t)r * nc + code1[n]) * S, sizeof(a));                 \
-      else ORC_MATVEC(NV, Pt1 + (size_t)r * S * S, c1 + ((size_t)n * R + r) * Sp, a);         \
-      if (tip2) memcpy(b, lut2 + ((size_t)r * nc + code2[n]) * S, sizeof(b));                 \
-      else ORC_MATVEC(NV, Pt2 + (size_t)r * S * S, c2 + ((size_t)n * R + r) * Sp, b);         \
+      if (tip1) { memset(a, 0, sizeof(a)); memcpy(a, lut1 + ((size_t)r * nc + code1[n]) * S, S * sizeof(double)); } \
+      else ORC_MATVEC(NV, Pt1 + (size_t)r * S * 4 * NV, c1 + ((size_t)n * R + r) * Sp, a);    \
+      if (tip2) { memset(b, 0, sizeof(b)); memcpy(b, lut2 + ((size_t)r * nc + code2[n]) * S, S * sizeof(double)); } \
+      else ORC_MATVEC(NV, Pt2 + (size_t)r * S * 4 * NV, c2 + ((size_t)n * R + r) * Sp, b);    \
       for (v = 0; v < NV; ++v)                                                                \
       {                                                                                       \
         const orc_v4 x = a[v] * b[v];                                                         \
-        memcpy(out + r * Sp + 4 * v, &x, sizeof(x));                                          \
+        const unsigned int left = Sp - 4 * v;                                                 \
+        memcpy(out + r * Sp + 4 * v, &x, (left < 4 ? left : 4) * sizeof(double));             \
         if (!(x[0] < PLL_SCALE_THRESHOLD && x[1] < PLL_SCALE_THRESHOLD &&                     \
               x[2] < PLL_SCALE_THRESHOLD && x[3] < PLL_SCALE_THRESHOLD)) all_small = 0;       \
       }                                                                                       \
@@ -177,17 +178,26 @@ static void partials_fast(pll_partition_t * p, double * parent, unsigned int * p
                           const double * lut1, const double * lut2)
 {
   const unsigned int S = p->states, Sp = p->states_padded, R = p->rate_cats, nc = p->maxstates;
-  double * Pt1 = (double *)malloc(sizeof(double) * 2 * R * S * S), * Pt2 = Pt1 + (size_t)R * S * S;
+  /* transposed, rows zero-padded to W = S rounded up to a multiple of 4: Pt[r][j][0..W) */
+  const unsigned int W = (S + 3u) & ~3u;
+  double * Pt1 = (double *)calloc((size_t)2 * R * S * W, sizeof(double)), * Pt2 = Pt1 + (size_t)R * S * W;
   unsigned int r, i, j;
   long n;
   for (r = 0; r < R; ++r)
     for (i = 0; i < S; ++i)
       for (j = 0; j < S; ++j)
       {
-        Pt1[((size_t)r * S + j) * S + i] = P1[((size_t)r * S + i) * Sp + j];
-        Pt2[((size_t)r * S + j) * S + i] = P2[((size_t)r * S + i) * Sp + j];
+        Pt1[((size_t)r * S + j) * W + i] = P1[((size_t)r * S + i) * Sp + j];
+        Pt2[((size_t)r * S + j) * W + i] = P2[((size_t)r * S + i) * Sp + j];
       }
-  if (S == 20)
+  if (W == 64)
+  {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if ((size_t)p->sites * R * S * S > 4000000)
+#endif
+    ORC_FAST_BODY(16)
+  }
+  else if (S == 20)
   {
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) if ((size_t)p->sites * R * S * S > 4000000)
@@ -239,7 +249,7 @@ void pll_update_partials(pll_partition_t * p, const pll_operation_t * ops,
       return;
     }
 
-    if (orc_fast() && (S == 20 || S == 4) && Sp == S)
+    if (orc_fast() && (S == 20 || S == 4 || S == 61))
     {
       partials_fast(p, parent, ps, s1, s2, P1, P2, tip1, tip2, code1, code2, c1, c2, lut1, lut2);
       free(lut1);

@@ -151,8 +151,8 @@ def test_error_reporting(oracle):
 
 
 def test_vectorised_partials_agree_with_the_scalar_path():
-    """ORC_FAST=1 (what bench.py's cpu_baseline times) reorders the sums of the 4- and
-    20-state partials; it must give the scalar path's numbers to rounding, scalers exactly"""
+    """ORC_FAST=1 (what bench.py's cpu_baseline times) reorders the sums of the 4-, 20- and
+    61-state partials; it must give the scalar path's numbers to rounding, scalers exactly"""
     import os
     import subprocess
     import sys
@@ -162,7 +162,7 @@ sys.path.insert(0, %r)
 import numpy as np
 import pllhip_ctypes as pc
 lib = pc.PllLib(%r)
-for S, n in ((20, 120), (4, 300)):
+for S, n in ((20, 120), (4, 300), (61, 60)):
     with pc.build_instance(lib, states=S, rate_cats=4, ntips=n, nsites=61, coded=True) as a:
         l = pc.full_traversal(a)
         root = a.tree.root_a
