@@ -144,6 +144,11 @@ __global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, 
     unsigned child_cnt = 0;
     if (op.parent_scaler && nsc < N)
       child_cnt = (op.scaler1 ? op.scaler1[nsc] : 0u) + (op.scaler2 ? op.scaler2[nsc] : 0u);
+    // the tip codes of the chunk's 64 sites: one coalesced byte load per child (lane l holds
+    // site l); an iteration picks its site's code with a lane shuffle
+    const unsigned long long ncode = nsc < N ? nsc : 0ULL;
+    const int cb1 = op.codes1 ? (int)op.codes1[ncode] : 0;
+    const int cb2 = op.codes2 ? (int)op.codes2[ncode] : 0;
     for (unsigned k0 = 0; k0 < group; k0 += U)
     {
       double2 in1[U], in2[U];
@@ -152,21 +157,23 @@ __global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, 
       for (unsigned u = 0; u < U; ++u)
       {
         const unsigned long long gu = hc0 + (unsigned long long)(k0 + u) * 64ULL;
+        const int src = (int)(((k0 + u) * spi + (lane >> (rs + 1))) & 63u);
         live[u] = (k0 + u < group) && gu < total;
         in1[u] = in2[u] = make_double2(0.0, 0.0);
+        const int code1 = op.codes1 ? __shfl(cb1, src, 64) : 0;
+        const int code2 = op.codes2 ? __shfl(cb2, src, 64) : 0;
         if (live[u])
         {
-          const unsigned long long n = (gu >> 1) >> rs;
           if (!op.codes1) in1[u] = *reinterpret_cast<const double2 *>(op.clv1 + gu * 2);
           else if (lut_lds)
-            in1[u] = *reinterpret_cast<const double2 *>(&lut_s[0][(r * 16 + op.codes1[n]) * 4 + 2 * h]);
+            in1[u] = *reinterpret_cast<const double2 *>(&lut_s[0][(r * 16 + code1) * 4 + 2 * h]);
           else
-            in1[u] = *reinterpret_cast<const double2 *>(op.lut1 + ((size_t)r * lut_codes + op.codes1[n]) * 4 + 2 * h);
+            in1[u] = *reinterpret_cast<const double2 *>(op.lut1 + ((size_t)r * lut_codes + code1) * 4 + 2 * h);
           if (!op.codes2) in2[u] = *reinterpret_cast<const double2 *>(op.clv2 + gu * 2);
           else if (lut_lds)
-            in2[u] = *reinterpret_cast<const double2 *>(&lut_s[1][(r * 16 + op.codes2[n]) * 4 + 2 * h]);
+            in2[u] = *reinterpret_cast<const double2 *>(&lut_s[1][(r * 16 + code2) * 4 + 2 * h]);
           else
-            in2[u] = *reinterpret_cast<const double2 *>(op.lut2 + ((size_t)r * lut_codes + op.codes2[n]) * 4 + 2 * h);
+            in2[u] = *reinterpret_cast<const double2 *>(op.lut2 + ((size_t)r * lut_codes + code2) * 4 + 2 * h);
         }
       }
 #pragma unroll
@@ -264,6 +271,12 @@ __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
         if (op.scaler2) child_cnt += (carried == 2) ? xcnt : op.scaler2[nsc];
       }
       unsigned scaled_mask = 0;
+      // the tip codes of the chunk's 64 sites: one coalesced byte load per child (lane l holds
+      // site l of the chunk); an iteration picks its site's code with a lane shuffle, so no
+      // global load sits in front of the table lookup
+      const unsigned long long ncode = nsc < N ? nsc : 0ULL;
+      const int cb1 = op.codes1 ? (int)op.codes1[ncode] : 0;
+      const int cb2 = op.codes2 ? (int)op.codes2[ncode] : 0;
 #pragma unroll
       for (unsigned k0 = 0; k0 < group; k0 += U)
       {
@@ -273,16 +286,18 @@ __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
         for (unsigned u = 0; u < U; ++u)
         {
           const unsigned long long gu = hc0 + (unsigned long long)(k0 + u) * 64ULL;
+          const int src = (int)((k0 + u) * spi + lane / group);       // this lane's site within the chunk
           live[u] = gu < total;
           in1[u] = in2[u] = make_double2(0.0, 0.0);
+          const int code1 = op.codes1 ? __shfl(cb1, src, 64) : 0;
+          const int code2 = op.codes2 ? __shfl(cb2, src, 64) : 0;
           if (live[u])
           {
-            const unsigned long long n = (gu >> 1) >> rs;
             if (op.codes1)
-              in1[u] = *reinterpret_cast<const double2 *>(&base[r * S4_LUT_RS + op.codes1[n] * 4 + 2 * h]);
+              in1[u] = *reinterpret_cast<const double2 *>(&base[r * S4_LUT_RS + code1 * 4 + 2 * h]);
             else if (carried != 1) in1[u] = *reinterpret_cast<const double2 *>(op.clv1 + gu * 2);
             if (op.codes2)
-              in2[u] = *reinterpret_cast<const double2 *>(&base[T2 + r * S4_LUT_RS + op.codes2[n] * 4 + 2 * h]);
+              in2[u] = *reinterpret_cast<const double2 *>(&base[T2 + r * S4_LUT_RS + code2 * 4 + 2 * h]);
             else if (carried != 2) in2[u] = *reinterpret_cast<const double2 *>(op.clv2 + gu * 2);
           }
         }
