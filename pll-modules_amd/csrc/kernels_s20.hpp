@@ -111,10 +111,14 @@ __device__ inline void s20_child_inner(const double * unit, const double * frag_
   t[4] = make_double2(a1e[0], a1o[0]);
 }
 
+// row stride of a lookup table staged in LDS: 21 doubles -- with 20, codes that differ by a
+// multiple of 8 share all their banks (40 * code mod 64)
+constexpr unsigned S20_LUT_RS = 21;
+
 __device__ inline void s20_child_tip(const double * lut_r, unsigned code_e, unsigned code_o,
-                                     unsigned q, double2 t[5])
+                                     unsigned q, double2 t[5], unsigned stride = 20)
 {
-  const double * le = lut_r + code_e * 20, * lo = lut_r + code_o * 20;
+  const double * le = lut_r + code_e * stride, * lo = lut_r + code_o * stride;
 #pragma unroll
   for (unsigned k = 0; k < 5; ++k)
   {
@@ -178,17 +182,17 @@ __device__ inline void s20_op_body(const OpDesc & op, unsigned nblk, unsigned Rr
   const bool nt_ld = flags & 1u, nt_st = flags & 2u;
   const unsigned R = RT ? RT : Rrt;
   // each child owns R * S20_FRAGS doubles of LDS: the A fragments of its P-matrix,
-  // or -- for a coded tip -- its lookup table (fits while lut_codes <= 32); LUT
+  // or -- for a coded tip -- its lookup table (fits while lut_codes <= 30, rows padded to 21); LUT
   // gathers then hit LDS banks instead of the L1 address pipeline, which is what
   // bounds tip x tip operations otherwise
-  const bool lut_lds = lut_codes <= 32;
+  const bool lut_lds = lut_codes * S20_LUT_RS <= S20_FRAGS;
   double * const frag2 = frag + R * S20_FRAGS;
   if (!op.codes1) s20_fill_frags(frag, op.pmat1, R);
   else if (lut_lds)
-    for (unsigned e = threadIdx.x; e < R * lut_codes * 20; e += blockDim.x) frag[e] = op.lut1[e];
+    for (unsigned e = threadIdx.x; e < R * lut_codes * 20; e += blockDim.x) frag[(e / 20) * S20_LUT_RS + e % 20] = op.lut1[e];
   if (!op.codes2) s20_fill_frags(frag2, op.pmat2, R);
   else if (lut_lds)
-    for (unsigned e = threadIdx.x; e < R * lut_codes * 20; e += blockDim.x) frag2[e] = op.lut2[e];
+    for (unsigned e = threadIdx.x; e < R * lut_codes * 20; e += blockDim.x) frag2[(e / 20) * S20_LUT_RS + e % 20] = op.lut2[e];
   __syncthreads();
 
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -215,10 +219,10 @@ __device__ inline void s20_op_body(const OpDesc & op, unsigned nblk, unsigned Rr
         const size_t ubase = ((size_t)blk * RT + r) * S20_UNIT;
         double2 t2[5];
         if (!op.codes1) s20_child_inner(op.clv1 + ubase, frag + r * S20_FRAGS, lane, out[r], nt_ld);
-        else if (lut_lds) s20_child_tip(frag + r * lut_codes * 20, c1e, c1o, q, out[r]);
+        else if (lut_lds) s20_child_tip(frag + r * lut_codes * S20_LUT_RS, c1e, c1o, q, out[r], S20_LUT_RS);
         else s20_child_tip(op.lut1 + (size_t)r * lut_codes * 20, c1e, c1o, q, out[r]);
         if (!op.codes2) s20_child_inner(op.clv2 + ubase, frag2 + r * S20_FRAGS, lane, t2, nt_ld);
-        else if (lut_lds) s20_child_tip(frag2 + r * lut_codes * 20, c2e, c2o, q, t2);
+        else if (lut_lds) s20_child_tip(frag2 + r * lut_codes * S20_LUT_RS, c2e, c2o, q, t2, S20_LUT_RS);
         else s20_child_tip(op.lut2 + (size_t)r * lut_codes * 20, c2e, c2o, q, t2);
 #pragma unroll
         for (int k = 0; k < 5; ++k)
@@ -260,10 +264,10 @@ __device__ inline void s20_op_body(const OpDesc & op, unsigned nblk, unsigned Rr
       const size_t ubase = ((size_t)blk * R + r) * S20_UNIT;
       double2 t1[5], t2[5];
       if (!op.codes1) s20_child_inner(op.clv1 + ubase, frag + r * S20_FRAGS, lane, t1, nt_ld);
-      else if (lut_lds) s20_child_tip(frag + r * lut_codes * 20, c1e, c1o, q, t1);
+      else if (lut_lds) s20_child_tip(frag + r * lut_codes * S20_LUT_RS, c1e, c1o, q, t1, S20_LUT_RS);
       else s20_child_tip(op.lut1 + (size_t)r * lut_codes * 20, c1e, c1o, q, t1);
       if (!op.codes2) s20_child_inner(op.clv2 + ubase, frag2 + r * S20_FRAGS, lane, t2, nt_ld);
-      else if (lut_lds) s20_child_tip(frag2 + r * lut_codes * 20, c2e, c2o, q, t2);
+      else if (lut_lds) s20_child_tip(frag2 + r * lut_codes * S20_LUT_RS, c2e, c2o, q, t2, S20_LUT_RS);
       else s20_child_tip(op.lut2 + (size_t)r * lut_codes * 20, c2e, c2o, q, t2);
 #pragma unroll
       for (int k = 0; k < 5; ++k)
@@ -371,11 +375,11 @@ __device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2
     double2 t1[5], t2[5];
     if (carried == 1) s20_child_regs(X[r], frag + r * S20_FRAGS, lane, t1);
     else if (!op.codes1) s20_child_inner(op.clv1 + ubase, frag + r * S20_FRAGS, lane, t1, nt_ld);
-    else if (lut_lds) s20_child_tip(frag + r * lut_codes * 20, c1e, c1o, q, t1);
+    else if (lut_lds) s20_child_tip(frag + r * lut_codes * S20_LUT_RS, c1e, c1o, q, t1, S20_LUT_RS);
     else s20_child_tip(op.lut1 + (size_t)r * lut_codes * 20, c1e, c1o, q, t1);
     if (carried == 2) s20_child_regs(X[r], frag2 + r * S20_FRAGS, lane, t2);
     else if (!op.codes2) s20_child_inner(op.clv2 + ubase, frag2 + r * S20_FRAGS, lane, t2, nt_ld);
-    else if (lut_lds) s20_child_tip(frag2 + r * lut_codes * 20, c2e, c2o, q, t2);
+    else if (lut_lds) s20_child_tip(frag2 + r * lut_codes * S20_LUT_RS, c2e, c2o, q, t2, S20_LUT_RS);
     else s20_child_tip(op.lut2 + (size_t)r * lut_codes * 20, c2e, c2o, q, t2);
     // X[r] has been consumed (if it was an operand at all): it now takes the result
 #pragma unroll
@@ -433,10 +437,10 @@ __device__ inline void s20_fill_op(double * frag, const OpDesc & op, unsigned R,
   double * const frag2 = frag + R * S20_FRAGS;
   if (!op.codes1) s20_fill_frags(frag, op.pmat1, R);
   else if (lut_lds)
-    for (unsigned e = threadIdx.x; e < R * lut_codes * 20; e += blockDim.x) frag[e] = op.lut1[e];
+    for (unsigned e = threadIdx.x; e < R * lut_codes * 20; e += blockDim.x) frag[(e / 20) * S20_LUT_RS + e % 20] = op.lut1[e];
   if (!op.codes2) s20_fill_frags(frag2, op.pmat2, R);
   else if (lut_lds)
-    for (unsigned e = threadIdx.x; e < R * lut_codes * 20; e += blockDim.x) frag2[e] = op.lut2[e];
+    for (unsigned e = threadIdx.x; e < R * lut_codes * 20; e += blockDim.x) frag2[(e / 20) * S20_LUT_RS + e % 20] = op.lut2[e];
 }
 
 // Chains of at most S20_CHAIN_MAX operations: the fragments of ALL of them stay in LDS
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_chain_s20(ChainBatc
 {
   extern __shared__ double lds[];
   const bool nt_ld = flags & 1u, nt_st = flags & 2u;
-  const bool lut_lds = lut_codes <= 32;
+  const bool lut_lds = lut_codes * S20_LUT_RS <= S20_FRAGS;
   const unsigned first = batch.first[blockIdx.y], len = batch.len[blockIdx.y];
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // (filling twice costs 5 % at 125 k sites and nothing at 1 M: the fill is not what small

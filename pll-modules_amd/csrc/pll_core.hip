@@ -422,10 +422,10 @@ static int ensure_luts(pll_partition_t * p)
   if (!e->d_lut || e->lut_codes < want)
   {
     // grow with head-room so that a few late codes do not re-allocate
-    // (but never past the size the 20-/61-state kernels can stage in LDS: 32 / 67 codes)
+    // (but never past the size the 20-/61-state kernels can stage in LDS: 30 / 67 codes)
     unsigned cap = std::min<unsigned>(PLL_ASCII_SIZE, std::max(want, (e->S == 4) ? 16u : want + 8u));
     if (e->family == KernelFamily::S61 && want <= 67u) cap = std::min(cap, 67u);
-    if (e->family == KernelFamily::S20 && want <= 32u) cap = std::min(cap, 32u);
+    if (e->family == KernelFamily::S20 && want <= 30u) cap = std::min(cap, 30u);
     if (e->d_lut) { PLLHIP_TRY(hipStreamSynchronize(e->stream)); (void)hipFree(e->d_lut); e->d_lut = nullptr; }
     if (!dev_alloc(&e->d_lut, (size_t)e->nmat * e->R * cap * e->S, "tip lookup tables")) return PLL_FAILURE;
     e->lut_codes = cap;
