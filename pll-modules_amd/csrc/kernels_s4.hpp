@@ -40,9 +40,20 @@ __device__ inline double dot4(const double * row, const d4 & c)
   return row[0] * c.x + row[1] * c.y + row[2] * c.z + row[3] * c.w;
 }
 
+// lane ^ 1 / lane ^ 2 within a quad: DPP quad permutes, no LDS round trip
+template <int CTRL>
+__device__ inline double dpp_quad(double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ inline double group_sum(double v, unsigned R)
 {
-  for (unsigned off = 1; off < R; off <<= 1) v += __shfl_xor(v, off, 64);
+  if (R >= 2) v += dpp_quad<0xB1>(v);            // quad_perm [1,0,3,2]
+  if (R >= 4) v += dpp_quad<0x4E>(v);            // quad_perm [2,3,0,1]
+  for (unsigned off = 4; off < R; off <<= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
 
@@ -374,6 +385,7 @@ __global__ __launch_bounds__(256) void k_edge_lnl_s4(ModelView mv, ParamIdx fidx
     d4 cv[4], pv[4];
     bool live[4];
     unsigned long long nn[4];
+    unsigned cnt[4], wgt[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
     {
@@ -382,11 +394,15 @@ __global__ __launch_bounds__(256) void k_edge_lnl_s4(ModelView mv, ParamIdx fidx
       nn[u] = live[u] ? gu >> rs : 0;
       cv[u] = d4{0, 0, 0, 0};
       pv[u] = d4{0, 0, 0, 0};
+      cnt[u] = wgt[u] = 0;
       if (live[u])
       {
         cv[u] = child.codes ? load4(lut + ((size_t)r * lut_codes + child.codes[nn[u]]) * 4)
                             : load4(child.clv + gu * 4);
         pv[u] = parent.codes ? tip_value4(tipmap[parent.codes[nn[u]]]) : load4(parent.clv + gu * 4);
+        // needed only after the reduction over the rates: fetch them with the vectors, not after
+        cnt[u] = (ps ? ps[nn[u]] : 0u) + (cs ? cs[nn[u]] : 0u);
+        wgt[u] = weights[nn[u]];
       }
     }
 #pragma unroll
@@ -407,10 +423,9 @@ __global__ __launch_bounds__(256) void k_edge_lnl_s4(ModelView mv, ParamIdx fidx
       if (live[u] && r == 0)
       {
         const unsigned long long n = nn[u];
-        const unsigned cnt = (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
-        const double l = site_loglh(lr, cnt, inv);
+        const double l = site_loglh(lr, cnt[u], inv);
         if (persite) persite[n] = l;
-        acc += l * (double)weights[n];
+        acc += l * (double)wgt[u];
       }
     }
   }
