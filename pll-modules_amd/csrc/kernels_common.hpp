@@ -133,6 +133,32 @@ __device__ inline void grid_reduce_finish2(double a, double b, const ReduceOut &
   grid_reduce_finish<2>(t, ro, scratch);
 }
 
+// per-site side values of a reduction kernel (scaler counts of both ends, pattern weight)
+// for the two sites of a lane: fetched at the top of a block iteration -- they are needed
+// only after the reduction over states and rates, and a load issued there would sit in
+// front of the log / division with its full latency
+struct SiteSide { unsigned cnt_e, cnt_o, w_e, w_o; };
+
+__device__ inline SiteSide load_site_side(const unsigned * ps, const unsigned * cs, const unsigned * weights,
+                                          size_t site0, unsigned N, bool active)
+{
+  SiteSide sd = {0u, 0u, 0u, 0u};
+  if (active)
+  {
+    if (site0 < N)
+    {
+      sd.cnt_e = (ps ? ps[site0] : 0u) + (cs ? cs[site0] : 0u);
+      sd.w_e = weights[site0];
+    }
+    if (site0 + 1 < N)
+    {
+      sd.cnt_o = (ps ? ps[site0 + 1] : 0u) + (cs ? cs[site0 + 1] : 0u);
+      sd.w_o = weights[site0 + 1];
+    }
+  }
+  return sd;
+}
+
 // log of the site likelihood.  x is the likelihood carrying `cnt` scaling
 // steps (true value x * 2^(-256 cnt)); inv is the unscaled invariant-site
 // term.  Same case split as the oracle (oracle/orc_kernels.c site_loglh).

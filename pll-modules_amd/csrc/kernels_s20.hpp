@@ -507,6 +507,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_lnl_s20(ModelView mv, ParamIdx 
   for (unsigned blk = blockIdx.x * 4 + wave; blk < nblk; blk += wstride)
   {
     const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+    const SiteSide sd = load_site_side(ps, cs, weights, site0, N, q == 0 && blk < nblk);
     unsigned cce = 0, cco = 0;
     unsigned long long pme = 0, pmo = 0;
     if (child.codes) { cce = child.codes[site0]; cco = child.codes[site0 + 1]; }
@@ -562,17 +563,17 @@ __global__ __launch_bounds__(256, 2) void k_edge_lnl_s20(ModelView mv, ParamIdx 
     {
       if (site0 < N)
       {
-        const unsigned cnt = (ps ? ps[site0] : 0u) + (cs ? cs[site0] : 0u);
+        const unsigned cnt = sd.cnt_e;
         const double l = site_loglh(site_e, cnt, inv_e);
         if (persite) persite[site0] = l;
-        acc += l * (double)weights[site0];
+        acc += l * (double)sd.w_e;
       }
       if (site0 + 1 < N)
       {
-        const unsigned cnt = (ps ? ps[site0 + 1] : 0u) + (cs ? cs[site0 + 1] : 0u);
+        const unsigned cnt = sd.cnt_o;
         const double l = site_loglh(site_o, cnt, inv_o);
         if (persite) persite[site0 + 1] = l;
-        acc += l * (double)weights[site0 + 1];
+        acc += l * (double)sd.w_o;
       }
     }
   }
@@ -650,6 +651,7 @@ __global__ __launch_bounds__(256) void k_derivatives_s20(ModelView mv, ParamIdx 
   for (unsigned blk = blockIdx.x * 4 + wave; blk < nblk; blk += wstride)
   {
     const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+    const SiteSide sd = load_site_side(ps, cs, weights, site0, N, q == 0 && blk < nblk);
     double Ae = 0, Be = 0, Ce = 0, Ao = 0, Bo = 0, Co = 0, inv_e = 0, inv_o = 0;
     for (unsigned r = 0; r < R; ++r)
     {
@@ -679,10 +681,10 @@ __global__ __launch_bounds__(256) void k_derivatives_s20(ModelView mv, ParamIdx 
       {
         if (inv_e > 0.0)
         {
-          const unsigned cnt = (ps ? ps[site0] : 0u) + (cs ? cs[site0] : 0u);
+          const unsigned cnt = sd.cnt_e;
           Ae += (cnt <= 3) ? ldexp(inv_e, 256 * (int)cnt) : INFINITY;
         }
-        const double w = (double)weights[site0], ba = Be / Ae, ca = Ce / Ae;
+        const double w = (double)sd.w_e, ba = Be / Ae, ca = Ce / Ae;
         df -= w * ba;
         ddf += w * (ba * ba - ca);
       }
@@ -690,10 +692,10 @@ __global__ __launch_bounds__(256) void k_derivatives_s20(ModelView mv, ParamIdx 
       {
         if (inv_o > 0.0)
         {
-          const unsigned cnt = (ps ? ps[site0 + 1] : 0u) + (cs ? cs[site0 + 1] : 0u);
+          const unsigned cnt = sd.cnt_o;
           Ao += (cnt <= 3) ? ldexp(inv_o, 256 * (int)cnt) : INFINITY;
         }
-        const double w = (double)weights[site0 + 1], ba = Bo / Ao, ca = Co / Ao;
+        const double w = (double)sd.w_o, ba = Bo / Ao, ca = Co / Ao;
         df -= w * ba;
         ddf += w * (ba * ba - ca);
       }

@@ -500,12 +500,14 @@ __global__ __launch_bounds__(256) void k_derivatives_s4(ModelView mv, ParamIdx p
   {
     d4 sv[4];
     bool live[4];
+    unsigned wgt[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
     {
       const unsigned long long gu = g + u * stride;
       live[u] = gu < total;
       sv[u] = live[u] ? load4(sumtable + gu * 4) : d4{0, 0, 0, 0};
+      wgt[u] = live[u] ? weights[gu >> rs] : 0u;     // with the table, not behind the reduction
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(256) void k_derivatives_s4(ModelView mv, ParamIdx p
           const unsigned cnt = (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
           A += (cnt <= 3) ? ldexp(inv, 256 * (int)cnt) : INFINITY;
         }
-        const double w = (double)weights[n], ba = B / A, ca = C / A;
+        const double w = (double)wgt[u], ba = B / A, ca = C / A;
         df -= w * ba;
         ddf += w * (ba * ba - ca);
       }

@@ -515,6 +515,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_lnl_s61(ModelView mv, ParamIdx 
     const unsigned blk = tile * 4 + wave;
     const bool live = blk < nblk;
     const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+    const SiteSide sd = load_site_side(ps, cs, weights, site0, N, q == 0 && blk < nblk);
     unsigned cce = 0, cco = 0;
     unsigned long long pme = 0, pmo = 0;
     int inv_e = -1, inv_o = -1;
@@ -577,17 +578,17 @@ __global__ __launch_bounds__(256, 2) void k_edge_lnl_s61(ModelView mv, ParamIdx 
     {
       if (site0 < N)
       {
-        const unsigned cnt = (ps ? ps[site0] : 0u) + (cs ? cs[site0] : 0u);
+        const unsigned cnt = sd.cnt_e;
         const double l = site_loglh(site_e, cnt, ie);
         if (persite) persite[site0] = l;
-        acc += l * (double)weights[site0];
+        acc += l * (double)sd.w_e;
       }
       if (site0 + 1 < N)
       {
-        const unsigned cnt = (ps ? ps[site0 + 1] : 0u) + (cs ? cs[site0 + 1] : 0u);
+        const unsigned cnt = sd.cnt_o;
         const double l = site_loglh(site_o, cnt, io);
         if (persite) persite[site0 + 1] = l;
-        acc += l * (double)weights[site0 + 1];
+        acc += l * (double)sd.w_o;
       }
     }
   }
@@ -635,6 +636,7 @@ __global__ __launch_bounds__(256, 1) void k_edge_lnl_s61_r4(ModelView mv, ParamI
     const unsigned blk = first + 4 * i;
     const unsigned blkn = first + 4 * (i + 1 < nb ? i + 1 : i);
     const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+    const SiteSide sd = load_site_side(ps, cs, weights, site0, N, q == 0 && blk < nblk);
     unsigned long long pme = 0, pmo = 0;
     int inv_e = -1, inv_o = -1;
     if (parent.codes) { pme = tipmap[parent.codes[site0]]; pmo = tipmap[parent.codes[site0 + 1]]; }
@@ -694,17 +696,17 @@ __global__ __launch_bounds__(256, 1) void k_edge_lnl_s61_r4(ModelView mv, ParamI
     {
       if (site0 < N)
       {
-        const unsigned cnt = (ps ? ps[site0] : 0u) + (cs ? cs[site0] : 0u);
+        const unsigned cnt = sd.cnt_e;
         const double l = site_loglh(site_e, cnt, ie);
         if (persite) persite[site0] = l;
-        acc_lnl += l * (double)weights[site0];
+        acc_lnl += l * (double)sd.w_e;
       }
       if (site0 + 1 < N)
       {
-        const unsigned cnt = (ps ? ps[site0 + 1] : 0u) + (cs ? cs[site0 + 1] : 0u);
+        const unsigned cnt = sd.cnt_o;
         const double l = site_loglh(site_o, cnt, io);
         if (persite) persite[site0 + 1] = l;
-        acc_lnl += l * (double)weights[site0 + 1];
+        acc_lnl += l * (double)sd.w_o;
       }
     }
   }
@@ -783,6 +785,7 @@ __global__ __launch_bounds__(256) void k_derivatives_s61(ModelView mv, ParamIdx 
   for (unsigned blk = blockIdx.x * 4 + wave; blk < nblk; blk += wstride)
   {
     const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+    const SiteSide sd = load_site_side(ps, cs, weights, site0, N, q == 0 && blk < nblk);
     double Ae = 0, Be = 0, Ce = 0, Ao = 0, Bo = 0, Co = 0, inv_e = 0, inv_o = 0;
     for (unsigned r = 0; r < R; ++r)
     {
@@ -812,10 +815,10 @@ __global__ __launch_bounds__(256) void k_derivatives_s61(ModelView mv, ParamIdx 
       {
         if (inv_e > 0.0)
         {
-          const unsigned cnt = (ps ? ps[site0] : 0u) + (cs ? cs[site0] : 0u);
+          const unsigned cnt = sd.cnt_e;
           Ae += (cnt <= 3) ? ldexp(inv_e, 256 * (int)cnt) : INFINITY;
         }
-        const double w = (double)weights[site0], ba = Be / Ae, ca = Ce / Ae;
+        const double w = (double)sd.w_e, ba = Be / Ae, ca = Ce / Ae;
         df -= w * ba;
         ddf += w * (ba * ba - ca);
       }
@@ -823,10 +826,10 @@ __global__ __launch_bounds__(256) void k_derivatives_s61(ModelView mv, ParamIdx 
       {
         if (inv_o > 0.0)
         {
-          const unsigned cnt = (ps ? ps[site0 + 1] : 0u) + (cs ? cs[site0 + 1] : 0u);
+          const unsigned cnt = sd.cnt_o;
           Ao += (cnt <= 3) ? ldexp(inv_o, 256 * (int)cnt) : INFINITY;
         }
-        const double w = (double)weights[site0 + 1], ba = Bo / Ao, ca = Co / Ao;
+        const double w = (double)sd.w_o, ba = Bo / Ao, ca = Co / Ao;
         df -= w * ba;
         ddf += w * (ba * ba - ca);
       }
