@@ -74,6 +74,10 @@ __device__ inline d4 tip_value4(unsigned long long mask)
 // grid = (gx, ops), block = 256.
 struct HalfP { double own[4], oth[4]; };   // [a*2+b]
 
+// rate stride of a lookup table [rate][16 codes][4] staged in LDS: 68 doubles -- with 64 all
+// rates of a code share their banks
+constexpr unsigned S4_LUT_RS = 68;
+
 __device__ inline HalfP s4_load_half_p(const double * pmat, unsigned r, unsigned h)
 {
   HalfP q;
@@ -128,12 +132,12 @@ __global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, 
   // Inner children stage their R 4x4 matrices the same way (one global load per
   // thread instead of sixteen scattered ones per lane: the prologue of a workgroup
   // that lives for a few chunks only).
-  __shared__ double lut_s[2][16 * 16 * 4];
+  __shared__ double lut_s[2][16 * S4_LUT_RS];        // [rate][16 codes][4], rate stride padded (bank spread)
   __shared__ double pm_s[2][16 * 16];
   const bool lut_lds = lut_codes == 16;              // always true for DNA tip codes
-  if (op.codes1) { if (lut_lds) for (unsigned e = threadIdx.x; e < R * 64; e += 256) lut_s[0][e] = op.lut1[e]; }
+  if (op.codes1) { if (lut_lds) for (unsigned e = threadIdx.x; e < R * 64; e += 256) lut_s[0][(e >> 6) * S4_LUT_RS + (e & 63)] = op.lut1[e]; }
   else for (unsigned e = threadIdx.x; e < R * 16; e += 256) pm_s[0][e] = op.pmat1[e];
-  if (op.codes2) { if (lut_lds) for (unsigned e = threadIdx.x; e < R * 64; e += 256) lut_s[1][e] = op.lut2[e]; }
+  if (op.codes2) { if (lut_lds) for (unsigned e = threadIdx.x; e < R * 64; e += 256) lut_s[1][(e >> 6) * S4_LUT_RS + (e & 63)] = op.lut2[e]; }
   else for (unsigned e = threadIdx.x; e < R * 16; e += 256) pm_s[1][e] = op.pmat2[e];
   __syncthreads();
   HalfP p1 = {}, p2 = {};
@@ -177,12 +181,12 @@ __global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, 
         {
           if (!op.codes1) in1[u] = *reinterpret_cast<const double2 *>(op.clv1 + gu * 2);
           else if (lut_lds)
-            in1[u] = *reinterpret_cast<const double2 *>(&lut_s[0][(r * 16 + code1) * 4 + 2 * h]);
+            in1[u] = *reinterpret_cast<const double2 *>(&lut_s[0][r * S4_LUT_RS + code1 * 4 + 2 * h]);
           else
             in1[u] = *reinterpret_cast<const double2 *>(op.lut1 + ((size_t)r * lut_codes + code1) * 4 + 2 * h);
           if (!op.codes2) in2[u] = *reinterpret_cast<const double2 *>(op.clv2 + gu * 2);
           else if (lut_lds)
-            in2[u] = *reinterpret_cast<const double2 *>(&lut_s[1][(r * 16 + code2) * 4 + 2 * h]);
+            in2[u] = *reinterpret_cast<const double2 *>(&lut_s[1][r * S4_LUT_RS + code2 * 4 + 2 * h]);
           else
             in2[u] = *reinterpret_cast<const double2 *>(op.lut2 + ((size_t)r * lut_codes + code2) * 4 + 2 * h);
         }
@@ -230,7 +234,6 @@ __global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, 
 constexpr unsigned S4_CHAIN_MAX = 8;
 // LDS doubles per operation: two tables [R][16][4] (rate stride padded to 68 doubles: with 64
 // all rates of a code share their banks), two matrix sets [R][16]
-constexpr unsigned S4_LUT_RS = 68;
 constexpr unsigned s4_chain_op_lds(unsigned R) { return 2 * R * S4_LUT_RS + 2 * R * 16; }
 
 // (152 VGPRs, three waves per SIMD; forcing four costs 24 spilled registers and 25 % of the rate)
