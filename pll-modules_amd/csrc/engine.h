@@ -75,6 +75,8 @@ struct ChainBatch
   unsigned char len[MAX_OPS_PER_LAUNCH];         // per chain: number of ops
   unsigned char carried[MAX_OPS_PER_LAUNCH];     // per op: 0 = both children from memory,
                                                  // 1 / 2 = child 1 / 2 is the previous op's parent
+  unsigned short slot1[MAX_OPS_PER_LAUNCH];      // per op (20 states): LDS offsets, in doubles from the
+  unsigned short slot2[MAX_OPS_PER_LAUNCH];      // start of its chain's area, of the two children's tables
 };
 
 enum class KernelFamily { Generic, S4, S20, S61 };

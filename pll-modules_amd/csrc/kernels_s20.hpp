@@ -352,15 +352,77 @@ __device__ inline void s20_child_regs(const double2 b[5], const double * frag_r,
   t[4] = make_double2(a1e[0], a1o[0]);
 }
 
+// LDS economy of the chain kernel.  The second M-tile of a 20 x 20 matrix holds rows 16..19
+// only, i.e. just the lanes with (lane & 15) < 4 carry a value: those 16 lanes per k-step
+// are stored densely (80 instead of 320 doubles per rate), the others use a literal 0.  A
+// tip table is staged with the codes in use and rows of S20_LUT_RS doubles.  Per child:
+//   inner: RT * S20_CFRAGS doubles (12.5 KiB for four rates instead of 20 KiB)
+//   tip:   RT * codes * S20_LUT_RS doubles (13.8 KiB for 21 codes instead of 20 KiB)
+// so that five to six operations fit the 160 KiB instead of four.
+constexpr unsigned S20_CFRAGS = 5 * 64 + 5 * 16;      // compact A fragments per (child, rate)
+constexpr unsigned S20_CHAIN_LDS = 20480;             // doubles: the whole LDS of a CU
+constexpr unsigned S20_CHAIN_MAX = 8;                 // operations per chain (the LDS usually ends it earlier)
+constexpr unsigned S20_CHAIN_WAVES = 8;
+
+// cfrag[r*400 + ks*64 + lane]                  = M[r][lane & 15][4 ks + (lane >> 4)]
+// cfrag[r*400 + 320 + ks*16 + q*4 + n] (n < 4) = M[r][16 + n][4 ks + q]
+__device__ inline void s20_fill_cfrags(double * cfrag, const double * mats, unsigned R)
+{
+  for (unsigned e = threadIdx.x; e < R * S20_CFRAGS; e += blockDim.x)
+  {
+    const unsigned r = e / S20_CFRAGS, x = e % S20_CFRAGS;
+    unsigned i, j;
+    if (x < 320) { i = x & 15; j = 4 * (x >> 6) + ((x & 63) >> 4); }
+    else { const unsigned y = x - 320; i = 16 + (y & 3); j = 4 * (y >> 4) + ((y >> 2) & 3); }
+    cfrag[e] = mats[((size_t)r * 20 + i) * 20 + j];
+  }
+}
+
+// child term from a B operand in registers (b[ks] = rows 4 ks + q of the child vector)
+__device__ inline void s20_child_regs_c(const double2 b[5], const double * cfrag_r, unsigned lane,
+                                        double2 t[5])
+{
+  const unsigned q = lane >> 4, n = lane & 15;
+  const bool tail = n < 4;
+  const double * tail_r = cfrag_r + 320 + q * 4 + (tail ? n : 0);
+  v4d a0e = {0, 0, 0, 0}, a0o = {0, 0, 0, 0}, a1e = {0, 0, 0, 0}, a1o = {0, 0, 0, 0};
+#pragma unroll
+  for (int ks = 0; ks < 5; ++ks)
+  {
+    const double f0 = cfrag_r[ks * 64 + lane];
+    const double f1r = tail_r[ks * 16];
+    const double f1 = tail ? f1r : 0.0;
+    a0e = mfma_f64(f0, b[ks].x, a0e);
+    a0o = mfma_f64(f0, b[ks].y, a0o);
+    a1e = mfma_f64(f1, b[ks].x, a1e);
+    a1o = mfma_f64(f1, b[ks].y, a1o);
+  }
+  t[0] = make_double2(a0e[0], a0o[0]);
+  t[1] = make_double2(a0e[1], a0o[1]);
+  t[2] = make_double2(a0e[2], a0o[2]);
+  t[3] = make_double2(a0e[3], a0o[3]);
+  t[4] = make_double2(a1e[0], a1o[0]);
+}
+
+__device__ inline void s20_child_inner_c(const double * unit, const double * cfrag_r, unsigned lane,
+                                         double2 t[5], bool nt)
+{
+  double2 b[5];
+#pragma unroll
+  for (int ks = 0; ks < 5; ++ks)
+    b[ks] = s20_ld(unit + ks * 128 + lane * 2, nt);
+  s20_child_regs_c(b, cfrag_r, lane, t);
+}
+
 // one operation for one site block; X holds the handed-over operand on entry (when
-// carried != 0) and the result on exit
+// carried != 0) and the result on exit.  s1 / s2: the children's LDS tables.
 template <unsigned RT>
 __device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2 X[RT][5],
-                                    const double * frag, unsigned lut_codes, bool lut_lds,
+                                    const double * s1, const double * s2,
+                                    unsigned lut_codes, unsigned lut_used, bool lut_lds,
                                     unsigned blk, unsigned lane, bool nt_ld, bool nt_st,
                                     unsigned & xe, unsigned & xo)
 {
-  const double * frag2 = frag + RT * S20_FRAGS;
   const unsigned q = lane >> 4, n = lane & 15;
   const size_t site0 = (size_t)blk * S20_BS + 2 * n;
   unsigned c1e = 0, c1o = 0, c2e = 0, c2o = 0;
@@ -373,13 +435,13 @@ __device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2
   {
     const size_t ubase = ((size_t)blk * RT + r) * S20_UNIT;
     double2 t1[5], t2[5];
-    if (carried == 1) s20_child_regs(X[r], frag + r * S20_FRAGS, lane, t1);
-    else if (!op.codes1) s20_child_inner(op.clv1 + ubase, frag + r * S20_FRAGS, lane, t1, nt_ld);
-    else if (lut_lds) s20_child_tip(frag + r * lut_codes * S20_LUT_RS, c1e, c1o, q, t1, S20_LUT_RS);
+    if (carried == 1) s20_child_regs_c(X[r], s1 + r * S20_CFRAGS, lane, t1);
+    else if (!op.codes1) s20_child_inner_c(op.clv1 + ubase, s1 + r * S20_CFRAGS, lane, t1, nt_ld);
+    else if (lut_lds) s20_child_tip(s1 + r * lut_used * S20_LUT_RS, c1e, c1o, q, t1, S20_LUT_RS);
     else s20_child_tip(op.lut1 + (size_t)r * lut_codes * 20, c1e, c1o, q, t1);
-    if (carried == 2) s20_child_regs(X[r], frag2 + r * S20_FRAGS, lane, t2);
-    else if (!op.codes2) s20_child_inner(op.clv2 + ubase, frag2 + r * S20_FRAGS, lane, t2, nt_ld);
-    else if (lut_lds) s20_child_tip(frag2 + r * lut_codes * S20_LUT_RS, c2e, c2o, q, t2, S20_LUT_RS);
+    if (carried == 2) s20_child_regs_c(X[r], s2 + r * S20_CFRAGS, lane, t2);
+    else if (!op.codes2) s20_child_inner_c(op.clv2 + ubase, s2 + r * S20_CFRAGS, lane, t2, nt_ld);
+    else if (lut_lds) s20_child_tip(s2 + r * lut_used * S20_LUT_RS, c2e, c2o, q, t2, S20_LUT_RS);
     else s20_child_tip(op.lut2 + (size_t)r * lut_codes * 20, c2e, c2o, q, t2);
     // X[r] has been consumed (if it was an operand at all): it now takes the result
 #pragma unroll
@@ -432,40 +494,41 @@ __device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2
   xo = co;
 }
 
-__device__ inline void s20_fill_op(double * frag, const OpDesc & op, unsigned R, unsigned lut_codes, bool lut_lds)
+// stage one child's table: compact fragments, or the rows of the codes in use of a tip table
+__device__ inline void s20_fill_slot(double * slot, const double * pmat, const double * lut,
+                                     unsigned R, unsigned lut_codes, unsigned lut_used, bool lut_lds)
 {
-  double * const frag2 = frag + R * S20_FRAGS;
-  if (!op.codes1) s20_fill_frags(frag, op.pmat1, R);
+  if (!lut) s20_fill_cfrags(slot, pmat, R);
   else if (lut_lds)
-    for (unsigned e = threadIdx.x; e < R * lut_codes * 20; e += blockDim.x) frag[(e / 20) * S20_LUT_RS + e % 20] = op.lut1[e];
-  if (!op.codes2) s20_fill_frags(frag2, op.pmat2, R);
-  else if (lut_lds)
-    for (unsigned e = threadIdx.x; e < R * lut_codes * 20; e += blockDim.x) frag2[(e / 20) * S20_LUT_RS + e % 20] = op.lut2[e];
+    for (unsigned e = threadIdx.x; e < R * lut_used * 20; e += blockDim.x)
+    {
+      const unsigned r = e / (lut_used * 20), x = e % (lut_used * 20), c = x / 20, i = x % 20;
+      slot[(r * lut_used + c) * S20_LUT_RS + i] = lut[((size_t)r * lut_codes + c) * 20 + i];
+    }
 }
 
-// Chains of at most S20_CHAIN_MAX operations: the fragments of ALL of them stay in LDS
-// (40 KiB each), so -- exactly like k_partials_s20 -- a workgroup fills LDS once and its
-// waves then stream site blocks independently, without any barrier; per block a wave
-// runs the chain bottom-up with the intermediate vector in registers.  One 512-thread
-// workgroup per CU (eight waves share the fragments: same occupancy as two 256-thread
-// workgroups, half the LDS).
-// grid = (gx, chains), block = 512, dynamic LDS = S20_CHAIN_MAX * 2 * RT * S20_FRAGS doubles.
-constexpr unsigned S20_CHAIN_MAX = 4;
-constexpr unsigned S20_CHAIN_WAVES = 8;
-
+// Operation chains: the tables of ALL operations of a chain stay in LDS, so -- exactly like
+// k_partials_s20 -- a workgroup fills LDS once and its waves then stream site blocks
+// independently, without any barrier; per block a wave runs the chain bottom-up with the
+// intermediate vector in registers.  One 512-thread workgroup per CU (eight waves share the
+// tables: same occupancy as two 256-thread workgroups, half the LDS).
+// grid = (gx, chains), block = 512, dynamic LDS = the largest chain area of the launch.
 template <unsigned RT>
 __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_chain_s20(ChainBatch batch, unsigned nblk,
-                                                                        unsigned lut_codes, unsigned flags)
+                                                                        unsigned lut_codes, unsigned lut_used,
+                                                                        unsigned flags)
 {
   extern __shared__ double lds[];
   const bool nt_ld = flags & 1u, nt_st = flags & 2u;
-  const bool lut_lds = lut_codes * S20_LUT_RS <= S20_FRAGS;
+  const bool lut_lds = (flags & 8u) != 0;             // tip tables are staged (decided by the host)
   const unsigned first = batch.first[blockIdx.y], len = batch.len[blockIdx.y];
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // (filling twice costs 5 % at 125 k sites and nothing at 1 M: the fill is not what small
-  // slices wait for)
   for (unsigned i = 0; i < len; ++i)
-    s20_fill_op(lds + i * 2 * RT * S20_FRAGS, batch.op[first + i], RT, lut_codes, lut_lds);
+  {
+    const OpDesc & op = batch.op[first + i];
+    s20_fill_slot(lds + batch.slot1[first + i], op.pmat1, op.codes1 ? op.lut1 : nullptr, RT, lut_codes, lut_used, lut_lds);
+    s20_fill_slot(lds + batch.slot2[first + i], op.pmat2, op.codes2 ? op.lut2 : nullptr, RT, lut_codes, lut_used, lut_lds);
+  }
   __syncthreads();
 
   const unsigned wstride = gridDim.x * S20_CHAIN_WAVES;
@@ -476,7 +539,8 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_chain_s20(ChainBatc
 #pragma unroll 1
     for (unsigned i = 0; i < len; ++i)
       s20_chain_op<RT>(batch.op[first + i], i ? batch.carried[first + i] : 0u, X,
-                       lds + i * 2 * RT * S20_FRAGS, lut_codes, lut_lds, blk, lane, nt_ld, nt_st, xe, xo);
+                       lds + batch.slot1[first + i], lds + batch.slot2[first + i],
+                       lut_codes, lut_used, lut_lds, blk, lane, nt_ld, nt_st, xe, xo);
   }
 }
 
@@ -768,27 +832,38 @@ static int launch_partials_s20(Engine * e, const OpBatch & batch, unsigned nops)
 
 static bool chains_supported_s20(const Engine * e) { return e->R == 4 || e->R == 2 || e->R == 1; }
 
-static unsigned s20_chain_max(const Engine *) { return S20_CHAIN_MAX; }
+// LDS doubles of the two children's tables of an operation in a chain (0: read from global)
+static bool s20_chain_lut_lds(const Engine * e, unsigned lut_used)
+{
+  return e->R * lut_used * S20_LUT_RS <= 2560u;       // keeps a tip table at most as large as before
+}
+
+static unsigned s20_chain_slot(const Engine * e, bool tip, unsigned lut_used)
+{
+  if (!tip) return e->R * S20_CFRAGS;
+  return s20_chain_lut_lds(e, lut_used) ? ((e->R * lut_used * S20_LUT_RS + 7u) & ~7u) : 0u;
+}
 
 // (A second geometry for small slices -- chains of two, two 256-thread workgroups per CU, so
 // that one workgroup's fragment fill overlaps the other's streaming -- was measured at
 // 125 k / 250 k / 500 k sites and is 13 % / 15 % / 0 % slower than this one: the extra
 // re-reads cost more than the overlap gains.)
-static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned nchains, unsigned longest)
+static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned nchains, unsigned lds_doubles,
+                             unsigned lut_used)
 {
-  (void)longest;
-  const size_t lds = sizeof(double) * S20_CHAIN_MAX * 2 * e->R * S20_FRAGS;
-  static const unsigned flags = getenv("PLLHIP_S20_NT") ? (unsigned)atoi(getenv("PLLHIP_S20_NT")) : 0u;
+  const size_t lds = sizeof(double) * lds_doubles;
+  const unsigned env_flags = []() { const char * v = getenv("PLLHIP_S20_NT"); return v ? (unsigned)atoi(v) & 3u : 0u; }();
+  const unsigned flags = env_flags | (s20_chain_lut_lds(e, lut_used) ? 8u : 0u);
   static bool attr_set = false;
   if (!attr_set)
   {
-    const int cap = (int)(sizeof(double) * S20_CHAIN_MAX * 8 * S20_FRAGS);
+    const int cap = (int)(sizeof(double) * S20_CHAIN_LDS);
     PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_s20<4>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_s20<2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, cap / 2));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_s20<1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, cap / 4));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     attr_set = true;
   }
   // workgroups per CU and chain (measured at 1 M sites: 1 beats 2 and 4)
@@ -797,11 +872,11 @@ static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned ncha
   const unsigned gx = std::max(1u, std::min(need, e->cu_count * (unsigned)std::max(1, env_bpc)));
   const dim3 grid(gx, nchains), block(64 * S20_CHAIN_WAVES);
   if (e->R == 4)
-    hipLaunchKernelGGL(k_chain_s20<4>, grid, block, lds, e->stream, batch, e->nblk, e->lut_codes, flags);
+    hipLaunchKernelGGL(k_chain_s20<4>, grid, block, lds, e->stream, batch, e->nblk, e->lut_codes, lut_used, flags);
   else if (e->R == 2)
-    hipLaunchKernelGGL(k_chain_s20<2>, grid, block, lds, e->stream, batch, e->nblk, e->lut_codes, flags);
+    hipLaunchKernelGGL(k_chain_s20<2>, grid, block, lds, e->stream, batch, e->nblk, e->lut_codes, lut_used, flags);
   else
-    hipLaunchKernelGGL(k_chain_s20<1>, grid, block, lds, e->stream, batch, e->nblk, e->lut_codes, flags);
+    hipLaunchKernelGGL(k_chain_s20<1>, grid, block, lds, e->stream, batch, e->nblk, e->lut_codes, lut_used, flags);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

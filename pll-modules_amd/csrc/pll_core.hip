@@ -587,12 +587,22 @@ struct ChainPlan
 {
   std::vector<std::vector<unsigned>> chains;     // op indices, bottom to top
   std::vector<int> launch;                       // per chain: launch round
+  std::vector<unsigned> lds;                     // per chain: LDS doubles of its operations' tables
   std::vector<unsigned char> carried;            // per op
   int rounds = 0;
 };
 
+// LDS doubles the tables of operation `op` take in a chain kernel (20 states; 0 otherwise)
+static unsigned chain_op_lds(const Engine * e, const pll_operation_t & op, unsigned lut_used)
+{
+  if (e->family != KernelFamily::S20) return 0u;
+  const bool t1 = e->coded_tips && op.child1_clv_index < e->tips;
+  const bool t2 = e->coded_tips && op.child2_clv_index < e->tips;
+  return s20_chain_slot(e, t1, lut_used) + s20_chain_slot(e, t2, lut_used);
+}
+
 static bool plan_chains(const Engine * e, const pll_operation_t * ops, unsigned count, unsigned max_len,
-                        ChainPlan & plan)
+                        unsigned lds_cap, unsigned lut_used, ChainPlan & plan)
 {
   std::vector<int> producer(e->nodes, -1), sc_writer(e->nscalers, -1), chain_of(count, -1);
   std::vector<char> read_ext(e->nodes, 0), sc_read_ext(e->nscalers, 0);
@@ -635,7 +645,9 @@ static bool plan_chains(const Engine * e, const pll_operation_t * ops, unsigned 
     int heavy = -1;                               // which child (0 / 1) continues a chain
     if (pr[0] >= 0 && (pr[1] < 0 || size[pr[0]] >= size[pr[1]])) heavy = 0;
     else if (pr[1] >= 0) heavy = 1;
-    if (heavy >= 0 && plan.chains[chain_of[pr[heavy]]].size() >= max_len) heavy = -1;
+    const unsigned cost = chain_op_lds(e, op, lut_used);
+    if (heavy >= 0 && (plan.chains[chain_of[pr[heavy]]].size() >= max_len ||
+                       plan.lds[chain_of[pr[heavy]]] + cost > lds_cap)) heavy = -1;
     int round = 0;
     for (int c = 0; c < 2; ++c)
       if (pr[c] >= 0 && c != heavy) round = std::max(round, plan.launch[chain_of[pr[c]]] + 1);
@@ -643,6 +655,7 @@ static bool plan_chains(const Engine * e, const pll_operation_t * ops, unsigned 
     {
       const int ch = chain_of[pr[heavy]];
       plan.chains[ch].push_back(k);
+      plan.lds[ch] += cost;
       plan.launch[ch] = std::max(plan.launch[ch], round);
       plan.carried[k] = (unsigned char)(heavy + 1);
       chain_of[k] = ch;
@@ -651,6 +664,7 @@ static bool plan_chains(const Engine * e, const pll_operation_t * ops, unsigned 
     {
       chain_of[k] = (int)plan.chains.size();
       plan.chains.push_back(std::vector<unsigned>(1, k));
+      plan.lds.push_back(cost);
       plan.launch.push_back(round);
     }
     plan.rounds = std::max(plan.rounds, plan.launch[chain_of[k]] + 1);
@@ -779,12 +793,15 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
   if (use_chains && count >= 2 && (chains20 || chains4))
   {
     ChainPlan plan;
-    if (plan_chains(e, ops, count, chains20 ? s20_chain_max(e) : S4_CHAIN_MAX, plan))
+    // tip tables are staged with the codes in use (at least one: an untouched partition)
+    const unsigned lut_used = std::max(1u, std::min(p->maxstates, e->lut_codes));
+    if (plan_chains(e, ops, count, chains20 ? S20_CHAIN_MAX : S4_CHAIN_MAX,
+                    chains20 ? S20_CHAIN_LDS : ~0u, lut_used, plan))
     {
       for (int round = 0; round < plan.rounds; ++round)
       {
         ChainBatch cb;
-        unsigned nops = 0, nchains = 0, longest = 0;
+        unsigned nops = 0, nchains = 0, longest = 0, lds_max = 0;
         double bytes = 0.0, flops = 0.0;
         auto flush = [&]() -> int
         {
@@ -797,11 +814,12 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
             for (unsigned i = 0; i < nops; ++i) ob.op[i] = cb.op[i];
             if (!launch_partials(e, ob, nops)) return PLL_FAILURE;
           }
-          else if (chains20 ? !launch_chains_s20(e, cb, nchains, longest) : !launch_chains_s4(e, cb, nchains, longest))
+          else if (chains20 ? !launch_chains_s20(e, cb, nchains, lds_max, lut_used)
+                            : !launch_chains_s4(e, cb, nchains, longest))
             return PLL_FAILURE;
           if (!prof_end(ev1, bytes, flops, nops)) return PLL_FAILURE;
           e->counters.partial_launches++;
-          nops = nchains = longest = 0;
+          nops = nchains = longest = lds_max = 0;
           bytes = flops = 0.0;
           return PLL_SUCCESS;
         };
@@ -818,12 +836,25 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
           if (nops + ch.size() > MAX_OPS_PER_LAUNCH && !flush()) return PLL_FAILURE;
           cb.first[nchains] = (unsigned char)nops;
           cb.len[nchains] = (unsigned char)ch.size();
+          unsigned off = 0;
           for (size_t i = 0; i < ch.size(); ++i)
           {
-            fill_desc(ops[ch[i]], cb.op[nops], bytes, flops);
+            const pll_operation_t & o = ops[ch[i]];
+            fill_desc(o, cb.op[nops], bytes, flops);
             cb.carried[nops] = i ? plan.carried[ch[i]] : 0;
+            if (chains20)
+            {
+              const bool t1 = e->coded_tips && o.child1_clv_index < e->tips;
+              const bool t2 = e->coded_tips && o.child2_clv_index < e->tips;
+              cb.slot1[nops] = (unsigned short)off;
+              off += s20_chain_slot(e, t1, lut_used);
+              cb.slot2[nops] = (unsigned short)off;
+              off += s20_chain_slot(e, t2, lut_used);
+            }
+            else cb.slot1[nops] = cb.slot2[nops] = 0;
             ++nops;
           }
+          lds_max = std::max(lds_max, off);
           ++nchains;
           longest = std::max<unsigned>(longest, (unsigned)ch.size());
         }
