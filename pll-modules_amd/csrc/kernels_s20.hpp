@@ -327,30 +327,8 @@ __global__ __launch_bounds__(256, 2) void k_partials_s20(OpBatch batch, unsigned
 // and multiplies it straight into the next operation: the carried child is never
 // re-read, which removes one of the three HBM streams of an inner x inner operation.
 // Every vector is still stored (later partial traversals need it), bit-identical to
-// what k_partials_s20 stores.  A workgroup walks the chain in lockstep (the LDS
-// fragments are per operation); every wave owns one site block per pass.
-// grid = (gx, chains), block = 256, dynamic LDS = 2 * RT * S20_FRAGS doubles.
+// what k_partials_s20 stores (k_chain_s20 below).
 // ---------------------------------------------------------------------------
-__device__ inline void s20_child_regs(const double2 b[5], const double * frag_r, unsigned lane,
-                                      double2 t[5])
-{
-  v4d a0e = {0, 0, 0, 0}, a0o = {0, 0, 0, 0}, a1e = {0, 0, 0, 0}, a1o = {0, 0, 0, 0};
-#pragma unroll
-  for (int ks = 0; ks < 5; ++ks)
-  {
-    const double f0 = frag_r[ks * 64 + lane];
-    const double f1 = frag_r[(5 + ks) * 64 + lane];
-    a0e = mfma_f64(f0, b[ks].x, a0e);
-    a0o = mfma_f64(f0, b[ks].y, a0o);
-    a1e = mfma_f64(f1, b[ks].x, a1e);
-    a1o = mfma_f64(f1, b[ks].y, a1o);
-  }
-  t[0] = make_double2(a0e[0], a0o[0]);
-  t[1] = make_double2(a0e[1], a0o[1]);
-  t[2] = make_double2(a0e[2], a0o[2]);
-  t[3] = make_double2(a0e[3], a0o[3]);
-  t[4] = make_double2(a1e[0], a1o[0]);
-}
 
 // LDS economy of the chain kernel.  The second M-tile of a 20 x 20 matrix holds rows 16..19
 // only, i.e. just the lanes with (lane & 15) < 4 carry a value: those 16 lanes per k-step

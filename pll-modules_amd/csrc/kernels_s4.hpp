@@ -240,7 +240,7 @@ constexpr unsigned s4_chain_op_lds(unsigned R) { return 2 * R * S4_LUT_RS + 2 * 
 template <unsigned U, unsigned R>      // R in {1, 2, 4}; U <= 2R loads issued per batch
 __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
 {
-  constexpr unsigned group = 2 * R, spi = 64 / group, rs = (R == 4) ? 2 : (R == 2) ? 1 : 0;
+  constexpr unsigned group = 2 * R, spi = 64 / group;
   constexpr unsigned S4_CHAIN_OP_LDS = s4_chain_op_lds(R), T2 = R * S4_LUT_RS, M1 = 2 * R * S4_LUT_RS,
                      M2 = 2 * R * S4_LUT_RS + R * 16;
   extern __shared__ double lds[];
