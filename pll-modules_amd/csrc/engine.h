@@ -45,6 +45,7 @@ struct OpDesc
   const unsigned * scaler2;
   double * parent;
   unsigned * parent_scaler;
+  const double * pfrag1, * pfrag2;   // 20 states: the children's matrices in fragment order (or null)
   unsigned parent_index;      // CLV indices (host bookkeeping of per-vector side arrays)
   unsigned child1_index, child2_index;
 };
@@ -104,6 +105,7 @@ struct Engine
   std::vector<uint8_t *> d_codes;     // [tips], nullptr unless coded
   unsigned * d_scalers = nullptr;     // [nscalers][N]
   double * d_pmat = nullptr;          // [nmat][R][S][Sp]
+  double * d_pfrag = nullptr;         // 20 states: [nmat][R][400] the same matrices as compact MFMA A fragments
   double * d_lut = nullptr;           // [nmat][R][lut_codes][S]   (coded tips only)
   unsigned long long result_seq = 0;  // sequence word of the mapped result buffer (finish_reduction)
   uint8_t * d_s61_votes = nullptr;

@@ -28,7 +28,8 @@ struct PmatBatch
 __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, PmatBatch batch,
                                                  unsigned R, double * pmat, double * lut,
                                                  unsigned lut_codes,
-                                                 const unsigned long long * tipmap, int staged)
+                                                 const unsigned long long * tipmap, int staged,
+                                                 double * pfrag)
 {
   // staged (S*Sp <= 4096):  A[S*Sp] = V diag(exp(lambda rho t)) | B[S*Sp] = V^-1; P overwrites A
   // otherwise:              expk[Sp] | P[S*Sp], operands read from global memory
@@ -96,6 +97,19 @@ __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, 
   }
   __syncthreads();
   for (unsigned e = threadIdx.x; e < S * Sp; e += blockDim.x) P[e] = Pl[e];
+  if (pfrag)
+  {
+    // 20 states: the matrix once more as compact MFMA A fragments (kernels_s20.hpp, s20_fill_cfrags),
+    // so that the chain kernel fills its LDS with a plain copy
+    double * F = pfrag + ((size_t)m * R + r) * 400;
+    for (unsigned x = threadIdx.x; x < 400; x += blockDim.x)
+    {
+      unsigned i, j;
+      if (x < 320) { i = x & 15; j = 4 * (x >> 6) + ((x & 63) >> 4); }
+      else { const unsigned y = x - 320; i = 16 + (y & 3); j = 4 * (y >> 4) + ((y >> 2) & 3); }
+      F[x] = Pl[i * Sp + j];
+    }
+  }
   if (lut)
   {
     double * T = lut + ((size_t)m * R + r) * lut_codes * S;

@@ -472,11 +472,24 @@ __device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2
   xo = co;
 }
 
+// row-major [R][20][20] matrix sets -> compact fragment order (after a host upload of the
+// P-matrices; k_pmatrix writes both forms itself).  grid = matrices, block = 256
+__global__ __launch_bounds__(256) void k_s20_pfrag(const double * pmat, double * pfrag, unsigned R)
+{
+  s20_fill_cfrags(pfrag + (size_t)blockIdx.x * R * S20_CFRAGS, pmat + (size_t)blockIdx.x * R * 400, R);
+}
+
 // stage one child's table: compact fragments, or the rows of the codes in use of a tip table
-__device__ inline void s20_fill_slot(double * slot, const double * pmat, const double * lut,
+__device__ inline void s20_fill_slot(double * slot, const double * pmat, const double * pfrag, const double * lut,
                                      unsigned R, unsigned lut_codes, unsigned lut_used, bool lut_lds)
 {
-  if (!lut) s20_fill_cfrags(slot, pmat, R);
+  if (!lut)
+  {
+    if (pfrag)        // written in fragment order by k_pmatrix: a plain, coalesced copy
+      for (unsigned e = threadIdx.x; e < R * S20_CFRAGS / 2; e += blockDim.x)
+        reinterpret_cast<double2 *>(slot)[e] = reinterpret_cast<const double2 *>(pfrag)[e];
+    else s20_fill_cfrags(slot, pmat, R);
+  }
   else if (lut_lds)
     for (unsigned e = threadIdx.x; e < R * lut_used * 20; e += blockDim.x)
     {
@@ -504,8 +517,8 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_chain_s20(ChainBatc
   for (unsigned i = 0; i < len; ++i)
   {
     const OpDesc & op = batch.op[first + i];
-    s20_fill_slot(lds + batch.slot1[first + i], op.pmat1, op.codes1 ? op.lut1 : nullptr, RT, lut_codes, lut_used, lut_lds);
-    s20_fill_slot(lds + batch.slot2[first + i], op.pmat2, op.codes2 ? op.lut2 : nullptr, RT, lut_codes, lut_used, lut_lds);
+    s20_fill_slot(lds + batch.slot1[first + i], op.pmat1, op.pfrag1, op.codes1 ? op.lut1 : nullptr, RT, lut_codes, lut_used, lut_lds);
+    s20_fill_slot(lds + batch.slot2[first + i], op.pmat2, op.pfrag2, op.codes2 ? op.lut2 : nullptr, RT, lut_codes, lut_used, lut_lds);
   }
   __syncthreads();
 

@@ -149,6 +149,10 @@ Engine * engine_create(pll_partition_t * p)
                                    std::max<size_t>(1, (size_t)e->nscalers * e->Nalloc) * sizeof(unsigned),
                                    e->stream), "memset scalers");
   ok = ok && dev_alloc(&e->d_pmat, pm_len, "P-matrices");
+  if (e->family == KernelFamily::S20)
+    ok = ok && dev_alloc(&e->d_pfrag, std::max<size_t>(1, (size_t)e->nmat * e->R * 400), "P-matrix fragments") &&
+         hip_ok(hipMemsetAsync(e->d_pfrag, 0, std::max<size_t>(1, (size_t)e->nmat * e->R * 400) * sizeof(double), e->stream),
+                "memset fragments");
   ok = ok && hip_ok(hipMemsetAsync(e->d_pmat, 0, std::max<size_t>(1, pm_len) * sizeof(double), e->stream),
                     "memset pmat");
   ok = ok && dev_alloc(&e->d_weights, (size_t)e->N, "pattern weights");
@@ -206,6 +210,7 @@ void engine_destroy(Engine * e)
   for (auto & kv : e->sumtables) (void)hipFree(kv.second);
   (void)hipFree(e->d_scalers);
   (void)hipFree(e->d_pmat);
+  (void)hipFree(e->d_pfrag);
   (void)hipFree(e->d_lut);
   (void)hipFree(e->d_s61_votes);
   for (auto & slot : e->s61_pred) { if (slot.buf[0]) (void)hipFree(slot.buf[0]); if (slot.buf[1]) (void)hipFree(slot.buf[1]); }
@@ -378,7 +383,7 @@ int flush_pmatrices(pll_partition_t * p)
     }
     hipLaunchKernelGGL(k_pmatrix, dim3(nb, e->R), dim3(256), lds, e->stream,
                        mv, e->pend_params, batch, e->R, e->d_pmat,
-                       e->coded_tips ? e->d_lut : nullptr, e->lut_codes, e->d_tipmap, staged);
+                       e->coded_tips ? e->d_lut : nullptr, e->lut_codes, e->d_tipmap, staged, e->d_pfrag);
     PLLHIP_TRY(hipGetLastError());
     e->counters.pmatrix_launches++;
   }
@@ -738,6 +743,8 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     d.clv1 = t1 ? nullptr : e->d_clv[op.child1_clv_index];
     d.codes1 = t1 ? e->d_codes[op.child1_clv_index] : nullptr;
     d.pmat1 = e->d_pmat + pm_stride * op.child1_matrix_index;
+    d.pfrag1 = e->d_pfrag ? e->d_pfrag + (size_t)op.child1_matrix_index * e->R * 400 : nullptr;
+    d.pfrag2 = e->d_pfrag ? e->d_pfrag + (size_t)op.child2_matrix_index * e->R * 400 : nullptr;
     d.lut1 = t1 ? e->d_lut + lut_stride * op.child1_matrix_index : nullptr;
     d.clv2 = t2 ? nullptr : e->d_clv[op.child2_clv_index];
     d.codes2 = t2 ? e->d_codes[op.child2_clv_index] : nullptr;
@@ -1347,6 +1354,11 @@ int pllhip_sync_to_device(pll_partition_t * p, unsigned int what)
     PLLHIP_TRY(hipStreamSynchronize(e->stream));
     e->pmat_host_dirty = false;
     invalidate_luts(p);
+    if (e->d_pfrag)
+    {
+      hipLaunchKernelGGL(k_s20_pfrag, dim3(e->nmat), dim3(256), 0, e->stream, e->d_pmat, e->d_pfrag, e->R);
+      PLLHIP_TRY(hipGetLastError());
+    }
   }
   if (what & PLLHIP_SYNC_CLV)
     for (unsigned i = 0; i < e->nodes; ++i)
