@@ -24,7 +24,7 @@ namespace pllhip {
 
 constexpr unsigned MAX_RATE_CATS = 16;   // params_indices travel by value in kernel args
 constexpr unsigned MAX_OPS_PER_LAUNCH = 24;
-constexpr unsigned MAX_PMAT_PER_LAUNCH = 64;
+constexpr unsigned MAX_PMAT_PER_LAUNCH = 200;   // requests of one k_pmatrix launch (by value in the kernel arguments)
 constexpr unsigned REDUCE_BLOCKS = 4096; // upper bound of per-block partial sums
 constexpr unsigned MAX_SUMTABLES = 4;    // device sumtables kept per partition (LRU)
 

@@ -353,7 +353,7 @@ int sync_model(pll_partition_t * p)
 
 // Launch the queued P-matrix requests.  pll-modules asks for one matrix per call
 // (src/tree/treeinfo.c:845-865: 2n-3 calls per evaluation); the requests are
-// queued on the host and go to the device up to 64 per launch as soon as a
+// queued on the host and go to the device up to 200 per launch as soon as a
 // consumer of P-matrices (partials, lnL, host mirror) or a model change needs them.
 int flush_pmatrices(pll_partition_t * p)
 {
