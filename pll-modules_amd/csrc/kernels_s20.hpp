@@ -845,7 +845,8 @@ static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned ncha
   const size_t lds = sizeof(double) * lds_doubles;
   const unsigned env_flags = []() { const char * v = getenv("PLLHIP_S20_NT"); return v ? (unsigned)atoi(v) & 3u : 0u; }();
   const unsigned flags = env_flags | (s20_chain_lut_lds(e, lut_used) ? 8u : 0u);
-  static bool attr_set = false;
+  static bool attr_set_dev[64] = {false};          // per device: one process may drive several GPUs
+  bool & attr_set = attr_set_dev[e->device & 63];
   if (!attr_set)
   {
     const int cap = (int)(sizeof(double) * S20_CHAIN_LDS);

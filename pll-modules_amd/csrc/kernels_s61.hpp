@@ -916,7 +916,8 @@ static int launch_edge_lnl_s61(Engine * e, const ModelView & mv, const ParamIdx 
   if (env_r4 && pm && !child.codes && e->R <= 4 && e->nblk)
   {
     const size_t lds = sizeof(double) * ((size_t)e->R * S61_FRAGS + (size_t)e->R * 64);
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {false};        // per device: one process may drive several GPUs
+    bool & attr_set = attr_set_dev[e->device & 63];
     if (!attr_set)
     {
       PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_lnl_s61_r4),
