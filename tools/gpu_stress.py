@@ -10,12 +10,12 @@ import test_eval_driver as t
 product = pc.PllLib(pc.PRODUCT_LIB)
 oracle = pc.PllLib(os.path.join("oracle", "_build", "libpll_oracle.so"))
 bad = 0
-for seed in range(10, 30):
+for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10, (int(sys.argv[1]) if len(sys.argv) > 1 else 10) + 20):
     g = t._random_walk(product, 40, seed, ntips=12 + seed % 30)
     c = t._random_walk(oracle, 40, seed, ntips=12 + seed % 30)
     err = max(abs(x - y) / abs(y) for x, y in zip(g, c))
     if err > 1e-9: bad += 1; print("walk seed", seed, err)
-rng = np.random.default_rng(7)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 for trial in range(24):
     S = [4, 20, 61][trial % 3]; R = [1, 2, 4][(trial // 3) % 3]
     n = int(rng.integers(5, 60)) if S < 61 else int(rng.integers(5, 14)); N = int(rng.integers(1, 700))
