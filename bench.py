@@ -14,9 +14,15 @@ Default workload: BASELINE.json's target configuration C3 (20 states, Gamma4,
 200 taxa, 1M sites; the "LG-shaped" seeded model because the real LG table is
 unavailable offline).  `--config c2` selects the DNA configuration.
 
-Multi-GPU: one process per GPU (torch.distributed.run); sites shard across the
-ranks.  `--scaling weak` (default) keeps the per-GPU slice at the configured
-site count; `--scaling strong` splits the configured site count over the ranks.
+Multi-GPU: one process per GPU; the sites of ONE alignment shard across the
+ranks (rank r owns a contiguous site range, so the summed lnL is the same number
+at every N).  `--scaling strong` (default; the north star's "1 M-site partition
+... >= 6x at 8 GPUs") splits the configured site count over the ranks;
+`--scaling weak` keeps the configured site count per GPU.  `python bench.py
+--gpus N` with no rank environment starts the N ranks itself (a
+torch.distributed.run child, created before anything in this process touches
+the GPU) and forwards the child's JSON line and exit code; under a launcher
+(RANK / WORLD_SIZE set) it is one of the ranks.
 
 Prints ONE JSON line on rank 0.
 """
@@ -24,6 +30,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -45,7 +53,7 @@ def parse_args():
     ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--sites", type=int, default=0, help="override the per-configuration site count")
     ap.add_argument("--taxa", type=int, default=0)
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--pmatrix-calls", default="per-branch", choices=["per-branch", "batched"],
                     help="per-branch = one pll_update_prob_matrices call per branch, as treeinfo issues "
                          "them (src/tree/treeinfo.c:845-865); batched = one call with count = 2n-3")
@@ -75,22 +83,34 @@ def partition_plan(config, states, nsites):
     return [(s, max(1, int(round(nsites * f)))) for s, f in C4_PARTS]
 
 
-def make_evaluation(pc, lib, tree, plan, rate_cats, seed, per_branch):
-    """one Evaluation (C driver) over the partitions of `plan` = [(states, sites), ...]"""
+def make_evaluation(pc, lib, tree, plan, rate_cats, seed, per_branch, first_sites=None):
+    """one Evaluation (C driver) over the partitions of `plan` = [(states, sites), ...];
+    partition k holds sites first_sites[k] .. of the alignment that seed + 101 k defines"""
     ev = pc.Evaluation(lib, tree.newick(), flags=1 if per_branch else 0, nparts=len(plan))
     insts = []
     for k, (states, nsites) in enumerate(plan):
         subst, freqs, alpha = model_of(pc, states)
-        codes = pc.random_codes(tree.ntips, nsites, states, seed + 101 * k)
+        codes = pc.random_codes(tree.ntips, nsites, states, seed + 101 * k,
+                                first_site=first_sites[k] if first_sites else 0)
         insts.append(ev.add_partition(k, states, nsites, rate_cats, codes, subst, freqs, alpha, coded=True))
     return ev, insts
 
 
-def cpu_baseline(pc, tree, config, states, rate_cats, nsites_gpu, cpu_sites, per_branch):
+def evaluate_with_persite(ev, plan):
+    """lnL and the per-site lnL of every partition, concatenated"""
+    lnl = ev.loglh()
+    persite = np.concatenate([ev.persite_lnl(k)[1] for k in range(len(plan))])
+    return lnl, persite
+
+
+def cpu_baseline(pc, product, tree, config, states, rate_cats, nsites_gpu, cpu_sites, per_branch):
     """the oracle (a from-scratch CPU port, NOT libpll) timed on the host cores
-    on a bounded sample of the same workload: same tree, model, tip generator and
-    C driver, fewer sites, sized for ~10-30 s of CPU work"""
-    threads = min(os.cpu_count() or 1, 16)      # the 1-GPU box share of host cores
+    on a bounded sample of the same workload: same tree, model, C driver and the
+    FIRST cpu_sites sites of the same alignment, sized for ~10-30 s of CPU work.
+    The same sample is then evaluated on the GPU: |dlnL| per site on identical
+    inputs (BASELINE.json's metric, second half)."""
+    host_cores = os.cpu_count() or 1
+    threads = min(host_cores, 16)      # the 1-GPU box share of host cores
     os.environ.setdefault("OMP_NUM_THREADS", str(threads))
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("ORC_FAST", "1")      # the oracle's AVX2-vectorised partials (4 / 20 / 61 states)
@@ -113,21 +133,98 @@ def cpu_baseline(pc, tree, config, states, rate_cats, nsites_gpu, cpu_sites, per
             if time.perf_counter() - t0 > 10.0 or reps >= 5:
                 break
         dt = time.perf_counter() - t0
+        lnl_cpu, persite_cpu = evaluate_with_persite(ev, plan)
+    gev, _ = make_evaluation(pc, product, tree, plan, rate_cats, 44, per_branch)
+    with gev:
+        lnl_gpu, persite_gpu = evaluate_with_persite(gev, plan)
     updates = reps * (ntips - 2) * cpu_sites * rate_cats
-    return {"value": updates / dt, "unit": "CLV site-updates/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} full evaluations of the same tree/model with {cpu_sites} sites "
-                      f"(oracle/, plain C + OpenMP over sites, AVX2-vectorised partials, "
-                      f"{threads} threads); lnL/site "
-                      f"{lnl / cpu_sites:.6f}"}
+    parity = {
+        "dlnl_per_site": abs(lnl_gpu - lnl_cpu) / cpu_sites,
+        "max_persite_dlnl": float(np.max(np.abs(persite_gpu - persite_cpu))),
+        "sample_sites": cpu_sites, "lnl_gpu": lnl_gpu, "lnl_cpu": lnl_cpu,
+        "against": "oracle/ (CPU restatement pinned by the reference's golden files; libpll itself is "
+                   "not available offline) on the first sample_sites sites of the benchmark alignment",
+        "tolerance_per_site": 1e-6,
+    }
+    base = {"value": updates / dt, "unit": "CLV site-updates/s", "cores": threads, "kind": "port",
+            "host_cores": host_cores, "threads": threads, "sample_sites": cpu_sites, "sample_evaluations": reps,
+            "lnl_per_site": lnl / cpu_sites,
+            "sample": f"{reps} full evaluations of the same tree/model on the first {cpu_sites} sites of the "
+                      f"benchmark alignment (oracle/, plain C + OpenMP over sites, AVX2-vectorised partials, "
+                      f"{threads} threads on a host with {host_cores} cores)"}
+    return base, parity
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` without a rank environment: start the N ranks as ONE child
+    process (torch.distributed.run -> one process per GPU).  Nothing in this process has
+    touched HIP or torch.cuda at this point, and nothing will: the parent only forwards
+    the child's JSON line and exit code."""
+    probe = os.environ.get("PLLHIP_BENCH_LAUNCH_PROBE") == "1"
+    if not probe:
+        import torch
+        have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        raise SystemExit(proc.returncode or 1)
+    if json.loads(line).get("n_gpus") != args.gpus:
+        raise SystemExit(f"bench.py: the ranks report n_gpus != {args.gpus}")
+    print(line)
+    raise SystemExit(0)
+
+
+def launch_probe(args, rank, world):
+    """PLLHIP_BENCH_LAUNCH_PROBE=1: the ranks only prove that they exist (gloo, no GPU);
+    tests/test_bench_launcher.py runs this where there is no GPU"""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    seen = [None] * world
+    dist.all_gather_object(seen, (rank, int(os.environ.get("LOCAL_RANK", "-1")), os.getpid()))
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "launch-probe", "n_gpus": world, "ranks": sorted(r for r, _, _ in seen),
+                          "local_ranks": sorted(l for _, l, _ in seen),
+                          "distinct_processes": len({p for _, _, p in seen})}))
 
 
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    in_rank_env = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not in_rank_env:
+        launch_ranks(args)                      # never returns
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        # never report a run of `world` ranks as a run of --gpus ranks
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("PLLHIP_BENCH_LAUNCH_PROBE") == "1":
+        return launch_probe(args, rank, world)
 
     import pllhip_ctypes as pc
     product = pc.PllLib(pc.PRODUCT_LIB)
@@ -149,26 +246,29 @@ def main():
         nsites = args.sites
     if args.taxa:
         ntips = args.taxa
-    if args.scaling == "strong" and world > 1:
-        local_sites = nsites * (rank + 1) // world - nsites * rank // world
-        total_sites = nsites
-    else:
-        local_sites = nsites
-        total_sites = nsites * world
     per_branch = args.pmatrix_calls == "per-branch"
-
     tree = pc.Tree(ntips, 42, 43)
-    # every rank owns a different slice of the alignment (different tip seed)
-    plan = partition_plan(args.config, states, local_sites)
+
+    # ONE alignment for the whole job; rank r owns a contiguous site range of every partition
+    # (strong: the configured site count is split; weak: it is the per-GPU share)
+    job_plan = partition_plan(args.config, states, nsites * (world if args.scaling == "weak" else 1))
+    plan, first_sites = [], []
+    for s_, n_ in job_plan:
+        lo, hi = n_ * rank // world, n_ * (rank + 1) // world
+        plan.append((s_, hi - lo))
+        first_sites.append(lo)
     local_sites = sum(n for _, n in plan)
-    total_sites = local_sites * world if not (args.scaling == "strong" and world > 1) else total_sites
-    ev, insts = make_evaluation(pc, product, tree, plan, rate_cats, 44 + 7919 * rank, per_branch)
+    total_sites = sum(n for _, n in job_plan)
+    if min(n for _, n in plan) < 1:
+        raise SystemExit("bench.py: fewer sites than ranks")
+    ev, insts = make_evaluation(pc, product, tree, plan, rate_cats, 44, per_branch, first_sites)
     inst = max(insts, key=lambda i: i.N * i.S)        # the partition that dominates the traffic
 
     if world > 1:
-        # the native reduce callback (RCCL in C, behind the reference's parallel_reduce_cb
-        # signature) gets its unique id through torch's store; the driver calls it after
-        # every edge log-likelihood, exactly where treeinfo does (src/tree/treeinfo.c:1061)
+        # one RCCL communicator per rank (C, behind the reference's parallel_reduce_cb
+        # semantics); its unique id travels through torch's store.  The driver leaves every
+        # partition's lnL in a device-resident slot and all-reduces the slots in place
+        # (src/tree/treeinfo.c:1061 is where the reference reduces).
         idbuf = C.create_string_buffer(128)
         if rank == 0 and not product.lib.pllhip_comm_get_unique_id(idbuf):
             raise SystemExit(product.errmsg)
@@ -177,8 +277,8 @@ def main():
         comm = product.lib.pllhip_comm_create(obj[0], rank, world, local_rank)
         if not comm:
             raise SystemExit(product.errmsg)
-        cb = C.cast(product.lib.pllhip_reduce_cb, C.c_void_p)
-        product.lib.pllhip_eval_set_parallel_context(ev.ev, comm, cb)
+        if not product.lib.pllhip_eval_attach_comm(ev.ev, comm):
+            raise SystemExit(product.errmsg)
 
     nops = ntips - 2
 
@@ -230,10 +330,13 @@ def main():
         # whole step instead (a lower bound of what they achieve)
         achieved = prof.algorithmic_bytes / elapsed / 1e9
     traffic = None
+    traffic_source = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and world == 1 and not args.sites and not args.taxa:
         try:
             traffic = json.load(open(tpath)).get(f"{args.config}:{kernel}")
+            traffic_source = ("profiles/traffic.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                              "this command (tools/gpu_profile.sh), NOT measured in this run")
         except Exception:
             traffic = None
     tflops = prof.algorithmic_flops / (prof.kernel_ms * 1e-3) / 1e12 if prof.kernel_ms > 0 else 0.0
@@ -246,7 +349,8 @@ def main():
         "peak": FP64_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
         "unit": "TFLOP/s" if mfma_bound else "GB/s",
         "frac": round(tflops / FP64_MFMA_PEAK_TFLOPS, 4) if mfma_bound else round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": traffic, "algorithmic_GBps": round(achieved, 1), "algorithmic_TFLOPs": round(tflops, 2),
+        "traffic": traffic, "traffic_source": traffic_source,
+        "algorithmic_GBps": round(achieved, 1), "algorithmic_TFLOPs": round(tflops, 2),
         "launches": int(prof.launches), "ops": int(prof.ops),
         "avg_launch_ms": round(prof.kernel_ms / max(1, prof.launches), 4),
         "algorithmic_bytes_per_launch": round(prof.algorithmic_bytes / max(1, prof.launches)),
@@ -265,16 +369,18 @@ def main():
                                      if traffic and prof.algorithmic_bytes > 0 and len(insts) == 1 else None),
         "method": ("algorithmic bytes of all partials launches / step wall time (partitions overlap on "
                    "concurrent streams)") if len(insts) > 1 else
-                  "algorithmic bytes of the partials launches / their HIP-event time",
+                  "algorithmic bytes of the partials launches / their HIP-event time (rank 0)",
     }
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(pc, tree, args.config, states, rate_cats, local_sites, args.cpu_sites, per_branch)
-
-    ev.close()
+    ev.close()                   # frees the CLVs: the parity sample below gets its own partitions
     if comm:
         product.lib.pllhip_comm_destroy(comm)
+
+    cpu = parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, parity = cpu_baseline(pc, product, tree, args.config, states, rate_cats, local_sites,
+                                   args.cpu_sites, per_branch)
+
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -285,7 +391,7 @@ def main():
                  "c5": "C5 codon GY94-shaped+G4"}
         evals = max(1, args.steps + args.warmup)
         out = {
-            "metric": "CLV site-updates/sec (sites x rates x edges)",
+            "metric": "CLV site-updates/sec (sites x rates x edges); |dlnL| vs ref",
             "value": value, "unit": "CLV site-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -293,8 +399,9 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": f"{names[args.config]}: {states} states, {rate_cats} rate cats, {ntips} taxa, "
-                            f"{total_sites} sites total ({local_sites} per GPU), full traversal "
-                            f"({nops} ops + {tree.nedges} P-matrices + edge lnL) per step",
+                            f"{total_sites} sites total ({local_sites} on rank 0), full traversal "
+                            f"({nops} ops + {tree.nedges} P-matrices + edge lnL"
+                            f"{' + RCCL all-reduce of the lnL' if world > 1 else ''}) per step",
                 "config": args.config, "states": states, "rate_cats": rate_cats, "taxa": ntips,
                 "sites_total": total_sites, "sites_per_gpu": local_sites, "ops_per_step": nops,
                 "partitions": [{"states": s, "sites_per_gpu": n} for s, n in plan],
@@ -302,8 +409,13 @@ def main():
                 "pmatrix_calls": args.pmatrix_calls,
                 "pmatrix_launches_per_step": counters.pmatrix_launches // evals,
                 "partial_launches_per_step": counters.partial_launches // evals,
+                "parallelism": f"sites sharded over {world} GPU(s), lnL all-reduced" if world > 1 else "1 GPU",
             },
+            # the same alignment at every N: the summed lnL must not depend on n_gpus
             "lnl": lnl, "lnl_per_site": lnl / total_sites,
+            "dlnl_per_site": parity["dlnl_per_site"] if parity else None,
+            "max_persite_dlnl": parity["max_persite_dlnl"] if parity else None,
+            "parity": parity,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

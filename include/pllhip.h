@@ -107,7 +107,8 @@ typedef struct pllhip_counters
   unsigned long long pmatrix_launches;     /* kernel launches that served them */
   unsigned long long lnl_calls;
   unsigned long long sumtable_calls;
-  unsigned long long derivative_calls;
+  unsigned long long derivative_calls;   /* sumtable scans                     */
+  unsigned long long derivative_points;  /* trial branch lengths evaluated by them */
   unsigned long long model_uploads;      /* host->device re-syncs of model state */
 } pllhip_counters_t;
 
@@ -151,8 +152,72 @@ PLL_EXPORT pllhip_comm_t * pllhip_comm_create(const unsigned char id[PLLHIP_COMM
                                               int rank, int nranks, int device);
 PLL_EXPORT void pllhip_comm_destroy(pllhip_comm_t * comm);
 
-/* drop-in value for treeinfo's parallel_reduce_cb with ctx = pllhip_comm_t* */
+PLL_EXPORT int pllhip_comm_rank(const pllhip_comm_t * comm);
+PLL_EXPORT int pllhip_comm_size(const pllhip_comm_t * comm);
+
+/* drop-in value for treeinfo's parallel_reduce_cb with ctx = pllhip_comm_t*.  The payload is
+   a host array (the library calls before it have returned doubles), staged through one pinned
+   buffer.  On a HIP / RCCL failure the payload is set to NaN and pll_errno is set: the
+   callback has no error channel, and a rank must not continue with its local value. */
 PLL_EXPORT void pllhip_reduce_cb(void * ctx, double * data, size_t n, int op);
+
+/* ---- several trial branch lengths per sumtable scan ------------------------
+ * pll_compute_likelihood_derivatives at `count` (1..8) branch lengths in ONE pass over the
+ * sumtable (src/optimize/pll_optimize.c:1223-1287 scans it once per Newton-Raphson
+ * iteration).  d_f[i], dd_f[i] are bit-identical to what the single-length call returns
+ * for branch_lengths[i], whatever else shares the launch. */
+PLL_EXPORT int pllhip_compute_likelihood_derivatives_multi(pll_partition_t * partition,
+                                                           int parent_scaler_index,
+                                                           int child_scaler_index,
+                                                           const double * branch_lengths,
+                                                           unsigned int count,
+                                                           const unsigned int * params_indices,
+                                                           const double * sumtable,
+                                                           double * d_f, double * dd_f);
+
+/* ---- deferred scalar results -----------------------------------------------
+ * pll_compute_edge_loglikelihood and pll_compute_likelihood_derivatives hand a double back
+ * to the host: one wait per call and partition, and with several workers a host-side
+ * reduce after it.  A result group collects the totals of several such computations -- the
+ * partitions of an evaluation (src/tree/treeinfo.c:1040-1067), the trial lengths of a
+ * Newton-Raphson round (src/optimize/pll_optimize.c:1240-1286) -- in device-resident slots:
+ * the pllhip_results_* calls only enqueue work; pllhip_results_fetch() all-reduces the slots
+ * in place over the communicator (when there is one), publishes them to mapped host memory
+ * and waits ONCE.  Slots nobody deposited to since the last fetch (partitions another worker
+ * owns) count as the identity of `op`.  One fetch completes all deposits made since the
+ * previous one.  Same numbers, bit for bit, as the blocking calls. */
+typedef struct pllhip_results pllhip_results_t;
+
+PLL_EXPORT pllhip_results_t * pllhip_results_create(pllhip_comm_t * comm /* or NULL */,
+                                                    unsigned int slots);
+PLL_EXPORT void pllhip_results_destroy(pllhip_results_t * results);
+
+/* 1 slot: the edge log-likelihood of `partition` */
+PLL_EXPORT int pllhip_results_edge_loglikelihood(pllhip_results_t * results, unsigned int slot,
+                                                 pll_partition_t * partition,
+                                                 unsigned int parent_clv_index, int parent_scaler_index,
+                                                 unsigned int child_clv_index, int child_scaler_index,
+                                                 unsigned int matrix_index,
+                                                 const unsigned int * freqs_indices);
+
+/* 2 * count slots: d_f[0], dd_f[0], d_f[1], dd_f[1], ... */
+PLL_EXPORT int pllhip_results_derivatives(pllhip_results_t * results, unsigned int slot,
+                                          pll_partition_t * partition,
+                                          int parent_scaler_index, int child_scaler_index,
+                                          const double * branch_lengths, unsigned int count,
+                                          const unsigned int * params_indices,
+                                          const double * sumtable);
+
+/* out[i] = reduce over all workers of slot first + i; NaN in every out[i] and
+   PLL_FAILURE on a HIP / RCCL error */
+PLL_EXPORT int pllhip_results_fetch(pllhip_results_t * results, unsigned int first,
+                                    unsigned int count, int op, double * out);
+
+/* give a pllhip_eval driver (include/pllhip_eval.h) a result group over `comm` (NULL: this
+   process only) sized for its partitions; the driver then reduces its lnL and
+   {df, ddf} on the device */
+struct pllhip_eval;
+PLL_EXPORT int pllhip_eval_attach_comm(struct pllhip_eval * ev, pllhip_comm_t * comm);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,13 @@ extern "C" {
 #endif
 
 #define PLLHIP_EVAL_PMATRIX_PER_BRANCH (1 << 0)
+/* Newton-Raphson evaluates only the current iterate per sumtable scan (the reference's
+   pattern, src/optimize/pll_optimize.c:1223-1287).  Without this flag every scan also
+   evaluates the iterates the step rule can produce by CLAMPING (+-dxmax, the bracket
+   ends: known before the derivatives are), and an iteration whose point was already
+   evaluated costs no scan.  The iterate sequence and every result are bit-identical
+   either way (include/pllhip.h: pllhip_compute_likelihood_derivatives_multi). */
+#define PLLHIP_EVAL_NO_SPECULATION     (1 << 1)
 
 #define PLLHIP_EVAL_RADIUS_ALL (-1)   /* PLLMOD_OPT_BRLEN_OPTIMIZE_ALL, src/optimize/pll_optimize.h:102 */
 
@@ -61,6 +68,30 @@ PLL_EXPORT int pllhip_eval_set_partition(pllhip_eval_t * ev, unsigned int index,
 
 PLL_EXPORT void pllhip_eval_set_parallel_context(pllhip_eval_t * ev, void * ctx,
                                                  pllhip_reduce_fn reduce_cb);
+
+/* Deferred scalar results (include/pllhip.h, pllhip_results_*): with such a table the
+   driver enqueues the edge log-likelihoods / derivative scans of ALL its partitions,
+   then fetches once -- one wait per evaluation or Newton-Raphson round instead of one per
+   partition, and the sum over the workers happens on the device (RCCL) inside the fetch.
+   It replaces the reduce callback for these two reductions.  The driver owns `results`
+   and calls destroy() on it.  libpll_hip.so provides pllhip_eval_attach_comm() to fill
+   this in; the table keeps this driver free of device code. */
+typedef struct pllhip_eval_fused
+{
+  void * results;
+  int (*edge_loglikelihood)(void * results, unsigned int slot, pll_partition_t * partition,
+                            unsigned int parent_clv_index, int parent_scaler_index,
+                            unsigned int child_clv_index, int child_scaler_index,
+                            unsigned int matrix_index, const unsigned int * freqs_indices);
+  int (*derivatives)(void * results, unsigned int slot, pll_partition_t * partition,
+                     int parent_scaler_index, int child_scaler_index,
+                     const double * branch_lengths, unsigned int count,
+                     const unsigned int * params_indices, const double * sumtable);
+  int (*fetch)(void * results, unsigned int first, unsigned int count, int op, double * out);
+  void (*destroy)(void * results);
+} pllhip_eval_fused_t;
+
+PLL_EXPORT void pllhip_eval_set_fused(pllhip_eval_t * ev, const pllhip_eval_fused_t * fused);
 
 PLL_EXPORT int pllhip_eval_set_root(pllhip_eval_t * ev, pll_unode_t * root);
 PLL_EXPORT pll_unode_t * pllhip_eval_root(const pllhip_eval_t * ev);
@@ -146,7 +177,8 @@ PLL_EXPORT double pllhip_eval_spr_round(pllhip_eval_t * ev, const pllhip_spr_par
 
 PLL_EXPORT unsigned long pllhip_eval_ops(const pllhip_eval_t * ev);
 PLL_EXPORT unsigned long pllhip_eval_pmatrix_updates(const pllhip_eval_t * ev);
-PLL_EXPORT unsigned long pllhip_eval_derivative_calls(const pllhip_eval_t * ev);
+PLL_EXPORT unsigned long pllhip_eval_derivative_calls(const pllhip_eval_t * ev);   /* sumtable scans */
+PLL_EXPORT unsigned long pllhip_eval_newton_iterations(const pllhip_eval_t * ev);  /* iterates consumed */
 
 #ifdef __cplusplus
 }

@@ -503,6 +503,21 @@ int pll_compute_likelihood_derivatives(pll_partition_t * p,
   return PLL_SUCCESS;
 }
 
+/* several trial branch lengths: the oracle simply repeats the single-length computation
+   (include/pllhip.h; the product evaluates them in one pass over the sumtable) */
+int pllhip_compute_likelihood_derivatives_multi(pll_partition_t * p, int psc, int csc,
+                                                const double * branch_lengths, unsigned int count,
+                                                const unsigned int * params_indices,
+                                                const double * sumtable, double * d_f, double * dd_f)
+{
+  unsigned int i;
+  for (i = 0; i < count; ++i)
+    if (!pll_compute_likelihood_derivatives(p, psc, csc, branch_lengths[i], params_indices, sumtable,
+                                            &d_f[i], &dd_f[i]))
+      return PLL_FAILURE;
+  return PLL_SUCCESS;
+}
+
 /* marginal ancestral state probabilities at a node: per site and state,
    sum over rates of w_r pi_i node[n,r,i] * (P other)[n,r,i], normalised */
 int pll_compute_node_ancestral(pll_partition_t * p,

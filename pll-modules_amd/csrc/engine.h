@@ -26,6 +26,11 @@ constexpr unsigned MAX_RATE_CATS = 16;   // params_indices travel by value in ke
 constexpr unsigned MAX_OPS_PER_LAUNCH = 24;
 constexpr unsigned MAX_PMAT_PER_LAUNCH = 200;   // requests of one k_pmatrix launch (by value in the kernel arguments)
 constexpr unsigned REDUCE_BLOCKS = 4096; // upper bound of per-block partial sums
+constexpr unsigned REDUCE_QUANTITIES = 16; // sums per launch: up to 8 trial branch lengths x {df, ddf}
+constexpr unsigned MAX_TRIAL_LENGTHS = 8;
+constexpr unsigned REDUCE_COUNTER_WORDS = 8 * 1024 + 1;  // kernels_common.hpp: 8 shard tickets 4 KiB apart + top ticket
+constexpr unsigned RESULT_WORDS = 32;     // mapped result buffer: 16 values, sequence word at RESULT_SEQ_SLOT
+constexpr unsigned RESULT_SEQ_SLOT = 24;
 constexpr unsigned MAX_SUMTABLES = 4;    // device sumtables kept per partition (LRU)
 
 void set_error(int code, const char * fmt, ...);
@@ -57,6 +62,9 @@ struct PredBatch
   const uint8_t * in[MAX_OPS_PER_LAUNCH];
   uint8_t * out[MAX_OPS_PER_LAUNCH];
 };
+
+// trial branch lengths of one derivative launch, by value in kernel arguments
+struct TrialLengths { double t[MAX_TRIAL_LENGTHS]; };
 
 // per-rate parameter-set indices, by value in kernel arguments
 struct ParamIdxHost { unsigned v[16]; };
@@ -143,11 +151,14 @@ struct Engine
   unsigned tipmap_codes_uploaded = 0;
 
   // reductions
-  double * d_partials = nullptr;      // [3 * REDUCE_BLOCKS]
-  double * h_partials = nullptr;      // pinned mirror (unused by the kernels that finish on device)
-  unsigned * d_counter = nullptr;     // arrival ticket of the grid-wide reductions
+  double * d_partials = nullptr;      // [REDUCE_QUANTITIES * REDUCE_BLOCKS]
+  unsigned * d_counter = nullptr;     // arrival tickets of the grid-wide reductions
   double * h_result = nullptr;        // pinned + device-mapped: final sums land here
   double * d_result = nullptr;        // device pointer of h_result
+  bool fused_finish = true;           // the reduction kernels finish the sum themselves (no k_final_sum launch)
+  // where the totals of the NEXT reduction launch go (set by the entry point before the launch):
+  // the mapped result buffer + its sequence word, or a slot of a deferred result group
+  struct Sink { double * dst = nullptr; unsigned long long * flag = nullptr; unsigned long long seq = 0; unsigned nq = 0; } sink;
   double * d_persite = nullptr;       // [N], allocated on first per-site request
 
   // caller-keyed device sumtables (pointer value is the key)
@@ -175,6 +186,14 @@ int eigen_decompose(unsigned S, unsigned Sp, const double * ex, const double * p
                     double * evecs, double * ievecs, double * evals);
 
 // --- engine services (pll_core.hip) ---
+double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsigned cc, int csc,
+                          int matrix_index, const unsigned * freqs_indices,
+                          double * persite_lnl, const Engine::Sink * deferred);
+int derivatives_impl(pll_partition_t * p, int parent_scaler_index, int child_scaler_index,
+                     const double * brlens, unsigned count, const unsigned * params_indices,
+                     const double * sumtable, const Engine::Sink * deferred,
+                     double * out_df, double * out_ddf);
+int wait_sequence(hipStream_t stream, const volatile unsigned long long * flag, unsigned long long seq);
 Engine * engine_create(pll_partition_t * p);
 void engine_destroy(Engine * e);
 int sync_model(pll_partition_t * p);              // host model arrays -> HBM if changed

@@ -5,6 +5,7 @@
  * interface, so the same file serves the HIP library and the CPU oracle.
  */
 #include "pllhip_eval_internal.h"
+#include "pllhip.h"
 #include <stdarg.h>
 
 static __thread pllhip_eval_t * cb_self;   /* pll_utree_traverse callbacks carry no user pointer */
@@ -45,7 +46,8 @@ pllhip_eval_t * pllhip_eval_create(pll_utree_t * tree, unsigned int partition_co
   ev->ops = (pll_operation_t *)calloc(ev->inner, sizeof(*ev->ops));
   ev->brlens = (double *)calloc(ev->edges, sizeof(double));
   ev->midx = (unsigned int *)calloc(ev->edges, sizeof(unsigned int));
-  if (!ev->parts || !ev->params || !ev->sumtables || !ev->part_lnl || !ev->clv_valid ||
+  ev->slot_buf = (double *)calloc((size_t)partition_count * 2 * PLLHIP_EVAL_MAX_TRIALS, sizeof(double));
+  if (!ev->slot_buf || !ev->parts || !ev->params || !ev->sumtables || !ev->part_lnl || !ev->clv_valid ||
       !ev->pmat_valid || !ev->trav || !ev->ops || !ev->brlens || !ev->midx)
     goto nomem;
   /* indices must address the flag arrays */
@@ -82,7 +84,8 @@ void pllhip_eval_destroy(pllhip_eval_t * ev)
   }
   free(ev->parts); free(ev->params); free(ev->sumtables); free(ev->part_lnl);
   free(ev->clv_valid); free(ev->pmat_valid); free(ev->trav); free(ev->ops);
-  free(ev->brlens); free(ev->midx);
+  free(ev->brlens); free(ev->midx); free(ev->slot_buf);
+  if (ev->fused.destroy && ev->fused.results) ev->fused.destroy(ev->fused.results);
   free(ev);
 }
 
@@ -121,6 +124,13 @@ void pllhip_eval_set_parallel_context(pllhip_eval_t * ev, void * ctx, pllhip_red
 {
   ev->ctx = ctx;
   ev->reduce_cb = reduce_cb;
+}
+
+void pllhip_eval_set_fused(pllhip_eval_t * ev, const pllhip_eval_fused_t * fused)
+{
+  if (ev->fused.destroy && ev->fused.results) ev->fused.destroy(ev->fused.results);
+  memset(&ev->fused, 0, sizeof(ev->fused));
+  if (fused) ev->fused = *fused;
 }
 
 int pllhip_eval_set_root(pllhip_eval_t * ev, pll_unode_t * root)
@@ -210,15 +220,29 @@ static double edge_loglh(pllhip_eval_t * ev, const pll_unode_t * e)
 {
   unsigned int p;
   double total = 0.0;
-  for (p = 0; p < ev->nparts; ++p)
+  if (ev->fused.fetch)
   {
-    ev->part_lnl[p] = 0.0;
-    if (!ev->parts[p]) continue;
-    ev->part_lnl[p] = pll_compute_edge_loglikelihood(ev->parts[p], e->clv_index, e->scaler_index,
-                                                     e->back->clv_index, e->back->scaler_index,
-                                                     e->pmatrix_index, ev->params[p], NULL);
+    /* every partition's kernel is enqueued, then ONE fetch: all-reduce on the device, one wait */
+    for (p = 0; p < ev->nparts; ++p)
+      if (ev->parts[p] &&
+          !ev->fused.edge_loglikelihood(ev->fused.results, p, ev->parts[p], e->clv_index, e->scaler_index,
+                                        e->back->clv_index, e->back->scaler_index, e->pmatrix_index,
+                                        ev->params[p]))
+        return NAN;
+    if (!ev->fused.fetch(ev->fused.results, 0, ev->nparts, 0 /* SUM */, ev->part_lnl)) return NAN;
   }
-  if (ev->reduce_cb) ev->reduce_cb(ev->ctx, ev->part_lnl, ev->nparts, 0 /* SUM */);
+  else
+  {
+    for (p = 0; p < ev->nparts; ++p)
+    {
+      ev->part_lnl[p] = 0.0;
+      if (!ev->parts[p]) continue;
+      ev->part_lnl[p] = pll_compute_edge_loglikelihood(ev->parts[p], e->clv_index, e->scaler_index,
+                                                       e->back->clv_index, e->back->scaler_index,
+                                                       e->pmatrix_index, ev->params[p], NULL);
+    }
+    if (ev->reduce_cb) ev->reduce_cb(ev->ctx, ev->part_lnl, ev->nparts, 0 /* SUM */);
+  }
   for (p = 0; p < ev->nparts; ++p) total += ev->part_lnl[p];
   return total;
 }
@@ -276,36 +300,94 @@ static int ensure_sumtables(pllhip_eval_t * ev)
   return PLL_SUCCESS;
 }
 
-/* first and second derivative of -lnL over all partitions at branch length t */
-static int derivatives(pllhip_eval_t * ev, const pll_unode_t * e, double t, double * f, double * df)
+/* first and second derivative of -lnL over all partitions at `count` trial branch
+   lengths from ONE scan of every partition's sumtable (and one reduce over the workers) */
+static int derivatives(pllhip_eval_t * ev, const pll_unode_t * e, const double * t, unsigned int count,
+                       double * f, double * df)
 {
-  unsigned int p;
-  double v[2] = {0.0, 0.0};
-  for (p = 0; p < ev->nparts; ++p)
+  unsigned int p, k;
+  double * buf = ev->slot_buf;
+  for (k = 0; k < count; ++k) f[k] = df[k] = 0.0;
+  if (ev->fused.fetch)
   {
-    double a, b;
-    if (!ev->parts[p]) continue;
-    if (!pll_compute_likelihood_derivatives(ev->parts[p], e->scaler_index, e->back->scaler_index, t,
-                                            ev->params[p], ev->sumtables[p], &a, &b))
-      return PLL_FAILURE;
-    v[0] += a;
-    v[1] += b;
+    for (p = 0; p < ev->nparts; ++p)
+      if (ev->parts[p] &&
+          !ev->fused.derivatives(ev->fused.results, p * 2 * count, ev->parts[p], e->scaler_index,
+                                 e->back->scaler_index, t, count, ev->params[p], ev->sumtables[p]))
+        return PLL_FAILURE;
+    if (!ev->fused.fetch(ev->fused.results, 0, ev->nparts * 2 * count, 0 /* SUM */, buf)) return PLL_FAILURE;
+    for (p = 0; p < ev->nparts; ++p)
+      for (k = 0; k < count; ++k)
+      {
+        f[k] += buf[(p * count + k) * 2];
+        df[k] += buf[(p * count + k) * 2 + 1];
+      }
+  }
+  else
+  {
+    double a[PLLHIP_EVAL_MAX_TRIALS], b[PLLHIP_EVAL_MAX_TRIALS];
+    for (p = 0; p < ev->nparts; ++p)
+    {
+      if (!ev->parts[p]) continue;
+      if (count == 1)
+      {
+        if (!pll_compute_likelihood_derivatives(ev->parts[p], e->scaler_index, e->back->scaler_index, t[0],
+                                                ev->params[p], ev->sumtables[p], &a[0], &b[0]))
+          return PLL_FAILURE;
+      }
+      else if (!pllhip_compute_likelihood_derivatives_multi(ev->parts[p], e->scaler_index,
+                                                            e->back->scaler_index, t, count, ev->params[p],
+                                                            ev->sumtables[p], a, b))
+        return PLL_FAILURE;
+      for (k = 0; k < count; ++k) { f[k] += a[k]; df[k] += b[k]; }
+    }
+    if (ev->reduce_cb)
+    {
+      /* {df, ddf} of every trial length in one message (src/optimize/pll_optimize.c:1281-1284) */
+      for (k = 0; k < count; ++k) { buf[2 * k] = f[k]; buf[2 * k + 1] = df[k]; }
+      ev->reduce_cb(ev->ctx, buf, 2 * count, 0 /* SUM */);
+      for (k = 0; k < count; ++k) { f[k] = buf[2 * k]; df[k] = buf[2 * k + 1]; }
+    }
   }
   ev->n_deriv++;
-  if (ev->reduce_cb) ev->reduce_cb(ev->ctx, v, 2, 0 /* SUM */);
-  *f = v[0];
-  *df = v[1];
   return PLL_SUCCESS;
 }
 
+/* the step rule of the reference's minimiser (opt_algorithms.c:208-240) clamps a Newton
+   step to +-dxmax and to the bracket [xl, xh]: those outcomes are known BEFORE the
+   derivatives are.  Returns the iterate a clamped step upwards (dir > 0) / downwards leads
+   to from x, computed with the step rule's own expressions so that it is that iterate bit
+   for bit. */
+static double clamped_iterate(const blo_t * b, double x, double xl, double xh, double dxmax, int dir)
+{
+  double dx = dir > 0 ? dxmax : -dxmax;
+  if (x + dx < xl) dx = xl - x;
+  if (x + dx > xh) dx = xh - x;
+  x += dx;
+  return PLL_MAX(PLL_MIN(x, b->bl_max), b->bl_min);
+}
+
+static unsigned int add_trial(double * t, unsigned int n, double v)
+{
+  unsigned int i;
+  for (i = 0; i < n; ++i) if (t[i] == v) return n;
+  if (n < PLLHIP_EVAL_MAX_TRIALS) t[n++] = v;
+  return n;
+}
+
 /* one-dimensional Newton-Raphson with bracketing: step rule of the reference's
-   multi-function minimiser for a single function (opt_algorithms.c:133-261) */
+   multi-function minimiser for a single function (opt_algorithms.c:133-261).  Each scan
+   of the sumtables evaluates the current iterate and the iterates clamped steps would
+   lead to (two levels); an iteration whose point is among the ones already evaluated
+   costs no scan.  Same iterates, same results as one scan per iteration. */
 static int newton(const blo_t * b, const pll_unode_t * e, double * x)
 {
   pllhip_eval_t * ev = b->ev;
   const double dxmax = b->bl_max / b->max_newton;
+  const int speculate = !(ev->flags & PLLHIP_EVAL_NO_SPECULATION);
   double xl = b->bl_min, xh = b->bl_max, f, df, dx;
-  unsigned int iter = 0;
+  double t[PLLHIP_EVAL_MAX_TRIALS], tf[PLLHIP_EVAL_MAX_TRIALS], tdf[PLLHIP_EVAL_MAX_TRIALS];
+  unsigned int nt = 0, k, iter = 0;
   *x = PLL_MAX(PLL_MIN(*x, b->bl_max), b->bl_min);
   for (;;)
   {
@@ -314,7 +396,29 @@ static int newton(const blo_t * b, const pll_unode_t * e, double * x)
       pllhip_eval_error(PLLHIP_EVAL_ERROR_NEWTON_LIMIT, "Exceeded maximum number of iterations");
       return PLL_FAILURE;
     }
-    if (!derivatives(ev, e, *x, &f, &df)) return PLL_FAILURE;
+    for (k = 0; k < nt; ++k) if (t[k] == *x) break;
+    if (k == nt)
+    {
+      nt = 0;
+      t[nt++] = *x;
+      if (speculate)
+      {
+        const double up = clamped_iterate(b, *x, xl, xh, dxmax, 1);
+        const double dn = clamped_iterate(b, *x, xl, xh, dxmax, -1);
+        nt = add_trial(t, nt, dn);
+        nt = add_trial(t, nt, up);
+        /* second level, while the scan stays at four lengths (beyond that the extra
+           arithmetic of a length shows in the scan time): brackets as they stand after a
+           step in that direction */
+        if (nt < PLLHIP_EVAL_SPECULATE_MAX) nt = add_trial(t, nt, clamped_iterate(b, dn, xl, *x, dxmax, -1));
+        if (nt < PLLHIP_EVAL_SPECULATE_MAX) nt = add_trial(t, nt, clamped_iterate(b, up, *x, xh, dxmax, 1));
+      }
+      if (!derivatives(ev, e, t, nt, tf, tdf)) return PLL_FAILURE;
+      k = 0;
+    }
+    f = tf[k];
+    df = tdf[k];
+    ev->n_newton++;
     if (!isfinite(f) || !isfinite(df))
     {
       pllhip_eval_error(PLLHIP_EVAL_ERROR_NEWTON_DERIV, "Wrong likelihood derivatives");
@@ -456,3 +560,4 @@ double pllhip_eval_optimize_impl(pllhip_eval_t * ev, double min_brlen, double ma
 unsigned long pllhip_eval_ops(const pllhip_eval_t * ev) { return ev->n_ops; }
 unsigned long pllhip_eval_pmatrix_updates(const pllhip_eval_t * ev) { return ev->n_pmat; }
 unsigned long pllhip_eval_derivative_calls(const pllhip_eval_t * ev) { return ev->n_deriv; }
+unsigned long pllhip_eval_newton_iterations(const pllhip_eval_t * ev) { return ev->n_newton; }

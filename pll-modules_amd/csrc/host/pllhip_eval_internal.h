@@ -25,8 +25,13 @@ struct pllhip_eval
   double * part_lnl;
   void * ctx;
   pllhip_reduce_fn reduce_cb;
-  unsigned long n_ops, n_pmat, n_deriv;
+  unsigned long n_ops, n_pmat, n_deriv, n_newton;
+  pllhip_eval_fused_t fused;      /* fused.fetch != NULL: deferred results */
+  double * slot_buf;              /* [nparts * 2 * PLLHIP_EVAL_MAX_TRIALS] */
 };
+
+#define PLLHIP_EVAL_MAX_TRIALS 8
+#define PLLHIP_EVAL_SPECULATE_MAX 4
 
 void pllhip_eval_error(int code, const char * fmt, ...);
 double pllhip_eval_optimize_impl(pllhip_eval_t * ev, double min_brlen, double max_brlen,

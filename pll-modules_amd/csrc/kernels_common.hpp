@@ -61,18 +61,31 @@ __device__ inline double block_sum_256(double v, double * scratch)
   return t;
 }
 
-// Grid-wide sums that end in host-visible memory without a device->host copy:
-// every block stores its total; a second, single-block kernel (k_final_sum, the
-// kernel boundary gives the visibility) adds the block totals in a FIXED order
-// and writes the result into pinned, device-mapped host memory.  Bit-reproducible
-// run to run.  (An in-kernel "last block finishes" variant with agent-scope
-// fences was measured 3x slower here: thousands of release fences from short
-// streaming blocks serialise on the XCD L2 write-back.)
+// Grid-wide sums that end where the caller wants them -- pinned, device-mapped host
+// memory (a scalar-returning call: no device->host copy) or a device-resident slot (a
+// deferred result, all-reduced by RCCL afterwards) -- in ONE launch and bit-reproducible
+// run to run:
+//   every block publishes its totals with write-through (sc1) stores, waits for them and
+//   draws a ticket (two levels: 8 shard counters on lines of their own, then a top
+//   counter, so that no single address takes more than gridDim.x / 8 adds); the block
+//   that draws the last ticket acquires once and adds all block totals in a FIXED order
+//   (by block index), whatever the arrival order was.  No release fence anywhere:
+//   `__threadfence()` in every block serialises on the L2 write-back (measured 3x slower
+//   in round 1; MI355X_MICROARCH.md, hand-off forms).
+// fused == 0 keeps the two-launch form (block totals, then k_final_sum).
+constexpr unsigned REDUCE_SHARDS = 8;
+constexpr unsigned REDUCE_SHARD_STRIDE = 1024;   // unsigned words: 4 KiB apart
+constexpr unsigned REDUCE_MAX_Q = 16;            // quantities per launch (8 trial lengths x {df, ddf})
+
 struct ReduceOut
 {
-  double * block_out;     // [quantities][gridDim.x] device scratch
-  unsigned * counter;     // zero before the launch; reset by the last block
-  double * host_result;   // device pointer of pinned host memory, [quantities]
+  double * block_out;          // [quantities][gridDim.x] device scratch
+  unsigned * counter;          // [REDUCE_SHARDS * REDUCE_SHARD_STRIDE + 1], zero between launches
+  double * dst;                // [quantities] mapped host memory or device slot
+  unsigned long long * flag;   // or null: takes `seq` once dst is visible to the host
+  unsigned long long seq;
+  int fused;
+  unsigned nq;                 // quantities to publish (a padded multi-length launch computes more)
 };
 
 inline ReduceOut reduce_out(const Engine * e)
@@ -80,45 +93,103 @@ inline ReduceOut reduce_out(const Engine * e)
   ReduceOut ro;
   ro.block_out = e->d_partials;
   ro.counter = e->d_counter;
-  ro.host_result = e->d_result;
+  ro.dst = e->sink.dst;
+  ro.flag = e->sink.flag;
+  ro.seq = e->sink.seq;
+  ro.fused = e->fused_finish ? 1 : 0;
+  ro.nq = e->sink.nq;
   return ro;
+}
+
+// sum of block_out[q][0 .. nblocks) in the fixed order both finishing forms share:
+// thread-strided partial sums, wave butterfly, four waves
+template <bool SC1>
+__device__ inline double final_sum_256(const double * col, unsigned nblocks, double * scratch)
+{
+  double a = 0.0;
+  for (unsigned b = threadIdx.x; b < nblocks; b += 256)
+    a += SC1 ? __hip_atomic_load(col + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : col[b];
+  return block_sum_256(a, scratch);
+}
+
+__device__ inline void publish_result(const ReduceOut & ro)
+{
+  // values first, then the sequence word the host polls
+  if (ro.flag)
+  {
+    __threadfence_system();
+    __hip_atomic_store(ro.flag, ro.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 template <int Q>
 __device__ inline void grid_reduce_finish(const double (&tot)[Q], const ReduceOut & ro,
                                           double * scratch)
 {
-  (void)scratch;
+  const unsigned G = gridDim.x, b = blockIdx.x;
+  if (!ro.fused)
+  {
+    if (threadIdx.x == 0)
+    {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) ro.block_out[(size_t)q * G + b] = tot[q];
+    }
+    return;
+  }
+  unsigned * s_last = reinterpret_cast<unsigned *>(scratch);   // block_sum_256 left it free
   if (threadIdx.x == 0)
   {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) ro.block_out[(size_t)q * gridDim.x + blockIdx.x] = tot[q];
+    for (int q = 0; q < Q; ++q)
+      __hip_atomic_store(ro.block_out + (size_t)q * G + b, tot[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned last = 0;
+    const unsigned shard = b % REDUCE_SHARDS;
+    const unsigned in_shard = (G - shard + REDUCE_SHARDS - 1) / REDUCE_SHARDS;     // blocks with this b % 8
+    const unsigned t1 = __hip_atomic_fetch_add(ro.counter + shard * REDUCE_SHARD_STRIDE, 1u,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t1 == in_shard - 1)
+    {
+      const unsigned shards = G < REDUCE_SHARDS ? G : REDUCE_SHARDS;
+      const unsigned t2 = __hip_atomic_fetch_add(ro.counter + REDUCE_SHARDS * REDUCE_SHARD_STRIDE, 1u,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = (t2 == shards - 1);
+    }
+    *s_last = last;
   }
-}
-
-// block_out[q][nblocks] -> host_result[q]; one block of 256 threads
-// host_result[RESULT_SEQ_SLOT] takes `seq` (as an integer) once the sums are visible to the
-// host: the caller may poll it instead of paying a stream synchronisation.
-constexpr unsigned RESULT_SEQ_SLOT = 7;
-
-__global__ __launch_bounds__(256) void k_final_sum(const double * block_out, unsigned nblocks,
-                                                   unsigned nq, double * host_result,
-                                                   unsigned long long seq)
-{
-  __shared__ double scratch[4];
-  for (unsigned q = 0; q < nq; ++q)
-  {
-    double a = 0.0;
-    for (unsigned b = threadIdx.x; b < nblocks; b += 256) a += block_out[(size_t)q * nblocks + b];
-    const double t = block_sum_256(a, scratch);
-    if (threadIdx.x == 0) host_result[q] = t;
-  }
+  __syncthreads();
+  const unsigned last = *s_last;
+  __syncthreads();
+  if (!last) return;                      // block-uniform
   if (threadIdx.x == 0)
   {
-    __threadfence_system();
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(host_result) + RESULT_SEQ_SLOT, seq,
-                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  __syncthreads();
+#pragma unroll 1
+  for (int q = 0; q < Q; ++q)
+  {
+    if ((unsigned)q >= ro.nq) break;
+    const double t = final_sum_256<true>(ro.block_out + (size_t)q * G, G, scratch);
+    if (threadIdx.x == 0) ro.dst[q] = t;
+  }
+  if (threadIdx.x <= REDUCE_SHARDS)       // tickets back to zero for the next launch on this stream
+    __hip_atomic_store(ro.counter + threadIdx.x * REDUCE_SHARD_STRIDE, 0u, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) publish_result(ro);
+}
+
+// two-launch form: block_out[q][nblocks] -> dst[q]; one block of 256 threads
+__global__ __launch_bounds__(256) void k_final_sum(ReduceOut ro, unsigned nblocks, unsigned nq)
+{
+  __shared__ double scratch[4];
+  for (unsigned q = 0; q < nq && q < ro.nq; ++q)
+  {
+    const double t = final_sum_256<false>(ro.block_out + (size_t)q * nblocks, nblocks, scratch);
+    if (threadIdx.x == 0) ro.dst[q] = t;
+  }
+  if (threadIdx.x == 0) publish_result(ro);
 }
 
 __device__ inline void grid_reduce_finish1(double a, const ReduceOut & ro, double * scratch)

@@ -334,11 +334,15 @@ __global__ __launch_bounds__(256) void k_sumtable_generic(ModelView mv, ParamIdx
 }
 
 // ---------------------------------------------------------------------------
-// derivatives of -lnL, generic: one thread per site; coefficient tables
-// e0/e1/e2[r][k] = w_r' exp(l t) {1, l, l^2}, l = lambda_k rate_r/(1-pinv),
-// are built per block in LDS.   block_out: [3][gridDim.x] (df, ddf)
+// derivatives of -lnL at K trial branch lengths from ONE pass over the sumtable,
+// generic: one thread per site; coefficient tables
+// e0/e1/e2[j][r][k] = w_r' exp(l t_j) {1, l, l^2}, l = lambda_k rate_r/(1-pinv),
+// are built per block in LDS.   totals: df[0], ddf[0], df[1], ddf[1], ...
+// Every trial length goes through the arithmetic of the K = 1 instance, so its
+// result does not depend on which other lengths share the launch.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_derivatives_generic(ModelView mv, ParamIdx params, double t,
+template <int K>
+__global__ __launch_bounds__(256) void k_derivatives_generic(ModelView mv, ParamIdx params, TrialLengths tl,
                                                              const double * sumtable,
                                                              const unsigned * ps, const unsigned * cs,
                                                              const unsigned * weights,
@@ -346,38 +350,33 @@ __global__ __launch_bounds__(256) void k_derivatives_generic(ModelView mv, Param
                                                              unsigned N, unsigned R,
                                                              ReduceOut block_out)
 {
-  extern __shared__ double lds[];          // e0 | e1 | e2, each R*S
+  extern __shared__ double lds[];          // per trial length: e0 | e1 | e2, each R*S
   __shared__ double scratch[4];
-  const unsigned S = mv.S, Sp = mv.Sp;
-  double * e0 = lds, * e1 = lds + R * S, * e2 = lds + 2 * R * S;
-  for (unsigned q = threadIdx.x; q < R * S; q += blockDim.x)
+  const unsigned S = mv.S, Sp = mv.Sp, RS = R * S;
+  for (unsigned x = threadIdx.x; x < K * RS; x += blockDim.x)
   {
+    const unsigned j = x / RS, q = x % RS;
     const unsigned r = q / S, k = q % S, pi_ = params.v[r];
     const double pinv = mv.pinv()[pi_];
     const double lam = mv.evals(pi_)[k] * mv.rates()[r] / (1.0 - pinv);
     const double wr = mv.weights()[r] * ((pinv > 0.0) ? (1.0 - pinv) : 1.0);
-    const double ex = exp(lam * t);
-    e0[q] = wr * ex;
-    e1[q] = wr * ex * lam;
-    e2[q] = wr * ex * lam * lam;
+    const double ex = exp(lam * tl.t[j]);
+    double * e = lds + (size_t)j * 3 * RS;
+    e[q] = wr * ex;
+    e[RS + q] = wr * ex * lam;
+    e[2 * RS + q] = wr * ex * lam * lam;
   }
   __syncthreads();
 
-  double df = 0.0, ddf = 0.0;
+  double df[K], ddf[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) df[j] = ddf[j] = 0.0;
   for (unsigned long long n = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; n < N;
        n += (unsigned long long)gridDim.x * blockDim.x)
   {
-    double A = 0.0, B = 0.0, C = 0.0, inv = 0.0;
+    double inv = 0.0;
     for (unsigned r = 0; r < R; ++r)
     {
-      const double * st = sumtable + (n * R + r) * Sp;
-      for (unsigned k = 0; k < S; ++k)
-      {
-        const double v = st[k];
-        A += v * e0[r * S + k];
-        B += v * e1[r * S + k];
-        C += v * e2[r * S + k];
-      }
       const unsigned pi_ = params.v[r];
       const double pinv = mv.pinv()[pi_];
       if (pinv > 0.0 && invariant && invariant[n] >= 0)
@@ -386,15 +385,39 @@ __global__ __launch_bounds__(256) void k_derivatives_generic(ModelView mv, Param
     if (inv > 0.0)
     {
       const unsigned cnt = (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
-      A += (cnt <= 3) ? ldexp(inv, 256 * (int)cnt) : INFINITY;
+      inv = (cnt <= 3) ? ldexp(inv, 256 * (int)cnt) : INFINITY;
     }
-    const double w = (double)weights[n], ba = B / A, ca = C / A;
-    df -= w * ba;
-    ddf += w * (ba * ba - ca);
+    const double w = (double)weights[n];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+    {
+      const double * e0 = lds + (size_t)j * 3 * RS, * e1 = e0 + RS, * e2 = e1 + RS;
+      double A = 0.0, B = 0.0, C = 0.0;
+      for (unsigned r = 0; r < R; ++r)
+      {
+        const double * st = sumtable + (n * R + r) * Sp;
+        for (unsigned k = 0; k < S; ++k)
+        {
+          const double v = st[k];
+          A += v * e0[r * S + k];
+          B += v * e1[r * S + k];
+          C += v * e2[r * S + k];
+        }
+      }
+      if (inv > 0.0) A += inv;
+      const double ba = B / A, ca = C / A;
+      df[j] -= w * ba;
+      ddf[j] += w * (ba * ba - ca);
+    }
   }
-  const double tdf = block_sum_256(df, scratch);
-  const double tddf = block_sum_256(ddf, scratch);
-  grid_reduce_finish2(tdf, tddf, block_out, scratch);
+  double tot[2 * K];
+#pragma unroll
+  for (int j = 0; j < K; ++j)
+  {
+    tot[2 * j] = block_sum_256(df[j], scratch);
+    tot[2 * j + 1] = block_sum_256(ddf[j], scratch);
+  }
+  grid_reduce_finish<2 * K>(tot, block_out, scratch);
 }
 
 // ---------------------------------------------------------------------------
@@ -534,14 +557,22 @@ static int launch_sumtable_generic(Engine * e, const ModelView & mv, const Param
   return PLL_SUCCESS;
 }
 
+// K trial lengths -> the smallest instance that holds them (1, 2, 4, 8); spare slots repeat the last length
+#define PLLHIP_DISPATCH_K(count, CALL) \
+  do { if ((count) <= 1) { CALL(1); } else if ((count) == 2) { CALL(2); } \
+       else if ((count) <= 4) { CALL(4); } else { CALL(8); } } while (0)
+
+inline unsigned trial_instance(unsigned count) { return count <= 1 ? 1u : count == 2 ? 2u : count <= 4 ? 4u : 8u; }
+
 static int launch_derivatives_generic(Engine * e, const ModelView & mv, const ParamIdx & params,
-                                      double t, const double * d_sum,
+                                      const TrialLengths & tl, unsigned count, const double * d_sum,
                                       const unsigned * ps, const unsigned * cs, unsigned nblocks)
 {
-  const size_t lds = sizeof(double) * 3 * e->R * e->S;
-  hipLaunchKernelGGL(k_derivatives_generic, dim3(nblocks), dim3(256), lds, e->stream,
-                     mv, params, t, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->R,
-                     reduce_out(e));
+#define PLLHIP_CALL(KK) \
+  hipLaunchKernelGGL(k_derivatives_generic<KK>, dim3(nblocks), dim3(256), sizeof(double) * 3 * KK * e->R * e->S, \
+                     e->stream, mv, params, tl, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->R, reduce_out(e))
+  PLLHIP_DISPATCH_K(count, PLLHIP_CALL);
+#undef PLLHIP_CALL
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

@@ -673,51 +673,72 @@ __global__ __launch_bounds__(256) void k_sumtable_prep_s20(ModelView mv, ParamId
 }
 
 // ---------------------------------------------------------------------------
-// derivatives of -lnL from a blocked sumtable.  block_out = [df | ddf]
-// dynamic LDS = 3 * R * 20 doubles
+// derivatives of -lnL at up to FOUR trial branch lengths from ONE pass over a blocked
+// sumtable, on the matrix cores (20- and 61-state families: KS = 5 / 16 k-steps).
+//   A_n(t) = sum_r sum_k sum[n,r,k] e0_t[r][k],  B_n, C_n with e1, e2    
+// is a [16 x rows] x [rows x 32 sites] product per rate, accumulated over the rates in one
+// accumulator: row j + 4c of the left operand holds e_c of trial length j (c = 0, 1, 2;
+// rows 12..15 are zero), and a unit of the sumtable IS the right operand (B layout of the
+// family).  In the D layout lane group q then holds A, B, C (registers 0, 1, 2) of trial
+// length j = q for its two sites: the per-site ratios need no cross-lane traffic at all.
+// Four lengths cost what one costs (the kernel stays HBM-bound: 2 KS MFMAs per 1 KiB x KS
+// loaded), and a row's result does not depend on the other rows, i.e. on which other
+// lengths share the launch.
+// dynamic LDS = R * KS * 64 doubles (the left operands as per-lane fragments)
+// totals: df[0], ddf[0], df[1], ddf[1], ...
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_derivatives_s20(ModelView mv, ParamIdx params, double t,
-                                                         const double * sumtable,
-                                                         const unsigned * ps, const unsigned * cs,
-                                                         const unsigned * weights, const int * invariant,
-                                                         unsigned N, unsigned nblk, unsigned R,
-                                                         ReduceOut block_out)
+template <unsigned KS, unsigned SREAL>
+__global__ __launch_bounds__(256) void k_derivatives_mfma(ModelView mv, ParamIdx params, TrialLengths tl,
+                                                          const double * sumtable,
+                                                          const unsigned * ps, const unsigned * cs,
+                                                          const unsigned * weights, const int * invariant,
+                                                          unsigned N, unsigned nblk, unsigned R,
+                                                          ReduceOut block_out)
 {
-  extern __shared__ double coef[];        // e0 | e1 | e2, each [R][20]
+  extern __shared__ double frag[];        // [r][ks][lane]
   __shared__ double scratch[4];
-  double * e0 = coef, * e1 = coef + R * 20, * e2 = coef + 2 * R * 20;
-  for (unsigned x = threadIdx.x; x < R * 20; x += blockDim.x)
+  constexpr unsigned UNIT = 4 * KS * S20_BS;
+  for (unsigned x = threadIdx.x; x < R * KS * 64; x += blockDim.x)
   {
-    const unsigned r = x / 20, k = x % 20, pi_ = params.v[r];
-    const double pinv = mv.pinv()[pi_];
-    const double lam = mv.evals(pi_)[k] * mv.rates()[r] / (1.0 - pinv);
-    const double wr = mv.weights()[r] * ((pinv > 0.0) ? (1.0 - pinv) : 1.0);
-    const double ex = exp(lam * t);
-    e0[x] = wr * ex;
-    e1[x] = wr * ex * lam;
-    e2[x] = wr * ex * lam * lam;
+    const unsigned l = x & 63, ks = (x >> 6) % KS, r = (x >> 6) / KS;
+    const unsigned rho = l & 15, j = rho & 3, c = rho >> 2, k = 4 * ks + (l >> 4);
+    double v = 0.0;
+    if (c < 3 && k < SREAL)
+    {
+      const unsigned pi_ = params.v[r];
+      const double pinv = mv.pinv()[pi_];
+      const double lam = mv.evals(pi_)[k] * mv.rates()[r] / (1.0 - pinv);
+      const double wr = mv.weights()[r] * ((pinv > 0.0) ? (1.0 - pinv) : 1.0);
+      const double ex = exp(lam * tl.t[j]);
+      v = (c == 0) ? wr * ex : (c == 1) ? wr * ex * lam : wr * ex * lam * lam;
+    }
+    frag[x] = v;
   }
   __syncthreads();
 
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned q = lane >> 4, n = lane & 15;
   const unsigned wstride = gridDim.x * 4;
-  double df = 0.0, ddf = 0.0;
+  double df = 0.0, ddf = 0.0;                 // of trial length q
   for (unsigned blk = blockIdx.x * 4 + wave; blk < nblk; blk += wstride)
   {
     const size_t site0 = (size_t)blk * S20_BS + 2 * n;
-    const SiteSide sd = load_site_side(ps, cs, weights, site0, N, q == 0 && blk < nblk);
-    double Ae = 0, Be = 0, Ce = 0, Ao = 0, Bo = 0, Co = 0, inv_e = 0, inv_o = 0;
+    const SiteSide sd = load_site_side(ps, cs, weights, site0, N, true);
+    v4d acc_e = {0, 0, 0, 0}, acc_o = {0, 0, 0, 0};
+    double inv_e = 0, inv_o = 0;
     for (unsigned r = 0; r < R; ++r)
     {
-      double2 s[5];
-      s20_load_d(sumtable + ((size_t)blk * R + r) * S20_UNIT, lane, s);
+      const double * unit = sumtable + ((size_t)blk * R + r) * UNIT + lane * 2;
+      double2 b[KS];
 #pragma unroll
-      for (unsigned k = 0; k < 5; ++k)
+      for (unsigned ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const double2 *>(unit + ks * 128);
+      const double * fr = frag + (size_t)r * KS * 64 + lane;
+#pragma unroll
+      for (unsigned ks = 0; ks < KS; ++ks)
       {
-        const unsigned row = r * 20 + s20_row(k, q);
-        Ae += s[k].x * e0[row]; Be += s[k].x * e1[row]; Ce += s[k].x * e2[row];
-        Ao += s[k].y * e0[row]; Bo += s[k].y * e1[row]; Co += s[k].y * e2[row];
+        const double f = fr[ks * 64];
+        acc_e = mfma_f64(f, b[ks].x, acc_e);
+        acc_o = mfma_f64(f, b[ks].y, acc_o);
       }
       const unsigned pi_ = params.v[r];
       const double pinv = mv.pinv()[pi_];
@@ -728,37 +749,31 @@ __global__ __launch_bounds__(256) void k_derivatives_s20(ModelView mv, ParamIdx 
         if (site0 + 1 < N && invariant[site0 + 1] >= 0) inv_o += w * mv.freqs(pi_)[invariant[site0 + 1]];
       }
     }
-    Ae = s20_sum_q(Ae); Be = s20_sum_q(Be); Ce = s20_sum_q(Ce);
-    Ao = s20_sum_q(Ao); Bo = s20_sum_q(Bo); Co = s20_sum_q(Co);
-    if (q == 0)
+    if (site0 < N)
     {
-      if (site0 < N)
-      {
-        if (inv_e > 0.0)
-        {
-          const unsigned cnt = sd.cnt_e;
-          Ae += (cnt <= 3) ? ldexp(inv_e, 256 * (int)cnt) : INFINITY;
-        }
-        const double w = (double)sd.w_e, ba = Be / Ae, ca = Ce / Ae;
-        df -= w * ba;
-        ddf += w * (ba * ba - ca);
-      }
-      if (site0 + 1 < N)
-      {
-        if (inv_o > 0.0)
-        {
-          const unsigned cnt = sd.cnt_o;
-          Ao += (cnt <= 3) ? ldexp(inv_o, 256 * (int)cnt) : INFINITY;
-        }
-        const double w = (double)sd.w_o, ba = Bo / Ao, ca = Co / Ao;
-        df -= w * ba;
-        ddf += w * (ba * ba - ca);
-      }
+      double a = acc_e[0];
+      if (inv_e > 0.0) a += (sd.cnt_e <= 3) ? ldexp(inv_e, 256 * (int)sd.cnt_e) : INFINITY;
+      const double w = (double)sd.w_e, ba = acc_e[1] / a, ca = acc_e[2] / a;
+      df -= w * ba;
+      ddf += w * (ba * ba - ca);
+    }
+    if (site0 + 1 < N)
+    {
+      double a = acc_o[0];
+      if (inv_o > 0.0) a += (sd.cnt_o <= 3) ? ldexp(inv_o, 256 * (int)sd.cnt_o) : INFINITY;
+      const double w = (double)sd.w_o, ba = acc_o[1] / a, ca = acc_o[2] / a;
+      df -= w * ba;
+      ddf += w * (ba * ba - ca);
     }
   }
-  const double tdf = block_sum_256(df, scratch);
-  const double tddf = block_sum_256(ddf, scratch);
-  grid_reduce_finish2(tdf, tddf, block_out, scratch);
+  double tot[8];
+#pragma unroll
+  for (unsigned j = 0; j < 4; ++j)
+  {
+    tot[2 * j] = block_sum_256(q == j ? df : 0.0, scratch);
+    tot[2 * j + 1] = block_sum_256(q == j ? ddf : 0.0, scratch);
+  }
+  grid_reduce_finish<8>(tot, block_out, scratch);
 }
 
 // ---------------------------------------------------------------------------
@@ -918,14 +933,15 @@ static int launch_sumtable_s20(Engine * e, const ModelView & mv, const ParamIdx 
   return launch_partials_s20(e, batch, 1);
 }
 
-static int launch_derivatives_s20(Engine * e, const ModelView & mv, const ParamIdx & params, double t,
+// up to 4 trial lengths per launch (spare rows repeat the last length)
+static int launch_derivatives_s20(Engine * e, const ModelView & mv, const ParamIdx & params,
+                                  const TrialLengths & tl, unsigned count,
                                   const double * d_sum, const unsigned * ps, const unsigned * cs,
                                   unsigned nblocks)
 {
-  const size_t lds = sizeof(double) * 3 * e->R * 20;
-  hipLaunchKernelGGL(k_derivatives_s20, dim3(nblocks), dim3(256), lds, e->stream,
-                     mv, params, t, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R,
-                     reduce_out(e));
+  (void)count;
+  hipLaunchKernelGGL((k_derivatives_mfma<5, 20>), dim3(nblocks), dim3(256), sizeof(double) * e->R * 5 * 64, e->stream,
+                     mv, params, tl, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, reduce_out(e));
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

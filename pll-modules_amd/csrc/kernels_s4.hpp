@@ -469,8 +469,10 @@ __global__ __launch_bounds__(256) void k_sumtable_s4(ModelView mv, ParamIdx para
   }
 }
 
-// derivatives of -lnL: lane = (site, rate); block_out = [df x nblocks | ddf x nblocks]
-__global__ __launch_bounds__(256) void k_derivatives_s4(ModelView mv, ParamIdx params, double t,
+// derivatives of -lnL at K trial branch lengths from ONE pass over the sumtable:
+// lane = (site, rate); totals: df[0], ddf[0], df[1], ddf[1], ...
+template <int K>
+__global__ __launch_bounds__(256) void k_derivatives_s4(ModelView mv, ParamIdx params, TrialLengths tl,
                                                         const double * sumtable,
                                                         const unsigned * ps, const unsigned * cs,
                                                         const unsigned * weights, const int * invariant,
@@ -487,16 +489,20 @@ __global__ __launch_bounds__(256) void k_derivatives_s4(ModelView mv, ParamIdx p
   const double rho = mv.rates()[r] / (1.0 - pinv);
   const double wr = mv.weights()[r] * ((pinv > 0.0) ? (1.0 - pinv) : 1.0);
   const double winv = (pinv > 0.0) ? mv.weights()[r] * pinv : 0.0;
-  double e0[4], e1[4], e2[4];
+  double e0[K][4], e1[K][4], e2[K][4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-  {
-    const double lam = mv.evals(pi_)[k] * rho, ex = exp(lam * t);
-    e0[k] = wr * ex;
-    e1[k] = wr * ex * lam;
-    e2[k] = wr * ex * lam * lam;
-  }
-  double df = 0.0, ddf = 0.0;
+  for (int j = 0; j < K; ++j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      const double lam = mv.evals(pi_)[k] * rho, ex = exp(lam * tl.t[j]);
+      e0[j][k] = wr * ex;
+      e1[j][k] = wr * ex * lam;
+      e2[j][k] = wr * ex * lam * lam;
+    }
+  double df[K], ddf[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) df[j] = ddf[j] = 0.0;
   const unsigned long long limit = (total + 63ULL) & ~63ULL;
   // four grid-stride iterations per trip (loads first, then the arithmetic)
   for (; g < limit; g += 4 * stride)
@@ -518,29 +524,40 @@ __global__ __launch_bounds__(256) void k_derivatives_s4(ModelView mv, ParamIdx p
       const unsigned long long gu = g + u * stride;
       if (gu >= limit) break;                        // wave-uniform
       const unsigned long long n = live[u] ? gu >> rs : 0;
-      double A = dot4(e0, sv[u]), B = dot4(e1, sv[u]), C = dot4(e2, sv[u]), inv = 0.0;
+      double inv = 0.0;
       if (live[u] && winv > 0.0 && invariant && invariant[n] >= 0)
         inv = winv * mv.freqs(pi_)[invariant[n]];
-      A = group_sum(A, R);
-      B = group_sum(B, R);
-      C = group_sum(C, R);
       inv = group_sum(inv, R);
-      if (live[u] && r == 0)
+      if (live[u] && r == 0 && inv > 0.0)
       {
-        if (inv > 0.0)
+        const unsigned cnt = (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
+        inv = (cnt <= 3) ? ldexp(inv, 256 * (int)cnt) : INFINITY;
+      }
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+      {
+        double A = dot4(e0[j], sv[u]), B = dot4(e1[j], sv[u]), C = dot4(e2[j], sv[u]);
+        A = group_sum(A, R);
+        B = group_sum(B, R);
+        C = group_sum(C, R);
+        if (live[u] && r == 0)
         {
-          const unsigned cnt = (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
-          A += (cnt <= 3) ? ldexp(inv, 256 * (int)cnt) : INFINITY;
+          if (inv > 0.0) A += inv;
+          const double w = (double)wgt[u], ba = B / A, ca = C / A;
+          df[j] -= w * ba;
+          ddf[j] += w * (ba * ba - ca);
         }
-        const double w = (double)wgt[u], ba = B / A, ca = C / A;
-        df -= w * ba;
-        ddf += w * (ba * ba - ca);
       }
     }
   }
-  const double tdf = block_sum_256(df, scratch);
-  const double tddf = block_sum_256(ddf, scratch);
-  grid_reduce_finish2(tdf, tddf, block_out, scratch);
+  double tot[2 * K];
+#pragma unroll
+  for (int j = 0; j < K; ++j)
+  {
+    tot[2 * j] = block_sum_256(df[j], scratch);
+    tot[2 * j + 1] = block_sum_256(ddf[j], scratch);
+  }
+  grid_reduce_finish<2 * K>(tot, block_out, scratch);
 }
 
 // --- launchers -------------------------------------------------------------
@@ -609,13 +626,16 @@ static int launch_sumtable_s4(Engine * e, const ModelView & mv, const ParamIdx &
   return PLL_SUCCESS;
 }
 
-static int launch_derivatives_s4(Engine * e, const ModelView & mv, const ParamIdx & params, double t,
+static int launch_derivatives_s4(Engine * e, const ModelView & mv, const ParamIdx & params,
+                                 const TrialLengths & tl, unsigned count,
                                  const double * d_sum, const unsigned * ps, const unsigned * cs,
                                  unsigned nblocks)
 {
-  hipLaunchKernelGGL(k_derivatives_s4, dim3(nblocks), dim3(256), 0, e->stream,
-                     mv, params, t, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->R,
-                     reduce_out(e));
+#define PLLHIP_CALL(KK) \
+  hipLaunchKernelGGL(k_derivatives_s4<KK>, dim3(nblocks), dim3(256), 0, e->stream, \
+                     mv, params, tl, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->R, reduce_out(e))
+  PLLHIP_DISPATCH_K(count, PLLHIP_CALL);
+#undef PLLHIP_CALL
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

@@ -751,94 +751,7 @@ __global__ __launch_bounds__(256) void k_sumtable_prep_s61(ModelView mv, ParamId
   }
 }
 
-// derivatives of -lnL from a blocked sumtable; dynamic LDS = 3 * R * 64 doubles
-__global__ __launch_bounds__(256) void k_derivatives_s61(ModelView mv, ParamIdx params, double t,
-                                                         const double * sumtable,
-                                                         const unsigned * ps, const unsigned * cs,
-                                                         const unsigned * weights, const int * invariant,
-                                                         unsigned N, unsigned nblk, unsigned R,
-                                                         ReduceOut block_out)
-{
-  extern __shared__ double coef[];        // e0 | e1 | e2, each [R][64]
-  __shared__ double scratch[4];
-  double * e0 = coef, * e1 = coef + R * S61_SP, * e2 = coef + 2 * R * S61_SP;
-  for (unsigned x = threadIdx.x; x < R * S61_SP; x += blockDim.x)
-  {
-    const unsigned r = x / S61_SP, k = x % S61_SP, pi_ = params.v[r];
-    double a = 0.0, b = 0.0, c = 0.0;
-    if (k < S61_S)
-    {
-      const double pinv = mv.pinv()[pi_];
-      const double lam = mv.evals(pi_)[k] * mv.rates()[r] / (1.0 - pinv);
-      const double wr = mv.weights()[r] * ((pinv > 0.0) ? (1.0 - pinv) : 1.0);
-      const double ex = exp(lam * t);
-      a = wr * ex; b = wr * ex * lam; c = wr * ex * lam * lam;
-    }
-    e0[x] = a; e1[x] = b; e2[x] = c;
-  }
-  __syncthreads();
-
-  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned q = lane >> 4, n = lane & 15;
-  const unsigned wstride = gridDim.x * 4;
-  double df = 0.0, ddf = 0.0;
-  for (unsigned blk = blockIdx.x * 4 + wave; blk < nblk; blk += wstride)
-  {
-    const size_t site0 = (size_t)blk * S20_BS + 2 * n;
-    const SiteSide sd = load_site_side(ps, cs, weights, site0, N, q == 0 && blk < nblk);
-    double Ae = 0, Be = 0, Ce = 0, Ao = 0, Bo = 0, Co = 0, inv_e = 0, inv_o = 0;
-    for (unsigned r = 0; r < R; ++r)
-    {
-      double2 s[S61_KS];
-      s61_load_d(sumtable + ((size_t)blk * R + r) * S61_UNIT, lane, s);
-#pragma unroll
-      for (unsigned k = 0; k < S61_KS; ++k)
-      {
-        const unsigned row = r * S61_SP + 4 * k + q;
-        Ae += s[k].x * e0[row]; Be += s[k].x * e1[row]; Ce += s[k].x * e2[row];
-        Ao += s[k].y * e0[row]; Bo += s[k].y * e1[row]; Co += s[k].y * e2[row];
-      }
-      const unsigned pi_ = params.v[r];
-      const double pinv = mv.pinv()[pi_];
-      if (pinv > 0.0 && invariant)
-      {
-        const double w = mv.weights()[r] * pinv;
-        if (site0 < N && invariant[site0] >= 0) inv_e += w * mv.freqs(pi_)[invariant[site0]];
-        if (site0 + 1 < N && invariant[site0 + 1] >= 0) inv_o += w * mv.freqs(pi_)[invariant[site0 + 1]];
-      }
-    }
-    Ae = s20_sum_q(Ae); Be = s20_sum_q(Be); Ce = s20_sum_q(Ce);
-    Ao = s20_sum_q(Ao); Bo = s20_sum_q(Bo); Co = s20_sum_q(Co);
-    if (q == 0)
-    {
-      if (site0 < N)
-      {
-        if (inv_e > 0.0)
-        {
-          const unsigned cnt = sd.cnt_e;
-          Ae += (cnt <= 3) ? ldexp(inv_e, 256 * (int)cnt) : INFINITY;
-        }
-        const double w = (double)sd.w_e, ba = Be / Ae, ca = Ce / Ae;
-        df -= w * ba;
-        ddf += w * (ba * ba - ca);
-      }
-      if (site0 + 1 < N)
-      {
-        if (inv_o > 0.0)
-        {
-          const unsigned cnt = sd.cnt_o;
-          Ao += (cnt <= 3) ? ldexp(inv_o, 256 * (int)cnt) : INFINITY;
-        }
-        const double w = (double)sd.w_o, ba = Bo / Ao, ca = Co / Ao;
-        df -= w * ba;
-        ddf += w * (ba * ba - ca);
-      }
-    }
-  }
-  const double tdf = block_sum_256(df, scratch);
-  const double tddf = block_sum_256(ddf, scratch);
-  grid_reduce_finish2(tdf, tddf, block_out, scratch);
-}
+// derivatives of -lnL: k_derivatives_mfma<16, 61> (kernels_s20.hpp)
 
 // --- launchers -------------------------------------------------------------
 
@@ -970,14 +883,31 @@ static int launch_sumtable_s61(Engine * e, const ModelView & mv, const ParamIdx 
   return launch_partials_s61(e, batch, 1);
 }
 
-static int launch_derivatives_s61(Engine * e, const ModelView & mv, const ParamIdx & params, double t,
+static int launch_derivatives_s61(Engine * e, const ModelView & mv, const ParamIdx & params,
+                                  const TrialLengths & tl, unsigned count,
                                   const double * d_sum, const unsigned * ps, const unsigned * cs,
                                   unsigned nblocks)
 {
-  const size_t lds = sizeof(double) * 3 * e->R * S61_SP;
-  hipLaunchKernelGGL(k_derivatives_s61, dim3(nblocks), dim3(256), lds, e->stream,
-                     mv, params, t, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R,
-                     reduce_out(e));
+  (void)count;
+  const size_t lds = sizeof(double) * e->R * S61_KS * 64;
+  if (lds > 160 * 1024)
+  {
+    set_error(PLL_ERROR_PARAM_INVALID, "derivatives: %u rate categories exceed the LDS operand tables", e->R);
+    return PLL_FAILURE;
+  }
+  if (lds > 64 * 1024)
+  {
+    static bool attr_set_dev[64] = {false};        // per device: one process may drive several GPUs
+    bool & attr_set = attr_set_dev[e->device & 63];
+    if (!attr_set)
+    {
+      PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_derivatives_mfma<S61_KS, S61_S>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL((k_derivatives_mfma<S61_KS, S61_S>), dim3(nblocks), dim3(256), lds, e->stream,
+                     mv, params, tl, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, reduce_out(e));
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

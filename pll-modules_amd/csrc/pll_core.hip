@@ -159,16 +159,16 @@ Engine * engine_create(pll_partition_t * p)
   ok = ok && dev_alloc(&e->d_tipmap, (size_t)PLL_ASCII_SIZE, "tipmap");
   ok = ok && hip_ok(hipMemsetAsync(e->d_tipmap, 0, PLL_ASCII_SIZE * sizeof(unsigned long long), e->stream),
                     "memset tipmap");
-  ok = ok && dev_alloc(&e->d_partials, (size_t)3 * REDUCE_BLOCKS, "reduction partials");
-  ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void **>(&e->h_partials),
-                                  3 * REDUCE_BLOCKS * sizeof(double), hipHostMallocDefault),
-                    "hipHostMalloc");
-  ok = ok && dev_alloc(&e->d_counter, (size_t)4, "reduction ticket");
-  ok = ok && hip_ok(hipMemsetAsync(e->d_counter, 0, 4 * sizeof(unsigned), e->stream), "memset ticket");
-  ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void **>(&e->h_result), 8 * sizeof(double),
+  ok = ok && dev_alloc(&e->d_partials, (size_t)REDUCE_QUANTITIES * REDUCE_BLOCKS, "reduction partials");
+  ok = ok && dev_alloc(&e->d_counter, (size_t)REDUCE_COUNTER_WORDS, "reduction tickets");
+  ok = ok && hip_ok(hipMemsetAsync(e->d_counter, 0, REDUCE_COUNTER_WORDS * sizeof(unsigned), e->stream),
+                    "memset tickets");
+  ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void **>(&e->h_result), RESULT_WORDS * sizeof(double),
                                   hipHostMallocMapped), "hipHostMalloc result");
+  if (ok) memset(e->h_result, 0, RESULT_WORDS * sizeof(double));   // the sequence word starts at 0 (recycled pinned pages)
   ok = ok && hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->d_result), e->h_result, 0),
                     "hipHostGetDevicePointer");
+  if (const char * ff = getenv("PLLHIP_FUSED_FINISH")) e->fused_finish = atoi(ff) != 0;
   e->pmat_brlen.assign(e->nmat, std::numeric_limits<double>::quiet_NaN());
   e->pmat_params.assign(e->nmat, std::vector<unsigned>());
 
@@ -221,7 +221,6 @@ void engine_destroy(Engine * e)
   (void)hipFree(e->d_partials);
   (void)hipFree(e->d_persite);
   (void)hipFree(e->d_sum_scratch);
-  if (e->h_partials) (void)hipHostFree(e->h_partials);
   if (e->h_result) (void)hipHostFree(e->h_result);
   (void)hipFree(e->d_counter);
   for (auto & ev : e->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -491,21 +490,33 @@ static unsigned reduce_grid(const Engine * e)
   return (unsigned)std::max<unsigned long long>(1ULL, std::min<unsigned long long>(need, std::min(cap, (unsigned)REDUCE_BLOCKS)));
 }
 
-// finish a reduction: a single-block kernel adds the block totals in a fixed
-// order straight into pinned host memory; then wait for the stream
-static int finish_reduction(Engine * e, unsigned nblocks, unsigned n_quant, double * out)
+// Scalar results.  A reduction launch leaves its totals in the engine's current sink
+// (Engine::sink): by default the pinned, device-mapped result buffer, whose sequence word
+// the host polls; a deferred result (pllhip_results_*) points the sink at a device slot.
+static void sink_to_host(Engine * e)
 {
-  const unsigned long long seq = ++e->result_seq;
-  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, e->stream,
-                     e->d_partials, nblocks, n_quant, e->d_result, seq);
+  e->sink.dst = e->d_result;
+  e->sink.flag = reinterpret_cast<unsigned long long *>(e->d_result) + RESULT_SEQ_SLOT;
+  e->sink.seq = ++e->result_seq;
+}
+
+// after the reduction kernel: the two-launch form adds the block totals in a second,
+// single-block kernel; the fused form has nothing left to launch
+static int finish_launch(Engine * e, unsigned nblocks, unsigned n_quant)
+{
+  if (e->fused_finish) return PLL_SUCCESS;
+  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, e->stream, reduce_out(e), nblocks, n_quant);
   PLLHIP_TRY(hipGetLastError());
-  // Scalar-returning calls are latency-bound for small slices (Newton-Raphson: a 14 us
-  // kernel per call): poll the sequence word the kernel writes into the mapped result
-  // buffer for a short while before falling back to a blocking stream synchronisation.
-  // PLLHIP_SPIN_US=0 disables the polling.
+  return PLL_SUCCESS;
+}
+
+// wait until the host sees sequence number `seq` in `flag` (mapped memory): poll for a short
+// while -- scalar-returning calls are latency-bound for small slices (Newton-Raphson: a
+// 14 us kernel per call) -- then fall back to a blocking stream synchronisation.
+// PLLHIP_SPIN_US=0 disables the polling.
+int wait_sequence(hipStream_t stream, const volatile unsigned long long * flag, unsigned long long seq)
+{
   static const long spin_us = getenv("PLLHIP_SPIN_US") ? atol(getenv("PLLHIP_SPIN_US")) : 400;
-  const volatile unsigned long long * flag =
-      reinterpret_cast<const volatile unsigned long long *>(e->h_result) + RESULT_SEQ_SLOT;
   bool done = false;
   if (spin_us > 0)
   {
@@ -518,7 +529,24 @@ static int finish_reduction(Engine * e, unsigned nblocks, unsigned n_quant, doub
         break;
     }
   }
-  if (!done) PLLHIP_TRY(hipStreamSynchronize(e->stream));
+  if (!done)
+  {
+    PLLHIP_TRY(hipStreamSynchronize(stream));
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq)
+    {
+      set_error(PLL_ERROR_HIP_RUNTIME, "a reduction finished without publishing its result");
+      return PLL_FAILURE;
+    }
+  }
+  return PLL_SUCCESS;
+}
+
+static int finish_reduction(Engine * e, unsigned nblocks, unsigned n_quant, double * out)
+{
+  if (!finish_launch(e, nblocks, n_quant)) return PLL_FAILURE;
+  const volatile unsigned long long * flag =
+      reinterpret_cast<const volatile unsigned long long *>(e->h_result) + RESULT_SEQ_SLOT;
+  if (!wait_sequence(e->stream, flag, e->sink.seq)) return PLL_FAILURE;
   for (unsigned q = 0; q < n_quant; ++q) out[q] = e->h_result[q];
   return PLL_SUCCESS;
 }
@@ -956,9 +984,17 @@ void pll_update_partials(pll_partition_t * p, const pll_operation_t * ops, unsig
   (void)update_partials_impl(p, ops, count);
 }
 
-static double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsigned cc, int csc,
-                                 int matrix_index, const unsigned * freqs_indices,
-                                 double * persite_lnl)
+} // extern "C"
+
+namespace pllhip {
+
+// lnL at an edge (matrix_index >= 0) or at a root vector.  `deferred` == nullptr: the
+// value comes back (one wait); otherwise the total is left at deferred->dst (a device
+// slot or mapped memory, with deferred->flag / seq if the host is to be told), nothing
+// is waited for and the return value is 0.
+double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsigned cc, int csc,
+                          int matrix_index, const unsigned * freqs_indices,
+                          double * persite_lnl, const Engine::Sink * deferred)
 {
   Engine * e = engine_of(p);
   const double fail = -std::numeric_limits<double>::infinity();
@@ -977,6 +1013,8 @@ static double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsi
   const ModelView mv = model_view(e);
   const ParamIdx fidx = make_params(p, freqs_indices);
   const NodeRef parent = node_ref(e, pc);
+  if (deferred) e->sink = *deferred; else sink_to_host(e);
+  e->sink.nq = 1;
   NodeRef child = {nullptr, nullptr};
   const double * pm = nullptr, * lut = nullptr;
   if (matrix_index >= 0)
@@ -1004,10 +1042,88 @@ static double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsi
     if (!hip_ok(hipMemcpyAsync(persite_lnl, e->d_persite, sizeof(double) * e->N,
                                hipMemcpyDeviceToHost, e->stream), "persite copy")) return fail;
   double total = 0.0;
-  if (!finish_reduction(e, nblocks, 1, &total)) return fail;
   e->counters.lnl_calls++;
+  if (deferred) return finish_launch(e, nblocks, 1) ? 0.0 : fail;
+  if (!finish_reduction(e, nblocks, 1, &total)) return fail;
   return total;
 }
+
+// K = up to MAX_TRIAL_LENGTHS trial branch lengths per sumtable scan; totals in the order
+// df[0], ddf[0], df[1], ddf[1], ...  (to out_df / out_ddf, or left at deferred->dst)
+int derivatives_impl(pll_partition_t * p, int parent_scaler_index, int child_scaler_index,
+                     const double * brlens, unsigned count, const unsigned * params_indices,
+                     const double * sumtable, const Engine::Sink * deferred,
+                     double * out_df, double * out_ddf)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  if (!check_scaler_index(e, parent_scaler_index) || !check_scaler_index(e, child_scaler_index))
+    return PLL_FAILURE;
+  if (!count || count > MAX_TRIAL_LENGTHS)
+  {
+    set_error(PLL_ERROR_PARAM_INVALID, "1 to %u trial branch lengths per call", MAX_TRIAL_LENGTHS);
+    return PLL_FAILURE;
+  }
+  double * d_sum = sumtable_device(e, sumtable, false);
+  if (!d_sum)
+  {
+    set_error(PLL_ERROR_PARAM_INVALID,
+              "pll_compute_likelihood_derivatives: no sumtable was computed for this buffer");
+    return PLL_FAILURE;
+  }
+  if (!sync_model(p) || !ensure_invariant(p)) return PLL_FAILURE;
+  const unsigned nblocks = reduce_grid(e);
+  const ModelView mv = model_view(e);
+  const ParamIdx params = make_params(p, params_indices);
+  // lengths per launch: the matrix-core kernel (20 / 61 states) takes four; the others are
+  // bounded by their coefficient tables (3 x R x S doubles per length, below 48 KiB of LDS)
+  unsigned kmax = MAX_TRIAL_LENGTHS;
+  if (e->blocked) kmax = 4;
+  else if (e->family != KernelFamily::S4)
+  {
+    while (kmax > 1 && (size_t)3 * kmax * e->R * e->S * sizeof(double) > 48 * 1024) kmax >>= 1;
+    if ((size_t)3 * e->R * e->S * sizeof(double) > 64 * 1024)
+    {
+      set_error(PLL_ERROR_PARAM_INVALID, "derivatives: %u rates x %u states exceed the LDS tables", e->R, e->S);
+      return PLL_FAILURE;
+    }
+  }
+  Engine::Sink base;
+  if (deferred) base = *deferred; else { sink_to_host(e); base = e->sink; }
+  for (unsigned first = 0; first < count; first += kmax)
+  {
+    const unsigned nb = std::min(kmax, count - first);
+    TrialLengths tl;
+    for (unsigned i = 0; i < MAX_TRIAL_LENGTHS; ++i) tl.t[i] = brlens[first + std::min(i, nb - 1)];
+    e->sink = base;
+    e->sink.dst = base.dst + 2 * first;
+    e->sink.nq = 2 * nb;
+    if (first + nb < count) e->sink.flag = nullptr;     // the last launch tells the host
+    const unsigned * ps = scaler_ptr(e, parent_scaler_index), * cs = scaler_ptr(e, child_scaler_index);
+    int rc;
+    if (e->family == KernelFamily::S4)
+      rc = launch_derivatives_s4(e, mv, params, tl, nb, d_sum, ps, cs, nblocks);
+    else if (e->family == KernelFamily::S20)
+      rc = launch_derivatives_s20(e, mv, params, tl, nb, d_sum, ps, cs, nblocks);
+    else if (e->family == KernelFamily::S61)
+      rc = launch_derivatives_s61(e, mv, params, tl, nb, d_sum, ps, cs, nblocks);
+    else
+      rc = launch_derivatives_generic(e, mv, params, tl, nb, d_sum, ps, cs, nblocks);
+    if (!rc || !finish_launch(e, nblocks, e->blocked ? 8 : 2 * trial_instance(nb))) return PLL_FAILURE;
+  }
+  e->counters.derivative_calls++;
+  e->counters.derivative_points += count;
+  if (deferred) return PLL_SUCCESS;
+  const volatile unsigned long long * flag =
+      reinterpret_cast<const volatile unsigned long long *>(e->h_result) + RESULT_SEQ_SLOT;
+  if (!wait_sequence(e->stream, flag, base.seq)) return PLL_FAILURE;
+  for (unsigned i = 0; i < count; ++i) { out_df[i] = e->h_result[2 * i]; out_ddf[i] = e->h_result[2 * i + 1]; }
+  return PLL_SUCCESS;
+}
+
+} // namespace pllhip
+
+extern "C" {
 
 double pll_compute_edge_loglikelihood(pll_partition_t * p,
                                       unsigned int parent_clv_index, int parent_scaler_index,
@@ -1017,14 +1133,14 @@ double pll_compute_edge_loglikelihood(pll_partition_t * p,
                                       double * persite_lnl)
 {
   return loglikelihood_impl(p, parent_clv_index, parent_scaler_index, child_clv_index,
-                            child_scaler_index, (int)matrix_index, freqs_indices, persite_lnl);
+                            child_scaler_index, (int)matrix_index, freqs_indices, persite_lnl, nullptr);
 }
 
 double pll_compute_root_loglikelihood(pll_partition_t * p, unsigned int clv_index, int scaler_index,
                                       const unsigned int * freqs_indices, double * persite_lnl)
 {
   return loglikelihood_impl(p, clv_index, scaler_index, 0, PLL_SCALE_BUFFER_NONE, -1,
-                            freqs_indices, persite_lnl);
+                            freqs_indices, persite_lnl, nullptr);
 }
 
 int pll_update_sumtable(pll_partition_t * p,
@@ -1069,42 +1185,18 @@ int pll_compute_likelihood_derivatives(pll_partition_t * p,
                                        const unsigned int * params_indices,
                                        const double * sumtable, double * d_f, double * dd_f)
 {
-  Engine * e = engine_of(p);
-  PLLHIP_TRY(hipSetDevice(e->device));
-  if (!check_scaler_index(e, parent_scaler_index) || !check_scaler_index(e, child_scaler_index))
-    return PLL_FAILURE;
-  double * d_sum = sumtable_device(e, sumtable, false);
-  if (!d_sum)
-  {
-    set_error(PLL_ERROR_PARAM_INVALID,
-              "pll_compute_likelihood_derivatives: no sumtable was computed for this buffer");
-    return PLL_FAILURE;
-  }
-  if (!sync_model(p) || !ensure_invariant(p)) return PLL_FAILURE;
-  const unsigned nblocks = reduce_grid(e);
-  const ModelView mv = model_view(e);
-  const ParamIdx params = make_params(p, params_indices);
-  int rc;
-  if (e->family == KernelFamily::S4)
-    rc = launch_derivatives_s4(e, mv, params, branch_length, d_sum, scaler_ptr(e, parent_scaler_index),
-                               scaler_ptr(e, child_scaler_index), nblocks);
-  else if (e->family == KernelFamily::S20)
-    rc = launch_derivatives_s20(e, mv, params, branch_length, d_sum, scaler_ptr(e, parent_scaler_index),
-                                scaler_ptr(e, child_scaler_index), nblocks);
-  else if (e->family == KernelFamily::S61)
-    rc = launch_derivatives_s61(e, mv, params, branch_length, d_sum, scaler_ptr(e, parent_scaler_index),
-                                scaler_ptr(e, child_scaler_index), nblocks);
-  else
-    rc = launch_derivatives_generic(e, mv, params, branch_length, d_sum,
-                                    scaler_ptr(e, parent_scaler_index),
-                                    scaler_ptr(e, child_scaler_index), nblocks);
-  if (!rc) return PLL_FAILURE;
-  double out[2] = {0.0, 0.0};
-  if (!finish_reduction(e, nblocks, 2, out)) return PLL_FAILURE;
-  *d_f = out[0];
-  *dd_f = out[1];
-  e->counters.derivative_calls++;
-  return PLL_SUCCESS;
+  return derivatives_impl(p, parent_scaler_index, child_scaler_index, &branch_length, 1, params_indices,
+                          sumtable, nullptr, d_f, dd_f);
+}
+
+int pllhip_compute_likelihood_derivatives_multi(pll_partition_t * p,
+                                                int parent_scaler_index, int child_scaler_index,
+                                                const double * branch_lengths, unsigned int count,
+                                                const unsigned int * params_indices,
+                                                const double * sumtable, double * d_f, double * dd_f)
+{
+  return derivatives_impl(p, parent_scaler_index, child_scaler_index, branch_lengths, count, params_indices,
+                          sumtable, nullptr, d_f, dd_f);
 }
 
 int pll_update_invariant_sites(pll_partition_t * p)

@@ -1,16 +1,33 @@
-// pllhip_comm.hip -- the reference's parallelism hook, implemented on RCCL.
+// pllhip_comm.hip -- the reference's parallelism hook on RCCL, and deferred scalar results.
 //
 // pll-modules synchronises its workers through exactly one callback,
 //   void (*parallel_reduce_cb)(void *ctx, double *data, size_t n, int op)
 // (src/tree/pll_tree.h:274-276; ops SUM/MAX/MIN = 0/1/2, src/pllmod_common.h:29-31;
 // 16 call sites).  Payloads are 8 B .. 8*P B and every
 // caller keeps using the result in place: all-reduce semantics.  With one
-// process per GPU the natural transport is an RCCL all-reduce over xGMI; the
-// call is latency-bound, so the staging buffers are allocated once and the
-// host blocks on one stream synchronise per call.
+// process per GPU the transport is an RCCL all-reduce over xGMI.
+//
+// Two forms:
+//   pllhip_reduce_cb     the callback itself, for unmodified pll-modules code: the payload
+//                        is on the host (the library calls have returned doubles), so it is
+//                        staged through one pinned buffer: H2D, all-reduce, D2H, one wait.
+//   pllhip_results_*     deferred results: the reduction kernels of several calls (the
+//                        partitions of an evaluation, the trial lengths of a Newton-Raphson
+//                        round) leave their totals in device-resident slots, which are
+//                        all-reduced IN PLACE on the device; one small kernel publishes
+//                        them to mapped host memory and the host waits once.  No host round
+//                        trip between the reduction kernel and the collective
+//                        (src/tree/treeinfo.c:1058-1067, src/optimize/pll_optimize.c:1270-1286
+//                        are the reduces this serves; {df, ddf} travel as one message there too).
 #include "engine.h"
+#include "pllhip_eval.h"
+extern "C" {
+#include "host/pllhip_eval_internal.h"
+}
 #include <rccl/rccl.h>
+#include <cmath>
 #include <cstring>
+#include <limits>
 
 struct pllhip_comm
 {
@@ -29,6 +46,52 @@ static bool nccl_ok(ncclResult_t r, const char * what)
   if (r == ncclSuccess) return true;
   set_error(PLL_ERROR_HIP_RUNTIME, "RCCL error %d (%s) in %s", (int)r, ncclGetErrorString(r), what);
   return false;
+}
+
+static ncclRedOp_t nccl_op(int op)
+{
+  return (op == PLLHIP_REDUCE_MAX) ? ncclMax : (op == PLLHIP_REDUCE_MIN) ? ncclMin : ncclSum;
+}
+
+// ---------------------------------------------------------------------------
+// deferred results
+// ---------------------------------------------------------------------------
+constexpr unsigned RESULTS_MAX_PENDING = 64;
+
+struct pllhip_results
+{
+  pllhip_comm * comm = nullptr;
+  int device = 0;
+  unsigned nslots = 0;
+  double * d_slots = nullptr;                 // device: deposits + in-place all-reduce (communicator mode)
+  double * h_slots = nullptr;                 // pinned, device-mapped: what the host reads
+  double * hd_slots = nullptr;                // device view of h_slots
+  unsigned long long * h_flags = nullptr;     // mapped sequence words: [0] publish kernel, [1 + k] deposit k
+  unsigned long long * hd_flags = nullptr;
+  unsigned long long seq = 0;
+  hipStream_t stream = nullptr;               // collective + publish when deposits come from several streams
+  struct Pending { hipStream_t stream; unsigned flag; unsigned long long seq; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> events;
+  std::vector<char> deposited;                // per slot, since the last fetch
+};
+
+// slots -> mapped host memory, then the sequence word
+__global__ void k_publish_results(const double * src, double * dst, unsigned n,
+                                  unsigned long long * flag, unsigned long long seq)
+{
+  for (unsigned i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    __threadfence_system();
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+__global__ void k_fill_results(double * dst, unsigned n, double v)
+{
+  for (unsigned i = threadIdx.x; i < n; i += blockDim.x) dst[i] = v;
 }
 
 extern "C" {
@@ -73,23 +136,259 @@ void pllhip_comm_destroy(pllhip_comm_t * c)
   delete c;
 }
 
+int pllhip_comm_rank(const pllhip_comm_t * c) { return c ? c->rank : 0; }
+int pllhip_comm_size(const pllhip_comm_t * c) { return c ? c->nranks : 1; }
+
+// The reference callback has no error channel and its callers use the payload right
+// away: on a HIP / RCCL failure the payload is poisoned with NaN (pll_errno is set), so
+// that this rank fails loudly at once (treeinfo asserts lnL < 0, the Newton step rule
+// rejects non-finite derivatives) instead of continuing with a local value while its
+// peers hold the global one.
 void pllhip_reduce_cb(void * ctx, double * data, size_t n, int op)
 {
   pllhip_comm_t * c = static_cast<pllhip_comm_t *>(ctx);
   if (!c || !n) return;
-  (void)hipSetDevice(c->device);
-  const ncclRedOp_t rop = (op == PLLHIP_REDUCE_MAX) ? ncclMax : (op == PLLHIP_REDUCE_MIN) ? ncclMin : ncclSum;
-  for (size_t off = 0; off < n; off += c->cap)
+  bool ok = hip_ok(hipSetDevice(c->device), "hipSetDevice");
+  const ncclRedOp_t rop = nccl_op(op);
+  for (size_t off = 0; ok && off < n; off += c->cap)
   {
     const size_t m = (n - off < c->cap) ? n - off : c->cap;
     memcpy(c->h_buf, data + off, m * sizeof(double));
-    if (!hip_ok(hipMemcpyAsync(c->d_buf, c->h_buf, m * sizeof(double), hipMemcpyHostToDevice, c->stream), "H2D") ||
-        !nccl_ok(ncclAllReduce(c->d_buf, c->d_buf, m, ncclDouble, rop, c->comm, c->stream), "ncclAllReduce") ||
-        !hip_ok(hipMemcpyAsync(c->h_buf, c->d_buf, m * sizeof(double), hipMemcpyDeviceToHost, c->stream), "D2H") ||
-        !hip_ok(hipStreamSynchronize(c->stream), "sync"))
-      return;   // pll_errno is set; the reference callback has no error channel
-    memcpy(data + off, c->h_buf, m * sizeof(double));
+    ok = hip_ok(hipMemcpyAsync(c->d_buf, c->h_buf, m * sizeof(double), hipMemcpyHostToDevice, c->stream), "H2D") &&
+         nccl_ok(ncclAllReduce(c->d_buf, c->d_buf, m, ncclDouble, rop, c->comm, c->stream), "ncclAllReduce") &&
+         hip_ok(hipMemcpyAsync(c->h_buf, c->d_buf, m * sizeof(double), hipMemcpyDeviceToHost, c->stream), "D2H") &&
+         hip_ok(hipStreamSynchronize(c->stream), "sync");
+    if (ok) memcpy(data + off, c->h_buf, m * sizeof(double));
   }
+  if (!ok)
+    for (size_t i = 0; i < n; ++i) data[i] = std::numeric_limits<double>::quiet_NaN();
+}
+
+// ---------------------------------------------------------------------------
+
+pllhip_results_t * pllhip_results_create(pllhip_comm_t * comm, unsigned int slots)
+{
+  if (!slots) { set_error(PLL_ERROR_PARAM_INVALID, "a result group needs at least one slot"); return nullptr; }
+  const int device = comm ? comm->device : pllhip_get_device();
+  if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return nullptr;
+  pllhip_results_t * rs = new (std::nothrow) pllhip_results();
+  if (!rs) { set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate result group"); return nullptr; }
+  rs->comm = comm;
+  rs->device = device;
+  rs->nslots = slots;
+  rs->deposited.assign(slots, 0);
+  const size_t flag_bytes = (1 + RESULTS_MAX_PENDING) * sizeof(unsigned long long);
+  bool ok = hip_ok(hipHostMalloc(reinterpret_cast<void **>(&rs->h_slots), slots * sizeof(double),
+                                 hipHostMallocMapped), "hipHostMalloc slots") &&
+            hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&rs->hd_slots), rs->h_slots, 0), "map slots") &&
+            hip_ok(hipHostMalloc(reinterpret_cast<void **>(&rs->h_flags), flag_bytes, hipHostMallocMapped),
+                   "hipHostMalloc flags") &&
+            hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&rs->hd_flags), rs->h_flags, 0), "map flags") &&
+            hip_ok(hipStreamCreateWithFlags(&rs->stream, hipStreamNonBlocking), "hipStreamCreate");
+  if (ok)
+  {
+    memset(rs->h_slots, 0, slots * sizeof(double));
+    memset(rs->h_flags, 0, flag_bytes);
+  }
+  if (ok && comm)
+    ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&rs->d_slots), slots * sizeof(double)), "hipMalloc slots") &&
+         hip_ok(hipMemset(rs->d_slots, 0, slots * sizeof(double)), "memset slots");
+  if (!ok) { pllhip_results_destroy(rs); return nullptr; }
+  return rs;
+}
+
+void pllhip_results_destroy(pllhip_results_t * rs)
+{
+  if (!rs) return;
+  (void)hipSetDevice(rs->device);
+  if (rs->stream) { (void)hipStreamSynchronize(rs->stream); (void)hipStreamDestroy(rs->stream); }
+  for (hipEvent_t ev : rs->events) (void)hipEventDestroy(ev);
+  if (rs->d_slots) (void)hipFree(rs->d_slots);
+  if (rs->h_slots) (void)hipHostFree(rs->h_slots);
+  if (rs->h_flags) (void)hipHostFree(rs->h_flags);
+  delete rs;
 }
 
 } // extern "C"
+
+// where the next reduction of partition `p` leaves `n` totals; remembers what to wait for
+static int results_sink(pllhip_results_t * rs, pll_partition_t * p, unsigned slot, unsigned n,
+                        Engine::Sink * sink)
+{
+  if (slot + n > rs->nslots || slot + n < slot)
+  {
+    set_error(PLL_ERROR_PARAM_INVALID, "result slots %u..%u out of range (%u)", slot, slot + n, rs->nslots);
+    return PLL_FAILURE;
+  }
+  Engine * e = engine_of(p);
+  if (e->device != rs->device)
+  {
+    set_error(PLL_ERROR_PARAM_INVALID, "partition on device %d, result group on device %d", e->device, rs->device);
+    return PLL_FAILURE;
+  }
+  if (rs->pending.size() >= RESULTS_MAX_PENDING)
+  {
+    set_error(PLL_ERROR_PARAM_INVALID, "more than %u deferred results without a fetch", RESULTS_MAX_PENDING);
+    return PLL_FAILURE;
+  }
+  pllhip_results::Pending pd;
+  pd.stream = e->stream;
+  pd.flag = 1 + (unsigned)rs->pending.size();
+  pd.seq = ++rs->seq;
+  if (rs->comm)
+  {
+    sink->dst = rs->d_slots + slot;
+    sink->flag = nullptr;
+  }
+  else
+  {
+    sink->dst = rs->hd_slots + slot;          // straight into mapped memory, with its own sequence word
+    sink->flag = rs->hd_flags + pd.flag;
+  }
+  sink->seq = pd.seq;
+  sink->nq = n;
+  rs->pending.push_back(pd);
+  for (unsigned i = 0; i < n; ++i) rs->deposited[slot + i] = 1;
+  return PLL_SUCCESS;
+}
+
+extern "C" {
+
+int pllhip_results_edge_loglikelihood(pllhip_results_t * rs, unsigned int slot, pll_partition_t * p,
+                                      unsigned int parent_clv_index, int parent_scaler_index,
+                                      unsigned int child_clv_index, int child_scaler_index,
+                                      unsigned int matrix_index, const unsigned int * freqs_indices)
+{
+  Engine::Sink sink;
+  if (!results_sink(rs, p, slot, 1, &sink)) return PLL_FAILURE;
+  const double v = loglikelihood_impl(p, parent_clv_index, parent_scaler_index, child_clv_index,
+                                      child_scaler_index, (int)matrix_index, freqs_indices, nullptr, &sink);
+  return (v == 0.0) ? PLL_SUCCESS : PLL_FAILURE;
+}
+
+int pllhip_results_derivatives(pllhip_results_t * rs, unsigned int slot, pll_partition_t * p,
+                               int parent_scaler_index, int child_scaler_index,
+                               const double * branch_lengths, unsigned int count,
+                               const unsigned int * params_indices, const double * sumtable)
+{
+  Engine::Sink sink;
+  if (!results_sink(rs, p, slot, 2 * count, &sink)) return PLL_FAILURE;
+  return derivatives_impl(p, parent_scaler_index, child_scaler_index, branch_lengths, count, params_indices,
+                          sumtable, &sink, nullptr, nullptr);
+}
+
+int pllhip_results_fetch(pllhip_results_t * rs, unsigned int first, unsigned int count, int op, double * out)
+{
+  if (first + count > rs->nslots || !count)
+  {
+    set_error(PLL_ERROR_PARAM_INVALID, "result slots %u..%u out of range (%u)", first, first + count, rs->nslots);
+    return PLL_FAILURE;
+  }
+  PLLHIP_TRY(hipSetDevice(rs->device));
+  const double identity = (op == PLLHIP_REDUCE_MAX) ? -INFINITY : (op == PLLHIP_REDUCE_MIN) ? INFINITY : 0.0;
+  int rc = PLL_SUCCESS;
+  if (!rs->comm)
+  {
+    // every deposit went straight to mapped memory with a sequence word of its own
+    for (const auto & pd : rs->pending)
+      if (!wait_sequence(pd.stream, rs->h_flags + pd.flag, pd.seq)) rc = PLL_FAILURE;
+    for (unsigned i = 0; i < count; ++i)
+      out[i] = rs->deposited[first + i] ? rs->h_slots[first + i] : identity;
+  }
+  else
+  {
+    // one stream carries the collective: the depositing stream itself when there is only
+    // one (a single partition per rank: no event, no cross-stream wait), else the group's
+    // stream behind an event of every depositing stream
+    hipStream_t run = rs->stream;
+    bool single = !rs->pending.empty();
+    for (const auto & pd : rs->pending) if (pd.stream != rs->pending[0].stream) single = false;
+    if (single) run = rs->pending[0].stream;
+    else
+    {
+      std::vector<hipStream_t> seen;
+      for (const auto & pd : rs->pending)
+      {
+        bool dup = false;
+        for (hipStream_t s : seen) if (s == pd.stream) dup = true;
+        if (dup) continue;
+        if (seen.size() == rs->events.size())
+        {
+          hipEvent_t ev;
+          PLLHIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+          rs->events.push_back(ev);
+        }
+        hipEvent_t ev = rs->events[seen.size()];
+        seen.push_back(pd.stream);
+        PLLHIP_TRY(hipEventRecord(ev, pd.stream));
+        PLLHIP_TRY(hipStreamWaitEvent(run, ev, 0));
+      }
+    }
+    // slots nobody deposited to (partitions another worker owns) take the identity
+    for (unsigned i = 0; i < count; )
+    {
+      if (rs->deposited[first + i]) { ++i; continue; }
+      unsigned j = i;
+      while (j < count && !rs->deposited[first + j]) ++j;
+      hipLaunchKernelGGL(k_fill_results, dim3(1), dim3(64), 0, run, rs->d_slots + first + i, j - i, identity);
+      PLLHIP_TRY(hipGetLastError());
+      i = j;
+    }
+    const unsigned long long seq = ++rs->seq;
+    if (!nccl_ok(ncclAllReduce(rs->d_slots + first, rs->d_slots + first, count, ncclDouble, nccl_op(op),
+                               rs->comm->comm, run), "ncclAllReduce"))
+      rc = PLL_FAILURE;
+    else
+    {
+      hipLaunchKernelGGL(k_publish_results, dim3(1), dim3(64), 0, run, rs->d_slots + first, rs->hd_slots + first,
+                         count, rs->hd_flags, seq);
+      if (!hip_ok(hipGetLastError(), "publish") || !wait_sequence(run, rs->h_flags, seq)) rc = PLL_FAILURE;
+    }
+    for (unsigned i = 0; i < count; ++i) out[i] = rs->h_slots[first + i];
+  }
+  rs->pending.clear();
+  for (unsigned i = 0; i < count; ++i) rs->deposited[first + i] = 0;
+  if (!rc)
+    for (unsigned i = 0; i < count; ++i) out[i] = std::numeric_limits<double>::quiet_NaN();
+  return rc;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------
+// the evaluation driver (include/pllhip_eval.h) on deferred results
+// ---------------------------------------------------------------------------
+static int fused_edge(void * rs, unsigned int slot, pll_partition_t * p, unsigned int pc, int psc,
+                      unsigned int cc, int csc, unsigned int m, const unsigned int * f)
+{
+  return pllhip_results_edge_loglikelihood(static_cast<pllhip_results_t *>(rs), slot, p, pc, psc, cc, csc, m, f);
+}
+
+static int fused_deriv(void * rs, unsigned int slot, pll_partition_t * p, int psc, int csc,
+                       const double * t, unsigned int count, const unsigned int * params, const double * sumtable)
+{
+  return pllhip_results_derivatives(static_cast<pllhip_results_t *>(rs), slot, p, psc, csc, t, count, params,
+                                    sumtable);
+}
+
+static int fused_fetch(void * rs, unsigned int first, unsigned int count, int op, double * out)
+{
+  return pllhip_results_fetch(static_cast<pllhip_results_t *>(rs), first, count, op, out);
+}
+
+static void fused_destroy(void * rs) { pllhip_results_destroy(static_cast<pllhip_results_t *>(rs)); }
+
+extern "C" int pllhip_eval_attach_comm(struct pllhip_eval * ev, pllhip_comm_t * comm)
+{
+  if (!ev) { set_error(PLL_ERROR_PARAM_INVALID, "no evaluator"); return PLL_FAILURE; }
+  pllhip_results_t * rs = pllhip_results_create(comm, ev->nparts * 2 * PLLHIP_EVAL_MAX_TRIALS);
+  if (!rs) return PLL_FAILURE;
+  pllhip_eval_fused_t table;
+  table.results = rs;
+  table.edge_loglikelihood = fused_edge;
+  table.derivatives = fused_deriv;
+  table.fetch = fused_fetch;
+  table.destroy = fused_destroy;
+  pllhip_eval_set_fused(ev, &table);
+  return PLL_SUCCESS;
+}

@@ -88,7 +88,7 @@ class UTree(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_ulonglong) for n in (
         "partial_ops", "partial_launches", "site_updates", "pmatrix_updates", "pmatrix_launches",
-        "lnl_calls", "sumtable_calls", "derivative_calls", "model_uploads")]
+        "lnl_calls", "sumtable_calls", "derivative_calls", "derivative_points", "model_uploads")]
 
 
 class Profile(C.Structure):
@@ -121,14 +121,18 @@ PLLHIP_EVAL_H_FUNCTIONS = """pllhip_eval_create pllhip_eval_destroy pllhip_eval_
 pllhip_eval_set_parallel_context pllhip_eval_set_root pllhip_eval_root pllhip_eval_invalidate_all
 pllhip_eval_invalidate_pmatrix pllhip_eval_invalidate_clv pllhip_eval_loglh
 pllhip_eval_set_branch_length pllhip_eval_optimize_branches pllhip_eval_ops
-pllhip_eval_pmatrix_updates pllhip_eval_derivative_calls pllhip_eval_spr_round""".split()
+pllhip_eval_pmatrix_updates pllhip_eval_derivative_calls pllhip_eval_spr_round
+pllhip_eval_set_fused pllhip_eval_newton_iterations""".split()
 
 PLLHIP_H_FUNCTIONS = """pllhip_device_count pllhip_set_device pllhip_get_device
 pllhip_device_arch pllhip_eigen_decompose pllhip_sync_to_host pllhip_sync_to_device pllhip_get_clv
 pllhip_get_scaler pllhip_get_sumtable pllhip_set_clv pllhip_set_scaler pllhip_synchronize
 pllhip_stream pllhip_get_counters pllhip_reset_counters pllhip_partials_kernel_name
 pllhip_comm_get_unique_id pllhip_comm_create pllhip_comm_destroy pllhip_reduce_cb
-pllhip_profile_partials pllhip_profile_read""".split()
+pllhip_profile_partials pllhip_profile_read pllhip_comm_rank pllhip_comm_size
+pllhip_compute_likelihood_derivatives_multi pllhip_results_create pllhip_results_destroy
+pllhip_results_edge_loglikelihood pllhip_results_derivatives pllhip_results_fetch
+pllhip_eval_attach_comm""".split()
 
 
 def _u32(a):
@@ -218,7 +222,8 @@ class PllLib:
             L.pllhip_eval_spr_round.restype = C.c_double
             L.pllhip_eval_spr_round.argtypes = [C.c_void_p, C.POINTER(SprParams), C.POINTER(SprCutoff),
                                                 C.POINTER(SprStats)]
-            for fn in ("pllhip_eval_ops", "pllhip_eval_pmatrix_updates", "pllhip_eval_derivative_calls"):
+            for fn in ("pllhip_eval_ops", "pllhip_eval_pmatrix_updates", "pllhip_eval_derivative_calls",
+                       "pllhip_eval_newton_iterations"):
                 getattr(L, fn).restype = C.c_ulong
                 getattr(L, fn).argtypes = [C.c_void_p]
         if self.is_product:
@@ -249,6 +254,20 @@ class PllLib:
             L.pllhip_comm_destroy.argtypes = [C.c_void_p]
             L.pllhip_reduce_cb.restype = None
             L.pllhip_reduce_cb.argtypes = [C.c_void_p, c_double_p, C.c_size_t, C.c_int]
+            L.pllhip_comm_rank.argtypes = [C.c_void_p]
+            L.pllhip_comm_size.argtypes = [C.c_void_p]
+            L.pllhip_eval_attach_comm.argtypes = [C.c_void_p, C.c_void_p]
+            L.pllhip_results_create.restype = C.c_void_p
+            L.pllhip_results_create.argtypes = [C.c_void_p, C.c_uint]
+            L.pllhip_results_destroy.argtypes = [C.c_void_p]
+            L.pllhip_results_edge_loglikelihood.argtypes = [C.c_void_p, C.c_uint, pp, C.c_uint, C.c_int,
+                                                            C.c_uint, C.c_int, C.c_uint, c_uint_p]
+            L.pllhip_results_derivatives.argtypes = [C.c_void_p, C.c_uint, pp, C.c_int, C.c_int, c_double_p,
+                                                     C.c_uint, c_uint_p, c_double_p]
+            L.pllhip_results_fetch.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_int, c_double_p]
+        if hasattr(L, "pllhip_compute_likelihood_derivatives_multi"):
+            L.pllhip_compute_likelihood_derivatives_multi.argtypes = [pp, C.c_int, C.c_int, c_double_p, C.c_uint,
+                                                                      c_uint_p, c_double_p, c_double_p, c_double_p]
 
     # --- error state ------------------------------------------------------
     @property
@@ -405,6 +424,16 @@ class Instance:
             raise RuntimeError(self.lib.errmsg)
         return df.value, ddf.value
 
+    def derivatives_multi(self, psc, csc, ts, st):
+        """(df[], ddf[]) at several branch lengths from one sumtable scan"""
+        t = _f64(ts)
+        df, ddf = np.zeros(len(t)), np.zeros(len(t))
+        if not self.L.pllhip_compute_likelihood_derivatives_multi(
+                self.p, psc, csc, t.ctypes.data_as(c_double_p), len(t), self.params_p, st,
+                df.ctypes.data_as(c_double_p), ddf.ctypes.data_as(c_double_p)):
+            raise RuntimeError(self.lib.errmsg)
+        return df, ddf
+
     # --- read-back (works for both libraries) -------------------------------
     def get_clv(self, idx):
         n = self.N * self.R * self.Sp
@@ -455,10 +484,11 @@ class Instance:
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
-def splitmix64(seed, n):
-    """n values of the splitmix64 stream started at `seed` (vectorised)."""
+def splitmix64(seed, n, start=0):
+    """values start .. start+n-1 of the splitmix64 stream started at `seed` (vectorised;
+    the stream is counter-based, so any range can be generated on its own)"""
     with np.errstate(over="ignore"):
-        z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * np.arange(1, n + 1, dtype=np.uint64)
+        z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * np.arange(start + 1, start + n + 1, dtype=np.uint64)
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         return z ^ (z >> np.uint64(31))
@@ -592,11 +622,13 @@ def codon_model(kappa=2.0, omega=0.2, seed_freqs=48):
     return np.array(rates), g / g.sum()
 
 
-def random_codes(ntips, nsites, nstates, seed=44):
-    """iid uniform unambiguous state index per (tip, site) -> uint8 [tips][sites]"""
+def random_codes(ntips, nsites, nstates, seed=44, first_site=0):
+    """iid uniform unambiguous state index per (tip, site) -> uint8 [tips][sites];
+    sites first_site .. first_site+nsites-1 of the alignment that `seed` defines (a
+    rank of a multi-GPU run generates just its slice)"""
     out = np.empty((ntips, nsites), dtype=np.uint8)
     for t in range(ntips):
-        out[t] = (splitmix64(seed + 1000003 * t, nsites) % np.uint64(nstates)).astype(np.uint8)
+        out[t] = (splitmix64(seed + 1000003 * t, nsites, first_site) % np.uint64(nstates)).astype(np.uint8)
     return out
 
 
@@ -693,6 +725,35 @@ class Evaluation:
             raise RuntimeError(self.lib.errmsg)
         self.parts.append(inst)
         return inst
+
+    def add_remote_partition(self, index):
+        """a partition another worker owns: a NULL slot (src/tree/treeinfo.c:1024-1031)"""
+        if not self.L.pllhip_eval_set_partition(self.ev, index, None, None):
+            raise RuntimeError(self.lib.errmsg)
+
+    def set_parallel_context(self, cb, ctx=None):
+        """cb: a REDUCE_CB instance (kept alive here) or a raw function pointer"""
+        self._cb = cb
+        self.L.pllhip_eval_set_parallel_context(self.ev, ctx, C.cast(cb, C.c_void_p))
+
+    def attach_comm(self, comm=None):
+        """deferred results (device-side reduce); product library only"""
+        if not self.L.pllhip_eval_attach_comm(self.ev, comm):
+            raise RuntimeError(self.lib.errmsg)
+
+    def newton_iterations(self):
+        return self.L.pllhip_eval_newton_iterations(self.ev)
+
+    def root_edge(self):
+        """(clv, scaler, back clv, back scaler, pmatrix) of the edge the lnL is computed at"""
+        r = self.L.pllhip_eval_root(self.ev).contents
+        b = r.back.contents
+        return r.clv_index, r.scaler_index, b.clv_index, b.scaler_index, r.pmatrix_index
+
+    def persite_lnl(self, index=0):
+        """per-site lnL of partition `index` at the root edge (CLVs must be valid: call loglh first)"""
+        pc_, psc, cc, csc, m = self.root_edge()
+        return self.parts[index].edge_lnl(pc_, psc, cc, csc, m, persite=True)
 
     def loglh(self, incremental=False):
         v = self.L.pllhip_eval_loglh(self.ev, 1 if incremental else 0)

@@ -260,3 +260,38 @@ def test_random_incremental_walk_on_gpu_matches_oracle(product, oracle, seed):
     for x, y in zip(g, c):
         assert abs(x - y) < 1e-9 * abs(y)
     assert abs(g[-1] - g[-2]) < 1e-10 * abs(g[-1])
+
+
+def check_speculative_newton(lib):
+    """Newton-Raphson with several trial lengths per sumtable scan (the clamped outcomes of the
+    step rule) makes the same iterates and returns the same numbers, bit for bit, as one scan
+    per iteration -- with fewer scans"""
+    runs = []
+    for flags in (0, 2):                                  # 2 = PLLHIP_EVAL_NO_SPECULATION
+        with build(lib, flags=flags) as ev:
+            ev.loglh()
+            opt = ev.optimize_branches(1e-4, 10.0, 0.01, 8, -1)
+            runs.append((opt, ev.newick(), ev.counters()[2], ev.newton_iterations()))
+    (opt_s, tree_s, scans_s, iters_s), (opt_1, tree_1, scans_1, iters_1) = runs
+    assert opt_s == opt_1 and tree_s == tree_1 and iters_s == iters_1
+    assert scans_1 == iters_1 and scans_s < scans_1
+    return scans_s, scans_1
+
+
+def test_speculative_newton_on_oracle(oracle):
+    check_speculative_newton(oracle)
+
+
+def test_multi_length_derivatives_on_oracle(oracle):
+    inst = pc.build_instance(oracle, states=20, rate_cats=4, ntips=8, nsites=200, coded=True)
+    with inst:
+        pc.full_traversal(inst)
+        t = inst.tree
+        st = inst.alloc_sumtable()
+        a = (t.root_a, t.root_b, t.scaler_of(t.root_a), t.scaler_of(t.root_b))
+        inst.update_sumtable(*a, st)
+        ts = [0.3, 1e-4, 0.05, 2.0, 0.3]
+        df, ddf = inst.derivatives_multi(a[2], a[3], ts, st)
+        for k, x in enumerate(ts):
+            assert (df[k], ddf[k]) == inst.derivatives(a[2], a[3], x, st)
+        inst.free_sumtable(st)

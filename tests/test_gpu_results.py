@@ -1,0 +1,206 @@
+"""Deferred scalar results, several trial lengths per sumtable scan, the single-launch
+reduction and the device-side reduce (include/pllhip.h) on the GPU: every one of them must
+return what the blocking libpll-style calls return, bit for bit."""
+import ctypes as C
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import pllhip_ctypes as pc
+from conftest import ROOT
+from test_eval_driver import build, check_speculative_newton
+
+pytestmark = pytest.mark.gpu
+
+
+def _edge(inst):
+    t = inst.tree
+    return t.root_a, t.scaler_of(t.root_a), t.root_b, t.scaler_of(t.root_b), t.root_matrix
+
+
+@pytest.mark.parametrize("states,rate_cats", [(4, 4), (4, 1), (20, 4), (20, 2), (61, 4), (5, 4), (7, 3)])
+def test_multi_length_derivatives(product, oracle, states, rate_cats):
+    ntips, nsites = (7, 300) if states > 20 else (10, 1031)
+    a = pc.build_instance(product, states=states, rate_cats=rate_cats, ntips=ntips, nsites=nsites, pinv=0.1)
+    b = pc.build_instance(oracle, states=states, rate_cats=rate_cats, ntips=ntips, nsites=nsites, pinv=0.1,
+                          tree=a.tree)
+    with a, b:
+        for inst in (a, b):
+            inst.L.pll_update_invariant_sites(inst.p)
+            pc.full_traversal(inst)
+        pcl, psc, ccl, csc, _ = _edge(a)
+        sa, sb = a.alloc_sumtable(), b.alloc_sumtable()
+        a.update_sumtable(pcl, ccl, psc, csc, sa)
+        b.update_sumtable(pcl, ccl, psc, csc, sb)
+        ts = [0.2, 1e-4, 0.033, 1.7, 9.0, 0.2, 0.5, 0.01]
+        single = [a.derivatives(psc, csc, x, sa) for x in ts]
+        for count in range(1, 9):
+            df, ddf = a.derivatives_multi(psc, csc, ts[:count], sa)
+            for k in range(count):
+                # a length's result does not depend on what shares the launch
+                assert (df[k], ddf[k]) == single[k], (count, k)
+        want = [b.derivatives(psc, csc, x, sb) for x in ts]
+        for (g0, g1), (w0, w1) in zip(single, want):
+            assert abs(g0 - w0) <= 1e-9 * max(1.0, abs(w0)) and abs(g1 - w1) <= 1e-9 * max(1.0, abs(w1))
+        with pytest.raises(RuntimeError):
+            a.derivatives_multi(psc, csc, ts + [0.3], sa)           # at most 8 per call
+        c = a.counters()
+        assert c.derivative_points > c.derivative_calls
+        a.free_sumtable(sa)
+        b.free_sumtable(sb)
+
+
+def test_speculative_newton_on_gpu(product):
+    check_speculative_newton(product)
+
+
+def _results_group(product, comm, insts, ts):
+    """lnL of every partition + derivatives at `ts`, through one result group; returns the
+    fetched numbers"""
+    L = product.lib
+    K = len(ts)
+    rs = L.pllhip_results_create(comm, len(insts) * 2 * 8)
+    assert rs, product.errmsg
+    try:
+        for k, inst in enumerate(insts):
+            pcl, psc, ccl, csc, m = _edge(inst)
+            assert L.pllhip_results_edge_loglikelihood(rs, k, inst.p, pcl, psc, ccl, csc, m, inst.params_p)
+        lnl = np.zeros(len(insts))
+        assert L.pllhip_results_fetch(rs, 0, len(insts), 0, lnl.ctypes.data_as(pc.c_double_p)), product.errmsg
+        tt = pc._f64(ts)
+        for k, inst in enumerate(insts):
+            _, psc, _, csc, _ = _edge(inst)
+            assert L.pllhip_results_derivatives(rs, k * 2 * K, inst.p, psc, csc, tt.ctypes.data_as(pc.c_double_p),
+                                                K, inst.params_p, inst.sumtable), product.errmsg
+        d = np.zeros(len(insts) * 2 * K)
+        assert L.pllhip_results_fetch(rs, 0, len(d), 0, d.ctypes.data_as(pc.c_double_p)), product.errmsg
+        # a slot nobody deposited to is the identity of the operation
+        extra = np.ones(3)
+        assert L.pllhip_results_fetch(rs, 5, 3, 0, extra.ctypes.data_as(pc.c_double_p))
+        assert list(extra) == [0.0, 0.0, 0.0]
+        return lnl, d.reshape(len(insts), K, 2)
+    finally:
+        L.pllhip_results_destroy(rs)
+
+
+def _three_partitions(product):
+    insts = []
+    for states, R, n in ((4, 4, 3000), (20, 4, 777), (61, 2, 130)):
+        inst = pc.build_instance(product, states=states, rate_cats=R, ntips=8, nsites=n)
+        pc.full_traversal(inst)
+        pcl, psc, ccl, csc, _ = _edge(inst)
+        inst.sumtable = inst.alloc_sumtable()
+        inst.update_sumtable(pcl, ccl, psc, csc, inst.sumtable)
+        insts.append(inst)
+    return insts
+
+
+def _blocking(insts, ts):
+    lnl = np.array([i.edge_lnl(*_edge(i)) for i in insts])
+    d = np.array([[i.derivatives(_edge(i)[1], _edge(i)[3], x, i.sumtable) for x in ts] for i in insts])
+    return lnl, d
+
+
+@pytest.mark.parametrize("ntrial", [1, 3, 4, 6])
+def test_deferred_results_equal_blocking_calls(product, ntrial):
+    ts = [0.11, 1e-4, 0.9, 0.35, 2.0, 0.07][:ntrial]
+    insts = _three_partitions(product)
+    try:
+        want = _blocking(insts, ts)
+        got = _results_group(product, None, insts, ts)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    finally:
+        for i in insts:
+            i.free_sumtable(i.sumtable)
+            i.close()
+
+
+def test_deferred_results_through_rccl_world_of_one(product):
+    """the communicator path (device slots, ncclAllReduce in place, publish kernel, one wait)
+    with the one rank this box has: same numbers as the blocking calls"""
+    L = product.lib
+    idbuf = C.create_string_buffer(128)
+    assert L.pllhip_comm_get_unique_id(idbuf), product.errmsg
+    comm = L.pllhip_comm_create(idbuf.raw, 0, 1, 0)
+    assert comm, product.errmsg
+    insts = _three_partitions(product)
+    try:
+        assert L.pllhip_comm_size(comm) == 1 and L.pllhip_comm_rank(comm) == 0
+        ts = [0.11, 1e-4, 0.9]
+        want = _blocking(insts, ts)
+        for _ in range(3):                       # sequence words, pending lists and slots are reused
+            got = _results_group(product, comm, insts, ts)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        # the host-payload callback on the same communicator
+        buf = np.array([1.5, -2.0, 7.0])
+        L.pllhip_reduce_cb(comm, buf.ctypes.data_as(pc.c_double_p), 3, 0)
+        assert list(buf) == [1.5, -2.0, 7.0]
+    finally:
+        for i in insts:
+            i.free_sumtable(i.sumtable)
+            i.close()
+        L.pllhip_comm_destroy(comm)
+
+
+def test_driver_on_deferred_results(product):
+    """the C driver with a result group attached (what bench.py runs): identical likelihoods and
+    branch-length optimisation, one wait per evaluation / Newton round instead of one per partition"""
+    L = product.lib
+    idbuf = C.create_string_buffer(128)
+    assert L.pllhip_comm_get_unique_id(idbuf)
+    comm = L.pllhip_comm_create(idbuf.raw, 0, 1, 0)
+    assert comm, product.errmsg
+    try:
+        out = []
+        for attach in (None, "local", "rccl"):
+            with build(product, ntips=12) as ev:
+                if attach:
+                    ev.attach_comm(comm if attach == "rccl" else None)
+                lnl = ev.loglh()
+                opt = ev.optimize_branches(1e-4, 10.0, 0.01, 4, -1)
+                out.append((lnl, opt, ev.newick(), ev.counters()[2], ev.newton_iterations()))
+        assert out[0] == out[1] == out[2]
+    finally:
+        L.pllhip_comm_destroy(comm)
+
+
+def test_single_launch_reduction_equals_two_launch_form(product):
+    """PLLHIP_FUSED_FINISH=0 keeps the block totals + k_final_sum form of round 1: same bits"""
+    vals = []
+    for fused in ("1", "0"):
+        os.environ["PLLHIP_FUSED_FINISH"] = fused
+        try:
+            row = []
+            for states, n in ((4, 100003), (20, 40001), (61, 3001), (5, 2000)):
+                inst = pc.build_instance(product, states=states, rate_cats=4, ntips=7, nsites=n, pinv=0.05)
+                with inst:
+                    inst.L.pll_update_invariant_sites(inst.p)
+                    row.append(pc.full_traversal(inst))
+                    pcl, psc, ccl, csc, _ = _edge(inst)
+                    st = inst.alloc_sumtable()
+                    inst.update_sumtable(pcl, ccl, psc, csc, st)
+                    row.append(inst.derivatives(psc, csc, 0.21, st))
+                    row.append(tuple(map(tuple, inst.derivatives_multi(psc, csc, [0.3, 0.01, 5.0], st))))
+                    for _ in range(20):          # tickets return to zero after every launch
+                        assert inst.derivatives(psc, csc, 0.21, st) == row[-2]
+                    inst.free_sumtable(st)
+            vals.append(row)
+        finally:
+            del os.environ["PLLHIP_FUSED_FINISH"]
+    assert vals[0] == vals[1]
+
+
+def test_c_driver_across_two_processes_on_one_gpu(tmp_path):
+    """two worker processes share GPU 0, each with its own partitions of the HIP engine (sites
+    sharded / partitions distributed with NULL slots), synchronised through the reduce callback:
+    the product's N > 1 control flow where only one GPU exists"""
+    from test_multirank import _run_driver_workers, check_driver_ranks
+    for mode in ("sites", "parts"):
+        d = tmp_path / mode
+        d.mkdir()
+        check_driver_ranks(_run_driver_workers("product", mode, d))

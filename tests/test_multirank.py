@@ -36,3 +36,61 @@ def test_two_ranks_match_single_rank(oracle, tmp_path, states):
     assert abs(r0["ddf"] - r0["full_ddf"]) < 1e-9 * max(1.0, abs(r0["full_ddf"]))
     assert r0["max"] == [2.0, 0.0] and r0["min"] == [1.0]
     assert r0["wsum"] == r0["full_wsum"]      # pattern_weight_sum is per slice (treeinfo.c:1166)
+
+
+def _run_driver_workers(lib, mode, tmp_path, nproc=2):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "_evaldriver_worker.py"), lib, mode, str(tmp_path)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    subprocess.run(cmd, check=True, env=env, timeout=900, capture_output=True)
+    return [json.load(open(tmp_path / f"rank{r}.json")) for r in range(nproc)]
+
+
+def check_driver_ranks(ranks):
+    r0 = ranks[0]
+    single = r0["single"]
+    for r in ranks[1:]:
+        # all-reduce semantics: every worker holds the same numbers and makes the same decisions
+        for k in ("lnl", "lnl_opt", "lnl_after", "newick", "scans", "iterations", "reduce_calls", "payloads"):
+            assert r[k] == r0[k], k
+    assert abs(r0["lnl"] - single["lnl"]) < 1e-9 * abs(single["lnl"])
+    # the optimiser follows the same path: sums over the workers differ from the single
+    # process only in rounding (1e-13 relative), the Newton iterates likewise
+    assert abs(r0["lnl_opt"] - single["lnl_opt"]) < 1e-7 * abs(single["lnl_opt"])
+    assert abs(r0["lnl_after"] - single["lnl_after"]) < 1e-7 * abs(single["lnl_after"])
+    assert r0["iterations"] == single["iterations"]
+    assert r0["reduce_calls"] > 0
+    # one message per reduce: P lnL values, or {df, ddf} of every trial length of a scan
+    assert r0["payloads"][0] >= 2 and all(n == 3 or n % 2 == 0 for n in r0["payloads"])
+
+
+@pytest.mark.parametrize("mode", ["sites", "parts"])
+def test_c_driver_across_two_processes(oracle, tmp_path, mode):
+    """the C driver itself (pllhip_eval_set_parallel_context; in "parts" mode with NULL
+    partition slots) run by two gloo processes reproduces the single-process evaluation and
+    branch-length optimisation"""
+    check_driver_ranks(_run_driver_workers("oracle", mode, tmp_path))
+
+
+def test_bench_launcher_starts_the_ranks(tmp_path):
+    """`python bench.py --gpus N` without a rank environment starts N ranks itself (child
+    process, before any GPU call) and forwards their line; PLLHIP_BENCH_LAUNCH_PROBE=1 makes
+    the ranks prove their existence over gloo instead of running the GPU workload"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["PLLHIP_BENCH_LAUNCH_PROBE"] = "1"
+    for n in (2, 3):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)],
+                             env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == n and line["ranks"] == list(range(n))
+        assert line["local_ranks"] == list(range(n)) and line["distinct_processes"] == n
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """a rank environment that does not match --gpus is an error, never a line with the wrong n_gpus"""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", PLLHIP_BENCH_LAUNCH_PROBE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
