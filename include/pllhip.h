@@ -175,6 +175,13 @@ PLL_EXPORT int pllhip_compute_likelihood_derivatives_multi(pll_partition_t * par
                                                            const double * sumtable,
                                                            double * d_f, double * dd_f);
 
+/* how many trial lengths one scan of this partition's sumtable evaluates at (about) the
+   price of one: 4 where the scan runs on the matrix cores (20- and 61-state families: the
+   lengths are rows of an MFMA operand and the scan stays HBM-bound), 1 elsewhere (the
+   4-state scan is bound by its per-site divisions).  Callers that speculate on trial
+   lengths (include/pllhip_eval.h) use it to decide whether speculation is free. */
+PLL_EXPORT unsigned int pllhip_free_trial_lengths(const pll_partition_t * partition);
+
 /* ---- deferred scalar results -----------------------------------------------
  * pll_compute_edge_loglikelihood and pll_compute_likelihood_derivatives hand a double back
  * to the host: one wait per call and partition, and with several workers a host-side

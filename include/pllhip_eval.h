@@ -35,13 +35,16 @@ extern "C" {
 #endif
 
 #define PLLHIP_EVAL_PMATRIX_PER_BRANCH (1 << 0)
-/* Newton-Raphson evaluates only the current iterate per sumtable scan (the reference's
-   pattern, src/optimize/pll_optimize.c:1223-1287).  Without this flag every scan also
-   evaluates the iterates the step rule can produce by CLAMPING (+-dxmax, the bracket
-   ends: known before the derivatives are), and an iteration whose point was already
-   evaluated costs no scan.  The iterate sequence and every result are bit-identical
-   either way (include/pllhip.h: pllhip_compute_likelihood_derivatives_multi). */
+/* Newton-Raphson trial lengths.  The reference evaluates the current iterate per sumtable
+   scan (src/optimize/pll_optimize.c:1223-1287).  Where a scan evaluates several lengths
+   at the price of one (pllhip_free_trial_lengths() of EVERY partition of every worker,
+   agreed through one MIN reduce) the driver also evaluates the iterates the step rule can
+   produce by CLAMPING (+-dxmax, the bracket ends: known before the derivatives are), and
+   an iteration whose point was already evaluated costs no scan.  The iterate sequence
+   and every result are bit-identical either way.
+   NO_SPECULATION: never; ALWAYS_SPECULATE: even where extra lengths cost time (tests). */
 #define PLLHIP_EVAL_NO_SPECULATION     (1 << 1)
+#define PLLHIP_EVAL_ALWAYS_SPECULATE   (1 << 2)
 
 #define PLLHIP_EVAL_RADIUS_ALL (-1)   /* PLLMOD_OPT_BRLEN_OPTIMIZE_ALL, src/optimize/pll_optimize.h:102 */
 

@@ -503,6 +503,8 @@ int pll_compute_likelihood_derivatives(pll_partition_t * p,
   return PLL_SUCCESS;
 }
 
+unsigned int pllhip_free_trial_lengths(const pll_partition_t * p) { (void)p; return 1; }
+
 /* several trial branch lengths: the oracle simply repeats the single-length computation
    (include/pllhip.h; the product evaluates them in one pass over the sumtable) */
 int pllhip_compute_likelihood_derivatives_multi(pll_partition_t * p, int psc, int csc,

@@ -116,6 +116,7 @@ int pllhip_eval_set_partition(pllhip_eval_t * ev, unsigned int index, pll_partit
     for (r = 0; params_indices && r < partition->rate_cats; ++r) ev->params[index][r] = params_indices[r];
   }
   ev->parts[index] = partition;
+  ev->spec_trials = 0;
   pllhip_eval_invalidate_all(ev);
   return PLL_SUCCESS;
 }
@@ -124,6 +125,7 @@ void pllhip_eval_set_parallel_context(pllhip_eval_t * ev, void * ctx, pllhip_red
 {
   ev->ctx = ctx;
   ev->reduce_cb = reduce_cb;
+  ev->spec_trials = 0;
 }
 
 void pllhip_eval_set_fused(pllhip_eval_t * ev, const pllhip_eval_fused_t * fused)
@@ -353,6 +355,25 @@ static int derivatives(pllhip_eval_t * ev, const pll_unode_t * e, const double *
   return PLL_SUCCESS;
 }
 
+/* trial lengths per scan: every worker must scan with the same number (the reduce payloads
+   have to match), so the local minimum over the partitions goes through one MIN reduce */
+static unsigned int speculation_width(pllhip_eval_t * ev)
+{
+  unsigned int p;
+  double v = PLLHIP_EVAL_SPECULATE_MAX;
+  if (ev->spec_trials) return ev->spec_trials;
+  if (ev->flags & PLLHIP_EVAL_NO_SPECULATION) v = 1;
+  else if (!(ev->flags & PLLHIP_EVAL_ALWAYS_SPECULATE))
+  {
+    for (p = 0; p < ev->nparts; ++p)
+      if (ev->parts[p]) v = PLL_MIN(v, (double)pllhip_free_trial_lengths(ev->parts[p]));
+    if (ev->reduce_cb) ev->reduce_cb(ev->ctx, &v, 1, 2 /* MIN */);
+    if (v < 3) v = 1;             /* the current iterate + both clamped outcomes, or nothing */
+  }
+  ev->spec_trials = (unsigned int)v;
+  return ev->spec_trials;
+}
+
 /* the step rule of the reference's minimiser (opt_algorithms.c:208-240) clamps a Newton
    step to +-dxmax and to the bracket [xl, xh]: those outcomes are known BEFORE the
    derivatives are.  Returns the iterate a clamped step upwards (dir > 0) / downwards leads
@@ -384,7 +405,8 @@ static int newton(const blo_t * b, const pll_unode_t * e, double * x)
 {
   pllhip_eval_t * ev = b->ev;
   const double dxmax = b->bl_max / b->max_newton;
-  const int speculate = !(ev->flags & PLLHIP_EVAL_NO_SPECULATION);
+  const unsigned int width = speculation_width(ev);
+  const int speculate = width > 1;
   double xl = b->bl_min, xh = b->bl_max, f, df, dx;
   double t[PLLHIP_EVAL_MAX_TRIALS], tf[PLLHIP_EVAL_MAX_TRIALS], tdf[PLLHIP_EVAL_MAX_TRIALS];
   unsigned int nt = 0, k, iter = 0;
@@ -410,8 +432,8 @@ static int newton(const blo_t * b, const pll_unode_t * e, double * x)
         /* second level, while the scan stays at four lengths (beyond that the extra
            arithmetic of a length shows in the scan time): brackets as they stand after a
            step in that direction */
-        if (nt < PLLHIP_EVAL_SPECULATE_MAX) nt = add_trial(t, nt, clamped_iterate(b, dn, xl, *x, dxmax, -1));
-        if (nt < PLLHIP_EVAL_SPECULATE_MAX) nt = add_trial(t, nt, clamped_iterate(b, up, *x, xh, dxmax, 1));
+        if (nt < width) nt = add_trial(t, nt, clamped_iterate(b, dn, xl, *x, dxmax, -1));
+        if (nt < width) nt = add_trial(t, nt, clamped_iterate(b, up, *x, xh, dxmax, 1));
       }
       if (!derivatives(ev, e, t, nt, tf, tdf)) return PLL_FAILURE;
       k = 0;

@@ -28,6 +28,7 @@ struct pllhip_eval
   unsigned long n_ops, n_pmat, n_deriv, n_newton;
   pllhip_eval_fused_t fused;      /* fused.fetch != NULL: deferred results */
   double * slot_buf;              /* [nparts * 2 * PLLHIP_EVAL_MAX_TRIALS] */
+  unsigned int spec_trials;       /* trial lengths per scan; 0 = not decided yet */
 };
 
 #define PLLHIP_EVAL_MAX_TRIALS 8

@@ -122,27 +122,15 @@ __device__ inline void publish_result(const ReduceOut & ro)
   }
 }
 
+// what every block does after its totals are stored (write-through) and waited for:
+// draw the ticket(s); the last block adds all block totals and publishes
 template <int Q>
-__device__ inline void grid_reduce_finish(const double (&tot)[Q], const ReduceOut & ro,
-                                          double * scratch)
+__device__ inline void grid_reduce_tail(const ReduceOut & ro, double * scratch)
 {
   const unsigned G = gridDim.x, b = blockIdx.x;
-  if (!ro.fused)
-  {
-    if (threadIdx.x == 0)
-    {
-#pragma unroll
-      for (int q = 0; q < Q; ++q) ro.block_out[(size_t)q * G + b] = tot[q];
-    }
-    return;
-  }
   unsigned * s_last = reinterpret_cast<unsigned *>(scratch);   // block_sum_256 left it free
   if (threadIdx.x == 0)
   {
-#pragma unroll
-    for (int q = 0; q < Q; ++q)
-      __hip_atomic_store(ro.block_out + (size_t)q * G + b, tot[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned last = 0;
     const unsigned shard = b % REDUCE_SHARDS;
     const unsigned in_shard = (G - shard + REDUCE_SHARDS - 1) / REDUCE_SHARDS;     // blocks with this b % 8
@@ -167,17 +155,77 @@ __device__ inline void grid_reduce_finish(const double (&tot)[Q], const ReduceOu
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-#pragma unroll 1
+  // all quantities at once: the loads of every quantity are in flight together (one memory
+  // latency, not Q of them -- the totals were stored write-through, so they come from memory),
+  // each quantity still adds its blocks in ascending order per thread
+  double a[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) a[q] = 0.0;
+  for (unsigned bb = threadIdx.x; bb < G; bb += 256)
+  {
+    double v[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+      v[q] = ((unsigned)q < ro.nq)
+                 ? __hip_atomic_load(ro.block_out + (size_t)q * G + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                 : 0.0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) a[q] += v[q];
+  }
+#pragma unroll
   for (int q = 0; q < Q; ++q)
   {
     if ((unsigned)q >= ro.nq) break;
-    const double t = final_sum_256<true>(ro.block_out + (size_t)q * G, G, scratch);
+    const double t = block_sum_256(a[q], scratch);
     if (threadIdx.x == 0) ro.dst[q] = t;
   }
   if (threadIdx.x <= REDUCE_SHARDS)       // tickets back to zero for the next launch on this stream
     __hip_atomic_store(ro.counter + threadIdx.x * REDUCE_SHARD_STRIDE, 0u, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 0) publish_result(ro);
+}
+
+// block totals in thread 0 (tot[0 .. Q))
+template <int Q>
+__device__ inline void grid_reduce_finish(const double (&tot)[Q], const ReduceOut & ro,
+                                          double * scratch)
+{
+  const unsigned G = gridDim.x, b = blockIdx.x;
+  if (threadIdx.x == 0)
+  {
+    if (!ro.fused)
+    {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) ro.block_out[(size_t)q * G + b] = tot[q];
+    }
+    else
+    {
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+        __hip_atomic_store(ro.block_out + (size_t)q * G + b, tot[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  if (ro.fused) grid_reduce_tail<Q>(ro, scratch);
+}
+
+// block total of quantity t in thread t (t < Q <= 64: all of them lanes of wave 0, whose one
+// wait covers every store)
+template <int Q>
+__device__ inline void grid_reduce_finish_lanes(double mine, const ReduceOut & ro, double * scratch)
+{
+  const unsigned G = gridDim.x, b = blockIdx.x;
+  if (threadIdx.x < 64)
+  {
+    if (threadIdx.x < Q)
+    {
+      if (!ro.fused) ro.block_out[(size_t)threadIdx.x * G + b] = mine;
+      else __hip_atomic_store(ro.block_out + (size_t)threadIdx.x * G + b, mine, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (ro.fused) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (ro.fused) grid_reduce_tail<Q>(ro, scratch);
 }
 
 // two-launch form: block_out[q][nblocks] -> dst[q]; one block of 256 threads

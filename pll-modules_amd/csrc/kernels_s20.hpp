@@ -689,6 +689,7 @@ __global__ __launch_bounds__(256) void k_sumtable_prep_s20(ModelView mv, ParamId
 // ---------------------------------------------------------------------------
 template <unsigned KS, unsigned SREAL>
 __global__ __launch_bounds__(256) void k_derivatives_mfma(ModelView mv, ParamIdx params, TrialLengths tl,
+                                                          unsigned ntrial,
                                                           const double * sumtable,
                                                           const unsigned * ps, const unsigned * cs,
                                                           const unsigned * weights, const int * invariant,
@@ -698,82 +699,122 @@ __global__ __launch_bounds__(256) void k_derivatives_mfma(ModelView mv, ParamIdx
   extern __shared__ double frag[];        // [r][ks][lane]
   __shared__ double scratch[4];
   constexpr unsigned UNIT = 4 * KS * S20_BS;
-  for (unsigned x = threadIdx.x; x < R * KS * 64; x += blockDim.x)
-  {
-    const unsigned l = x & 63, ks = (x >> 6) % KS, r = (x >> 6) / KS;
-    const unsigned rho = l & 15, j = rho & 3, c = rho >> 2, k = 4 * ks + (l >> 4);
-    double v = 0.0;
-    if (c < 3 && k < SREAL)
-    {
-      const unsigned pi_ = params.v[r];
-      const double pinv = mv.pinv()[pi_];
-      const double lam = mv.evals(pi_)[k] * mv.rates()[r] / (1.0 - pinv);
-      const double wr = mv.weights()[r] * ((pinv > 0.0) ? (1.0 - pinv) : 1.0);
-      const double ex = exp(lam * tl.t[j]);
-      v = (c == 0) ? wr * ex : (c == 1) ? wr * ex * lam : wr * ex * lam * lam;
-    }
-    frag[x] = v;
-  }
-  __syncthreads();
-
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned q = lane >> 4, n = lane & 15;
   const unsigned wstride = gridDim.x * 4;
+  unsigned blk = blockIdx.x * 4 + wave;
+  double2 bufA[KS], bufB[KS];
+  auto load_unit = [&](double2 (&b)[KS], unsigned blk_, unsigned r_)
+  {
+    const double * unit = sumtable + ((size_t)blk_ * R + r_) * UNIT + lane * 2;
+#pragma unroll
+    for (unsigned ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const double2 *>(unit + ks * 128);
+  };
+  if (blk < nblk) load_unit(bufA, blk, 0);
+  // left operands: one exp per (rate, eigenvalue, trial length) and block -- the three powers
+  // of lambda share it, rows of unused trial slots repeat the last length
+  for (unsigned x = threadIdx.x; x < R * KS * 64; x += blockDim.x) frag[x] = 0.0;
+  __syncthreads();
+  for (unsigned x = threadIdx.x; x < R * SREAL * ntrial; x += blockDim.x)
+  {
+    const unsigned j = x % ntrial, k = (x / ntrial) % SREAL, r = x / (ntrial * SREAL);
+    const unsigned pi_ = params.v[r];
+    const double pinv = mv.pinv()[pi_];
+    const double lam = mv.evals(pi_)[k] * mv.rates()[r] / (1.0 - pinv);
+    const double wr = mv.weights()[r] * ((pinv > 0.0) ? (1.0 - pinv) : 1.0);
+    const double ex = exp(lam * tl.t[j]);
+    const double e0 = wr * ex, e1 = wr * ex * lam, e2 = wr * ex * lam * lam;
+    double * f = frag + ((size_t)r * KS + (k >> 2)) * 64 + (k & 3) * 16;     // lane = (k & 3) * 16 + row
+    for (unsigned jj = j; jj < 4; jj += (j + 1 == ntrial) ? 1u : 4u)
+    {
+      f[jj] = e0;
+      f[jj + 4] = e1;
+      f[jj + 8] = e2;
+    }
+  }
+  __syncthreads();
+
   double df = 0.0, ddf = 0.0;                 // of trial length q
-  for (unsigned blk = blockIdx.x * 4 + wave; blk < nblk; blk += wstride)
-  {
-    const size_t site0 = (size_t)blk * S20_BS + 2 * n;
-    const SiteSide sd = load_site_side(ps, cs, weights, site0, N, true);
-    v4d acc_e = {0, 0, 0, 0}, acc_o = {0, 0, 0, 0};
-    double inv_e = 0, inv_o = 0;
-    for (unsigned r = 0; r < R; ++r)
-    {
-      const double * unit = sumtable + ((size_t)blk * R + r) * UNIT + lane * 2;
-      double2 b[KS];
-#pragma unroll
-      for (unsigned ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const double2 *>(unit + ks * 128);
-      const double * fr = frag + (size_t)r * KS * 64 + lane;
-#pragma unroll
-      for (unsigned ks = 0; ks < KS; ++ks)
-      {
-        const double f = fr[ks * 64];
-        acc_e = mfma_f64(f, b[ks].x, acc_e);
-        acc_o = mfma_f64(f, b[ks].y, acc_o);
-      }
-      const unsigned pi_ = params.v[r];
-      const double pinv = mv.pinv()[pi_];
-      if (pinv > 0.0 && invariant)
-      {
-        const double w = mv.weights()[r] * pinv;
-        if (site0 < N && invariant[site0] >= 0) inv_e += w * mv.freqs(pi_)[invariant[site0]];
-        if (site0 + 1 < N && invariant[site0 + 1] >= 0) inv_o += w * mv.freqs(pi_)[invariant[site0 + 1]];
-      }
-    }
-    if (site0 < N)
-    {
-      double a = acc_e[0];
-      if (inv_e > 0.0) a += (sd.cnt_e <= 3) ? ldexp(inv_e, 256 * (int)sd.cnt_e) : INFINITY;
-      const double w = (double)sd.w_e, ba = acc_e[1] / a, ca = acc_e[2] / a;
-      df -= w * ba;
-      ddf += w * (ba * ba - ca);
-    }
-    if (site0 + 1 < N)
-    {
-      double a = acc_o[0];
-      if (inv_o > 0.0) a += (sd.cnt_o <= 3) ? ldexp(inv_o, 256 * (int)sd.cnt_o) : INFINITY;
-      const double w = (double)sd.w_o, ba = acc_o[1] / a, ca = acc_o[2] / a;
-      df -= w * ba;
-      ddf += w * (ba * ba - ca);
-    }
+  // The wave walks its (site block, rate) units with two alternating operand buffers: the
+  // loads of unit u + 1 are in flight while the MFMAs of unit u run (the very first unit was
+  // requested before the tables above were built).
+  v4d acc_e = {0, 0, 0, 0}, acc_o = {0, 0, 0, 0};
+  double inv_e = 0, inv_o = 0;
+  SiteSide sd = {0u, 0u, 0u, 0u};
+  unsigned r = 0;
+#define PLLHIP_DERIV_UNIT(CUR, NXT)                                                                   \
+  {                                                                                                   \
+    unsigned nr = r + 1, nb = blk;                                                                    \
+    if (nr == R) { nr = 0; nb = blk + wstride; }                                                      \
+    const bool more = nb < nblk;                                                                      \
+    if (more) load_unit(NXT, nb, nr);                                                                 \
+    const size_t site0 = (size_t)blk * S20_BS + 2 * n;                                                \
+    if (r == 0) sd = load_site_side(ps, cs, weights, site0, N, true);                                 \
+    const double * fr = frag + (size_t)r * KS * 64 + lane;                                            \
+    _Pragma("unroll") for (unsigned ks = 0; ks < KS; ++ks)                                            \
+    {                                                                                                 \
+      const double f = fr[ks * 64];                                                                   \
+      acc_e = mfma_f64(f, CUR[ks].x, acc_e);                                                          \
+      acc_o = mfma_f64(f, CUR[ks].y, acc_o);                                                          \
+    }                                                                                                 \
+    if (invariant)                                                                                    \
+    {                                                                                                 \
+      const unsigned pi_ = params.v[r];                                                               \
+      const double pinv = mv.pinv()[pi_];                                                             \
+      if (pinv > 0.0)                                                                                 \
+      {                                                                                               \
+        const double w = mv.weights()[r] * pinv;                                                      \
+        if (site0 < N && invariant[site0] >= 0) inv_e += w * mv.freqs(pi_)[invariant[site0]];        \
+        if (site0 + 1 < N && invariant[site0 + 1] >= 0) inv_o += w * mv.freqs(pi_)[invariant[site0 + 1]]; \
+      }                                                                                               \
+    }                                                                                                 \
+    if (r == R - 1)                                                                                   \
+    {                                                                                                 \
+      if (site0 < N)                                                                                  \
+      {                                                                                               \
+        double a = acc_e[0];                                                                          \
+        if (inv_e > 0.0) a += (sd.cnt_e <= 3) ? ldexp(inv_e, 256 * (int)sd.cnt_e) : INFINITY;         \
+        const double w = (double)sd.w_e, ba = acc_e[1] / a, ca = acc_e[2] / a;                        \
+        df -= w * ba;                                                                                 \
+        ddf += w * (ba * ba - ca);                                                                    \
+      }                                                                                               \
+      if (site0 + 1 < N)                                                                              \
+      {                                                                                               \
+        double a = acc_o[0];                                                                          \
+        if (inv_o > 0.0) a += (sd.cnt_o <= 3) ? ldexp(inv_o, 256 * (int)sd.cnt_o) : INFINITY;         \
+        const double w = (double)sd.w_o, ba = acc_o[1] / a, ca = acc_o[2] / a;                        \
+        df -= w * ba;                                                                                 \
+        ddf += w * (ba * ba - ca);                                                                    \
+      }                                                                                               \
+      acc_e = v4d{0, 0, 0, 0};                                                                        \
+      acc_o = v4d{0, 0, 0, 0};                                                                        \
+      inv_e = inv_o = 0.0;                                                                            \
+    }                                                                                                 \
+    blk = nb;                                                                                         \
+    r = nr;                                                                                           \
+    if (!more) break;                                                                                 \
   }
-  double tot[8];
-#pragma unroll
-  for (unsigned j = 0; j < 4; ++j)
+  while (blk < nblk)
   {
-    tot[2 * j] = block_sum_256(q == j ? df : 0.0, scratch);
-    tot[2 * j + 1] = block_sum_256(q == j ? ddf : 0.0, scratch);
+    PLLHIP_DERIV_UNIT(bufA, bufB)
+    PLLHIP_DERIV_UNIT(bufB, bufA)
   }
-  grid_reduce_finish<8>(tot, block_out, scratch);
+#undef PLLHIP_DERIV_UNIT
+  // lane group q holds trial length q: sums over the 16 lanes of a group (fixed butterfly), then
+  // over the four waves through LDS -- one barrier pair whatever the number of lengths
+  __shared__ double part[4][8];
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1)
+  {
+    df += __shfl_xor(df, off, 64);
+    ddf += __shfl_xor(ddf, off, 64);
+  }
+  if (n == 0) { part[wave][2 * q] = df; part[wave][2 * q + 1] = ddf; }
+  __syncthreads();
+  double mine = 0.0;
+  if (threadIdx.x < 8) mine = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+  __syncthreads();
+  grid_reduce_finish_lanes<8>(mine, block_out, scratch);
 }
 
 // ---------------------------------------------------------------------------
@@ -939,9 +980,8 @@ static int launch_derivatives_s20(Engine * e, const ModelView & mv, const ParamI
                                   const double * d_sum, const unsigned * ps, const unsigned * cs,
                                   unsigned nblocks)
 {
-  (void)count;
   hipLaunchKernelGGL((k_derivatives_mfma<5, 20>), dim3(nblocks), dim3(256), sizeof(double) * e->R * 5 * 64, e->stream,
-                     mv, params, tl, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, reduce_out(e));
+                     mv, params, tl, count, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, reduce_out(e));
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

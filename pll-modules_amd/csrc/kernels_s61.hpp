@@ -714,11 +714,12 @@ __global__ __launch_bounds__(256, 1) void k_edge_lnl_s61_r4(ModelView mv, ParamI
   acc_lnl = wave_sum(acc_lnl);
   if (lane == 0) scratch[wave] = acc_lnl;
   __syncthreads();
-  if (threadIdx.x == 0)
-  {
-    block_out.block_out[blockIdx.x] = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+  const double tot = (threadIdx.x == 0) ? (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]) : 0.0;
+  __syncthreads();
+  // two-launch form: k_final_sum adds nreduce slots, the ones beyond this grid are zero
+  if (!block_out.fused && threadIdx.x == 0)
     for (unsigned b = blockIdx.x + gridDim.x; b < nreduce; b += gridDim.x) block_out.block_out[b] = 0.0;
-  }
+  grid_reduce_finish1(tot, block_out, scratch);
 }
 
 // sumtable preparation: Lm[r][k][i] = pi_i V[i][k], Rm[r][k][j] = V^-1[k][j] in
@@ -888,7 +889,6 @@ static int launch_derivatives_s61(Engine * e, const ModelView & mv, const ParamI
                                   const double * d_sum, const unsigned * ps, const unsigned * cs,
                                   unsigned nblocks)
 {
-  (void)count;
   const size_t lds = sizeof(double) * e->R * S61_KS * 64;
   if (lds > 160 * 1024)
   {
@@ -907,7 +907,7 @@ static int launch_derivatives_s61(Engine * e, const ModelView & mv, const ParamI
     }
   }
   hipLaunchKernelGGL((k_derivatives_mfma<S61_KS, S61_S>), dim3(nblocks), dim3(256), lds, e->stream,
-                     mv, params, tl, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, reduce_out(e));
+                     mv, params, tl, count, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, reduce_out(e));
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

@@ -1072,7 +1072,10 @@ int derivatives_impl(pll_partition_t * p, int parent_scaler_index, int child_sca
     return PLL_FAILURE;
   }
   if (!sync_model(p) || !ensure_invariant(p)) return PLL_FAILURE;
-  const unsigned nblocks = reduce_grid(e);
+  unsigned nblocks = reduce_grid(e);
+  // the matrix-core scan pipelines its loads across the units a wave walks: a few long-lived
+  // workgroups per CU (tables built, totals reduced and published less often)
+  if (e->blocked) nblocks = std::min(nblocks, 4u * e->cu_count);
   const ModelView mv = model_view(e);
   const ParamIdx params = make_params(p, params_indices);
   // lengths per launch: the matrix-core kernel (20 / 61 states) takes four; the others are
@@ -1187,6 +1190,11 @@ int pll_compute_likelihood_derivatives(pll_partition_t * p,
 {
   return derivatives_impl(p, parent_scaler_index, child_scaler_index, &branch_length, 1, params_indices,
                           sumtable, nullptr, d_f, dd_f);
+}
+
+unsigned int pllhip_free_trial_lengths(const pll_partition_t * p)
+{
+  return engine_of(p)->blocked ? 4u : 1u;
 }
 
 int pllhip_compute_likelihood_derivatives_multi(pll_partition_t * p,

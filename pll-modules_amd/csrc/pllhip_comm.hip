@@ -390,5 +390,7 @@ extern "C" int pllhip_eval_attach_comm(struct pllhip_eval * ev, pllhip_comm_t * 
   table.fetch = fused_fetch;
   table.destroy = fused_destroy;
   pllhip_eval_set_fused(ev, &table);
+  // control decisions of the driver (MIN / MAX of host values) go through the callback
+  if (comm) pllhip_eval_set_parallel_context(ev, comm, pllhip_reduce_cb);
   return PLL_SUCCESS;
 }

@@ -130,7 +130,7 @@ pllhip_get_scaler pllhip_get_sumtable pllhip_set_clv pllhip_set_scaler pllhip_sy
 pllhip_stream pllhip_get_counters pllhip_reset_counters pllhip_partials_kernel_name
 pllhip_comm_get_unique_id pllhip_comm_create pllhip_comm_destroy pllhip_reduce_cb
 pllhip_profile_partials pllhip_profile_read pllhip_comm_rank pllhip_comm_size
-pllhip_compute_likelihood_derivatives_multi pllhip_results_create pllhip_results_destroy
+pllhip_compute_likelihood_derivatives_multi pllhip_free_trial_lengths pllhip_results_create pllhip_results_destroy
 pllhip_results_edge_loglikelihood pllhip_results_derivatives pllhip_results_fetch
 pllhip_eval_attach_comm""".split()
 

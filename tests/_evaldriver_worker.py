@@ -31,10 +31,10 @@ def model_of(states):
     return r, f, 0.5
 
 
-def build(lib, tree, owned, site_range, cb=None):
+def build(lib, tree, owned, site_range, cb=None, flags=0):
     """Evaluation over PARTS; partition k is present if k in owned, holding sites
     site_range(k) = (lo, hi) of its alignment"""
-    ev = pc.Evaluation(lib, tree.newick(), nparts=len(PARTS))
+    ev = pc.Evaluation(lib, tree.newick(), flags=flags, nparts=len(PARTS))
     for k, (states, R, nsites) in enumerate(PARTS):
         if k not in owned:
             ev.add_remote_partition(k)
@@ -79,12 +79,15 @@ def main():
     else:
         owned = {k for k in range(len(PARTS)) if k % world == rank}
         rng = lambda k, n: (0, n)
-    with build(lib, tree, owned, rng, cb) as ev:
+    # "sites": several trial lengths per scan everywhere (PLLHIP_EVAL_ALWAYS_SPECULATE), so the
+    # {df, ddf} messages carry more than one length; "parts": the policy the libraries ask for
+    flags = 4 if mode == "sites" else 0
+    with build(lib, tree, owned, rng, cb, flags) as ev:
         out = run(ev)
     out["reduce_calls"] = len(calls)
     out["payloads"] = sorted(set(n for n, _ in calls))
     if rank == 0:
-        with build(lib, tree, set(range(len(PARTS))), lambda k, n: (0, n)) as ev:
+        with build(lib, tree, set(range(len(PARTS))), lambda k, n: (0, n), None, flags) as ev:
             out["single"] = run(ev)
     with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
         json.dump(out, f)

@@ -267,7 +267,7 @@ def check_speculative_newton(lib):
     step rule) makes the same iterates and returns the same numbers, bit for bit, as one scan
     per iteration -- with fewer scans"""
     runs = []
-    for flags in (0, 2):                                  # 2 = PLLHIP_EVAL_NO_SPECULATION
+    for flags in (4, 2):                 # PLLHIP_EVAL_ALWAYS_SPECULATE, PLLHIP_EVAL_NO_SPECULATION
         with build(lib, flags=flags) as ev:
             ev.loglh()
             opt = ev.optimize_branches(1e-4, 10.0, 0.01, 8, -1)

@@ -45,8 +45,11 @@ def test_multi_length_derivatives(product, oracle, states, rate_cats):
                 # a length's result does not depend on what shares the launch
                 assert (df[k], ddf[k]) == single[k], (count, k)
         want = [b.derivatives(psc, csc, x, sb) for x in ts]
+        # 61 states: each engine runs its own eigen-solver; tests/test_expm_fixtures.py pins both
+        # against an independent matrix exponential, here only the kernels' agreement is at stake
+        rel = 1e-9 if states <= 20 else 1e-7
         for (g0, g1), (w0, w1) in zip(single, want):
-            assert abs(g0 - w0) <= 1e-9 * max(1.0, abs(w0)) and abs(g1 - w1) <= 1e-9 * max(1.0, abs(w1))
+            assert abs(g0 - w0) <= rel * max(1.0, abs(w0)) and abs(g1 - w1) <= rel * max(1.0, abs(w1))
         with pytest.raises(RuntimeError):
             a.derivatives_multi(psc, csc, ts + [0.3], sa)           # at most 8 per call
         c = a.counters()

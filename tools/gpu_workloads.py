@@ -60,6 +60,13 @@ def w2(lib, cfg, out):
         out[f"W2_{cfg}"] = {"ms": dt * 1e3, "us_per_derivative_call": (dt * 1e6) / 17,
                             "algorithmic_GBps": nbytes / dt / 1e9,
                             "what": "1 sumtable + 16 derivative evaluations, host sync per derivative"}
+        for K in (1, 2, 4, 8):
+            tt = [float(b) for b in brl[:K]]
+            inst.derivatives_multi(args[2], args[3], tt, st)
+            t0 = time.perf_counter()
+            for _ in range(50):
+                inst.derivatives_multi(args[2], args[3], tt, st)
+            out[f"W2_{cfg}"][f"us_per_scan_K{K}"] = (time.perf_counter() - t0) / 50 * 1e6
         inst.free_sumtable(st)
 
 
@@ -142,18 +149,26 @@ def blo(lib, cfg, out, nsites=None):
         (subst, freqs), alpha = pc.protein_model(), 0.5
     inst = ev.add_partition(0, S, N, R, pc.random_codes(ntips, N, S), subst, freqs, alpha)
     with ev:
+        if os.environ.get("PLLHIP_WORKLOAD_ATTACH", "1") != "0":
+            ev.attach_comm(None)              # deferred results (what bench.py runs)
         l0 = ev.loglh()
         lib.lib.pllhip_synchronize(inst.p)
         ops0, pm0, d0 = ev.counters()
+        n0 = ev.newton_iterations()
         t0 = time.perf_counter()
         l1 = ev.optimize_branches(1e-4, 10.0, 0.01, 1, -1)
         dt = time.perf_counter() - t0
         ops1, pm1, d1 = ev.counters()
+        n1 = ev.newton_iterations()
         out[f"BLO_{cfg}_{N}"] = {"s_per_smoothing_pass": dt, "lnl_before": l0, "lnl_after": l1,
-                                 "derivative_calls": d1 - d0, "single_op_updates": ops1 - ops0,
+                                 "sumtable_scans": d1 - d0, "newton_iterations": n1 - n0,
+                                 "single_op_updates": ops1 - ops0,
                                  "pmatrix_updates": pm1 - pm0, "branches": t.nedges,
-                                 "us_per_derivative_call_incl_everything": dt / max(1, d1 - d0) * 1e6,
-                                 "what": "pllhip_eval_optimize_branches(iters=1, radius=ALL), C driver"}
+                                 "us_per_scan_incl_everything": dt / max(1, d1 - d0) * 1e6,
+                                 "us_per_derivative_call_incl_everything": dt / max(1, n1 - n0) * 1e6,
+                                 "what": "pllhip_eval_optimize_branches(iters=1, radius=ALL), C driver; a "
+                                         "derivative call = one Newton-Raphson iterate (the reference scans the "
+                                         "sumtable once per iterate); scans evaluate up to 4 trial lengths"}
 
 
 def spr(lib, out, nsites=None, ntips=None, radius_max=5, thorough=False):
@@ -188,6 +203,10 @@ def main():
     lib = pc.PllLib(pc.PRODUCT_LIB)
     out = {}
     which = sys.argv[1:] or ["w2", "w3", "c4", "blo"]
+    if "blo125" in which:
+        blo(lib, "c3", out, nsites=125_000)
+    if "blo_c2" in which:
+        blo(lib, "c2", out, nsites=125_000)
     if "blo" in which:
         blo(lib, "c3", out)
         blo(lib, "c2", out)
