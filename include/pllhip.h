@@ -57,7 +57,8 @@ PLL_EXPORT int pllhip_device_arch(int device, char * out, size_t out_len);
 
 /* host-only: eigen-decomposition of the reversible rate matrix built from
    `subst_params` (upper triangle, row-major) and `frequencies`, normalised to
-   mean rate 1.  eigenvecs[i*Sp+k] = V[i][k], inv_eigenvecs[k*Sp+j] = V^-1[k][j].
+   mean rate 1, Q = V L V^-1.  Storage follows libpll-2: inv_eigenvecs[i*Sp+k] = V[i][k],
+   eigenvecs[k*Sp+j] = V^-1[k][j], i.e. P(t) = inv_eigenvecs * diag(exp(L t)) * eigenvecs.
    This is what pll_update_prob_matrices runs when eigen_decomp_valid[i] == 0. */
 PLL_EXPORT int pllhip_eigen_decompose(unsigned int states, unsigned int states_padded,
                                       const double * subst_params,

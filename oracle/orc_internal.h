@@ -26,7 +26,7 @@ void orc_set_error(int code, const char * fmt, ...);
 /* symmetric eigen-decomposition by cyclic Jacobi rotations.
    a: n*n row-major symmetric (destroyed), w: eigenvalues, v: n*n row-major,
    column k of v is eigenvector k. */
-void orc_jacobi_eigen(double * a, unsigned int n, double * w, double * v);
+void orc_jacobi_eigen(long double * a, unsigned int n, long double * w, long double * v);
 
 /* (re)build eigenvecs/inv_eigenvecs/eigenvals of one rate matrix */
 int orc_update_eigen(pll_partition_t * p, unsigned int params_index);

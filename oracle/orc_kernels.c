@@ -55,7 +55,7 @@ int pll_update_prob_matrices(pll_partition_t * p,
     {
       unsigned int pi_ = params_indices[r];
       double * P = p->pmatrix[matrix_indices[m]] + (size_t)r * S * Sp;
-      const double * V = p->eigenvecs[pi_], * Vi = p->inv_eigenvecs[pi_];
+      const double * V = p->inv_eigenvecs[pi_], * Vi = p->eigenvecs[pi_];   /* libpll-2 naming */
       const double * L = p->eigenvals[pi_];
       double pinv = p->prop_invar[pi_];
       memset(P, 0, sizeof(double) * S * Sp);
@@ -69,9 +69,10 @@ int pll_update_prob_matrices(pll_partition_t * p,
       for (i = 0; i < S; ++i)
         for (j = 0; j < S; ++j)
         {
-          double s = 0.0;
-          for (k = 0; k < S; ++k) s += V[i * Sp + k] * ex[k] * Vi[k * Sp + j];
-          P[i * Sp + j] = s;
+          /* extended-precision accumulation: the sum cancels down to ~1e-13 at 61 states */
+          long double s = 0.0L;
+          for (k = 0; k < S; ++k) s += (long double)V[i * Sp + k] * ex[k] * Vi[k * Sp + j];
+          P[i * Sp + j] = (double)s;
         }
     }
   }
@@ -420,7 +421,7 @@ int pll_update_sumtable(pll_partition_t * p,
     {
       unsigned int pi_ = params_indices[r];
       const double * pi = p->frequencies[pi_];
-      const double * V = p->eigenvecs[pi_], * Vi = p->inv_eigenvecs[pi_];
+      const double * V = p->inv_eigenvecs[pi_], * Vi = p->eigenvecs[pi_];   /* libpll-2 naming */
       double * out = sumtable + ((size_t)n * R + r) * Sp;
       for (k = 0; k < S; ++k)
       {

@@ -21,49 +21,61 @@
 #include "orc_internal.h"
 
 /* ------------------------------------------------------------------ */
-/* symmetric eigenproblem: cyclic Jacobi                              */
+/* symmetric eigenproblem: cyclic Jacobi, in extended precision         */
 /* ------------------------------------------------------------------ */
+/* The oracle is the checker, so it is made as exact as fp64 storage allows: the
+   decomposition runs in long double (x87, 64-bit mantissa) until no rotation is left,
+   and its results are rounded to fp64 once.  Measured against 60-digit matrix
+   exponentials (tests/golden/make_expm_fixtures.py) the P-matrices built from it are
+   correct to ~1e-16 absolute at 61 states; an fp64 Jacobi reached 1.6e-14, which showed
+   as 1e-7 in single-site log-likelihoods of a codon alignment. */
+typedef long double orc_ld;
 
-void orc_jacobi_eigen(double * a, unsigned int n, double * w, double * v)
+void orc_jacobi_eigen(orc_ld * a, unsigned int n, orc_ld * w, orc_ld * v)
 {
   unsigned int i, j, k, sweep;
   for (i = 0; i < n; ++i)
-    for (j = 0; j < n; ++j) v[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (j = 0; j < n; ++j) v[i * n + j] = (i == j) ? 1.0L : 0.0L;
 
-  for (sweep = 0; sweep < 100; ++sweep)
+  for (sweep = 0; sweep < 200; ++sweep)
   {
-    double off = 0.0;
-    for (i = 0; i < n; ++i)
-      for (j = i + 1; j < n; ++j) off += a[i * n + j] * a[i * n + j];
-    if (off < 1e-300) break;
-
+    int rotated = 0;
     for (i = 0; i + 1 < n; ++i)
       for (j = i + 1; j < n; ++j)
       {
-        double apq = a[i * n + j];
-        if (fabs(apq) < 1e-300) continue;
-        double theta = (a[j * n + j] - a[i * n + i]) / (2.0 * apq);
-        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        orc_ld apq = a[i * n + j];
+        /* a rotation that no longer changes the diagonal is skipped */
+        if (apq == 0.0L ||
+            (fabsl(a[i * n + i]) + fabsl(apq) * 1e-4L == fabsl(a[i * n + i]) &&
+             fabsl(a[j * n + j]) + fabsl(apq) * 1e-4L == fabsl(a[j * n + j])))
+        {
+          a[i * n + j] = a[j * n + i] = 0.0L;
+          continue;
+        }
+        rotated = 1;
+        orc_ld theta = (a[j * n + j] - a[i * n + i]) / (2.0L * apq);
+        orc_ld t = (theta >= 0 ? 1.0L : -1.0L) / (fabsl(theta) + sqrtl(theta * theta + 1.0L));
+        orc_ld c = 1.0L / sqrtl(t * t + 1.0L), s = t * c;
         for (k = 0; k < n; ++k)
         {
-          double akp = a[k * n + i], akq = a[k * n + j];
+          orc_ld akp = a[k * n + i], akq = a[k * n + j];
           a[k * n + i] = c * akp - s * akq;
           a[k * n + j] = s * akp + c * akq;
         }
         for (k = 0; k < n; ++k)
         {
-          double apk = a[i * n + k], aqk = a[j * n + k];
+          orc_ld apk = a[i * n + k], aqk = a[j * n + k];
           a[i * n + k] = c * apk - s * aqk;
           a[j * n + k] = s * apk + c * aqk;
         }
         for (k = 0; k < n; ++k)
         {
-          double vkp = v[k * n + i], vkq = v[k * n + j];
+          orc_ld vkp = v[k * n + i], vkq = v[k * n + j];
           v[k * n + i] = c * vkp - s * vkq;
           v[k * n + j] = s * vkp + c * vkq;
         }
       }
+    if (!rotated) break;
   }
   for (i = 0; i < n; ++i) w[i] = a[i * n + i];
 }
@@ -71,15 +83,16 @@ void orc_jacobi_eigen(double * a, unsigned int n, double * w, double * v)
 /* Q from exchangeabilities (upper triangle, row-major) and frequencies,
    normalised to one expected substitution per unit time; then
    A = D^1/2 Q D^-1/2 = U L U^T,  V = D^-1/2 U,  V^-1 = U^T D^1/2.
-   eigenvecs[i*Sp + k] = V[i][k], inv_eigenvecs[k*Sp + j] = V^-1[k][j]. */
+   libpll-2 storage: inv_eigenvecs[i*Sp + k] = V[i][k], eigenvecs[k*Sp + j] = V^-1[k][j]
+   (P = inv_eigenvecs * diag * eigenvecs). */
 int orc_update_eigen(pll_partition_t * p, unsigned int idx)
 {
   unsigned int S = p->states, Sp = p->states_padded, i, j, k;
   const double * pi = p->frequencies[idx];
   const double * ex = p->subst_params[idx];
-  double * q = (double *)calloc((size_t)S * S, sizeof(double));
-  double * u = (double *)calloc((size_t)S * S, sizeof(double));
-  double * w = (double *)calloc(S, sizeof(double));
+  orc_ld * q = (orc_ld *)calloc((size_t)S * S, sizeof(orc_ld));
+  orc_ld * u = (orc_ld *)calloc((size_t)S * S, sizeof(orc_ld));
+  orc_ld * w = (orc_ld *)calloc(S, sizeof(orc_ld));
   if (!q || !u || !w)
   {
     free(q); free(u); free(w);
@@ -90,18 +103,18 @@ int orc_update_eigen(pll_partition_t * p, unsigned int idx)
   for (i = 0, k = 0; i < S; ++i)
     for (j = i + 1; j < S; ++j, ++k)
     {
-      q[i * S + j] = ex[k] * pi[j];
-      q[j * S + i] = ex[k] * pi[i];
+      q[i * S + j] = (orc_ld)ex[k] * pi[j];
+      q[j * S + i] = (orc_ld)ex[k] * pi[i];
     }
-  double mean = 0.0;
+  orc_ld mean = 0.0L;
   for (i = 0; i < S; ++i)
   {
-    double row = 0.0;
+    orc_ld row = 0.0L;
     for (j = 0; j < S; ++j) if (j != i) row += q[i * S + j];
     q[i * S + i] = -row;
     mean += pi[i] * row;
   }
-  if (!(mean > 0.0))
+  if (!(mean > 0.0L))
   {
     free(q); free(u); free(w);
     orc_set_error(PLL_ERROR_PARAM_INVALID, "Degenerate rate matrix");
@@ -111,13 +124,13 @@ int orc_update_eigen(pll_partition_t * p, unsigned int idx)
   for (i = 0; i < S; ++i)
     for (j = 0; j < S; ++j)
       q[i * S + j] = (pi[i] > 0 && pi[j] > 0)
-                         ? q[i * S + j] * sqrt(pi[i]) / sqrt(pi[j]) / mean
-                         : 0.0;
+                         ? q[i * S + j] * sqrtl((orc_ld)pi[i]) / sqrtl((orc_ld)pi[j]) / mean
+                         : 0.0L;
   /* enforce exact symmetry before Jacobi */
   for (i = 0; i < S; ++i)
     for (j = i + 1; j < S; ++j)
     {
-      double m = 0.5 * (q[i * S + j] + q[j * S + i]);
+      orc_ld m = 0.5L * (q[i * S + j] + q[j * S + i]);
       q[i * S + j] = q[j * S + i] = m;
     }
   orc_jacobi_eigen(q, S, w, u);
@@ -125,13 +138,13 @@ int orc_update_eigen(pll_partition_t * p, unsigned int idx)
   memset(p->eigenvecs[idx], 0, sizeof(double) * S * Sp);
   memset(p->inv_eigenvecs[idx], 0, sizeof(double) * S * Sp);
   memset(p->eigenvals[idx], 0, sizeof(double) * Sp);
-  for (k = 0; k < S; ++k) p->eigenvals[idx][k] = w[k];
+  for (k = 0; k < S; ++k) p->eigenvals[idx][k] = (double)w[k];
   for (i = 0; i < S; ++i)
     for (k = 0; k < S; ++k)
     {
-      double sq = sqrt(pi[i]);
-      p->eigenvecs[idx][i * Sp + k] = (sq > 0) ? u[i * S + k] / sq : 0.0;
-      p->inv_eigenvecs[idx][k * Sp + i] = u[i * S + k] * sq;
+      orc_ld sq = sqrtl((orc_ld)pi[i]);
+      p->inv_eigenvecs[idx][i * Sp + k] = (sq > 0) ? (double)(u[i * S + k] / sq) : 0.0;
+      p->eigenvecs[idx][k * Sp + i] = (double)(u[i * S + k] * sq);
     }
   p->eigen_decomp_valid[idx] = 1;
   free(q); free(u); free(w);

@@ -329,8 +329,10 @@ int sync_model(pll_partition_t * p)
   {
     memcpy(&cur[e->off_freqs + (size_t)m * e->Sp], p->frequencies[m], sizeof(double) * e->Sp);
     memcpy(&cur[e->off_evals + (size_t)m * e->Sp], p->eigenvals[m], sizeof(double) * e->Sp);
-    memcpy(&cur[e->off_evecs + (size_t)m * e->S * e->Sp], p->eigenvecs[m], sizeof(double) * e->S * e->Sp);
-    memcpy(&cur[e->off_ievecs + (size_t)m * e->S * e->Sp], p->inv_eigenvecs[m], sizeof(double) * e->S * e->Sp);
+    // device slots: evecs = V, ievecs = V^-1; the partition fields follow libpll-2's naming,
+    // where `inv_eigenvecs` is V and `eigenvecs` is V^-1 (pll_model.cpp)
+    memcpy(&cur[e->off_evecs + (size_t)m * e->S * e->Sp], p->inv_eigenvecs[m], sizeof(double) * e->S * e->Sp);
+    memcpy(&cur[e->off_ievecs + (size_t)m * e->S * e->Sp], p->eigenvecs[m], sizeof(double) * e->S * e->Sp);
   }
   if (memcmp(cur.data(), e->model_shadow.data(), sizeof(double) * e->model_len) != 0)
   {

@@ -155,7 +155,11 @@ static bool ql_implicit(std::vector<double> & d, std::vector<double> & e, unsign
 
 // Q from exchangeabilities + frequencies, normalised to mean rate 1;
 // A = D^1/2 Q D^-1/2 = U L U^T;  V = D^-1/2 U;  V^-1 = U^T D^1/2.
-// eigenvecs[i*Sp + k] = V[i][k], inv_eigenvecs[k*Sp + j] = V^-1[k][j].
+// evecs[i*Sp + k] = V[i][k], ievecs[k*Sp + j] = V^-1[k][j]  (P(t) = V exp(L t) V^-1).
+// NOTE the partition fields: libpll-2 stores V in `inv_eigenvecs` and V^-1 in `eigenvecs`
+// (its P-matrix is inv_eigenvecs * diag * eigenvecs; [libpll-2 knowledge]),
+// and so does this library: update_eigen_host() and pllhip_eigen_decompose() below pass the
+// fields in that order.
 int eigen_decompose(unsigned S, unsigned Sp, const double * ex, const double * pi,
                     double * evecs, double * ievecs, double * evals)
 {
@@ -216,7 +220,7 @@ int eigen_decompose(unsigned S, unsigned Sp, const double * ex, const double * p
 int update_eigen_host(pll_partition_t * p, unsigned idx)
 {
   if (!eigen_decompose(p->states, p->states_padded, p->subst_params[idx], p->frequencies[idx],
-                       p->eigenvecs[idx], p->inv_eigenvecs[idx], p->eigenvals[idx]))
+                       p->inv_eigenvecs[idx], p->eigenvecs[idx], p->eigenvals[idx]))
     return PLL_FAILURE;
   p->eigen_decomp_valid[idx] = 1;
   return PLL_SUCCESS;
@@ -355,7 +359,7 @@ extern "C" int pllhip_eigen_decompose(unsigned int states, unsigned int states_p
                                      double * eigenvecs, double * inv_eigenvecs, double * eigenvals)
 {
   return pllhip::eigen_decompose(states, states_padded, subst_params, frequencies,
-                                 eigenvecs, inv_eigenvecs, eigenvals);
+                                 inv_eigenvecs, eigenvecs, eigenvals);
 }
 
 extern "C" int pll_compute_gamma_cats(double alpha, unsigned int K, double * out, int mode)

@@ -95,7 +95,8 @@ def test_eigen_decomposition_reconstructs_rate_matrix(product_nogpu, states):
     assert product_nogpu.lib.pllhip_eigen_decompose(
         S, Sp, np.ascontiguousarray(ex).ctypes.data_as(dp), np.ascontiguousarray(pi).ctypes.data_as(dp),
         ev.ctypes.data_as(dp), iv.ctypes.data_as(dp), lam.ctypes.data_as(dp))
-    V = ev.reshape(S, Sp)[:, :S]; Vi = iv.reshape(S, Sp)[:, :S]; L = lam[:S]
+    # libpll-2 storage convention: `inv_eigenvecs` holds V, `eigenvecs` holds V^-1
+    V = iv.reshape(S, Sp)[:, :S]; Vi = ev.reshape(S, Sp)[:, :S]; L = lam[:S]
     Q = np.zeros((S, S)); k = 0
     for i in range(S):
         for j in range(i + 1, S):

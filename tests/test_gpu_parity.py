@@ -2,12 +2,16 @@
 
 Tolerances: scalers, tip codes and invariant-site indices are integers and must
 be bit-exact.  Floating point follows BASELINE.json's north star
-(|dlnL| < 1e-6 per site); the tests hold the engine to far tighter bounds
-(lnL: 1e-12 relative or 2e-9 per site, whichever is larger -- the two engines use
-different eigen-solvers, which shows at ~1e-11 relative in small 61-state P-matrix
-entries; CLV entries: 1e-8 relative, errors accumulate along the tree depth):
-CLV / sumtable entries rel 1e-9 (P-matrix entries come out of an eigen sum with
-cancellation, and device exp() differs from libm by an ulp), lnL rel 1e-12 of |lnL|, derivatives rel 1e-9.
+(|dlnL| < 1e-6 per site); the tests hold the engine to far tighter bounds.  Up to 20 states:
+lnL 1e-12 relative or 2e-9 per site, CLV / sumtable entries 1e-8 of their vector's maximum
+(errors accumulate along the tree depth), derivatives 1e-9.  61 states: every engine runs its
+OWN eigen-solver (nothing is injected); codon P-matrices hold entries down to 1e-19 which fp64
+storage resolves to 1e-16 ABSOLUTE at best, and with random sequences whole sites consist of
+such entries -- tests/test_expm_fixtures.py measures both engines against 60-digit matrix
+exponentials (oracle 1.3e-16, product 2.7e-15 in P).  Hence for 61 states: lnL 5e-8 per site,
+CLV entries 1e-7 of the largest entry of their SITE (all rates: the quantity the site
+likelihood and the scaling rule see), derivatives 2e-6.  Measured deviations go to
+gpurun_out/parity_measured.jsonl (condensed into profiles/r02_parity.json).
 """
 import ctypes as C
 import os
@@ -25,8 +29,30 @@ REL_LNL = 1e-12
 PER_SITE = 2e-9
 
 
-def lnl_close(la, lb, nsites):
+PER_SITE_61 = 5e-8     # measured <= 7e-9 (profiles/r02_parity.json)
+CLV_SITE_61 = 1e-7     # measured <= 5e-9
+
+
+def lnl_close(la, lb, nsites, states=4):
+    if states > 20:
+        return abs(la - lb) <= PER_SITE_61 * nsites
     return abs(la - lb) <= max(REL_LNL * abs(lb), PER_SITE * nsites)
+
+
+def site_err(a, b):
+    """largest deviation of a CLV [site][rate][state], measured against the largest entry of the
+    same SITE over all rates and states"""
+    scale = np.maximum(np.abs(b).max(axis=(1, 2), keepdims=True), 1e-300)
+    return float(np.max(np.abs(a - b) / scale))
+
+
+def record(test, **values):
+    """measured deviations -> gpurun_out/parity_measured.jsonl"""
+    import json
+    d = os.path.join(common.ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity_measured.jsonl"), "a") as f:
+            f.write(json.dumps({"test": test, **{k: float(v) for k, v in values.items()}}) + "\n")
 
 
 def _pair(product, oracle, **kw):
@@ -35,46 +61,27 @@ def _pair(product, oracle, **kw):
     return a, b
 
 
-def share_eigen(a, b):
-    """copy the oracle's (b) eigen-decomposition into the product partition (a), so that
-    both engines build their P-matrices from the same eigen system"""
-    assert b.L.pll_update_eigen(b.p, 0)
-    pa, pb = a.p.contents, b.p.contents
-    n = a.S * a.Sp
-    for dst, src, ln in ((pa.eigenvecs[0], pb.eigenvecs[0], n), (pa.inv_eigenvecs[0], pb.inv_eigenvecs[0], n),
-                         (pa.eigenvals[0], pb.eigenvals[0], a.Sp)):
-        if a.Sp == b.Sp:
-            C.memmove(dst, src, 8 * ln)
-        else:
-            src_a = np.ctypeslib.as_array(src, shape=(ln // a.Sp * b.Sp,)).reshape(-1, b.Sp)
-            dst_a = np.ctypeslib.as_array(dst, shape=(ln,)).reshape(-1, a.Sp)
-            dst_a[:, :b.Sp] = src_a
-    pa.eigen_decomp_valid[0] = 1
-
-
-def _compare_full(a, b, check_clvs=True, codon_clv_tol=1e-5):
-    if a.S > 20:
-        # codon P-matrices hold entries down to ~1e-13 (three-step changes) that any
-        # eigen-solver only gets to ~1e-14 ABSOLUTE (checked against scipy expm): with
-        # random sequences such entries dominate whole CLV vectors, so the two
-        # engines are compared on the same eigen system here; the product's own
-        # solver is checked by the lnL of this test's (20, 5, 4)-state siblings and
-        # by tests/test_boundary.py
-        share_eigen(a, b)
+def _compare_full(a, b, check_clvs=True):
     la = pc.full_traversal(a)
     lb = pc.full_traversal(b)
     assert np.isfinite(lb) and lb < 0
-    assert lnl_close(la, lb, a.N), (la, lb)
+    assert lnl_close(la, lb, a.N, a.S), (la, lb, abs(la - lb) / a.N)
+    worst = 0.0
     if check_clvs:
         t = a.tree
         for op in t.ops:
             ca, cb = a.get_clv(op[0]), b.get_clv(op[0])
-            # even on a shared eigen system the tiny codon P-matrix entries differ at
-            # ~1e-5 relative between device exp() and libm (1 ulp on cancelling terms)
-            if a.S <= 20 or codon_clv_tol is not None:
-                assert common.vec_err(ca, cb) < (REL_CLV if a.S <= 20 else codon_clv_tol), f"CLV {op[0]}"
+            if a.S <= 20:
+                err = common.vec_err(ca, cb)
+                assert err < REL_CLV, f"CLV {op[0]}"
+            else:
+                err = site_err(ca, cb)
+                assert err < CLV_SITE_61, f"CLV {op[0]}: {err}"
+            worst = max(worst, err)
             if a.nscalers:
                 assert np.array_equal(a.get_scaler(op[1]), b.get_scaler(op[1])), f"scaler {op[1]}"
+    if a.S > 20:
+        record("full_traversal_61", sites=a.N, rate_cats=a.R, dlnl_per_site=abs(la - lb) / a.N, clv_site_err=worst)
     return la, lb
 
 
@@ -140,11 +147,9 @@ def test_many_ambiguity_codes(product, oracle, states, ncodes):
         insts.append((inst, l_plain))
     (a, la0), (b, lb0) = insts
     with a, b:
-        if states > 20:
-            share_eigen(a, b)
         assert a.p.contents.maxstates == b.p.contents.maxstates >= min(len(masks), ncodes) - 1
         la, lb = pc.full_traversal(a), pc.full_traversal(b)
-        assert lnl_close(la, lb, nsites), (la, lb)
+        assert lnl_close(la, lb, nsites, states), (la, lb)
         assert abs(la - la0) > 1.0                   # the ambiguous alignment really is different
         t = a.tree
         sa, sb = a.alloc_sumtable(), b.alloc_sumtable()
@@ -169,11 +174,13 @@ def test_deep_tree_scaling_is_bit_exact(product, oracle, states, ntips, rate_cat
     agree exactly and lnL must survive"""
     a, b = _pair(product, oracle, states=states, rate_cats=rate_cats, ntips=ntips, nsites=97, coded=True)
     with a, b:
-        # codon matrices: the ulp-level exp() differences on the tiny P-matrix entries (see
-        # _compare_full) grow with the depth in the improbable components of a vector (3.5e-4
-        # of the vector maximum after 130 levels), while lnL still agrees to 1e-12: for 61
-        # states this test checks the scaler counts (exact) and lnL, not the small components
-        la, lb = _compare_full(a, b, codon_clv_tol=None)
+        # 61 states: the improbable components of a vector drift apart with the depth (each
+        # engine's own 1e-15 in the small P-matrix entries, 130 levels): this test checks the
+        # scaler counts (exact) and lnL, not the small components
+        la, lb = _compare_full(a, b, check_clvs=states <= 20)
+        if states > 20:
+            for op in a.tree.ops:
+                assert np.array_equal(a.get_scaler(op[1]), b.get_scaler(op[1]))
         root_sc = a.get_scaler(a.tree.scaler_of(a.tree.root_a))
         assert root_sc.max() >= 1, "test did not reach the scaling regime"
 
@@ -272,10 +279,12 @@ def test_sumtable_and_derivatives(product, oracle, states, coded):
     with a, b:
         pc.full_traversal(a); pc.full_traversal(b)
         t = a.tree
-        # the oracle's eigenvectors are injected into the product so that the two
-        # sumtables are comparable entry by entry (eigenvectors are unique only up
-        # to sign/order); the product's own solver is covered by the lnL tests
-        share_eigen(a, b)
+        # eigenvectors are unique only up to sign and order, so sumtable entries of two solvers
+        # are not comparable one by one; what is: sum_k sumtable[n,r,k] exp(lambda_k x) -- the
+        # likelihood of (site, rate) as a function of the branch length -- with each engine's
+        # own eigenvalues
+        la_ = np.ctypeslib.as_array(a.p.contents.eigenvals[0], shape=(a.Sp,))[:a.S].copy()
+        lb_ = np.ctypeslib.as_array(b.p.contents.eigenvals[0], shape=(b.Sp,))[:b.S].copy()
         sa_, sb_ = a.alloc_sumtable(), b.alloc_sumtable()
         for (pc_, cc_) in ((t.root_a, t.root_b), (t.root_b, t.root_a)):
             if coded and pc_ < t.ntips and cc_ < t.ntips:
@@ -283,8 +292,12 @@ def test_sumtable_and_derivatives(product, oracle, states, coded):
             args = (pc_, cc_, t.scaler_of(pc_), t.scaler_of(cc_))
             a.update_sumtable(*args, sa_)
             b.update_sumtable(*args, sb_)
-            if a.Sp == b.Sp:
-                assert common.vec_err(a.get_sumtable(sa_), b.get_sumtable(sb_)) < 1e-9
+            ta, tb = a.get_sumtable(sa_), b.get_sumtable(sb_)
+            for x in (0.0, 0.05, 0.7):
+                fa, fb = ta @ np.exp(la_ * x), tb @ np.exp(lb_ * x)          # [site][rate]
+                scale = np.abs(fb).max(axis=1, keepdims=True)
+                # 61 states: products of two CLVs that each carry up to 2e-6 of their site's maximum
+                assert (np.abs(fa - fb) / scale).max() < (1e-9 if states <= 20 else 2e-5)
             for bl in (1e-4, 0.013, 0.1, 0.77, 5.0, 90.0):
                 da = a.derivatives(args[2], args[3], bl, sa_)
                 db = b.derivatives(args[2], args[3], bl, sb_)
@@ -340,14 +353,12 @@ def test_node_ancestral_states(product, oracle, states):
     """marginal ancestral state probabilities (src/tree/treeinfo.c:1698)"""
     a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=7, nsites=77, coded=True)
     with a, b:
-        if states > 20:
-            share_eigen(a, b)
         pc.full_traversal(a); pc.full_traversal(b)
         t = a.tree
         args = (t.root_a, t.scaler_of(t.root_a), t.root_b, t.scaler_of(t.root_b), t.root_matrix)
         pa, pb = a.node_ancestral(*args), b.node_ancestral(*args)
         assert np.allclose(pa.sum(axis=1), 1.0, atol=1e-12)
-        assert np.allclose(pa, pb, rtol=1e-9 if states <= 20 else 1e-5, atol=1e-12)
+        assert np.allclose(pa, pb, rtol=1e-9, atol=1e-12 if states <= 20 else 2e-6)
 
 
 def test_host_model_arrays_are_source_of_truth(product, oracle):
@@ -480,8 +491,12 @@ def test_baseline_sizes_through_tiling(product, oracle, cfg, tile):
         tile_codes = small.codes
     with pc.build_instance(product, states=S, rate_cats=R, ntips=ntips, nsites=tile, coded=True, tree=t) as ref:
         l_ref = pc.full_traversal(ref)
-    # own eigen-solver vs the oracle's on codon matrices: see _compare_full
-    tol = 2e-6 * abs(l_tile) if S > 20 else max(REL_LNL * abs(l_tile), PER_SITE * tile)
+    # the north star itself at 61 states (|dlnL| < 1e-6 per site), far tighter below; each engine
+    # with its own eigen-solver
+    tol = 1e-6 * tile if S > 20 else max(REL_LNL * abs(l_tile), PER_SITE * tile)
+    record("baseline_tile", config=int(cfg[1]), tile_sites=tile, dlnl_per_site=abs(l_ref - l_tile) / tile,
+           lnl_per_site=l_tile / tile)
+    print(f"\n[{cfg}] |dlnL| per site, HIP vs oracle on the {tile}-site tile: {abs(l_ref - l_tile) / tile:.3e}")
     assert abs(l_ref - l_tile) <= tol
     with pc.Instance(product, ntips, S, tile * K, R, attributes=pc.PLL_ATTRIB_PATTERN_TIP) as big:
         big.set_model(subst, freqs, product.gamma_cats(alpha, R))
