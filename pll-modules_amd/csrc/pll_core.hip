@@ -903,13 +903,51 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     }
   }
 
+  // 61 states: operations with matrix work are bound by the FP64 matrix pipe, tip x tip
+  // operations (two table look-ups, one vector out) by HBM.  In the plain level schedule all
+  // tip x tip operations of a traversal share launch 0 and leave the matrix cores idle; run
+  // as LATE as their consumer allows, they share a launch with matrix-bound operations and
+  // the two pipes overlap.  Only for lists with the shape of a tree traversal (plan_chains'
+  // test); PLLHIP_S61_ALAP=0 keeps the plain schedule.
+  static const int use_alap = getenv("PLLHIP_S61_ALAP") ? atoi(getenv("PLLHIP_S61_ALAP")) : 1;
+  std::vector<char> light(count, 0);
+  if (use_alap && e->family == KernelFamily::S61 && e->coded_tips && count >= 3)
+  {
+    ChainPlan shape;
+    if (plan_chains(e, ops, count, 1, ~0u, 1u, shape))
+    {
+      std::vector<int> producer(e->nodes, -1), consumer(count, -1);
+      for (unsigned k = 0; k < count; ++k)
+      {
+        const int p1 = producer[ops[k].child1_clv_index], p2 = producer[ops[k].child2_clv_index];
+        if (p1 >= 0) consumer[p1] = (int)k;
+        if (p2 >= 0) consumer[p2] = (int)k;
+        producer[ops[k].parent_clv_index] = (int)k;
+      }
+      for (unsigned k = 0; k < count; ++k)
+      {
+        const bool tt = ops[k].child1_clv_index < e->tips && ops[k].child2_clv_index < e->tips;
+        if (tt && consumer[k] >= 0 && level[consumer[k]] - 1 > level[k])
+        {
+          level[k] = level[consumer[k]] - 1;
+          light[k] = 1;
+        }
+        else if (tt) light[k] = 1;
+      }
+    }
+  }
+
   for (int l = 0; l <= max_level; ++l)
   {
     OpBatch batch;
     unsigned nb = 0;
     double batch_bytes = 0.0, batch_flops = 0.0;
+    // matrix-bound operations first, the light ones behind them (their workgroups fill the tail)
+    for (unsigned pass = 0; pass < 2; ++pass)
     for (unsigned k = 0; k <= count; ++k)
     {
+      if (k < count && (light[k] != (char)pass)) continue;
+      if (k == count && pass == 0) continue;
       if (k < count && level[k] == l) fill_desc(ops[k], batch.op[nb++], batch_bytes, batch_flops);
       if (nb == MAX_OPS_PER_LAUNCH || (k == count && nb))
       {

@@ -61,7 +61,7 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     which, mode, outdir = sys.argv[1], sys.argv[2], sys.argv[3]
-    path = pc.PRODUCT_LIB if which == "product" else os.path.join(ROOT, "oracle", "_build", "libpll_oracle.so")
+    path = pc.PRODUCT_LIB if which == "product" else (os.environ.get("PLLHIP_ORACLE_LIB") or os.path.join(ROOT, "oracle", "_build", "libpll_oracle.so"))
     lib = pc.PllLib(path)
     ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}
     calls = []

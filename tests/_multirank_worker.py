@@ -24,7 +24,7 @@ import pllhip_ctypes as pc  # noqa: E402
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    lib = pc.PllLib(os.path.join(ROOT, "oracle", "_build", "libpll_oracle.so"))
+    lib = pc.PllLib((os.environ.get("PLLHIP_ORACLE_LIB") or os.path.join(ROOT, "oracle", "_build", "libpll_oracle.so")))
     states, R, ntips, nsites = int(sys.argv[1]), 4, 9, 1001
 
     ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}
