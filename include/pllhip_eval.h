@@ -54,6 +54,19 @@ extern "C" {
 #define PLLHIP_EVAL_ERROR_NEWTON_LIMIT 2220
 #define PLLHIP_EVAL_ERROR_NEWTON_WORSE 2240
 
+/* branch-length linkage across partitions (PLLMOD_COMMON_BRLEN_*, src/pllmod_common.h:25-27):
+   LINKED    one length per branch, the tree's;
+   SCALED    the tree's length times a per-partition scaler (src/tree/treeinfo.c:849-852,
+             chain rule in the derivatives: src/optimize/pll_optimize.c:1240-1262);
+   UNLINKED  every partition has its own length per branch (src/tree/treeinfo.c:176-183);
+             Newton-Raphson then runs one function per partition with its own bracket and
+             convergence flag (src/optimize/opt_algorithms.c:133-261), the lengths of
+             partitions other workers own arrive through a MAX reduce
+             (src/optimize/pll_optimize.c:1431-1442). */
+#define PLLHIP_EVAL_BRLEN_LINKED   0
+#define PLLHIP_EVAL_BRLEN_SCALED   1
+#define PLLHIP_EVAL_BRLEN_UNLINKED 2
+
 typedef struct pllhip_eval pllhip_eval_t;
 
 typedef void (*pllhip_reduce_fn)(void * ctx, double * data, size_t n, int op);
@@ -95,6 +108,18 @@ typedef struct pllhip_eval_fused
 } pllhip_eval_fused_t;
 
 PLL_EXPORT void pllhip_eval_set_fused(pllhip_eval_t * ev, const pllhip_eval_fused_t * fused);
+
+/* linkage mode (default LINKED).  UNLINKED copies the tree's current lengths into every
+   partition's own array, like pllmod_treeinfo_create does (src/tree/treeinfo.c:1266-1277). */
+PLL_EXPORT int pllhip_eval_set_brlen_linkage(pllhip_eval_t * ev, int linkage);
+PLL_EXPORT int pllhip_eval_set_brlen_scaler(pllhip_eval_t * ev, unsigned int partition, double scaler);
+PLL_EXPORT double pllhip_eval_get_brlen_scaler(const pllhip_eval_t * ev, unsigned int partition);
+/* the length partition `partition` sees on `edge` before scaling: its own (UNLINKED) or the tree's */
+PLL_EXPORT double pllhip_eval_get_partition_branch_length(const pllhip_eval_t * ev, unsigned int partition,
+                                                          const pll_unode_t * edge);
+/* UNLINKED only (src/tree/treeinfo.c:456-472) */
+PLL_EXPORT int pllhip_eval_set_partition_branch_length(pllhip_eval_t * ev, unsigned int partition,
+                                                       const pll_unode_t * edge, double length);
 
 PLL_EXPORT int pllhip_eval_set_root(pllhip_eval_t * ev, pll_unode_t * root);
 PLL_EXPORT pll_unode_t * pllhip_eval_root(const pllhip_eval_t * ev);

@@ -44,10 +44,20 @@ pllhip_eval_t * pllhip_eval_create(pll_utree_t * tree, unsigned int partition_co
   ev->pmat_valid = (char *)calloc(ev->edges, 1);
   ev->trav = (pll_unode_t **)calloc(ev->tips + ev->inner, sizeof(*ev->trav));
   ev->ops = (pll_operation_t *)calloc(ev->inner, sizeof(*ev->ops));
-  ev->brlens = (double *)calloc(ev->edges, sizeof(double));
+  ev->brlens = (double *)calloc((size_t)2 * ev->edges, sizeof(double));   /* tree lengths | one partition's view */
   ev->midx = (unsigned int *)calloc(ev->edges, sizeof(unsigned int));
   ev->slot_buf = (double *)calloc((size_t)partition_count * 2 * PLLHIP_EVAL_MAX_TRIALS, sizeof(double));
-  if (!ev->slot_buf || !ev->parts || !ev->params || !ev->sumtables || !ev->part_lnl || !ev->clv_valid ||
+  ev->brlen_scalers = (double *)calloc(partition_count, sizeof(double));
+  ev->nr_x = (double *)calloc((size_t)partition_count * 6, sizeof(double));
+  ev->nr_converged = (int *)calloc(partition_count, sizeof(int));
+  if (ev->nr_x)
+  {
+    ev->nr_xl = ev->nr_x + partition_count;      ev->nr_xh = ev->nr_xl + partition_count;
+    ev->nr_f = ev->nr_xh + partition_count;      ev->nr_df = ev->nr_f + partition_count;
+    ev->nr_orig = ev->nr_df + partition_count;
+  }
+  for (i = 0; ev->brlen_scalers && i < partition_count; ++i) ev->brlen_scalers[i] = 1.0;
+  if (!ev->brlen_scalers || !ev->nr_x || !ev->nr_converged || !ev->slot_buf || !ev->parts || !ev->params || !ev->sumtables || !ev->part_lnl || !ev->clv_valid ||
       !ev->pmat_valid || !ev->trav || !ev->ops || !ev->brlens || !ev->midx)
     goto nomem;
   /* indices must address the flag arrays */
@@ -85,6 +95,12 @@ void pllhip_eval_destroy(pllhip_eval_t * ev)
   free(ev->parts); free(ev->params); free(ev->sumtables); free(ev->part_lnl);
   free(ev->clv_valid); free(ev->pmat_valid); free(ev->trav); free(ev->ops);
   free(ev->brlens); free(ev->midx); free(ev->slot_buf);
+  free(ev->brlen_scalers); free(ev->nr_x); free(ev->nr_converged);
+  if (ev->part_brlens)
+  {
+    for (p = 0; p < ev->nparts; ++p) free(ev->part_brlens[p]);
+    free(ev->part_brlens);
+  }
   if (ev->fused.destroy && ev->fused.results) ev->fused.destroy(ev->fused.results);
   free(ev);
 }
@@ -135,6 +151,88 @@ void pllhip_eval_set_fused(pllhip_eval_t * ev, const pllhip_eval_fused_t * fused
   if (fused) ev->fused = *fused;
 }
 
+int pllhip_eval_set_brlen_linkage(pllhip_eval_t * ev, int linkage)
+{
+  unsigned int p, i;
+  if (linkage < PLLHIP_EVAL_BRLEN_LINKED || linkage > PLLHIP_EVAL_BRLEN_UNLINKED)
+  {
+    pllhip_eval_error(PLL_ERROR_PARAM_INVALID, "unknown branch-length linkage %d", linkage);
+    return PLL_FAILURE;
+  }
+  if (linkage == PLLHIP_EVAL_BRLEN_UNLINKED && !ev->part_brlens)
+  {
+    ev->part_brlens = (double **)calloc(ev->nparts, sizeof(double *));
+    for (p = 0; ev->part_brlens && p < ev->nparts; ++p)
+      if (!(ev->part_brlens[p] = (double *)calloc(ev->edges, sizeof(double)))) break;
+    if (!ev->part_brlens || p < ev->nparts)
+    {
+      pllhip_eval_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate per-partition branch lengths");
+      return PLL_FAILURE;
+    }
+    /* every partition starts from the tree's lengths */
+    for (i = 0; i < ev->tips + ev->inner; ++i)
+    {
+      const pll_unode_t * n = ev->tree->nodes[i], * s2 = n;
+      do
+      {
+        for (p = 0; p < ev->nparts; ++p) ev->part_brlens[p][s2->pmatrix_index] = s2->length;
+        s2 = s2->next;
+      } while (s2 && s2 != n);
+    }
+  }
+  ev->linkage = linkage;
+  if (linkage != PLLHIP_EVAL_BRLEN_SCALED)
+    for (p = 0; p < ev->nparts; ++p) ev->brlen_scalers[p] = 1.0;
+  pllhip_eval_invalidate_all(ev);
+  return PLL_SUCCESS;
+}
+
+int pllhip_eval_set_brlen_scaler(pllhip_eval_t * ev, unsigned int partition, double scaler)
+{
+  if (partition >= ev->nparts || ev->linkage != PLLHIP_EVAL_BRLEN_SCALED || !(scaler > 0.0))
+  {
+    pllhip_eval_error(PLL_ERROR_PARAM_INVALID, "branch-length scalers need SCALED linkage, a valid "
+                      "partition and a positive value");
+    return PLL_FAILURE;
+  }
+  ev->brlen_scalers[partition] = scaler;
+  pllhip_eval_invalidate_all(ev);
+  return PLL_SUCCESS;
+}
+
+double pllhip_eval_get_brlen_scaler(const pllhip_eval_t * ev, unsigned int partition)
+{
+  return partition < ev->nparts ? ev->brlen_scalers[partition] : 0.0;
+}
+
+double pllhip_eval_get_partition_branch_length(const pllhip_eval_t * ev, unsigned int partition,
+                                               const pll_unode_t * edge)
+{
+  if (partition >= ev->nparts) return 0.0;
+  return ev->part_brlens ? ev->part_brlens[partition][edge->pmatrix_index] : edge->length;
+}
+
+int pllhip_eval_set_partition_branch_length(pllhip_eval_t * ev, unsigned int partition,
+                                            const pll_unode_t * edge, double length)
+{
+  if (partition >= ev->nparts || ev->linkage != PLLHIP_EVAL_BRLEN_UNLINKED || !(length >= 0.0))
+  {
+    pllhip_eval_error(PLL_ERROR_PARAM_INVALID, "per-partition branch lengths need UNLINKED linkage");
+    return PLL_FAILURE;
+  }
+  ev->part_brlens[partition][edge->pmatrix_index] = length;
+  ev->pmat_valid[edge->pmatrix_index] = 0;
+  memset(ev->clv_valid, 0, ev->records);
+  return PLL_SUCCESS;
+}
+
+/* the branch length partition p's P-matrix of branch m is computed for */
+static double effective_length(const pllhip_eval_t * ev, unsigned int p, unsigned int m, double tree_length)
+{
+  const double t = ev->part_brlens ? ev->part_brlens[p][m] : tree_length;
+  return (ev->linkage == PLLHIP_EVAL_BRLEN_SCALED) ? t * ev->brlen_scalers[p] : t;
+}
+
 int pllhip_eval_set_root(pllhip_eval_t * ev, pll_unode_t * root)
 {
   if (!root || !root->next)
@@ -166,7 +264,9 @@ void pllhip_eval_invalidate_clv(pllhip_eval_t * ev, const pll_unode_t * node)
 
 void pllhip_eval_set_branch_length(pllhip_eval_t * ev, pll_unode_t * edge, double length)
 {
+  unsigned int p;
   edge->length = edge->back->length = length;
+  for (p = 0; ev->part_brlens && p < ev->nparts; ++p) ev->part_brlens[p][edge->pmatrix_index] = length;
   ev->pmat_valid[edge->pmatrix_index] = 0;
   /* every CLV that looks across this edge depends on it: all records on the far
      side pointing this way.  Conservative and cheap: drop all CLV flags. */
@@ -204,14 +304,21 @@ static int update_pmatrices(pllhip_eval_t * ev)
   if (!k) return PLL_SUCCESS;
   for (p = 0; p < ev->nparts; ++p)
   {
+    double * bl = ev->brlens;
     if (!ev->parts[p]) continue;
+    if (ev->linkage != PLLHIP_EVAL_BRLEN_LINKED)
+    {
+      /* this partition's own view of the invalid branches (scaled or unlinked lengths) */
+      bl = ev->brlens + ev->edges;
+      for (i = 0; i < k; ++i) bl[i] = effective_length(ev, p, ev->midx[i], ev->brlens[i]);
+    }
     if (ev->flags & PLLHIP_EVAL_PMATRIX_PER_BRANCH)
     {
       for (i = 0; i < k; ++i)
-        if (!pll_update_prob_matrices(ev->parts[p], ev->params[p], &ev->midx[i], &ev->brlens[i], 1))
+        if (!pll_update_prob_matrices(ev->parts[p], ev->params[p], &ev->midx[i], &bl[i], 1))
           return PLL_FAILURE;
     }
-    else if (!pll_update_prob_matrices(ev->parts[p], ev->params[p], ev->midx, ev->brlens, k))
+    else if (!pll_update_prob_matrices(ev->parts[p], ev->params[p], ev->midx, bl, k))
       return PLL_FAILURE;
   }
   ev->n_pmat += k;
@@ -303,45 +410,56 @@ static int ensure_sumtables(pllhip_eval_t * ev)
 }
 
 /* first and second derivative of -lnL over all partitions at `count` trial branch
-   lengths from ONE scan of every partition's sumtable (and one reduce over the workers) */
+   lengths from ONE scan of every partition's sumtable (and one reduce over the workers).
+   SCALED linkage: partition p is evaluated at s_p t and contributes s_p df, s_p^2 ddf (chain
+   rule, src/optimize/pll_optimize.c:1240-1262). */
 static int derivatives(pllhip_eval_t * ev, const pll_unode_t * e, const double * t, unsigned int count,
                        double * f, double * df)
 {
   unsigned int p, k;
   double * buf = ev->slot_buf;
+  double tp[PLLHIP_EVAL_MAX_TRIALS];
   for (k = 0; k < count; ++k) f[k] = df[k] = 0.0;
   if (ev->fused.fetch)
   {
     for (p = 0; p < ev->nparts; ++p)
-      if (ev->parts[p] &&
-          !ev->fused.derivatives(ev->fused.results, p * 2 * count, ev->parts[p], e->scaler_index,
-                                 e->back->scaler_index, t, count, ev->params[p], ev->sumtables[p]))
+    {
+      if (!ev->parts[p]) continue;
+      for (k = 0; k < count; ++k) tp[k] = ev->brlen_scalers[p] * t[k];
+      if (!ev->fused.derivatives(ev->fused.results, p * 2 * count, ev->parts[p], e->scaler_index,
+                                 e->back->scaler_index, tp, count, ev->params[p], ev->sumtables[p]))
         return PLL_FAILURE;
+    }
     if (!ev->fused.fetch(ev->fused.results, 0, ev->nparts * 2 * count, 0 /* SUM */, buf)) return PLL_FAILURE;
     for (p = 0; p < ev->nparts; ++p)
+    {
+      const double sc = ev->brlen_scalers[p];
       for (k = 0; k < count; ++k)
       {
-        f[k] += buf[(p * count + k) * 2];
-        df[k] += buf[(p * count + k) * 2 + 1];
+        f[k] += sc * buf[(p * count + k) * 2];
+        df[k] += sc * sc * buf[(p * count + k) * 2 + 1];
       }
+    }
   }
   else
   {
     double a[PLLHIP_EVAL_MAX_TRIALS], b[PLLHIP_EVAL_MAX_TRIALS];
     for (p = 0; p < ev->nparts; ++p)
     {
+      const double sc = ev->brlen_scalers[p];
       if (!ev->parts[p]) continue;
+      for (k = 0; k < count; ++k) tp[k] = sc * t[k];
       if (count == 1)
       {
-        if (!pll_compute_likelihood_derivatives(ev->parts[p], e->scaler_index, e->back->scaler_index, t[0],
+        if (!pll_compute_likelihood_derivatives(ev->parts[p], e->scaler_index, e->back->scaler_index, tp[0],
                                                 ev->params[p], ev->sumtables[p], &a[0], &b[0]))
           return PLL_FAILURE;
       }
       else if (!pllhip_compute_likelihood_derivatives_multi(ev->parts[p], e->scaler_index,
-                                                            e->back->scaler_index, t, count, ev->params[p],
+                                                            e->back->scaler_index, tp, count, ev->params[p],
                                                             ev->sumtables[p], a, b))
         return PLL_FAILURE;
-      for (k = 0; k < count; ++k) { f[k] += a[k]; df[k] += b[k]; }
+      for (k = 0; k < count; ++k) { f[k] += sc * a[k]; df[k] += sc * sc * b[k]; }
     }
     if (ev->reduce_cb)
     {
@@ -351,6 +469,39 @@ static int derivatives(pllhip_eval_t * ev, const pll_unode_t * e, const double *
       for (k = 0; k < count; ++k) { f[k] = buf[2 * k]; df[k] = buf[2 * k + 1]; }
     }
   }
+  ev->n_deriv++;
+  return PLL_SUCCESS;
+}
+
+/* UNLINKED: every partition at its own length x[p]; f[p], df[p] stay per partition
+   (src/optimize/pll_optimize.c:1229-1279; one message of 2 P values here) */
+static int derivatives_unlinked(pllhip_eval_t * ev, const pll_unode_t * e, const double * x,
+                                double * f, double * df)
+{
+  unsigned int p;
+  double * buf = ev->slot_buf;
+  if (ev->fused.fetch)
+  {
+    for (p = 0; p < ev->nparts; ++p)
+      if (ev->parts[p] &&
+          !ev->fused.derivatives(ev->fused.results, 2 * p, ev->parts[p], e->scaler_index,
+                                 e->back->scaler_index, &x[p], 1, ev->params[p], ev->sumtables[p]))
+        return PLL_FAILURE;
+    if (!ev->fused.fetch(ev->fused.results, 0, 2 * ev->nparts, 0 /* SUM */, buf)) return PLL_FAILURE;
+  }
+  else
+  {
+    for (p = 0; p < ev->nparts; ++p)
+    {
+      buf[2 * p] = buf[2 * p + 1] = 0.0;
+      if (ev->parts[p] &&
+          !pll_compute_likelihood_derivatives(ev->parts[p], e->scaler_index, e->back->scaler_index, x[p],
+                                              ev->params[p], ev->sumtables[p], &buf[2 * p], &buf[2 * p + 1]))
+        return PLL_FAILURE;
+    }
+    if (ev->reduce_cb) ev->reduce_cb(ev->ctx, buf, 2 * ev->nparts, 0 /* SUM */);
+  }
+  for (p = 0; p < ev->nparts; ++p) { f[p] = buf[2 * p]; df[p] = buf[2 * p + 1]; }
   ev->n_deriv++;
   return PLL_SUCCESS;
 }
@@ -405,7 +556,7 @@ static int newton(const blo_t * b, const pll_unode_t * e, double * x)
 {
   pllhip_eval_t * ev = b->ev;
   const double dxmax = b->bl_max / b->max_newton;
-  const unsigned int width = speculation_width(ev);
+  const unsigned int width = speculation_width(ev);     /* UNLINKED runs newton_unlinked instead */
   const int speculate = width > 1;
   double xl = b->bl_min, xh = b->bl_max, f, df, dx;
   double t[PLLHIP_EVAL_MAX_TRIALS], tf[PLLHIP_EVAL_MAX_TRIALS], tdf[PLLHIP_EVAL_MAX_TRIALS];
@@ -463,6 +614,64 @@ static int newton(const blo_t * b, const pll_unode_t * e, double * x)
   }
 }
 
+/* UNLINKED: one function per partition, each with its own bracket and convergence flag,
+   all evaluated by one scan per iteration (pllmod_opt_minimize_newton_multi,
+   src/optimize/opt_algorithms.c:133-261).  ev->nr_x holds the iterates. */
+static int newton_unlinked(const blo_t * b, const pll_unode_t * e)
+{
+  pllhip_eval_t * ev = b->ev;
+  const unsigned int n = ev->nparts;
+  const double dxmax = b->bl_max / b->max_newton;
+  double * x = ev->nr_x, * xl = ev->nr_xl, * xh = ev->nr_xh, * f = ev->nr_f, * df = ev->nr_df;
+  int * converged = ev->nr_converged;
+  unsigned int i, iter = 0;
+  int all_converged = 0;
+  for (i = 0; i < n; ++i)
+  {
+    x[i] = PLL_MAX(PLL_MIN(x[i], b->bl_max), b->bl_min);
+    xl[i] = b->bl_min;
+    xh[i] = b->bl_max;
+    converged[i] = 0;
+  }
+  while (!all_converged)
+  {
+    if (iter++ > b->max_newton)
+    {
+      pllhip_eval_error(PLLHIP_EVAL_ERROR_NEWTON_LIMIT, "Exceeded maximum number of iterations");
+      return PLL_FAILURE;
+    }
+    if (!derivatives_unlinked(ev, e, x, f, df)) return PLL_FAILURE;
+    ev->n_newton++;
+    all_converged = 1;
+    for (i = 0; i < n; ++i)
+    {
+      double dx;
+      if (converged[i]) continue;
+      if (!isfinite(f[i]) || !isfinite(df[i]))
+      {
+        pllhip_eval_error(PLLHIP_EVAL_ERROR_NEWTON_DERIV, "Wrong likelihood derivatives");
+        return PLL_FAILURE;
+      }
+      if (df[i] > 0.0)
+      {
+        if (fabs(f[i]) < b->tolerance) { converged[i] = 1; continue; }
+        if (f[i] < 0.0) xl[i] = x[i]; else xh[i] = x[i];
+        dx = -f[i] / df[i];
+      }
+      else
+        dx = -f[i] / fabs(df[i]);
+      dx = PLL_MAX(PLL_MIN(dx, dxmax), -dxmax);
+      if (x[i] + dx < xl[i]) dx = xl[i] - x[i];
+      if (x[i] + dx > xh[i]) dx = xh[i] - x[i];
+      if (fabs(dx) < b->tolerance) { converged[i] = 1; continue; }
+      x[i] += dx;
+      x[i] = PLL_MAX(PLL_MIN(x[i], b->bl_max), b->bl_min);
+      all_converged = 0;
+    }
+  }
+  return PLL_SUCCESS;
+}
+
 /* recompute the CLV at `parent` from the far ends of c1 and c2
    (update_partials_and_scalers, src/optimize/pll_optimize.c:748-775) */
 static int reorient(pllhip_eval_t * ev, const pll_unode_t * parent, const pll_unode_t * c1,
@@ -484,13 +693,29 @@ static int reorient(pllhip_eval_t * ev, const pll_unode_t * parent, const pll_un
   return pll_errno ? PLL_FAILURE : PLL_SUCCESS;
 }
 
+/* this branch's P-matrix in every local partition, at the lengths now in force */
+static int refresh_pmatrix(pllhip_eval_t * ev, const pll_unode_t * edge)
+{
+  unsigned int p;
+  for (p = 0; p < ev->nparts; ++p)
+  {
+    double t;
+    if (!ev->parts[p]) continue;
+    t = effective_length(ev, p, edge->pmatrix_index, edge->length);
+    if (!pll_update_prob_matrices(ev->parts[p], ev->params[p], &edge->pmatrix_index, &t, 1))
+      return PLL_FAILURE;
+  }
+  ev->n_pmat++;
+  return PLL_SUCCESS;
+}
+
 static int optimise_around(const blo_t * b, pll_unode_t * p_edge, int radius)
 {
   pllhip_eval_t * ev = b->ev;
   pll_unode_t * q = p_edge->next, * z = q ? q->next : NULL;
-  const double xorig = p_edge->length;
-  double x = xorig;
+  const unsigned int m = p_edge->pmatrix_index;
   unsigned int p;
+  int changed = 0;
 
   for (p = 0; p < ev->nparts; ++p)
     if (ev->parts[p] &&
@@ -499,21 +724,44 @@ static int optimise_around(const blo_t * b, pll_unode_t * p_edge, int radius)
                              ev->sumtables[p]))
       return PLL_FAILURE;
 
-  if (!newton(b, p_edge, &x))
+  if (ev->linkage == PLLHIP_EVAL_BRLEN_UNLINKED)
   {
-    if (pll_errno != PLLHIP_EVAL_ERROR_NEWTON_LIMIT) return PLL_FAILURE;
-    x = xorig;                    /* no convergence, no lnL check: keep the old length */
-    pll_errno = 0;
-  }
-  if (fabs(x - xorig) >= 1e-10)
-  {
-    p_edge->length = p_edge->back->length = x;
+    double * x = ev->nr_x, * orig = ev->nr_orig;
+    for (p = 0; p < ev->nparts; ++p) x[p] = ev->parts[p] ? ev->part_brlens[p][m] : 0.0;
+    /* every worker needs all per-partition lengths (src/optimize/pll_optimize.c:1436-1442) */
+    if (ev->nparts > 1 && ev->reduce_cb) ev->reduce_cb(ev->ctx, x, ev->nparts, 1 /* MAX */);
+    memcpy(orig, x, sizeof(double) * ev->nparts);
+    if (!newton_unlinked(b, p_edge))
+    {
+      if (pll_errno != PLLHIP_EVAL_ERROR_NEWTON_LIMIT) return PLL_FAILURE;
+      for (p = 0; p < ev->nparts; ++p)
+        if (!ev->nr_converged[p]) x[p] = orig[p];      /* no lnL check: keep the old length */
+      pll_errno = 0;
+    }
     for (p = 0; p < ev->nparts; ++p)
-      if (ev->parts[p] &&
-          !pll_update_prob_matrices(ev->parts[p], ev->params[p], &p_edge->pmatrix_index, &x, 1))
-        return PLL_FAILURE;
-    ev->n_pmat++;
+    {
+      if (fabs(x[p] - orig[p]) < 1e-10) continue;
+      ev->part_brlens[p][m] = x[p];
+      changed = 1;
+    }
   }
+  else
+  {
+    const double xorig = p_edge->length;
+    double x = xorig;
+    if (!newton(b, p_edge, &x))
+    {
+      if (pll_errno != PLLHIP_EVAL_ERROR_NEWTON_LIMIT) return PLL_FAILURE;
+      x = xorig;                    /* no convergence, no lnL check: keep the old length */
+      pll_errno = 0;
+    }
+    if (fabs(x - xorig) >= 1e-10)
+    {
+      p_edge->length = p_edge->back->length = x;
+      changed = 1;
+    }
+  }
+  if (changed && !refresh_pmatrix(ev, p_edge)) return PLL_FAILURE;
   if (radius && q && z)
   {
     if (!reorient(ev, q, p_edge, z) || !optimise_around(b, q->back, radius - 1)) return PLL_FAILURE;

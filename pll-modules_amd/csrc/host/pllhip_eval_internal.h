@@ -29,6 +29,11 @@ struct pllhip_eval
   pllhip_eval_fused_t fused;      /* fused.fetch != NULL: deferred results */
   double * slot_buf;              /* [nparts * 2 * PLLHIP_EVAL_MAX_TRIALS] */
   unsigned int spec_trials;       /* trial lengths per scan; 0 = not decided yet */
+  int linkage;                    /* PLLHIP_EVAL_BRLEN_* */
+  double * brlen_scalers;         /* [nparts], 1.0 unless SCALED */
+  double ** part_brlens;          /* [nparts][edges] by pmatrix_index, UNLINKED only (else NULL) */
+  double * nr_x, * nr_xl, * nr_xh, * nr_f, * nr_df, * nr_orig;   /* [nparts] Newton-Raphson state, UNLINKED */
+  int * nr_converged;
 };
 
 #define PLLHIP_EVAL_MAX_TRIALS 8

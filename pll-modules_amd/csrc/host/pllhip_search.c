@@ -405,6 +405,13 @@ double pllhip_eval_spr_round(pllhip_eval_t * ev, const pllhip_spr_params_t * prm
     pllhip_eval_error(PLL_ERROR_PARAM_INVALID, "Invalid SPR round parameters");
     return 0.0;
   }
+  if (ev->linkage == PLLHIP_EVAL_BRLEN_UNLINKED)
+  {
+    /* the round saves and restores ONE length per branch (the tree's); per-partition
+       lengths would need the reference's topology snapshots (src/tree/treeinfo.c:570-700) */
+    pllhip_eval_error(PLL_ERROR_NOT_IMPLEMENTED, "SPR rounds need linked or scaled branch lengths");
+    return 0.0;
+  }
   pll_errno = 0;
   memset(&s, 0, sizeof(s));
   s.ev = ev; s.prm = prm; s.cut = cut; s.st = st;

@@ -122,7 +122,9 @@ pllhip_eval_set_parallel_context pllhip_eval_set_root pllhip_eval_root pllhip_ev
 pllhip_eval_invalidate_pmatrix pllhip_eval_invalidate_clv pllhip_eval_loglh
 pllhip_eval_set_branch_length pllhip_eval_optimize_branches pllhip_eval_ops
 pllhip_eval_pmatrix_updates pllhip_eval_derivative_calls pllhip_eval_spr_round
-pllhip_eval_set_fused pllhip_eval_newton_iterations""".split()
+pllhip_eval_set_fused pllhip_eval_newton_iterations pllhip_eval_set_brlen_linkage
+pllhip_eval_set_brlen_scaler pllhip_eval_get_brlen_scaler pllhip_eval_get_partition_branch_length
+pllhip_eval_set_partition_branch_length""".split()
 
 PLLHIP_H_FUNCTIONS = """pllhip_device_count pllhip_set_device pllhip_get_device
 pllhip_device_arch pllhip_eigen_decompose pllhip_sync_to_host pllhip_sync_to_device pllhip_get_clv
@@ -219,6 +221,13 @@ class PllLib:
             L.pllhip_eval_optimize_branches.restype = C.c_double
             L.pllhip_eval_optimize_branches.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double,
                                                         C.c_int, C.c_int]
+            L.pllhip_eval_set_brlen_linkage.argtypes = [C.c_void_p, C.c_int]
+            L.pllhip_eval_set_brlen_scaler.argtypes = [C.c_void_p, C.c_uint, C.c_double]
+            L.pllhip_eval_get_brlen_scaler.restype = C.c_double
+            L.pllhip_eval_get_brlen_scaler.argtypes = [C.c_void_p, C.c_uint]
+            L.pllhip_eval_get_partition_branch_length.restype = C.c_double
+            L.pllhip_eval_get_partition_branch_length.argtypes = [C.c_void_p, C.c_uint, up]
+            L.pllhip_eval_set_partition_branch_length.argtypes = [C.c_void_p, C.c_uint, up, C.c_double]
             L.pllhip_eval_spr_round.restype = C.c_double
             L.pllhip_eval_spr_round.argtypes = [C.c_void_p, C.POINTER(SprParams), C.POINTER(SprCutoff),
                                                 C.POINTER(SprStats)]
@@ -740,6 +749,41 @@ class Evaluation:
         """deferred results (device-side reduce); product library only"""
         if not self.L.pllhip_eval_attach_comm(self.ev, comm):
             raise RuntimeError(self.lib.errmsg)
+
+    def records(self):
+        """every node record of the tree (pll_unode_t pointers)"""
+        tr = self.utree.contents
+        for i in range(tr.tip_count + tr.inner_count):
+            n = tr.nodes[i]
+            s_ = n
+            while True:
+                yield s_
+                if not s_.contents.next:
+                    break
+                s_ = s_.contents.next
+                if C.addressof(s_.contents) == C.addressof(n.contents):
+                    break
+
+    def set_linkage(self, linkage, scalers=None):
+        """0 linked, 1 scaled (per-partition scalers), 2 unlinked (per-partition lengths =
+        tree length x scalers[p] to start with)"""
+        if not self.L.pllhip_eval_set_brlen_linkage(self.ev, linkage):
+            raise RuntimeError(self.lib.errmsg)
+        for p, sc in enumerate(scalers or []):
+            if linkage == 1:
+                if not self.L.pllhip_eval_set_brlen_scaler(self.ev, p, sc):
+                    raise RuntimeError(self.lib.errmsg)
+            elif linkage == 2:
+                for rec in self.records():
+                    if not self.L.pllhip_eval_set_partition_branch_length(self.ev, p, rec, rec.contents.length * sc):
+                        raise RuntimeError(self.lib.errmsg)
+
+    def partition_tree_length(self, p):
+        tot = 0.0
+        for rec in self.records():
+            tot += self.L.pllhip_eval_get_partition_branch_length(self.ev, p, rec) * \
+                self.L.pllhip_eval_get_brlen_scaler(self.ev, p) / 2
+        return tot
 
     def newton_iterations(self):
         return self.L.pllhip_eval_newton_iterations(self.ev)

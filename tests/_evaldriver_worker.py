@@ -4,6 +4,7 @@ slots) the way a pll-modules worker runs treeinfo (src/tree/treeinfo.c:215-227, 
 
   mode "sites"  every rank holds all partitions, each with its own slice of the sites
   mode "parts"  every rank holds only some partitions; the others are NULL slots
+  prefix "scaled-" / "unlinked-": branch-length linkage (per-partition scalers / lengths)
 
 The only exchange is the reduce callback (gloo here, so it runs without a GPU or with two
 processes on one GPU).  argv: <lib: oracle|product> <mode> <outdir>
@@ -31,7 +32,7 @@ def model_of(states):
     return r, f, 0.5
 
 
-def build(lib, tree, owned, site_range, cb=None, flags=0):
+def build(lib, tree, owned, site_range, cb=None, flags=0, linkage=0):
     """Evaluation over PARTS; partition k is present if k in owned, holding sites
     site_range(k) = (lo, hi) of its alignment"""
     ev = pc.Evaluation(lib, tree.newick(), flags=flags, nparts=len(PARTS))
@@ -45,6 +46,8 @@ def build(lib, tree, owned, site_range, cb=None, flags=0):
         ev.add_partition(k, states, hi - lo, R, codes, subst, freqs, alpha, coded=True)
     if cb is not None:
         ev.set_parallel_context(cb)
+    if linkage:
+        ev.set_linkage(linkage, [0.7, 1.0, 1.9])
     return ev
 
 
@@ -53,6 +56,7 @@ def run(ev):
     out["lnl_opt"] = ev.optimize_branches(bl_min=1e-4, bl_max=10.0, eps=0.01, iters=4)
     out["lnl_after"] = ev.loglh()
     out["newick"] = ev.newick()
+    out["tree_lengths"] = [ev.partition_tree_length(p) for p in range(len(PARTS))]
     out["scans"], out["iterations"] = ev.counters()[2], ev.newton_iterations()
     return out
 
@@ -73,6 +77,8 @@ def main():
     cb = pc.REDUCE_CB(reduce_cb)
 
     tree = pc.Tree(NTIPS, 42, 43)
+    linkage = 2 if mode.startswith("unlinked") else 1 if mode.startswith("scaled") else 0
+    mode = mode.split("-")[-1]
     if mode == "sites":
         owned = set(range(len(PARTS)))
         rng = lambda k, n: (n * rank // world, n * (rank + 1) // world)
@@ -82,12 +88,12 @@ def main():
     # "sites": several trial lengths per scan everywhere (PLLHIP_EVAL_ALWAYS_SPECULATE), so the
     # {df, ddf} messages carry more than one length; "parts": the policy the libraries ask for
     flags = 4 if mode == "sites" else 0
-    with build(lib, tree, owned, rng, cb, flags) as ev:
+    with build(lib, tree, owned, rng, cb, flags, linkage) as ev:
         out = run(ev)
     out["reduce_calls"] = len(calls)
     out["payloads"] = sorted(set(n for n, _ in calls))
     if rank == 0:
-        with build(lib, tree, set(range(len(PARTS))), lambda k, n: (0, n), None, flags) as ev:
+        with build(lib, tree, set(range(len(PARTS))), lambda k, n: (0, n), None, flags, linkage) as ev:
             out["single"] = run(ev)
     with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
         json.dump(out, f)

@@ -68,6 +68,40 @@ def test_reference_treeinfo_blo_and_spr_round_run_on_this_library(driver, args):
     assert abs(v["full recomputation"] - v["after SPR round"]) < 1e-6
 
 
+@pytest.fixture(scope="module")
+def linkage_driver(oracle, tmp_path_factory):
+    if not os.path.isdir(REF):
+        pytest.skip("reference tree not present on this box")
+    exe = tmp_path_factory.mktemp("dropin") / "linkage_driver"
+    src = [os.path.join(ROOT, "tests", "dropin", "linkage_driver.c")]
+    src += [os.path.join(REF, m) for m in MODULES] + sorted(glob.glob(f"{REF}/src/optimize/lbfgsb/*.c"))
+    inc = sum((["-I", d] for d in [f"{ROOT}/include", f"{REF}/src", f"{REF}/src/optimize", f"{REF}/src/tree",
+                                   f"{REF}/src/algorithm", f"{REF}/src/util"]), [])
+    libdir = os.path.dirname(ORACLE_LIB)
+    subprocess.run(["gcc", "-std=gnu99", "-D_GNU_SOURCE", "-O2", "-w", *inc, "-o", str(exe), *src,
+                    "-L", libdir, "-lpll_oracle", "-lm", f"-Wl,-rpath,{libdir}"], check=True)
+    return str(exe)
+
+
+@pytest.mark.parametrize("mode", ["scaled", "unlinked"])
+def test_scaled_and_unlinked_branch_lengths_match_the_reference(linkage_driver, mode):
+    """per-partition branch-length scalers / per-partition branch lengths: likelihood and
+    Newton-Raphson optimisation of this repository's driver against the reference's treeinfo +
+    pllmod_algo_opt_brlen_treeinfo (src/tree/treeinfo.c:176-183, 849-852;
+    src/optimize/pll_optimize.c:1223-1287, 1395-1712) on identical data"""
+    out = subprocess.run([linkage_driver, mode], check=True, capture_output=True, text=True, timeout=600).stdout
+    v = {k.strip(): float(x) for k, x in re.findall(r"^(.*?):\s+(-?[0-9.]+)$", out, re.M)}
+    assert abs(v["driver lnL"] - v["lnL"]) < 1e-6
+    assert v["after BLO"] > v["lnL"] + 1.0
+    assert abs(v["driver after BLO"] - v["after BLO"]) < 1e-5
+    assert abs(v["driver re-eval"] - v["driver after BLO"]) < 1e-6 and abs(v["re-eval"] - v["after BLO"]) < 1e-6
+    for p in range(3):
+        assert abs(v[f"driver tree length {p}"] - v[f"tree length {p}"]) < 1e-5
+        assert abs(v[f"driver branch 5 of {p}"] - v[f"branch 5 of {p}"]) < 1e-6
+    if mode == "unlinked":      # the partitions really ended up with different lengths
+        assert abs(v["tree length 0"] - v["tree length 2"]) > 0.1
+
+
 def test_tip_pattern_mode_gives_the_same_numbers(driver):
     a = subprocess.run([driver], check=True, capture_output=True, text=True).stdout
     b = subprocess.run([driver, "tv"], check=True, capture_output=True, text=True).stdout

@@ -295,3 +295,34 @@ def test_multi_length_derivatives_on_oracle(oracle):
         for k, x in enumerate(ts):
             assert (df[k], ddf[k]) == inst.derivatives(a[2], a[3], x, st)
         inst.free_sumtable(st)
+
+
+def run_linkage(lib, linkage, attach=False):
+    with build(lib, ntips=10) as ev:
+        if attach:
+            ev.attach_comm(None)
+        ev.set_linkage(linkage, [0.6, 1.8])
+        lnl = ev.loglh()
+        opt = ev.optimize_branches(1e-4, 10.0, 0.01, 6, -1)
+        return lnl, opt, ev.loglh(), ev.partition_tree_length(0), ev.partition_tree_length(1)
+
+
+@pytest.mark.parametrize("linkage", [1, 2])
+def test_scaled_and_unlinked_lengths_on_oracle(oracle, linkage):
+    """per-partition scalers / per-partition lengths (tests/test_dropin_modules.py pins both modes
+    against the reference's treeinfo): optimisation improves, re-evaluation agrees, and the two
+    partitions end up with different effective tree lengths"""
+    lnl, opt, again, t0, t1 = run_linkage(oracle, linkage)
+    assert opt > lnl + 1.0 and abs(again - opt) < 1e-6 * abs(opt)
+    assert abs(t0 - t1) > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("linkage", [1, 2])
+def test_scaled_and_unlinked_lengths_on_gpu_match_oracle(product, oracle, linkage):
+    g = run_linkage(product, linkage)
+    c = run_linkage(oracle, linkage)
+    f = run_linkage(product, linkage, attach=True)      # deferred results: same path, one wait per round
+    for x, y, z in zip(g, c, f):
+        assert abs(x - y) < 1e-7 * max(1.0, abs(y))
+        assert abs(z - x) < 1e-9 * max(1.0, abs(x))

@@ -52,7 +52,8 @@ def check_driver_ranks(ranks):
     single = r0["single"]
     for r in ranks[1:]:
         # all-reduce semantics: every worker holds the same numbers and makes the same decisions
-        for k in ("lnl", "lnl_opt", "lnl_after", "newick", "scans", "iterations", "reduce_calls", "payloads"):
+        for k in ("lnl", "lnl_opt", "lnl_after", "newick", "scans", "iterations", "reduce_calls", "payloads",
+                  "tree_lengths"):
             assert r[k] == r0[k], k
     assert abs(r0["lnl"] - single["lnl"]) < 1e-9 * abs(single["lnl"])
     # the optimiser follows the same path: sums over the workers differ from the single
@@ -61,12 +62,15 @@ def check_driver_ranks(ranks):
     assert abs(r0["lnl_after"] - single["lnl_after"]) < 1e-7 * abs(single["lnl_after"])
     assert r0["iterations"] == single["iterations"]
     assert r0["reduce_calls"] > 0
+    for a, b in zip(r0["tree_lengths"], single["tree_lengths"]):
+        assert abs(a - b) < 1e-6
     # one message per reduce: P = 3 lnL values, {df, ddf} of every trial length of a scan, or the
     # single MIN that agrees on the number of trial lengths
+    # (unlinked: P lengths through the MAX reduce, 2 P derivatives)
     assert all(n in (1, 3) or n % 2 == 0 for n in r0["payloads"])
 
 
-@pytest.mark.parametrize("mode", ["sites", "parts"])
+@pytest.mark.parametrize("mode", ["sites", "parts", "scaled-sites", "unlinked-parts", "unlinked-sites"])
 def test_c_driver_across_two_processes(oracle, tmp_path, mode):
     """the C driver itself (pllhip_eval_set_parallel_context; in "parts" mode with NULL
     partition slots) run by two gloo processes reproduces the single-process evaluation and
