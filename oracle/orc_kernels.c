@@ -22,6 +22,11 @@
  *   - p-inv: P-matrices use rate/(1-pinv); site likelihood is
  *     (1-pinv)*L + pinv*pi[invariant[n]].
  *   - t == 0 gives the identity matrix.
+ *   - PLL_ATTRIB_RATE_SCALERS: scale buffers hold one count per (site, rate),
+ *     scaler[n*R + r]; the all-small test and the 2^256 step act on the S entries of one
+ *     rate; a site's terms are brought to the smallest count among its rates
+ *     before they are added: a rate that is d counts above it is multiplied by 2^(-256
+ *     min(d, 4)) (libpll-2's PLL_SCALE_RATE_MAXDIFF), and the site carries that smallest count.
  */
 #include "orc_internal.h"
 
@@ -250,7 +255,7 @@ void pll_update_partials(pll_partition_t * p, const pll_operation_t * ops,
       return;
     }
 
-    if (orc_fast() && (S == 20 || S == 4 || S == 61))
+    if (orc_fast() && (S == 20 || S == 4 || S == 61) && !(p->attributes & PLL_ATTRIB_RATE_SCALERS))
     {
       partials_fast(p, parent, ps, s1, s2, P1, P2, tip1, tip2, code1, code2, c1, c2, lut1, lut2);
       free(lut1);
@@ -294,7 +299,22 @@ void pll_update_partials(pll_partition_t * p, const pll_operation_t * ops,
         }
         for (i = S; i < Sp; ++i) out[r * Sp + i] = 0.0;
       }
-      if (ps)
+      if (ps && (p->attributes & PLL_ATTRIB_RATE_SCALERS))
+      {
+        for (r = 0; r < R; ++r)
+        {
+          unsigned int cnt = (s1 ? s1[(size_t)n * R + r] : 0) + (s2 ? s2[(size_t)n * R + r] : 0);
+          int small = 1;
+          for (i = 0; i < S; ++i) if (!(out[r * Sp + i] < PLL_SCALE_THRESHOLD)) small = 0;
+          if (small)
+          {
+            for (i = 0; i < S; ++i) out[r * Sp + i] *= PLL_SCALE_FACTOR;
+            cnt += 1;
+          }
+          ps[(size_t)n * R + r] = cnt;
+        }
+      }
+      else if (ps)
       {
         unsigned int cnt = (s1 ? s1[n] : 0) + (s2 ? s2[n] : 0);
         if (all_small)
@@ -309,6 +329,28 @@ void pll_update_partials(pll_partition_t * p, const pll_operation_t * ops,
     free(lut1);
     free(lut2);
   }
+}
+
+#define ORC_SCALE_RATE_MAXDIFF 4
+
+/* per-rate scalers: counts of the R rates of site n (both ends of the edge), their
+   minimum, and the factor that brings rate r down to it */
+static unsigned int rate_counts(const pll_partition_t * p, const unsigned int * s1, const unsigned int * s2,
+                                unsigned int n, double * factor)
+{
+  unsigned int R = p->rate_cats, r, mn = ~0u, cnt[64];
+  for (r = 0; r < R; ++r)
+  {
+    cnt[r] = (s1 ? s1[(size_t)n * R + r] : 0) + (s2 ? s2[(size_t)n * R + r] : 0);
+    if (cnt[r] < mn) mn = cnt[r];
+  }
+  for (r = 0; r < R; ++r)
+  {
+    unsigned int d = cnt[r] - mn;
+    if (d > ORC_SCALE_RATE_MAXDIFF) d = ORC_SCALE_RATE_MAXDIFF;
+    factor[r] = d ? ldexp(1.0, -256 * (int)d) : 1.0;
+  }
+  return mn;
 }
 
 /* combine the scaled site likelihood `x` (true value x * 2^(-256 cnt)), the
@@ -336,11 +378,13 @@ double pll_compute_edge_loglikelihood(pll_partition_t * p,
   const unsigned int * s1 = (psc == PLL_SCALE_BUFFER_NONE) ? NULL : p->scale_buffer[psc];
   const unsigned int * s2 = (csc == PLL_SCALE_BUFFER_NONE) ? NULL : p->scale_buffer[csc];
   const double * P = p->pmatrix[matrix_index];
+  const int rate_scalers = (p->attributes & PLL_ATTRIB_RATE_SCALERS) != 0;
   double total = 0.0;
 
   for (n = 0; n < p->sites; ++n)
   {
-    double site = 0.0, inv_term = 0.0;
+    double site = 0.0, inv_term = 0.0, factor[64];
+    unsigned int min_cnt = rate_scalers ? rate_counts(p, s1, s2, n, factor) : 0;
     for (r = 0; r < R; ++r)
     {
       const double * pi = p->frequencies[freqs_indices[r]];
@@ -353,6 +397,7 @@ double pll_compute_edge_loglikelihood(pll_partition_t * p,
           a += P[((size_t)r * S + i) * Sp + j] * orc_clv_at(p, cc, n, r, j);
         lr += pi[i] * orc_clv_at(p, pc, n, r, i) * a;
       }
+      if (rate_scalers) lr *= factor[r];
       if (pinv > 0.0)
       {
         site += p->rate_weights[r] * (1.0 - pinv) * lr;
@@ -362,7 +407,7 @@ double pll_compute_edge_loglikelihood(pll_partition_t * p,
       else
         site += p->rate_weights[r] * lr;
     }
-    unsigned int cnt = (s1 ? s1[n] : 0) + (s2 ? s2[n] : 0);
+    unsigned int cnt = rate_scalers ? min_cnt : (s1 ? s1[n] : 0) + (s2 ? s2[n] : 0);
     double l = site_loglh(site, cnt, inv_term);
     if (persite_lnl) persite_lnl[n] = l;
     total += l * p->pattern_weights[n];
@@ -377,16 +422,19 @@ double pll_compute_root_loglikelihood(pll_partition_t * p,
 {
   unsigned int S = p->states, R = p->rate_cats, n, r, i;
   const unsigned int * s1 = (sc == PLL_SCALE_BUFFER_NONE) ? NULL : p->scale_buffer[sc];
+  const int rate_scalers = (p->attributes & PLL_ATTRIB_RATE_SCALERS) != 0;
   double total = 0.0;
   for (n = 0; n < p->sites; ++n)
   {
-    double site = 0.0, inv_term = 0.0;
+    double site = 0.0, inv_term = 0.0, factor[64];
+    unsigned int min_cnt = rate_scalers ? rate_counts(p, s1, NULL, n, factor) : 0;
     for (r = 0; r < R; ++r)
     {
       const double * pi = p->frequencies[freqs_indices[r]];
       double pinv = p->prop_invar[freqs_indices[r]];
       double lr = 0.0;
       for (i = 0; i < S; ++i) lr += pi[i] * orc_clv_at(p, clv, n, r, i);
+      if (rate_scalers) lr *= factor[r];
       if (pinv > 0.0)
       {
         site += p->rate_weights[r] * (1.0 - pinv) * lr;
@@ -396,7 +444,7 @@ double pll_compute_root_loglikelihood(pll_partition_t * p,
       else
         site += p->rate_weights[r] * lr;
     }
-    double l = site_loglh(site, s1 ? s1[n] : 0, inv_term);
+    double l = site_loglh(site, rate_scalers ? min_cnt : (s1 ? s1[n] : 0), inv_term);
     if (persite_lnl) persite_lnl[n] = l;
     total += l * p->pattern_weights[n];
   }
@@ -469,13 +517,30 @@ int pll_compute_likelihood_derivatives(pll_partition_t * p,
     }
   }
 
+  const int rate_scalers = (p->attributes & PLL_ATTRIB_RATE_SCALERS) != 0;
   double df = 0.0, ddf = 0.0;
   for (n = 0; n < p->sites; ++n)
   {
-    double A = 0.0, B = 0.0, C = 0.0, inv_term = 0.0;
+    double A = 0.0, B = 0.0, C = 0.0, inv_term = 0.0, factor[64];
+    unsigned int min_cnt = rate_scalers ? rate_counts(p, s1, s2, n, factor) : 0;
     for (r = 0; r < R; ++r)
     {
       const double * st = sumtable + ((size_t)n * R + r) * Sp;
+      if (rate_scalers)
+      {
+        /* the rate's sums first, then its factor */
+        double a = 0.0, b = 0.0, c = 0.0;
+        for (k = 0; k < S; ++k)
+        {
+          a += st[k] * e0[r * S + k];
+          b += st[k] * e1[r * S + k];
+          c += st[k] * e2[r * S + k];
+        }
+        A += factor[r] * a;
+        B += factor[r] * b;
+        C += factor[r] * c;
+      }
+      else
       for (k = 0; k < S; ++k)
       {
         A += st[k] * e0[r * S + k];
@@ -490,7 +555,7 @@ int pll_compute_likelihood_derivatives(pll_partition_t * p,
     if (inv_term > 0.0)
     {
       /* the invariant term is not scaled: bring it to the site's scale */
-      unsigned int cnt = (s1 ? s1[n] : 0) + (s2 ? s2[n] : 0);
+      unsigned int cnt = rate_scalers ? min_cnt : (s1 ? s1[n] : 0) + (s2 ? s2[n] : 0);
       A += (cnt <= 3) ? ldexp(inv_term, 256 * (int)cnt) : INFINITY;
     }
     double w = p->pattern_weights[n];

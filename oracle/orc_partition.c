@@ -82,11 +82,6 @@ pll_partition_t * pll_partition_create(unsigned int tips,
                   "Ascertainment bias correction is not supported");
     return NULL;
   }
-  if (attributes & PLL_ATTRIB_RATE_SCALERS)
-  {
-    orc_set_error(PLL_ERROR_PARAM_INVALID, "Per-rate scalers are not supported");
-    return NULL;
-  }
 
   p = (pll_partition_t *)calloc(1, sizeof(*p));
   if (!p) goto nomem;
@@ -150,7 +145,8 @@ pll_partition_t * pll_partition_create(unsigned int tips,
                                             sizeof(unsigned int *));
   if (!p->scale_buffer) goto nomem;
   for (i = 0; i < scale_buffers; ++i)
-    if (!(p->scale_buffer[i] = (unsigned int *)calloc(sites ? sites : 1,
+    if (!(p->scale_buffer[i] = (unsigned int *)calloc((sites ? sites : 1) *
+                                                      ((attributes & PLL_ATTRIB_RATE_SCALERS) ? (size_t)rate_cats : 1),
                                                       sizeof(unsigned int))))
       goto nomem;
 

@@ -98,6 +98,8 @@ struct Engine
   unsigned S = 0, Sp = 0, R = 0, N = 0;
   unsigned tips = 0, nodes = 0, nscalers = 0, nmat = 0, nrm = 0;
   bool coded_tips = false;
+  bool rate_scalers = false;          // PLL_ATTRIB_RATE_SCALERS: one count per (site, rate), scaler[n*R + r]
+  size_t sc_len = 0;                  // entries per scale buffer on the device
   KernelFamily family = KernelFamily::Generic;
   unsigned cu_count = 256;
   // S20 family: CLVs/sumtables live in 32-site blocks [block][rate][state][32]

@@ -278,6 +278,30 @@ __device__ inline SiteSide load_site_side(const unsigned * ps, const unsigned * 
   return sd;
 }
 
+// PLL_ATTRIB_RATE_SCALERS: scaler[n*R + r].  A site's terms are brought to the smallest count
+// among its rates; a rate d counts above it is multiplied by 2^(-256 min(d, 4)) (libpll-2's
+// PLL_SCALE_RATE_MAXDIFF; same rule as the oracle, oracle/orc_kernels.c rate_counts)
+constexpr unsigned SCALE_RATE_MAXDIFF = 4;
+
+__device__ inline unsigned rate_min_count(const unsigned * ps, const unsigned * cs, unsigned long long n, unsigned R)
+{
+  unsigned mn = ~0u;
+  for (unsigned r = 0; r < R; ++r)
+  {
+    const unsigned c = (ps ? ps[n * R + r] : 0u) + (cs ? cs[n * R + r] : 0u);
+    mn = c < mn ? c : mn;
+  }
+  return mn;
+}
+
+__device__ inline double rate_factor(const unsigned * ps, const unsigned * cs, unsigned long long n, unsigned R,
+                                     unsigned r, unsigned min_cnt)
+{
+  unsigned d = (ps ? ps[n * R + r] : 0u) + (cs ? cs[n * R + r] : 0u) - min_cnt;
+  d = d > SCALE_RATE_MAXDIFF ? SCALE_RATE_MAXDIFF : d;
+  return d ? ldexp(1.0, -256 * (int)d) : 1.0;
+}
+
 // log of the site likelihood.  x is the likelihood carrying `cnt` scaling
 // steps (true value x * 2^(-256 cnt)); inv is the unscaled invariant-site
 // term.  Same case split as the oracle (oracle/orc_kernels.c site_loglh).

@@ -160,9 +160,11 @@ constexpr unsigned GEN_MAX_ELEMS = 4;
 
 __global__ __launch_bounds__(256) void k_partials_generic(OpBatch batch, unsigned N, unsigned R,
                                                           unsigned S, unsigned Sp,
-                                                          unsigned lut_codes, unsigned spb)
+                                                          unsigned lut_codes, unsigned spb, unsigned rate_scalers)
 {
-  __shared__ int big[256];                 // big[s] != 0: site s has an entry >= threshold
+  // big[s] != 0: site s has an entry >= threshold; per-rate scalers: big[s * R + r] for (site, rate)
+  __shared__ int big[256];
+  const unsigned G = rate_scalers ? R : 1u;      // scaling groups per site
   const OpDesc & op = batch.op[blockIdx.y];
   const unsigned E = R * Sp;               // elements per site
   const unsigned per_step = spb * E;
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void k_partials_generic(OpBatch batch, unsigne
   for (unsigned long long n0 = (unsigned long long)blockIdx.x * spb; n0 < N;
        n0 += (unsigned long long)gridDim.x * spb)
   {
-    if (threadIdx.x < spb) big[threadIdx.x] = 0;
+    if (threadIdx.x < spb * G) big[threadIdx.x] = 0;
     __syncthreads();
     double val[GEN_MAX_ELEMS];
 #pragma unroll
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void k_partials_generic(OpBatch batch, unsigne
         for (unsigned j = 0; j < S; ++j) b += row[j] * c[j];
       }
       val[q] = a * b;
-      if (!(val[q] < SCALE_THRESHOLD)) big[s] = 1;   // benign race: all writers store 1
+      if (!(val[q] < SCALE_THRESHOLD)) big[rate_scalers ? s * R + r : s] = 1;   // benign race: all writers store 1
     }
     __syncthreads();
 #pragma unroll
@@ -213,12 +215,14 @@ __global__ __launch_bounds__(256) void k_partials_generic(OpBatch batch, unsigne
       const unsigned s = e / E, rem = e % E;
       const unsigned long long n = n0 + s;
       if (n >= N) continue;
-      const bool rescale = op.parent_scaler && !big[s];
+      const unsigned r = rem / Sp;
+      const bool rescale = op.parent_scaler && !big[rate_scalers ? s * R + r : s];
       op.parent[n * E + rem] = rescale ? val[q] * SCALE_FACTOR : val[q];
-      if (rem == 0 && op.parent_scaler)
+      if (op.parent_scaler && (rate_scalers ? rem % Sp == 0 : rem == 0))
       {
-        unsigned cnt = (op.scaler1 ? op.scaler1[n] : 0u) + (op.scaler2 ? op.scaler2[n] : 0u);
-        op.parent_scaler[n] = cnt + (rescale ? 1u : 0u);
+        const unsigned long long sx = rate_scalers ? n * R + r : n;
+        unsigned cnt = (op.scaler1 ? op.scaler1[sx] : 0u) + (op.scaler2 ? op.scaler2[sx] : 0u);
+        op.parent_scaler[sx] = cnt + (rescale ? 1u : 0u);
       }
     }
     __syncthreads();
@@ -249,7 +253,8 @@ __global__ __launch_bounds__(256) void k_edge_lnl_generic(ModelView mv, ParamIdx
                                                           const int * invariant,
                                                           const unsigned long long * tipmap,
                                                           unsigned N, unsigned R,
-                                                          double * persite, ReduceOut block_out)
+                                                          double * persite, ReduceOut block_out,
+                                                          unsigned rate_scalers)
 {
   __shared__ double scratch[4];
   const unsigned S = mv.S, Sp = mv.Sp;
@@ -258,6 +263,7 @@ __global__ __launch_bounds__(256) void k_edge_lnl_generic(ModelView mv, ParamIdx
        n += (unsigned long long)gridDim.x * blockDim.x)
   {
     double site = 0.0, inv = 0.0;
+    const unsigned min_cnt = rate_scalers ? rate_min_count(ps, cs, n, R) : 0u;
     for (unsigned r = 0; r < R; ++r)
     {
       const unsigned fi = freqs_idx.v[r];
@@ -280,6 +286,7 @@ __global__ __launch_bounds__(256) void k_edge_lnl_generic(ModelView mv, ParamIdx
         }
         lr += pi[i] * node_value(parent, tipmap, n, r, i, R, Sp) * a;
       }
+      if (rate_scalers) lr *= rate_factor(ps, cs, n, R, r, min_cnt);
       const double w = mv.weights()[r];
       if (pinv > 0.0)
       {
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(256) void k_edge_lnl_generic(ModelView mv, ParamIdx
       else
         site += w * lr;
     }
-    const unsigned cnt = (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
+    const unsigned cnt = rate_scalers ? min_cnt : (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
     const double l = site_loglh(site, cnt, inv);
     if (persite) persite[n] = l;
     acc += l * (double)weights[n];
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(256) void k_derivatives_generic(ModelView mv, Param
                                                              const unsigned * weights,
                                                              const int * invariant,
                                                              unsigned N, unsigned R,
-                                                             ReduceOut block_out)
+                                                             ReduceOut block_out, unsigned rate_scalers)
 {
   extern __shared__ double lds[];          // per trial length: e0 | e1 | e2, each R*S
   __shared__ double scratch[4];
@@ -382,9 +389,10 @@ __global__ __launch_bounds__(256) void k_derivatives_generic(ModelView mv, Param
       if (pinv > 0.0 && invariant && invariant[n] >= 0)
         inv += mv.weights()[r] * pinv * mv.freqs(pi_)[invariant[n]];
     }
+    const unsigned min_cnt = rate_scalers ? rate_min_count(ps, cs, n, R) : 0u;
     if (inv > 0.0)
     {
-      const unsigned cnt = (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
+      const unsigned cnt = rate_scalers ? min_cnt : (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
       inv = (cnt <= 3) ? ldexp(inv, 256 * (int)cnt) : INFINITY;
     }
     const double w = (double)weights[n];
@@ -396,6 +404,23 @@ __global__ __launch_bounds__(256) void k_derivatives_generic(ModelView mv, Param
       for (unsigned r = 0; r < R; ++r)
       {
         const double * st = sumtable + (n * R + r) * Sp;
+        if (rate_scalers)
+        {
+          // the rate's sums first, then the factor that brings it to the site's smallest count
+          double a = 0.0, b = 0.0, c = 0.0;
+          for (unsigned k = 0; k < S; ++k)
+          {
+            const double v = st[k];
+            a += v * e0[r * S + k];
+            b += v * e1[r * S + k];
+            c += v * e2[r * S + k];
+          }
+          const double f = rate_factor(ps, cs, n, R, r, min_cnt);
+          A += f * a;
+          B += f * b;
+          C += f * c;
+          continue;
+        }
         for (unsigned k = 0; k < S; ++k)
         {
           const double v = st[k];
@@ -527,7 +552,7 @@ static int launch_partials_generic(Engine * e, const OpBatch & batch, unsigned n
   const unsigned gx = (unsigned)std::max<unsigned long long>(
       1, std::min<unsigned long long>(groups, e->cu_count * 16ULL));
   hipLaunchKernelGGL(k_partials_generic, dim3(gx, nops), dim3(256), 0, e->stream,
-                     batch, e->N, e->R, e->S, e->Sp, e->lut_codes, spb);
+                     batch, e->N, e->R, e->S, e->Sp, e->lut_codes, spb, e->rate_scalers ? 1u : 0u);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }
@@ -540,7 +565,8 @@ static int launch_edge_lnl_generic(Engine * e, const ModelView & mv, const Param
 {
   hipLaunchKernelGGL(k_edge_lnl_generic, dim3(nblocks), dim3(256), 0, e->stream,
                      mv, fidx, parent, child, pm, lut, e->lut_codes, ps, cs,
-                     e->d_weights, e->d_invariant, e->d_tipmap, e->N, e->R, persite, reduce_out(e));
+                     e->d_weights, e->d_invariant, e->d_tipmap, e->N, e->R, persite, reduce_out(e),
+                     e->rate_scalers ? 1u : 0u);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }
@@ -570,7 +596,8 @@ static int launch_derivatives_generic(Engine * e, const ModelView & mv, const Pa
 {
 #define PLLHIP_CALL(KK) \
   hipLaunchKernelGGL(k_derivatives_generic<KK>, dim3(nblocks), dim3(256), sizeof(double) * 3 * KK * e->R * e->S, \
-                     e->stream, mv, params, tl, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->R, reduce_out(e))
+                     e->stream, mv, params, tl, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->R, reduce_out(e), \
+                     e->rate_scalers ? 1u : 0u)
   PLLHIP_DISPATCH_K(count, PLLHIP_CALL);
 #undef PLLHIP_CALL
   PLLHIP_TRY(hipGetLastError());

@@ -115,11 +115,14 @@ Engine * engine_create(pll_partition_t * p)
   e->tips = p->tips; e->nodes = p->nodes; e->nscalers = p->scale_buffers;
   e->nmat = p->prob_matrices; e->nrm = p->rate_matrices;
   e->coded_tips = (p->attributes & PLL_ATTRIB_PATTERN_TIP) != 0;
+  e->rate_scalers = (p->attributes & PLL_ATTRIB_RATE_SCALERS) != 0;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) e->cu_count = prop.multiProcessorCount;
 
   const char * force = getenv("PLLHIP_FORCE_GENERIC");
   if (force && atoi(force)) e->family = KernelFamily::Generic;
+  // per-rate scalers: the generic kernels carry them (the specialised families vote per site)
+  else if (e->rate_scalers) e->family = KernelFamily::Generic;
   else if (e->S == 4 && (e->R & (e->R - 1)) == 0) e->family = KernelFamily::S4;
   else if (e->S == 20 && e->R <= 8) e->family = KernelFamily::S20;
   else if (e->S == 61) e->family = KernelFamily::S61;
@@ -127,6 +130,7 @@ Engine * engine_create(pll_partition_t * p)
   e->blocked = (e->family == KernelFamily::S20 || e->family == KernelFamily::S61);
   e->nblk = (e->N + S20_BS - 1) / S20_BS;
   e->Nalloc = e->blocked ? e->nblk * S20_BS : e->N;
+  e->sc_len = (size_t)e->Nalloc * (e->rate_scalers ? e->R : 1);
 
   bool ok = hip_ok(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate");
   const size_t clv_len = e->blocked ? (size_t)e->nblk * e->R * e->Sp * S20_BS : (size_t)e->N * e->R * e->Sp;
@@ -144,9 +148,9 @@ Engine * engine_create(pll_partition_t * p)
                   "memset CLV");
   }
   const size_t pm_len = (size_t)e->nmat * e->R * e->S * e->Sp;
-  ok = ok && dev_alloc(&e->d_scalers, (size_t)e->nscalers * e->Nalloc, "scalers");
+  ok = ok && dev_alloc(&e->d_scalers, (size_t)e->nscalers * e->sc_len, "scalers");
   ok = ok && hip_ok(hipMemsetAsync(e->d_scalers, 0,
-                                   std::max<size_t>(1, (size_t)e->nscalers * e->Nalloc) * sizeof(unsigned),
+                                   std::max<size_t>(1, (size_t)e->nscalers * e->sc_len) * sizeof(unsigned),
                                    e->stream), "memset scalers");
   ok = ok && dev_alloc(&e->d_pmat, pm_len, "P-matrices");
   if (e->family == KernelFamily::S20)
@@ -474,7 +478,7 @@ static NodeRef node_ref(const Engine * e, unsigned clv_index)
 
 static const unsigned * scaler_ptr(const Engine * e, int idx)
 {
-  return (idx == PLL_SCALE_BUFFER_NONE) ? nullptr : e->d_scalers + (size_t)idx * e->Nalloc;
+  return (idx == PLL_SCALE_BUFFER_NONE) ? nullptr : e->d_scalers + (size_t)idx * e->sc_len;
 }
 
 static unsigned reduce_grid(const Engine * e)
@@ -1400,7 +1404,8 @@ int pllhip_get_scaler(pll_partition_t * p, unsigned int idx, unsigned int * out)
   PLLHIP_TRY(hipSetDevice(e->device));
   if (idx >= e->nscalers) { set_error(PLL_ERROR_PARAM_INVALID, "scaler index out of range"); return PLL_FAILURE; }
   if (!e->N) return PLL_SUCCESS;
-  PLLHIP_TRY(hipMemcpyAsync(out, e->d_scalers + (size_t)idx * e->Nalloc, sizeof(unsigned) * e->N,
+  PLLHIP_TRY(hipMemcpyAsync(out, e->d_scalers + (size_t)idx * e->sc_len,
+                            sizeof(unsigned) * e->N * (e->rate_scalers ? e->R : 1),
                             hipMemcpyDeviceToHost, e->stream));
   PLLHIP_TRY(hipStreamSynchronize(e->stream));
   return PLL_SUCCESS;
@@ -1412,7 +1417,8 @@ int pllhip_set_scaler(pll_partition_t * p, unsigned int idx, const unsigned int 
   PLLHIP_TRY(hipSetDevice(e->device));
   if (idx >= e->nscalers) { set_error(PLL_ERROR_PARAM_INVALID, "scaler index out of range"); return PLL_FAILURE; }
   if (!e->N) return PLL_SUCCESS;
-  PLLHIP_TRY(hipMemcpyAsync(e->d_scalers + (size_t)idx * e->Nalloc, in, sizeof(unsigned) * e->N,
+  PLLHIP_TRY(hipMemcpyAsync(e->d_scalers + (size_t)idx * e->sc_len, in,
+                            sizeof(unsigned) * e->N * (e->rate_scalers ? e->R : 1),
                             hipMemcpyHostToDevice, e->stream));
   PLLHIP_TRY(hipStreamSynchronize(e->stream));
   return PLL_SUCCESS;
@@ -1455,7 +1461,8 @@ int pllhip_sync_to_host(pll_partition_t * p, unsigned int what)
     for (unsigned i = 0; i < e->nscalers; ++i)
     {
       if (!p->scale_buffer[i])
-        p->scale_buffer[i] = static_cast<unsigned *>(calloc(e->N ? e->N : 1, sizeof(unsigned)));
+        p->scale_buffer[i] = static_cast<unsigned *>(calloc((e->N ? e->N : 1) * (e->rate_scalers ? (size_t)e->R : 1),
+                                                            sizeof(unsigned)));
       if (!p->scale_buffer[i]) { set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate host scaler mirror"); return PLL_FAILURE; }
       if (!pllhip_get_scaler(p, i, p->scale_buffer[i])) return PLL_FAILURE;
     }

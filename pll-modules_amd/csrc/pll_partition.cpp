@@ -108,11 +108,6 @@ pll_partition_t * pll_partition_create(unsigned int tips,
     set_error(PLL_ERROR_AB_NOSUPPORT, "Ascertainment bias correction is not supported");
     return nullptr;
   }
-  if (attributes & PLL_ATTRIB_RATE_SCALERS)
-  {
-    set_error(PLL_ERROR_PARAM_INVALID, "Per-rate scalers are not supported");
-    return nullptr;
-  }
 
   pll_partition_t * p = static_cast<pll_partition_t *>(calloc(1, sizeof(*p)));
   if (!p)
@@ -206,7 +201,9 @@ pll_partition_t * pll_partition_create(unsigned int tips,
     for (unsigned i = first; ok && i < p->nodes; ++i)
       ok = (p->clv[i] = static_cast<double *>(calloc(len ? len : 1, sizeof(double)))) != nullptr;
     for (unsigned i = 0; ok && i < scale_buffers; ++i)
-      ok = (p->scale_buffer[i] = static_cast<unsigned int *>(calloc(sites ? sites : 1, sizeof(unsigned int)))) != nullptr;
+      ok = (p->scale_buffer[i] = static_cast<unsigned int *>(
+                calloc((sites ? sites : 1) * ((attributes & PLL_ATTRIB_RATE_SCALERS) ? (size_t)rate_cats : 1),
+                       sizeof(unsigned int)))) != nullptr;
     if (!ok)
     {
       set_error(PLL_ERROR_MEM_ALLOC, "Unable to allocate the host mirrors.");

@@ -22,6 +22,9 @@ PRODUCT_LIB = os.path.join(HERE, "libpll_hip.so")
 
 PLL_SCALE_BUFFER_NONE = -1
 PLL_ATTRIB_PATTERN_TIP = 1 << 4
+PLL_ATTRIB_AB_LEWIS, PLL_ATTRIB_AB_FELSENSTEIN, PLL_ATTRIB_AB_STAMATAKIS = 1 << 5, 2 << 5, 3 << 5
+PLL_ATTRIB_AB_FLAG = 1 << 8
+PLL_ATTRIB_RATE_SCALERS = 1 << 9
 PLL_GAMMA_RATES_MEAN = 0
 PLL_TREE_TRAVERSE_POSTORDER = 1
 PLLHIP_SYNC_PMATRIX, PLLHIP_SYNC_CLV, PLLHIP_SYNC_SCALERS, PLLHIP_SYNC_TIPS, PLLHIP_SYNC_ALL = 1, 2, 4, 8, 15
@@ -313,6 +316,7 @@ class Instance:
         if not self.p:
             raise RuntimeError(f"pll_partition_create failed: [{lib.errno}] {lib.errmsg}")
         self.Sp = self.p.contents.states_padded
+        self.rate_scalers = bool(attributes & PLL_ATTRIB_RATE_SCALERS)
         self.params = _u32(np.zeros(rate_cats))
         self._keep = []
 
@@ -456,12 +460,14 @@ class Instance:
         return out.reshape(self.N, self.R, self.Sp)[:, :, :self.S]
 
     def get_scaler(self, idx):
-        out = np.zeros(self.N, dtype=np.uint32)
+        """scaler counts: [site], or [site][rate] with PLL_ATTRIB_RATE_SCALERS"""
+        n = self.N * (self.R if self.rate_scalers else 1)
+        out = np.zeros(n, dtype=np.uint32)
         if self.lib.is_product:
             if not self.L.pllhip_get_scaler(self.p, idx, out.ctypes.data_as(c_uint_p)):
                 raise RuntimeError(self.lib.errmsg)
         else:
-            out[:] = np.ctypeslib.as_array(self.p.contents.scale_buffer[idx], shape=(self.N,))
+            out[:] = np.ctypeslib.as_array(self.p.contents.scale_buffer[idx], shape=(n,))
         return out
 
     def get_pmatrix(self, idx):
@@ -868,11 +874,11 @@ CONFIGS = {
 
 
 def build_instance(lib, states, rate_cats, ntips, nsites, coded=True, scalers=True, alpha=None,
-                   seed_shift=0, tree=None, pinv=0.0):
+                   seed_shift=0, tree=None, pinv=0.0, attributes=0):
     """partition + tree + model + tips for one synthetic configuration"""
     tree = tree or Tree(ntips, 42 + seed_shift, 43 + seed_shift)
     inst = Instance(lib, ntips, states, nsites, rate_cats,
-                    attributes=PLL_ATTRIB_PATTERN_TIP if coded else 0, scalers=scalers)
+                    attributes=(PLL_ATTRIB_PATTERN_TIP if coded else 0) | attributes, scalers=scalers)
     if states == 4:
         subst, freqs, a = DNA_GTR_RATES, DNA_FREQS, 0.841
     elif states == 20:

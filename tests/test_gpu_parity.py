@@ -601,3 +601,44 @@ def test_deferred_pmatrix_requests(product, oracle):
             assert np.allclose(a.get_pmatrix(m), b.get_pmatrix(m), rtol=1e-10, atol=1e-15)
         c = a.counters()
         assert c.pmatrix_updates == 4 and c.pmatrix_launches == 2
+
+
+@pytest.mark.parametrize("states,ntips,rate_cats", [(4, 400, 4), (20, 200, 4), (61, 100, 4), (7, 250, 3), (2, 500, 4),
+                                                    (16, 200, 2), (10, 220, 4)])
+def test_per_rate_scalers(product, oracle, states, ntips, rate_cats):
+    """PLL_ATTRIB_RATE_SCALERS (one count per (site, rate), scaler[n*R + r]) on a deep tree with
+    strong rate heterogeneity: counts bit-exact against the oracle, lnL / derivatives in
+    tolerance, and the same likelihood as with per-site scalers"""
+    kw = dict(states=states, rate_cats=rate_cats, ntips=ntips, nsites=131, coded=True, alpha=0.3,
+              attributes=pc.PLL_ATTRIB_RATE_SCALERS)
+    a = pc.build_instance(product, **kw)
+    b = pc.build_instance(oracle, **kw, tree=a.tree)
+    kw.pop("attributes")
+    c = pc.build_instance(product, **kw, tree=a.tree)
+    with a, b, c:
+        la, lb, lc = pc.full_traversal(a), pc.full_traversal(b), pc.full_traversal(c)
+        assert lnl_close(la, lb, a.N, states), (la, lb)
+        assert abs(la - lc) < 1e-9 * abs(la)
+        t = a.tree
+        seen_diff = False
+        for op in t.ops:
+            sa, sb = a.get_scaler(op[1]), b.get_scaler(op[1])
+            assert sa.shape == (a.N * a.R,) and np.array_equal(sa, sb), f"scaler {op[1]}"
+            seen_diff |= bool((sb.reshape(a.N, a.R).max(axis=1) != sb.reshape(a.N, a.R).min(axis=1)).any())
+        assert seen_diff, "the rates never differed in their counts: not a test of per-rate scaling"
+        args = (t.root_a, t.root_b, t.scaler_of(t.root_a), t.scaler_of(t.root_b))
+        sta, stb = a.alloc_sumtable(), b.alloc_sumtable()
+        a.update_sumtable(*args, sta)
+        b.update_sumtable(*args, stb)
+        for x in (0.02, 0.4):
+            assert np.allclose(a.derivatives(args[2], args[3], x, sta), b.derivatives(args[2], args[3], x, stb),
+                               rtol=1e-8 if states <= 20 else 2e-6)
+        df, ddf = a.derivatives_multi(args[2], args[3], [0.02, 0.4, 1.5], sta)
+        assert (df[1], ddf[1]) == a.derivatives(args[2], args[3], 0.4, sta)
+        a.free_sumtable(sta)
+        b.free_sumtable(stb)
+        ra, rb = a.root_lnl(t.root_a, args[2]), b.root_lnl(t.root_a, args[2])
+        assert abs(ra - rb) < 1e-10 * abs(rb) if states <= 20 else abs(ra - rb) < PER_SITE_61 * a.N
+        assert product.lib.pllhip_sync_to_host(a.p, pc.PLLHIP_SYNC_SCALERS)        # mirrors hold sites x rates counts
+        m = np.ctypeslib.as_array(a.p.contents.scale_buffer[t.scaler_of(t.root_a)], shape=(a.N * a.R,))
+        assert np.array_equal(m, a.get_scaler(t.scaler_of(t.root_a)))

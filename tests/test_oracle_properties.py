@@ -179,3 +179,35 @@ for S, n in ((20, 120), (4, 300), (61, 60)):
         assert sa == sb and any(ch in "123456789" for ch in sa)    # same scaling decisions; scaling happened
         assert abs(float(la) - float(lb)) < 1e-12 * abs(float(la))
         assert abs(float(ca) - float(cb)) < 1e-11 * abs(float(ca))
+
+
+@pytest.mark.parametrize("states,ntips", [(4, 300), (20, 150), (7, 200)])
+def test_per_rate_scalers_agree_with_per_site_scalers(oracle, states, ntips):
+    """PLL_ATTRIB_RATE_SCALERS: one count per (site, rate).  On a deep tree with strong rate
+    heterogeneity the slow and the fast categories cross 2^-256 at different depths; the
+    likelihood must not depend on which scaling scheme carried it there."""
+    kw = dict(states=states, rate_cats=4, ntips=ntips, nsites=61, coded=True, alpha=0.3)
+    with pc.build_instance(oracle, **kw) as a, \
+         pc.build_instance(oracle, **kw, attributes=pc.PLL_ATTRIB_RATE_SCALERS) as b:
+        la, lb = pc.full_traversal(a), pc.full_traversal(b)
+        assert np.isfinite(la) and abs(la - lb) < 1e-9 * abs(la)
+        t = a.tree
+        sa = a.get_scaler(t.scaler_of(t.root_a))
+        sb = b.get_scaler(t.scaler_of(t.root_a)).reshape(a.N, a.R)
+        assert sa.max() >= 1 and (sb.max(axis=1) != sb.min(axis=1)).any()   # the rates really differ
+        # a per-site count can never exceed any of the per-rate counts of its site
+        assert (sa[:, None] <= sb).all()
+        # derivatives: same function, same slope and curvature
+        sta, stb = a.alloc_sumtable(), b.alloc_sumtable()
+        args = (t.root_a, t.root_b, t.scaler_of(t.root_a), t.scaler_of(t.root_b))
+        a.update_sumtable(*args, sta)
+        b.update_sumtable(*args, stb)
+        for x in (0.01, 0.3):
+            da, db = a.derivatives(args[2], args[3], x, sta), b.derivatives(args[2], args[3], x, stb)
+            assert np.allclose(da, db, rtol=1e-8)
+        a.free_sumtable(sta)
+        b.free_sumtable(stb)
+        # root form
+        ra = a.root_lnl(t.root_a, t.scaler_of(t.root_a))
+        rb = b.root_lnl(t.root_a, t.scaler_of(t.root_a))
+        assert abs(ra - rb) < 1e-9 * abs(ra)
