@@ -77,7 +77,7 @@ int pll_update_prob_matrices(pll_partition_t * p,
           /* extended-precision accumulation: the sum cancels down to ~1e-13 at 61 states */
           long double s = 0.0L;
           for (k = 0; k < S; ++k) s += (long double)V[i * Sp + k] * ex[k] * Vi[k * Sp + j];
-          P[i * Sp + j] = (double)s;
+          P[i * Sp + j] = (s > 0.0L) ? (double)s : 0.0;      /* a probability: cancellation noise is not allowed below 0 */
         }
     }
   }

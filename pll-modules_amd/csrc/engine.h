@@ -88,7 +88,7 @@ struct ChainBatch
   unsigned short slot2[MAX_OPS_PER_LAUNCH];      // start of its chain's area, of the two children's tables
 };
 
-enum class KernelFamily { Generic, S4, S20, S61 };
+enum class KernelFamily { Generic, S4, S16, S20, S61 };
 
 struct Engine
 {
@@ -106,6 +106,7 @@ struct Engine
   // (kernels_s20.hpp); per-site arrays are padded to whole blocks
   bool blocked = false;
   unsigned nblk = 0;                  // site blocks (blocked layout only)
+  unsigned rows = 0;                  // state rows per blocked unit (>= S, a multiple of 4; 0: API layout)
   size_t clv_len = 0;                 // doubles per CLV / sumtable buffer
   unsigned Nalloc = 0;                // per-site array length (N, or nblk*32)
   double * d_sum_scratch = nullptr;   // eigen-basis matrices + LUTs of the sumtable kernel

@@ -70,7 +70,10 @@ __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, 
         if (j < S)
           for (unsigned k = 0; k < S; ++k) acc += A[i * Sp + k] * B[k * Sp + j];
       }
-      res[u] = acc;
+      // a transition probability: the eigen sum leaves ~1e-15 of cancellation noise, which can
+      // come out negative where the true entry is smaller than that (three-step codon changes
+      // at a slow rate); a negative entry would pass every "all entries < 2^-256" scaling test
+      res[u] = acc > 0.0 ? acc : 0.0;
     }
     __syncthreads();
 #pragma unroll
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, 
       double acc = 0.0;
       if (j < S)
         for (unsigned k = 0; k < S; ++k) acc += V[i * Sp + k] * expk[k] * Vi[k * Sp + j];
-      Pl[e] = acc;
+      Pl[e] = acc > 0.0 ? acc : 0.0;
     }
   }
   __syncthreads();
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(256) void k_invariant(const double * const * tip_cl
                                                    const uint8_t * const * tip_codes,
                                                    const unsigned long long * tipmap,
                                                    unsigned tips, unsigned N, unsigned R,
-                                                   unsigned S, unsigned Sp, bool blocked32,
+                                                   unsigned S, unsigned Sp, unsigned brows,
                                                    int * invariant)
 {
   for (unsigned long long n = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; n < N;
@@ -471,8 +474,8 @@ __global__ __launch_bounds__(256) void k_invariant(const double * const * tip_cl
         for (unsigned j = 0; j < S; ++j)
         {
           // rate 0 of site n: API layout, or the 32-site blocked layout of kernels_s20.hpp
-          const double v = blocked32 ? tip_clv[t][(((n >> 5) * R) * Sp + j) * 32 + (n & 31)]
-                                     : tip_clv[t][n * R * Sp + j];
+          const double v = brows ? tip_clv[t][(((n >> 5) * R) * brows + j) * 32 + (n & 31)]
+                                 : tip_clv[t][n * R * Sp + j];
           if (v > 0.0) m |= (1ULL << j);
         }
       }
@@ -487,19 +490,19 @@ __global__ __launch_bounds__(256) void k_invariant(const double * const * tip_cl
 // marginal ancestral state probabilities at a node (src/tree/treeinfo.c:1698):
 //   anc[n][i] ~ sum_r w_r pi_i node[n,r,i] * sum_j P[r,i,j] other[n,r,j], normalised
 // one thread per site; works on the API layout and on the 32-site blocked layout
-// (element (n, r, j) at ((n/32 * R + r) * Sp + j) * 32 + n%32)
+// (element (n, r, j) at ((n/32 * R + r) * brows + j) * 32 + n%32, brows = state rows per unit)
 // ---------------------------------------------------------------------------
-__device__ inline double clv_elem(const NodeRef & nd, const unsigned long long * tipmap, bool blocked32,
+__device__ inline double clv_elem(const NodeRef & nd, const unsigned long long * tipmap, unsigned brows,
                                   unsigned long long n, unsigned r, unsigned j, unsigned R, unsigned Sp)
 {
   if (nd.codes) return (double)((tipmap[nd.codes[n]] >> j) & 1ULL);
-  return blocked32 ? nd.clv[(((n >> 5) * R + r) * Sp + j) * 32 + (n & 31)]
-                   : nd.clv[(n * R + r) * Sp + j];
+  return brows ? nd.clv[(((n >> 5) * R + r) * brows + j) * 32 + (n & 31)]
+               : nd.clv[(n * R + r) * Sp + j];
 }
 
 __global__ __launch_bounds__(256) void k_node_ancestral(ModelView mv, ParamIdx fidx, NodeRef node,
                                                         NodeRef other, const double * pmat,
-                                                        const unsigned long long * tipmap, bool blocked32,
+                                                        const unsigned long long * tipmap, unsigned brows,
                                                         unsigned N, unsigned R, double * out)
 {
   const unsigned S = mv.S, Sp = mv.Sp;
@@ -515,8 +518,8 @@ __global__ __launch_bounds__(256) void k_node_ancestral(ModelView mv, ParamIdx f
       {
         const double * row = pmat + ((size_t)r * S + i) * Sp;
         double a = 0.0;
-        for (unsigned j = 0; j < S; ++j) a += row[j] * clv_elem(other, tipmap, blocked32, n, r, j, R, Sp);
-        v += mv.weights()[r] * mv.freqs(fidx.v[r])[i] * clv_elem(node, tipmap, blocked32, n, r, i, R, Sp) * a;
+        for (unsigned j = 0; j < S; ++j) a += row[j] * clv_elem(other, tipmap, brows, n, r, j, R, Sp);
+        v += mv.weights()[r] * mv.freqs(fidx.v[r])[i] * clv_elem(node, tipmap, brows, n, r, i, R, Sp) * a;
       }
       o[i] = v;
       sum += v;

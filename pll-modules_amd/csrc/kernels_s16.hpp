@@ -1,0 +1,446 @@
+// kernels_s16.hpp -- 2 .. 16 states on the fp64 matrix cores: binary, genotype (10 / 16
+// states, src/util/models_gt.c), multistate alphabets (src/util/models_mult.c), and 4 states
+// with a rate count the 4-state family does not take.  Also the family that carries
+// PLL_ATTRIB_RATE_SCALERS for these alphabets.
+//
+// Same blocked device layout and lane mapping as the 20- and 61-state families
+// (kernels_s20.hpp): clv[site_block][rate][state row][32 sites]; a (block, rate) unit is a
+// (4 KS) x 32 fp64 matrix with KS = ceil(S / 4) k-steps (rows >= S are zero); lane
+// l = 16 q + n holds sites 2n, 2n + 1 and slot k of a lane is row 4 k + q -- for the MFMA B
+// operand (k-step k) and the MFMA D result (register k) alike, so every CLV access is a fully
+// coalesced 1 KiB wave instruction and what one operation stores is what the next one loads.
+// One 16-row M tile covers all states: KS MFMAs per child, unit and site parity.  The kernels
+// are HBM-bound at every S (S = 16: 512 MACs per 128 B loaded).
+//
+// Scaling: per site (all R x S entries below 2^-256: store unscaled, rare fix-up of the units
+// just written) or per (site, rate) with PLL_ATTRIB_RATE_SCALERS (the vote covers one unit:
+// decided and applied before the unit is stored; scaler[n * R + r]).
+#pragma once
+
+#include "kernels_common.hpp"
+#include "kernels_s20.hpp"
+#include "engine.h"
+
+namespace pllhip {
+
+constexpr unsigned S16_LUT_LDS = 3072;       // doubles of LDS a tip lookup table may take per child
+
+// A fragments of a matrix set [R][S][Sp] (row-major) into LDS:
+//   frag[(r * KS + ks) * 64 + lane] = M[r][lane & 15][4 ks + (lane >> 4)]   (0 beyond S)
+template <unsigned KS>
+__device__ inline void s16_fill_frags(double * frag, const double * mats, unsigned R, unsigned S, unsigned Sp)
+{
+  for (unsigned e = threadIdx.x; e < R * KS * 64; e += blockDim.x)
+  {
+    const unsigned lane = e & 63, f = e >> 6, ks = f % KS, r = f / KS;
+    const unsigned i = lane & 15, j = 4 * ks + (lane >> 4);
+    frag[e] = (i < S && j < S) ? mats[((size_t)r * S + i) * Sp + j] : 0.0;
+  }
+}
+
+// child term in D layout: t[v] = {even site, odd site} of row 4 v + q
+template <unsigned KS>
+__device__ inline void s16_child_inner(const double * unit, const double * frag_r, unsigned lane, double2 t[KS])
+{
+  double2 b[KS];
+#pragma unroll
+  for (unsigned ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const double2 *>(unit + ks * 128 + lane * 2);
+  v4d acc_e = {0, 0, 0, 0}, acc_o = {0, 0, 0, 0};
+#pragma unroll
+  for (unsigned ks = 0; ks < KS; ++ks)
+  {
+    const double f = frag_r[ks * 64 + lane];
+    acc_e = mfma_f64(f, b[ks].x, acc_e);
+    acc_o = mfma_f64(f, b[ks].y, acc_o);
+  }
+#pragma unroll
+  for (unsigned v = 0; v < KS; ++v) t[v] = make_double2(acc_e[v], acc_o[v]);
+}
+
+// lookup table rows [code][S]
+template <unsigned KS>
+__device__ inline void s16_child_tip(const double * lut_r, unsigned code_e, unsigned code_o, unsigned q,
+                                     unsigned S, double2 t[KS])
+{
+  const double * le = lut_r + code_e * S, * lo = lut_r + code_o * S;
+#pragma unroll
+  for (unsigned v = 0; v < KS; ++v)
+  {
+    const unsigned i = 4 * v + q;
+    t[v] = (i < S) ? make_double2(le[i], lo[i]) : make_double2(0.0, 0.0);
+  }
+}
+
+template <unsigned KS>
+__device__ inline void s16_tip_d(unsigned long long mask_e, unsigned long long mask_o, unsigned q, unsigned S,
+                                 double2 t[KS])
+{
+#pragma unroll
+  for (unsigned v = 0; v < KS; ++v)
+  {
+    const unsigned i = 4 * v + q;
+    t[v] = (i < S) ? make_double2((double)((mask_e >> i) & 1ULL), (double)((mask_o >> i) & 1ULL))
+                   : make_double2(0.0, 0.0);
+  }
+}
+
+template <unsigned KS>
+__device__ inline void s16_load_d(const double * unit, unsigned lane, double2 t[KS])
+{
+#pragma unroll
+  for (unsigned v = 0; v < KS; ++v) t[v] = *reinterpret_cast<const double2 *>(unit + v * 128 + lane * 2);
+}
+
+template <unsigned KS>
+__device__ inline void s16_store_d(double * unit, unsigned lane, const double2 t[KS])
+{
+#pragma unroll
+  for (unsigned v = 0; v < KS; ++v) *reinterpret_cast<double2 *>(unit + v * 128 + lane * 2) = t[v];
+}
+
+// ---------------------------------------------------------------------------
+// partials (also the sumtable, with eigen-basis matrices in place of the P-matrices)
+// grid = (gx, ops), block = 256 (4 independent waves); dynamic LDS = 2 tables:
+// per child R * KS * 64 doubles of A fragments, or its tip lookup table when that fits
+// ---------------------------------------------------------------------------
+template <unsigned KS>
+__global__ __launch_bounds__(256) void k_partials_s16(OpBatch batch, unsigned nblk, unsigned R, unsigned S,
+                                                      unsigned Sp, unsigned lut_codes, unsigned table,
+                                                      unsigned rate_scalers)
+{
+  extern __shared__ double lds[];
+  constexpr unsigned UNIT = 4 * KS * S20_BS;
+  const OpDesc & op = batch.op[blockIdx.y];
+  double * const tab1 = lds, * const tab2 = lds + table;
+  const bool lut_lds = R * lut_codes * S <= table;
+  if (!op.codes1) s16_fill_frags<KS>(tab1, op.pmat1, R, S, Sp);
+  else if (lut_lds)
+    for (unsigned e = threadIdx.x; e < R * lut_codes * S; e += blockDim.x) tab1[e] = op.lut1[e];
+  if (!op.codes2) s16_fill_frags<KS>(tab2, op.pmat2, R, S, Sp);
+  else if (lut_lds)
+    for (unsigned e = threadIdx.x; e < R * lut_codes * S; e += blockDim.x) tab2[e] = op.lut2[e];
+  __syncthreads();
+  const double * l1 = lut_lds ? tab1 : op.lut1, * l2 = lut_lds ? tab2 : op.lut2;
+
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, n = lane & 15;
+  const unsigned wstride = gridDim.x * 4;
+  const bool scaling = op.parent_scaler != nullptr;
+
+  for (unsigned blk = blockIdx.x * 4 + wave; blk < nblk; blk += wstride)
+  {
+    const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+    unsigned c1e = 0, c1o = 0, c2e = 0, c2o = 0;
+    if (op.codes1) { c1e = op.codes1[site0]; c1o = op.codes1[site0 + 1]; }
+    if (op.codes2) { c2e = op.codes2[site0]; c2o = op.codes2[site0 + 1]; }
+    int small_e = 1, small_o = 1;
+    for (unsigned r = 0; r < R; ++r)
+    {
+      const size_t ubase = ((size_t)blk * R + r) * UNIT;
+      double2 t1[KS], t2[KS];
+      if (!op.codes1) s16_child_inner<KS>(op.clv1 + ubase, tab1 + r * KS * 64, lane, t1);
+      else s16_child_tip<KS>(l1 + (size_t)r * lut_codes * S, c1e, c1o, q, S, t1);
+      if (!op.codes2) s16_child_inner<KS>(op.clv2 + ubase, tab2 + r * KS * 64, lane, t2);
+      else s16_child_tip<KS>(l2 + (size_t)r * lut_codes * S, c2e, c2o, q, S, t2);
+      int re = 1, ro = 1;
+#pragma unroll
+      for (unsigned v = 0; v < KS; ++v)
+      {
+        t1[v].x *= t2[v].x;
+        t1[v].y *= t2[v].y;
+        re &= (t1[v].x < SCALE_THRESHOLD);     // rows >= S are zero: they never veto
+        ro &= (t1[v].y < SCALE_THRESHOLD);
+      }
+      if (scaling && rate_scalers)
+      {
+        // the vote covers this unit only: decide, scale, store, count
+        re = s20_and_q(re);
+        ro = s20_and_q(ro);
+        const double fe = re ? SCALE_FACTOR : 1.0, fo = ro ? SCALE_FACTOR : 1.0;
+#pragma unroll
+        for (unsigned v = 0; v < KS; ++v) { t1[v].x *= fe; t1[v].y *= fo; }
+        if (q == 0)
+        {
+          const size_t xe = site0 * R + r, xo = (site0 + 1) * R + r;
+          unsigned ce = re ? 1u : 0u, co = ro ? 1u : 0u;
+          if (op.scaler1) { ce += op.scaler1[xe]; co += op.scaler1[xo]; }
+          if (op.scaler2) { ce += op.scaler2[xe]; co += op.scaler2[xo]; }
+          op.parent_scaler[xe] = ce;
+          op.parent_scaler[xo] = co;
+        }
+      }
+      small_e &= re;
+      small_o &= ro;
+      s16_store_d<KS>(op.parent + ubase, lane, t1);
+    }
+    if (scaling && !rate_scalers)
+    {
+      small_e = s20_and_q(small_e);
+      small_o = s20_and_q(small_o);
+      if (__any(small_e | small_o))
+      {
+        // rare: bring the just-written units of the flagged sites up by 2^256
+        const double fe = small_e ? SCALE_FACTOR : 1.0, fo = small_o ? SCALE_FACTOR : 1.0;
+        for (unsigned r = 0; r < R; ++r)
+        {
+          double * unit = op.parent + ((size_t)blk * R + r) * UNIT;
+          double2 t[KS];
+          s16_load_d<KS>(unit, lane, t);
+#pragma unroll
+          for (unsigned v = 0; v < KS; ++v) { t[v].x *= fe; t[v].y *= fo; }
+          s16_store_d<KS>(unit, lane, t);
+        }
+      }
+      if (q == 0)
+      {
+        unsigned ce = small_e ? 1u : 0u, co = small_o ? 1u : 0u;
+        if (op.scaler1) { ce += op.scaler1[site0]; co += op.scaler1[site0 + 1]; }
+        if (op.scaler2) { ce += op.scaler2[site0]; co += op.scaler2[site0 + 1]; }
+        op.parent_scaler[site0] = ce;
+        op.parent_scaler[site0 + 1] = co;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// edge / root log-likelihood.  grid = nblocks, block = 256; dynamic LDS = R * KS * 64 doubles
+// ---------------------------------------------------------------------------
+template <unsigned KS>
+__global__ __launch_bounds__(256) void k_edge_lnl_s16(ModelView mv, ParamIdx fidx, NodeRef parent, NodeRef child,
+                                                      const double * pmat, const double * lut, unsigned lut_codes,
+                                                      const unsigned * ps, const unsigned * cs,
+                                                      const unsigned * weights, const int * invariant,
+                                                      const unsigned long long * tipmap,
+                                                      unsigned N, unsigned nblk, unsigned R,
+                                                      double * persite, ReduceOut block_out, unsigned rate_scalers)
+{
+  extern __shared__ double frag[];
+  __shared__ double scratch[4];
+  constexpr unsigned UNIT = 4 * KS * S20_BS;
+  const unsigned S = mv.S;
+  if (pmat && !child.codes) s16_fill_frags<KS>(frag, pmat, R, S, mv.Sp);
+  __syncthreads();
+
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, n = lane & 15;
+  const unsigned wstride = gridDim.x * 4;
+  double acc = 0.0;
+
+  for (unsigned blk = blockIdx.x * 4 + wave; blk < nblk; blk += wstride)
+  {
+    const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+    SiteSide sd = {0u, 0u, 0u, 0u};
+    if (rate_scalers)
+    {
+      // every lane needs the per-rate factors of its two sites (padding sites carry zeros)
+      sd.cnt_e = rate_min_count(ps, cs, site0, R);
+      sd.cnt_o = rate_min_count(ps, cs, site0 + 1, R);
+      if (site0 < N) sd.w_e = weights[site0];
+      if (site0 + 1 < N) sd.w_o = weights[site0 + 1];
+    }
+    else sd = load_site_side(ps, cs, weights, site0, N, q == 0);
+    unsigned cce = 0, cco = 0;
+    unsigned long long pme = 0, pmo = 0;
+    if (child.codes) { cce = child.codes[site0]; cco = child.codes[site0 + 1]; }
+    if (parent.codes) { pme = tipmap[parent.codes[site0]]; pmo = tipmap[parent.codes[site0 + 1]]; }
+    double site_e = 0.0, site_o = 0.0, inv_e = 0.0, inv_o = 0.0;
+    int inv_state_e = -1, inv_state_o = -1;
+    if (invariant)
+    {
+      inv_state_e = (site0 < N) ? invariant[site0] : -1;
+      inv_state_o = (site0 + 1 < N) ? invariant[site0 + 1] : -1;
+    }
+    for (unsigned r = 0; r < R; ++r)
+    {
+      const size_t ubase = ((size_t)blk * R + r) * UNIT;
+      const unsigned fi = fidx.v[r];
+      const double * pi = mv.freqs(fi);
+      double2 t[KS], pv[KS];
+      if (!pmat)
+      {
+#pragma unroll
+        for (unsigned v = 0; v < KS; ++v) t[v] = make_double2(1.0, 1.0);
+      }
+      else if (child.codes) s16_child_tip<KS>(lut + (size_t)r * lut_codes * S, cce, cco, q, S, t);
+      else s16_child_inner<KS>(child.clv + ubase, frag + r * KS * 64, lane, t);
+      if (parent.codes) s16_tip_d<KS>(pme, pmo, q, S, pv);
+      else s16_load_d<KS>(parent.clv + ubase, lane, pv);
+      double le = 0.0, lo = 0.0;
+#pragma unroll
+      for (unsigned v = 0; v < KS; ++v)
+      {
+        const unsigned i = 4 * v + q;
+        const double f = (i < S) ? pi[i] : 0.0;
+        le += f * pv[v].x * t[v].x;
+        lo += f * pv[v].y * t[v].y;
+      }
+      le = s20_sum_q(le);
+      lo = s20_sum_q(lo);
+      if (rate_scalers)
+      {
+        le *= rate_factor(ps, cs, site0, R, r, sd.cnt_e);
+        lo *= rate_factor(ps, cs, site0 + 1, R, r, sd.cnt_o);
+      }
+      const double pinv = mv.pinv()[fi], w = mv.weights()[r];
+      if (pinv > 0.0)
+      {
+        site_e += w * (1.0 - pinv) * le;
+        site_o += w * (1.0 - pinv) * lo;
+        if (inv_state_e >= 0) inv_e += w * pinv * pi[inv_state_e];
+        if (inv_state_o >= 0) inv_o += w * pinv * pi[inv_state_o];
+      }
+      else
+      {
+        site_e += w * le;
+        site_o += w * lo;
+      }
+    }
+    if (q == 0)
+    {
+      if (site0 < N)
+      {
+        const double l = site_loglh(site_e, sd.cnt_e, inv_e);
+        if (persite) persite[site0] = l;
+        acc += l * (double)sd.w_e;
+      }
+      if (site0 + 1 < N)
+      {
+        const double l = site_loglh(site_o, sd.cnt_o, inv_o);
+        if (persite) persite[site0 + 1] = l;
+        acc += l * (double)sd.w_o;
+      }
+    }
+  }
+  const double tot = block_sum_256(acc, scratch);
+  grid_reduce_finish1(tot, block_out, scratch);
+}
+
+// ---------------------------------------------------------------------------
+// sumtable preparation: eigen-basis matrices in the [r][row][Sp] form the partials kernel
+// consumes, plus their tip lookup tables [r][code][S]
+//   Lm[r][k][i] = pi_i V[i][k],   Rm[r][k][j] = V^-1[k][j]
+// grid = R, block = 256
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sumtable_prep_s16(ModelView mv, ParamIdx params,
+                                                           const unsigned long long * tipmap,
+                                                           unsigned lut_codes, bool want_lut,
+                                                           double * Lm, double * Rm, double * lutL, double * lutR)
+{
+  const unsigned S = mv.S, Sp = mv.Sp;
+  const unsigned r = blockIdx.x, pi_ = params.v[r];
+  const double * pi = mv.freqs(pi_), * V = mv.evecs(pi_), * Vi = mv.ievecs(pi_);
+  double * L = Lm + (size_t)r * S * Sp, * Rr = Rm + (size_t)r * S * Sp;
+  for (unsigned e = threadIdx.x; e < S * Sp; e += blockDim.x)
+  {
+    const unsigned k = e / Sp, i = e % Sp;
+    L[e] = (i < S) ? pi[i] * V[i * Sp + k] : 0.0;
+    Rr[e] = (i < S) ? Vi[k * Sp + i] : 0.0;
+  }
+  if (!want_lut) return;
+  for (unsigned e = threadIdx.x; e < lut_codes * S; e += blockDim.x)
+  {
+    const unsigned c = e / S, k = e % S;
+    const unsigned long long mask = tipmap[c];
+    double a = 0.0, b = 0.0;
+    for (unsigned i = 0; i < S; ++i)
+      if ((mask >> i) & 1ULL) { a += pi[i] * V[i * Sp + k]; b += Vi[k * Sp + i]; }
+    lutL[((size_t)r * lut_codes + c) * S + k] = a;
+    lutR[((size_t)r * lut_codes + c) * S + k] = b;
+  }
+}
+
+// --- launchers -------------------------------------------------------------
+
+#define PLLHIP_DISPATCH_KS(ks, CALL) \
+  do { switch (ks) { case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; default: CALL(4); } } while (0)
+
+static unsigned s16_ks(const Engine * e) { return (e->S + 3) / 4; }
+
+static unsigned s16_grid(const Engine * e, unsigned blocks_per_cu)
+{
+  const unsigned need = (e->nblk + 3) / 4;
+  return std::max(1u, std::min(need, e->cu_count * blocks_per_cu));
+}
+
+// LDS doubles per child table: its A fragments, or its tip lookup table when that is small enough
+static unsigned s16_table(const Engine * e)
+{
+  const unsigned frags = e->R * s16_ks(e) * 64, lut = e->R * e->lut_codes * e->S;
+  return (e->coded_tips && lut <= S16_LUT_LDS) ? std::max(frags, lut) : frags;
+}
+
+static int launch_partials_s16(Engine * e, const OpBatch & batch, unsigned nops)
+{
+  const unsigned table = s16_table(e);
+#define PLLHIP_CALL(KK) \
+  hipLaunchKernelGGL(k_partials_s16<KK>, dim3(s16_grid(e, 8), nops), dim3(256), sizeof(double) * 2 * table, e->stream, \
+                     batch, e->nblk, e->R, e->S, e->Sp, e->lut_codes, table, e->rate_scalers ? 1u : 0u)
+  PLLHIP_DISPATCH_KS(s16_ks(e), PLLHIP_CALL);
+#undef PLLHIP_CALL
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+static int launch_edge_lnl_s16(Engine * e, const ModelView & mv, const ParamIdx & fidx,
+                               const NodeRef & parent, const NodeRef & child,
+                               const double * pm, const double * lut,
+                               const unsigned * ps, const unsigned * cs,
+                               double * persite, unsigned nblocks)
+{
+#define PLLHIP_CALL(KK) \
+  hipLaunchKernelGGL(k_edge_lnl_s16<KK>, dim3(nblocks), dim3(256), sizeof(double) * e->R * KK * 64, e->stream, \
+                     mv, fidx, parent, child, pm, lut, e->lut_codes, ps, cs, e->d_weights, e->d_invariant, \
+                     e->d_tipmap, e->N, e->nblk, e->R, persite, reduce_out(e), e->rate_scalers ? 1u : 0u)
+  PLLHIP_DISPATCH_KS(s16_ks(e), PLLHIP_CALL);
+#undef PLLHIP_CALL
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+static int launch_sumtable_s16(Engine * e, const ModelView & mv, const ParamIdx & params,
+                               const NodeRef & parent, const NodeRef & child, double * d_sum)
+{
+  // scratch: Lm | Rm | lutL | lutR
+  const size_t mats = (size_t)e->R * e->S * e->Sp, luts = (size_t)e->R * std::max(1u, e->lut_codes) * e->S;
+  if (!e->d_sum_scratch)
+  {
+    hipError_t err = hipMalloc(reinterpret_cast<void **>(&e->d_sum_scratch),
+                               sizeof(double) * 2 * (mats + (size_t)e->R * PLL_ASCII_SIZE * e->S));
+    if (err != hipSuccess)
+    {
+      set_error(PLL_ERROR_MEM_ALLOC, "hipMalloc for sumtable scratch failed");
+      return PLL_FAILURE;
+    }
+  }
+  double * Lm = e->d_sum_scratch, * Rm = Lm + mats, * lutL = Rm + mats, * lutR = lutL + luts;
+  const bool want_lut = parent.codes || child.codes;
+  hipLaunchKernelGGL(k_sumtable_prep_s16, dim3(e->R), dim3(256), 0, e->stream,
+                     mv, params, e->d_tipmap, e->lut_codes, want_lut, Lm, Rm, lutL, lutR);
+  PLLHIP_TRY(hipGetLastError());
+  OpBatch batch;
+  OpDesc & d = batch.op[0];
+  d.clv1 = parent.clv; d.codes1 = parent.codes; d.pmat1 = Lm; d.lut1 = lutL;
+  d.clv2 = child.clv;  d.codes2 = child.codes;  d.pmat2 = Rm; d.lut2 = lutR;
+  d.scaler1 = d.scaler2 = nullptr;
+  d.parent = d_sum;
+  d.parent_scaler = nullptr;
+  return launch_partials_s16(e, batch, 1);
+}
+
+static int launch_derivatives_s16(Engine * e, const ModelView & mv, const ParamIdx & params,
+                                  const TrialLengths & tl, unsigned count,
+                                  const double * d_sum, const unsigned * ps, const unsigned * cs,
+                                  unsigned nblocks)
+{
+#define PLLHIP_CALL(KK) \
+  hipLaunchKernelGGL((k_derivatives_mfma<KK, 0>), dim3(nblocks), dim3(256), sizeof(double) * e->R * KK * 64, e->stream, \
+                     mv, params, tl, count, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, \
+                     reduce_out(e), e->rate_scalers ? 1u : 0u)
+  PLLHIP_DISPATCH_KS(s16_ks(e), PLLHIP_CALL);
+#undef PLLHIP_CALL
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+} // namespace pllhip

@@ -694,11 +694,12 @@ __global__ __launch_bounds__(256) void k_derivatives_mfma(ModelView mv, ParamIdx
                                                           const unsigned * ps, const unsigned * cs,
                                                           const unsigned * weights, const int * invariant,
                                                           unsigned N, unsigned nblk, unsigned R,
-                                                          ReduceOut block_out)
+                                                          ReduceOut block_out, unsigned rate_scalers)
 {
   extern __shared__ double frag[];        // [r][ks][lane]
   __shared__ double scratch[4];
   constexpr unsigned UNIT = 4 * KS * S20_BS;
+  const unsigned SR = SREAL ? SREAL : mv.S;       // SREAL = 0: the state count is a run-time value
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned q = lane >> 4, n = lane & 15;
   const unsigned wstride = gridDim.x * 4;
@@ -715,9 +716,9 @@ __global__ __launch_bounds__(256) void k_derivatives_mfma(ModelView mv, ParamIdx
   // of lambda share it, rows of unused trial slots repeat the last length
   for (unsigned x = threadIdx.x; x < R * KS * 64; x += blockDim.x) frag[x] = 0.0;
   __syncthreads();
-  for (unsigned x = threadIdx.x; x < R * SREAL * ntrial; x += blockDim.x)
+  for (unsigned x = threadIdx.x; x < R * SR * ntrial; x += blockDim.x)
   {
-    const unsigned j = x % ntrial, k = (x / ntrial) % SREAL, r = x / (ntrial * SREAL);
+    const unsigned j = x % ntrial, k = (x / ntrial) % SR, r = x / (ntrial * SR);
     const unsigned pi_ = params.v[r];
     const double pinv = mv.pinv()[pi_];
     const double lam = mv.evals(pi_)[k] * mv.rates()[r] / (1.0 - pinv);
@@ -749,7 +750,22 @@ __global__ __launch_bounds__(256) void k_derivatives_mfma(ModelView mv, ParamIdx
     const bool more = nb < nblk;                                                                      \
     if (more) load_unit(NXT, nb, nr);                                                                 \
     const size_t site0 = (size_t)blk * S20_BS + 2 * n;                                                \
-    if (r == 0) sd = load_site_side(ps, cs, weights, site0, N, true);                                 \
+    if (r == 0)                                                                                       \
+    {                                                                                                 \
+      sd = load_site_side(rate_scalers ? nullptr : ps, rate_scalers ? nullptr : cs, weights, site0, N, true); \
+      if (rate_scalers)                                                                               \
+      {                                                                                               \
+        sd.cnt_e = rate_min_count(ps, cs, site0, R);                                                  \
+        sd.cnt_o = rate_min_count(ps, cs, site0 + 1, R);                                              \
+      }                                                                                               \
+    }                                                                                                 \
+    if (rate_scalers)                                                                                 \
+    {                                                                                                 \
+      /* per-rate counts: the unit is brought to the smallest count of its site first */             \
+      const double fe = rate_factor(ps, cs, site0, R, r, sd.cnt_e);                                   \
+      const double fo = rate_factor(ps, cs, site0 + 1, R, r, sd.cnt_o);                               \
+      _Pragma("unroll") for (unsigned ks = 0; ks < KS; ++ks) { CUR[ks].x *= fe; CUR[ks].y *= fo; }    \
+    }                                                                                                 \
     const double * fr = frag + (size_t)r * KS * 64 + lane;                                            \
     _Pragma("unroll") for (unsigned ks = 0; ks < KS; ++ks)                                            \
     {                                                                                                 \
@@ -824,8 +840,9 @@ __global__ __launch_bounds__(256) void k_derivatives_mfma(ModelView mv, ParamIdx
 // (shared by the 61-state family: `rows` = states_padded = rows per unit)
 __global__ __launch_bounds__(256) void k_s20_to_blocked(const double * api, double * blocked,
                                                         unsigned N, unsigned nblk, unsigned R,
-                                                        unsigned rows)
+                                                        unsigned Sp, unsigned rows)
 {
+  // API rows have stride Sp (states_padded); a blocked unit has `rows` >= S state rows
   const unsigned unit = rows * S20_BS;
   const unsigned long long total = (unsigned long long)nblk * R * unit;
   for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -835,19 +852,19 @@ __global__ __launch_bounds__(256) void k_s20_to_blocked(const double * api, doub
     const unsigned long long br = e / unit;
     const unsigned r = br % R;
     const unsigned long long n = (br / R) * S20_BS + s;
-    blocked[e] = (n < N) ? api[(n * R + r) * rows + j] : 0.0;
+    blocked[e] = (n < N && j < Sp) ? api[(n * R + r) * Sp + j] : 0.0;
   }
 }
 
 __global__ __launch_bounds__(256) void k_s20_from_blocked(const double * blocked, double * api,
-                                                          unsigned N, unsigned R, unsigned rows)
+                                                          unsigned N, unsigned R, unsigned Sp, unsigned rows)
 {
-  const unsigned long long total = (unsigned long long)N * R * rows;
+  const unsigned long long total = (unsigned long long)N * R * Sp;
   for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (unsigned long long)gridDim.x * blockDim.x)
   {
-    const unsigned j = e % rows, r = (e / rows) % R;
-    const unsigned long long n = e / rows / R;
+    const unsigned j = e % Sp, r = (e / Sp) % R;
+    const unsigned long long n = e / Sp / R;
     api[e] = blocked[(((n / S20_BS) * R + r) * rows + j) * S20_BS + (n % S20_BS)];
   }
 }
@@ -981,7 +998,7 @@ static int launch_derivatives_s20(Engine * e, const ModelView & mv, const ParamI
                                   unsigned nblocks)
 {
   hipLaunchKernelGGL((k_derivatives_mfma<5, 20>), dim3(nblocks), dim3(256), sizeof(double) * e->R * 5 * 64, e->stream,
-                     mv, params, tl, count, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, reduce_out(e));
+                     mv, params, tl, count, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, reduce_out(e), 0u);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

@@ -907,7 +907,7 @@ static int launch_derivatives_s61(Engine * e, const ModelView & mv, const ParamI
     }
   }
   hipLaunchKernelGGL((k_derivatives_mfma<S61_KS, S61_S>), dim3(nblocks), dim3(256), lds, e->stream,
-                     mv, params, tl, count, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, reduce_out(e));
+                     mv, params, tl, count, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, reduce_out(e), 0u);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

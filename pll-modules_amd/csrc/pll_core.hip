@@ -23,6 +23,7 @@
 #include "kernels_s4.hpp"
 #include "kernels_s20.hpp"
 #include "kernels_s61.hpp"
+#include "kernels_s16.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -120,20 +121,24 @@ Engine * engine_create(pll_partition_t * p)
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) e->cu_count = prop.multiProcessorCount;
 
   const char * force = getenv("PLLHIP_FORCE_GENERIC");
+  static const int no_s16 = getenv("PLLHIP_NO_S16") ? atoi(getenv("PLLHIP_NO_S16")) : 0;
   if (force && atoi(force)) e->family = KernelFamily::Generic;
-  // per-rate scalers: the generic kernels carry them (the specialised families vote per site)
-  else if (e->rate_scalers) e->family = KernelFamily::Generic;
+  // per-rate scalers: the 2..16-state family and the generic kernels carry them (the 4-, 20- and
+  // 61-state families vote per site)
+  else if (e->rate_scalers) e->family = (e->S <= 16 && !no_s16) ? KernelFamily::S16 : KernelFamily::Generic;
   else if (e->S == 4 && (e->R & (e->R - 1)) == 0) e->family = KernelFamily::S4;
   else if (e->S == 20 && e->R <= 8) e->family = KernelFamily::S20;
   else if (e->S == 61) e->family = KernelFamily::S61;
+  else if (e->S <= 16 && !no_s16) e->family = KernelFamily::S16;
   else e->family = KernelFamily::Generic;
-  e->blocked = (e->family == KernelFamily::S20 || e->family == KernelFamily::S61);
+  e->blocked = (e->family == KernelFamily::S20 || e->family == KernelFamily::S61 || e->family == KernelFamily::S16);
+  e->rows = !e->blocked ? 0u : (e->family == KernelFamily::S16) ? 4u * ((e->S + 3u) / 4u) : e->Sp;
   e->nblk = (e->N + S20_BS - 1) / S20_BS;
   e->Nalloc = e->blocked ? e->nblk * S20_BS : e->N;
   e->sc_len = (size_t)e->Nalloc * (e->rate_scalers ? e->R : 1);
 
   bool ok = hip_ok(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate");
-  const size_t clv_len = e->blocked ? (size_t)e->nblk * e->R * e->Sp * S20_BS : (size_t)e->N * e->R * e->Sp;
+  const size_t clv_len = e->blocked ? (size_t)e->nblk * e->R * e->rows * S20_BS : (size_t)e->N * e->R * e->Sp;
   e->clv_len = clv_len;
   e->d_clv.assign(e->nodes, nullptr);
   e->d_codes.assign(e->tips, nullptr);
@@ -279,7 +284,7 @@ static int store_clv(Engine * e, double * d_dst, const double * host_clv)
   if (!dev_alloc(&tmp, len, "layout staging")) return PLL_FAILURE;
   PLLHIP_TRY(hipMemcpyAsync(tmp, host_clv, len * sizeof(double), hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(k_s20_to_blocked, dim3(e->cu_count * 8), dim3(256), 0, e->stream,
-                     tmp, d_dst, e->N, e->nblk, e->R, e->Sp);
+                     tmp, d_dst, e->N, e->nblk, e->R, e->Sp, e->rows);
   PLLHIP_TRY(hipGetLastError());
   PLLHIP_TRY(hipStreamSynchronize(e->stream));
   (void)hipFree(tmp);
@@ -300,7 +305,7 @@ static int fetch_clv(Engine * e, const double * d_src, double * host_out)
   double * tmp = nullptr;
   if (!dev_alloc(&tmp, len, "layout staging")) return PLL_FAILURE;
   hipLaunchKernelGGL(k_s20_from_blocked, dim3(e->cu_count * 8), dim3(256), 0, e->stream,
-                     d_src, tmp, e->N, e->R, e->Sp);
+                     d_src, tmp, e->N, e->R, e->Sp, e->rows);
   PLLHIP_TRY(hipGetLastError());
   PLLHIP_TRY(hipMemcpyAsync(host_out, tmp, len * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   PLLHIP_TRY(hipStreamSynchronize(e->stream));
@@ -612,6 +617,8 @@ static int launch_partials(Engine * e, const OpBatch & batch, unsigned nops)
       return launch_partials_s20(e, batch, nops);
     case KernelFamily::S61:
       return launch_partials_s61(e, batch, nops);
+    case KernelFamily::S16:
+      return launch_partials_s16(e, batch, nops);
     default:
       break;
   }
@@ -1077,6 +1084,10 @@ double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsigned cc
   else if (e->family == KernelFamily::S61)
     rc = launch_edge_lnl_s61(e, mv, fidx, parent, child, pm, lut, scaler_ptr(e, psc), scaler_ptr(e, csc),
                              persite_lnl ? e->d_persite : nullptr, nblocks);
+  else if (e->family == KernelFamily::S16)
+    rc = launch_edge_lnl_s16(e, mv, fidx, parent, child, pm, lut, scaler_ptr(e, psc),
+                             (matrix_index >= 0) ? scaler_ptr(e, csc) : nullptr,
+                             persite_lnl ? e->d_persite : nullptr, nblocks);
   else
     rc = launch_edge_lnl_generic(e, mv, fidx, parent, child, pm, lut, scaler_ptr(e, psc),
                                  (matrix_index >= 0) ? scaler_ptr(e, csc) : nullptr,
@@ -1154,6 +1165,8 @@ int derivatives_impl(pll_partition_t * p, int parent_scaler_index, int child_sca
       rc = launch_derivatives_s20(e, mv, params, tl, nb, d_sum, ps, cs, nblocks);
     else if (e->family == KernelFamily::S61)
       rc = launch_derivatives_s61(e, mv, params, tl, nb, d_sum, ps, cs, nblocks);
+    else if (e->family == KernelFamily::S16)
+      rc = launch_derivatives_s16(e, mv, params, tl, nb, d_sum, ps, cs, nblocks);
     else
       rc = launch_derivatives_generic(e, mv, params, tl, nb, d_sum, ps, cs, nblocks);
     if (!rc || !finish_launch(e, nblocks, e->blocked ? 8 : 2 * trial_instance(nb))) return PLL_FAILURE;
@@ -1220,6 +1233,8 @@ int pll_update_sumtable(pll_partition_t * p,
     rc = launch_sumtable_s20(e, mv, params, parent, child, d_sum);
   else if (e->family == KernelFamily::S61)
     rc = launch_sumtable_s61(e, mv, params, parent, child, d_sum);
+  else if (e->family == KernelFamily::S16)
+    rc = launch_sumtable_s16(e, mv, params, parent, child, d_sum);
   else
     rc = launch_sumtable_generic(e, mv, params, parent, child, d_sum);
   e->counters.sumtable_calls++;
@@ -1276,7 +1291,7 @@ int pll_update_invariant_sites(pll_partition_t * p)
   PLLHIP_TRY(hipMemcpyAsync(d_tc, h_clv.data(), sizeof(void *) * h_clv.size(), hipMemcpyHostToDevice, e->stream));
   PLLHIP_TRY(hipMemcpyAsync(d_tk, h_codes.data(), sizeof(void *) * h_codes.size(), hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(k_invariant, dim3(reduce_grid(e)), dim3(256), 0, e->stream,
-                     d_tc, d_tk, e->d_tipmap, e->tips, e->N, e->R, e->S, e->Sp, e->blocked, e->d_invariant);
+                     d_tc, d_tk, e->d_tipmap, e->tips, e->N, e->R, e->S, e->Sp, e->rows, e->d_invariant);
   PLLHIP_TRY(hipGetLastError());
   if (e->N)
     PLLHIP_TRY(hipMemcpyAsync(p->invariant, e->d_invariant, sizeof(int) * e->N, hipMemcpyDeviceToHost, e->stream));
@@ -1311,7 +1326,7 @@ int pll_compute_node_ancestral(pll_partition_t * p, unsigned int node_clv_index,
   hipLaunchKernelGGL(k_node_ancestral, dim3(gx), dim3(256), 0, e->stream,
                      model_view(e), make_params(p, freqs_indices), node_ref(e, node_clv_index),
                      node_ref(e, other_clv_index),
-                     e->d_pmat + (size_t)matrix_index * e->R * e->S * e->Sp, e->d_tipmap, e->blocked,
+                     e->d_pmat + (size_t)matrix_index * e->R * e->S * e->Sp, e->d_tipmap, e->rows,
                      e->N, e->R, d_out);
   PLLHIP_TRY(hipGetLastError());
   PLLHIP_TRY(hipMemcpyAsync(ancestral, d_out, sizeof(double) * e->N * e->S, hipMemcpyDeviceToHost, e->stream));
@@ -1572,6 +1587,7 @@ const char * pllhip_partials_kernel_name(const pll_partition_t * p)
     case KernelFamily::S4: return "s4-valu";
     case KernelFamily::S20: return "s20-mfma";
     case KernelFamily::S61: return "s61-mfma";
+    case KernelFamily::S16: return "s16-mfma";
     default: return "generic";
   }
 }

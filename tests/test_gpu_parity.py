@@ -102,7 +102,9 @@ def test_golden_fixtures_on_gpu(product, name, coded):
 
 @pytest.mark.parametrize("states,rate_cats", [(4, 4), (4, 1), (4, 2), (4, 8), (4, 16), (4, 3),
                                               (20, 4), (20, 1), (20, 2), (20, 8), (20, 12),
-                                              (5, 4), (2, 3), (7, 4), (61, 2), (61, 4), (61, 1)])
+                                              (5, 4), (2, 3), (7, 4), (61, 2), (61, 4), (61, 1),
+                                              (2, 4), (3, 4), (10, 4), (16, 4), (16, 1), (13, 5), (8, 2), (4, 5),
+                                              (17, 4), (33, 2)])
 @pytest.mark.parametrize("coded", [True, False])
 def test_full_traversal_parity(product, oracle, states, rate_cats, coded):
     ntips, nsites = (9, 257) if states > 20 else (14, 1031)
@@ -112,7 +114,7 @@ def test_full_traversal_parity(product, oracle, states, rate_cats, coded):
         _compare_full(a, b)
 
 
-@pytest.mark.parametrize("states", [4, 20, 5, 61])
+@pytest.mark.parametrize("states", [4, 20, 5, 61, 10, 2])
 @pytest.mark.parametrize("nsites", [1, 2, 63, 64, 65, 255, 256, 1000, 4097])
 def test_ragged_site_counts(product, oracle, states, nsites):
     a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=6, nsites=nsites, coded=True)
@@ -168,7 +170,8 @@ def test_empty_partition(product):
         assert a.edge_lnl(3, 0, 2, NONE, 2) == 0.0
 
 
-@pytest.mark.parametrize("states,ntips,rate_cats", [(4, 600, 4), (20, 260, 4), (61, 130, 4), (61, 130, 1)])
+@pytest.mark.parametrize("states,ntips,rate_cats", [(4, 600, 4), (20, 260, 4), (61, 130, 4), (61, 130, 1),
+                                                    (10, 350, 4), (2, 900, 3), (16, 250, 2)])
 def test_deep_tree_scaling_is_bit_exact(product, oracle, states, ntips, rate_cats):
     """random sequences on a deep tree drive CLVs below 2^-256: scaler counts must
     agree exactly and lnL must survive"""
@@ -260,7 +263,7 @@ def test_persite_and_pattern_weights(product, oracle, states):
         assert lnl_close(la, lb, a.N)
 
 
-@pytest.mark.parametrize("states", [4, 20, 5, 61])
+@pytest.mark.parametrize("states", [4, 20, 5, 61, 2, 10, 16])
 def test_root_loglikelihood(product, oracle, states):
     a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=8, nsites=129, coded=False)
     with a, b:
@@ -272,7 +275,7 @@ def test_root_loglikelihood(product, oracle, states):
 
 
 @pytest.mark.parametrize("states,coded", [(4, True), (4, False), (20, True), (5, True), (20, False),
-                                          (61, True), (61, False)])
+                                          (61, True), (61, False), (2, True), (10, True), (10, False), (16, False)])
 def test_sumtable_and_derivatives(product, oracle, states, coded):
     nsites = 515 if states <= 20 else 131
     a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=10, nsites=nsites, coded=coded)
@@ -325,7 +328,7 @@ def test_derivatives_match_finite_differences(product, states):
         a.free_sumtable(st)
 
 
-@pytest.mark.parametrize("states", [4, 20, 5])
+@pytest.mark.parametrize("states", [4, 20, 5, 2, 10])
 def test_invariant_sites(product, oracle, states):
     a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=5, nsites=4000, coded=True)
     with a, b:
@@ -348,7 +351,7 @@ def test_invariant_sites(product, oracle, states):
         a.free_sumtable(sa_); b.free_sumtable(sb_)
 
 
-@pytest.mark.parametrize("states", [4, 20, 5, 61])
+@pytest.mark.parametrize("states", [4, 20, 5, 61, 10, 2])
 def test_node_ancestral_states(product, oracle, states):
     """marginal ancestral state probabilities (src/tree/treeinfo.c:1698)"""
     a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=7, nsites=77, coded=True)
@@ -434,8 +437,14 @@ def test_run_to_run_determinism(product):
 
 
 def test_specialised_kernels_are_the_ones_running(product):
-    for states, name in ((4, b"s4-valu"), (20, b"s20-mfma"), (61, b"s61-mfma"), (5, b"generic")):
+    for states, name in ((4, b"s4-valu"), (20, b"s20-mfma"), (61, b"s61-mfma"), (5, b"s16-mfma"), (2, b"s16-mfma"),
+                         (10, b"s16-mfma"), (16, b"s16-mfma"), (17, b"generic"), (33, b"generic")):
         with pc.Instance(product, 3, states, 8, 4) as a:
+            assert product.lib.pllhip_partials_kernel_name(a.p) == name
+    with pc.Instance(product, 3, 4, 8, 3) as a:                      # 4 states, odd rate count
+        assert product.lib.pllhip_partials_kernel_name(a.p) == b"s16-mfma"
+    for states, name in ((4, b"s16-mfma"), (10, b"s16-mfma"), (20, b"generic"), (61, b"generic")):
+        with pc.Instance(product, 3, states, 8, 4, attributes=pc.PLL_ATTRIB_RATE_SCALERS) as a:
             assert product.lib.pllhip_partials_kernel_name(a.p) == name
 
 
@@ -520,7 +529,7 @@ def test_baseline_sizes_through_tiling(product, oracle, cfg, tile):
         assert abs(l_rerooted - l_full) <= 1e-9 * abs(l_full)
 
 
-@pytest.mark.parametrize("states,coded", [(20, True), (4, False), (61, True)])
+@pytest.mark.parametrize("states,coded", [(20, True), (4, False), (61, True), (10, False), (2, True)])
 def test_host_mirrors_round_trip(product, states, coded):
     """what a checkpoint loader does on the GPU library (include/pllhip.h,
     PLLHIP_ATTRIB_HOST_MIRRORS): sync_to_host on the source sets the attribute; a partition
@@ -609,8 +618,11 @@ def test_per_rate_scalers(product, oracle, states, ntips, rate_cats):
     """PLL_ATTRIB_RATE_SCALERS (one count per (site, rate), scaler[n*R + r]) on a deep tree with
     strong rate heterogeneity: counts bit-exact against the oracle, lnL / derivatives in
     tolerance, and the same likelihood as with per-site scalers"""
-    kw = dict(states=states, rate_cats=rate_cats, ntips=ntips, nsites=131, coded=True, alpha=0.3,
-              attributes=pc.PLL_ATTRIB_RATE_SCALERS)
+    # 61 states: with alpha = 0.3 the slowest category (rate 0.005) has P-matrix entries of 1e-19,
+    # which NO fp64 eigen sum resolves (tests/test_expm_fixtures.py): its CLVs are noise in both
+    # engines and their 2^-256 crossings are not comparable; alpha = 1 keeps every entry resolved
+    kw = dict(states=states, rate_cats=rate_cats, ntips=ntips, nsites=131, coded=True,
+              alpha=0.3 if states <= 20 else 1.0, attributes=pc.PLL_ATTRIB_RATE_SCALERS)
     a = pc.build_instance(product, **kw)
     b = pc.build_instance(oracle, **kw, tree=a.tree)
     kw.pop("attributes")
