@@ -32,6 +32,13 @@ void orc_jacobi_eigen(long double * a, unsigned int n, long double * w, long dou
 int orc_update_eigen(pll_partition_t * p, unsigned int params_index);
 
 /* tip value helper: CLV entry (site n, rate r, state j) of any node */
+/* sites the arrays hold: the alignment patterns plus, with ascertainment-bias correction, one
+   constant pattern per state (site sites + k: every tip shows state k) */
+static inline unsigned int orc_salloc(const pll_partition_t * p)
+{
+  return p->sites + (p->asc_bias_alloc ? (unsigned int)p->asc_additional_sites : 0u);
+}
+
 static inline double orc_clv_at(const pll_partition_t * p, unsigned int node,
                                 unsigned int n, unsigned int r, unsigned int j)
 {

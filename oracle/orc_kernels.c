@@ -142,7 +142,7 @@ static int orc_fast(void)
   } while (0)
 
 #define ORC_FAST_BODY(NV)                                                                     \
-  for (n = 0; n < (long)p->sites; ++n)                                                        \
+  for (n = 0; n < (long)orc_salloc(p); ++n)                                                   \
   {                                                                                           \
     double * out = parent + (size_t)n * R * Sp;                                               \
     int all_small = 1;                                                                        \
@@ -267,7 +267,7 @@ void pll_update_partials(pll_partition_t * p, const pll_operation_t * ops,
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) if ((size_t)p->sites * R * S * S > 4000000)
 #endif
-    for (n = 0; n < (long)p->sites; ++n)
+    for (n = 0; n < (long)orc_salloc(p); ++n)
     {
       double * out = parent + (size_t)n * R * Sp;
       int all_small = 1;
@@ -366,6 +366,40 @@ static double site_loglh(double x, unsigned int cnt, double inv_term)
   return log(x + inv_term) - (double)cnt * ORC_LN_SCALE;
 }
 
+/* invariant state of pattern n: the alignment's (pll_update_invariant_sites), or the state an
+   ascertainment-bias column consists of */
+static int inv_state(const pll_partition_t * p, unsigned int n)
+{
+  if (n >= p->sites) return (int)(n - p->sites);
+  return p->invariant ? p->invariant[n] : -1;
+}
+
+/* ascertainment-bias correction from the log-likelihoods l[k] of the S constant patterns
+   (Leache et al. 2015):
+     Lewis        - W log(1 - sum_k L_k)      W = weight sum of the alignment patterns
+     Felsenstein  + w log(sum_k L_k)          w = sum of the state weights
+     Stamatakis   + sum_k w_k log(L_k) */
+static double asc_correction(const pll_partition_t * p, const double * l)
+{
+  const unsigned int S = p->states, * w = p->pattern_weights + p->sites;
+  unsigned int k, wsum = 0;
+  double mx = l[0], sum = 0.0, corr = 0.0;
+  for (k = 0; k < S; ++k) { if (l[k] > mx) mx = l[k]; wsum += w[k]; }
+  for (k = 0; k < S; ++k) sum += exp(l[k] - mx);            /* sum_k L_k = exp(mx) * sum */
+  switch (p->attributes & PLL_ATTRIB_AB_MASK)
+  {
+    case PLL_ATTRIB_AB_LEWIS:
+      return -(double)p->pattern_weight_sum * log1p(-exp(mx) * sum);
+    case PLL_ATTRIB_AB_FELSENSTEIN:
+      return (double)wsum * (mx + log(sum));
+    case PLL_ATTRIB_AB_STAMATAKIS:
+      for (k = 0; k < S; ++k) corr += (double)w[k] * l[k];
+      return corr;
+    default:
+      return 0.0;
+  }
+}
+
 double pll_compute_edge_loglikelihood(pll_partition_t * p,
                                       unsigned int pc, int psc,
                                       unsigned int cc, int csc,
@@ -379,9 +413,9 @@ double pll_compute_edge_loglikelihood(pll_partition_t * p,
   const unsigned int * s2 = (csc == PLL_SCALE_BUFFER_NONE) ? NULL : p->scale_buffer[csc];
   const double * P = p->pmatrix[matrix_index];
   const int rate_scalers = (p->attributes & PLL_ATTRIB_RATE_SCALERS) != 0;
-  double total = 0.0;
+  double total = 0.0, asc_l[64];
 
-  for (n = 0; n < p->sites; ++n)
+  for (n = 0; n < orc_salloc(p); ++n)
   {
     double site = 0.0, inv_term = 0.0, factor[64];
     unsigned int min_cnt = rate_scalers ? rate_counts(p, s1, s2, n, factor) : 0;
@@ -401,17 +435,19 @@ double pll_compute_edge_loglikelihood(pll_partition_t * p,
       if (pinv > 0.0)
       {
         site += p->rate_weights[r] * (1.0 - pinv) * lr;
-        if (p->invariant && p->invariant[n] >= 0)
-          inv_term += p->rate_weights[r] * pinv * pi[p->invariant[n]];
+        if (inv_state(p, n) >= 0)
+          inv_term += p->rate_weights[r] * pinv * pi[inv_state(p, n)];
       }
       else
         site += p->rate_weights[r] * lr;
     }
     unsigned int cnt = rate_scalers ? min_cnt : (s1 ? s1[n] : 0) + (s2 ? s2[n] : 0);
     double l = site_loglh(site, cnt, inv_term);
+    if (n >= p->sites) { asc_l[n - p->sites] = l; continue; }     /* a constant pattern of the correction */
     if (persite_lnl) persite_lnl[n] = l;
     total += l * p->pattern_weights[n];
   }
+  if (p->asc_bias_alloc) total += asc_correction(p, asc_l);
   return total;
 }
 
@@ -423,8 +459,8 @@ double pll_compute_root_loglikelihood(pll_partition_t * p,
   unsigned int S = p->states, R = p->rate_cats, n, r, i;
   const unsigned int * s1 = (sc == PLL_SCALE_BUFFER_NONE) ? NULL : p->scale_buffer[sc];
   const int rate_scalers = (p->attributes & PLL_ATTRIB_RATE_SCALERS) != 0;
-  double total = 0.0;
-  for (n = 0; n < p->sites; ++n)
+  double total = 0.0, asc_l[64];
+  for (n = 0; n < orc_salloc(p); ++n)
   {
     double site = 0.0, inv_term = 0.0, factor[64];
     unsigned int min_cnt = rate_scalers ? rate_counts(p, s1, NULL, n, factor) : 0;
@@ -438,16 +474,18 @@ double pll_compute_root_loglikelihood(pll_partition_t * p,
       if (pinv > 0.0)
       {
         site += p->rate_weights[r] * (1.0 - pinv) * lr;
-        if (p->invariant && p->invariant[n] >= 0)
-          inv_term += p->rate_weights[r] * pinv * pi[p->invariant[n]];
+        if (inv_state(p, n) >= 0)
+          inv_term += p->rate_weights[r] * pinv * pi[inv_state(p, n)];
       }
       else
         site += p->rate_weights[r] * lr;
     }
     double l = site_loglh(site, rate_scalers ? min_cnt : (s1 ? s1[n] : 0), inv_term);
+    if (n >= p->sites) { asc_l[n - p->sites] = l; continue; }
     if (persite_lnl) persite_lnl[n] = l;
     total += l * p->pattern_weights[n];
   }
+  if (p->asc_bias_alloc) total += asc_correction(p, asc_l);
   return total;
 }
 
@@ -464,7 +502,7 @@ int pll_update_sumtable(pll_partition_t * p,
     if (!p->eigen_decomp_valid[params_indices[r]])
       if (!orc_update_eigen(p, params_indices[r])) return PLL_FAILURE;
 
-  for (n = 0; n < p->sites; ++n)
+  for (n = 0; n < orc_salloc(p); ++n)
     for (r = 0; r < R; ++r)
     {
       unsigned int pi_ = params_indices[r];
@@ -484,6 +522,51 @@ int pll_update_sumtable(pll_partition_t * p,
       for (k = S; k < Sp; ++k) out[k] = 0.0;
     }
   return PLL_SUCCESS;
+}
+
+/* first and second derivative (by the branch length) of the ascertainment-bias correction from
+   the likelihoods A, their derivatives B, C of the S constant patterns, each carrying cnt[k]
+   scaling steps:  Lewis  W [B / (1 - A)],  W [C / (1 - A) + (B / (1 - A))^2]  with A, B, C summed
+   over k in true scale;  Felsenstein  w [B / A],  w [C / A - (B / A)^2]  (sums; the common scale
+   cancels);  Stamatakis  sum_k w_k [B_k / A_k],  sum_k w_k [C_k / A_k - (B_k / A_k)^2] */
+static void asc_derivatives(const pll_partition_t * p, const double * A, const double * B, const double * C,
+                            const unsigned int * cnt, double * d1, double * d2)
+{
+  const unsigned int S = p->states, * w = p->pattern_weights + p->sites;
+  unsigned int k, mn = ~0u, wsum = 0;
+  double a = 0.0, b = 0.0, c = 0.0;
+  *d1 = *d2 = 0.0;
+  for (k = 0; k < S; ++k) { if (cnt[k] < mn) mn = cnt[k]; wsum += w[k]; }
+  for (k = 0; k < S; ++k)
+  {
+    const unsigned int d = cnt[k] - mn;
+    const double f = (d == 0) ? 1.0 : (d <= 3) ? ldexp(1.0, -256 * (int)d) : 0.0;
+    a += f * A[k]; b += f * B[k]; c += f * C[k];
+  }
+  switch (p->attributes & PLL_ATTRIB_AB_MASK)
+  {
+    case PLL_ATTRIB_AB_LEWIS:
+    {
+      const double t = (mn == 0) ? 1.0 : (mn <= 3) ? ldexp(1.0, -256 * (int)mn) : 0.0;   /* to true scale */
+      const double q = t * b / (1.0 - t * a);
+      *d1 = (double)p->pattern_weight_sum * q;
+      *d2 = (double)p->pattern_weight_sum * (t * c / (1.0 - t * a) + q * q);
+      break;
+    }
+    case PLL_ATTRIB_AB_FELSENSTEIN:
+      *d1 = (double)wsum * (b / a);
+      *d2 = (double)wsum * (c / a - (b / a) * (b / a));
+      break;
+    case PLL_ATTRIB_AB_STAMATAKIS:
+      for (k = 0; k < S; ++k)
+      {
+        *d1 += (double)w[k] * (B[k] / A[k]);
+        *d2 += (double)w[k] * (C[k] / A[k] - (B[k] / A[k]) * (B[k] / A[k]));
+      }
+      break;
+    default:
+      break;
+  }
 }
 
 int pll_compute_likelihood_derivatives(pll_partition_t * p,
@@ -518,8 +601,9 @@ int pll_compute_likelihood_derivatives(pll_partition_t * p,
   }
 
   const int rate_scalers = (p->attributes & PLL_ATTRIB_RATE_SCALERS) != 0;
-  double df = 0.0, ddf = 0.0;
-  for (n = 0; n < p->sites; ++n)
+  double df = 0.0, ddf = 0.0, ascA[64], ascB[64], ascC[64];
+  unsigned int asc_cnt[64];
+  for (n = 0; n < orc_salloc(p); ++n)
   {
     double A = 0.0, B = 0.0, C = 0.0, inv_term = 0.0, factor[64];
     unsigned int min_cnt = rate_scalers ? rate_counts(p, s1, s2, n, factor) : 0;
@@ -549,19 +633,33 @@ int pll_compute_likelihood_derivatives(pll_partition_t * p,
       }
       unsigned int pi_ = params_indices[r];
       double pinv = p->prop_invar[pi_];
-      if (pinv > 0.0 && p->invariant && p->invariant[n] >= 0)
-        inv_term += p->rate_weights[r] * pinv * p->frequencies[pi_][p->invariant[n]];
+      if (pinv > 0.0 && inv_state(p, n) >= 0)
+        inv_term += p->rate_weights[r] * pinv * p->frequencies[pi_][inv_state(p, n)];
     }
+    const unsigned int cnt = rate_scalers ? min_cnt : (s1 ? s1[n] : 0) + (s2 ? s2[n] : 0);
     if (inv_term > 0.0)
     {
       /* the invariant term is not scaled: bring it to the site's scale */
-      unsigned int cnt = rate_scalers ? min_cnt : (s1 ? s1[n] : 0) + (s2 ? s2[n] : 0);
       A += (cnt <= 3) ? ldexp(inv_term, 256 * (int)cnt) : INFINITY;
+    }
+    if (n >= p->sites)
+    {
+      const unsigned int k2 = n - p->sites;
+      ascA[k2] = A; ascB[k2] = B; ascC[k2] = C; asc_cnt[k2] = cnt;
+      continue;
     }
     double w = p->pattern_weights[n];
     double ba = B / A, ca = C / A;
     df -= w * ba;
     ddf += w * (ba * ba - ca);
+  }
+  if (p->asc_bias_alloc)
+  {
+    /* d_f, dd_f are derivatives of -lnL */
+    double d1, d2;
+    asc_derivatives(p, ascA, ascB, ascC, asc_cnt, &d1, &d2);
+    df -= d1;
+    ddf -= d2;
   }
   *d_f = df;
   *dd_f = ddf;

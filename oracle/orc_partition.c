@@ -45,7 +45,7 @@ unsigned int pll_get_sites_number(const pll_partition_t * p, unsigned int clv_in
 unsigned int pll_get_clv_size(const pll_partition_t * p, unsigned int clv_index)
 {
   (void)clv_index;
-  return p->sites * p->rate_cats * p->states_padded;
+  return orc_salloc(p) * p->rate_cats * p->states_padded;
 }
 
 static double ** alloc_rows(unsigned int rows, size_t cols)
@@ -76,12 +76,6 @@ pll_partition_t * pll_partition_create(unsigned int tips,
     orc_set_error(PLL_ERROR_PARAM_INVALID, "Invalid partition dimensions");
     return NULL;
   }
-  if (attributes & (PLL_ATTRIB_AB_FLAG | PLL_ATTRIB_AB_MASK))
-  {
-    orc_set_error(PLL_ERROR_AB_NOSUPPORT,
-                  "Ascertainment bias correction is not supported");
-    return NULL;
-  }
 
   p = (pll_partition_t *)calloc(1, sizeof(*p));
   if (!p) goto nomem;
@@ -98,8 +92,17 @@ pll_partition_t * pll_partition_create(unsigned int tips,
   p->attributes = attributes;
   p->alignment = PLL_ALIGNMENT_CPU;
   p->states_padded = states;
+  /* ascertainment-bias correction: one extra constant pattern per state behind the alignment
+     (libpll-2: asc_bias_alloc / asc_additional_sites; src/tree/treeinfo.c:333-337 and
+     src/binary/binary_io_operations.c size their buffers for it) */
+  if (attributes & (PLL_ATTRIB_AB_FLAG | PLL_ATTRIB_AB_MASK))
+  {
+    p->asc_bias_alloc = 1;
+    p->asc_additional_sites = (int)states;
+  }
+  const unsigned int salloc = sites + (p->asc_bias_alloc ? states : 0);
 
-  size_t clv_len = (size_t)sites * rate_cats * p->states_padded;
+  size_t clv_len = (size_t)salloc * rate_cats * p->states_padded;
   p->clv = (double **)calloc(p->nodes ? p->nodes : 1, sizeof(double *));
   if (!p->clv) goto nomem;
   for (i = 0; i < p->nodes; ++i)
@@ -123,7 +126,7 @@ pll_partition_t * pll_partition_create(unsigned int tips,
   p->rate_weights = (double *)calloc(rate_cats, sizeof(double));
   p->prop_invar = (double *)calloc(rate_matrices, sizeof(double));
   p->eigen_decomp_valid = (int *)calloc(rate_matrices, sizeof(int));
-  p->pattern_weights = (unsigned int *)calloc(sites ? sites : 1, sizeof(unsigned int));
+  p->pattern_weights = (unsigned int *)calloc(salloc ? salloc : 1, sizeof(unsigned int));
   if (!p->rates || !p->rate_weights || !p->prop_invar ||
       !p->eigen_decomp_valid || !p->pattern_weights) goto nomem;
   for (i = 0; i < rate_cats; ++i)
@@ -131,7 +134,7 @@ pll_partition_t * pll_partition_create(unsigned int tips,
     p->rates[i] = 1.0;
     p->rate_weights[i] = 1.0 / rate_cats;
   }
-  for (i = 0; i < sites; ++i) p->pattern_weights[i] = 1;
+  for (i = 0; i < salloc; ++i) p->pattern_weights[i] = 1;
 
   p->subst_params = alloc_rows(rate_matrices, (size_t)states * (states - 1) / 2);
   p->frequencies = alloc_rows(rate_matrices, p->states_padded);
@@ -145,7 +148,7 @@ pll_partition_t * pll_partition_create(unsigned int tips,
                                             sizeof(unsigned int *));
   if (!p->scale_buffer) goto nomem;
   for (i = 0; i < scale_buffers; ++i)
-    if (!(p->scale_buffer[i] = (unsigned int *)calloc((sites ? sites : 1) *
+    if (!(p->scale_buffer[i] = (unsigned int *)calloc((salloc ? salloc : 1) *
                                                       ((attributes & PLL_ATTRIB_RATE_SCALERS) ? (size_t)rate_cats : 1),
                                                       sizeof(unsigned int))))
       goto nomem;
@@ -157,7 +160,7 @@ pll_partition_t * pll_partition_create(unsigned int tips,
     p->tipmap = (pll_state_t *)calloc(PLL_ASCII_SIZE, sizeof(pll_state_t));
     if (!p->tipchars || !p->charmap || !p->tipmap) goto nomem;
     for (i = 0; i < tips; ++i)
-      if (!(p->tipchars[i] = (unsigned char *)calloc(sites ? sites : 1, 1)))
+      if (!(p->tipchars[i] = (unsigned char *)calloc(salloc ? salloc : 1, 1)))
         goto nomem;
     if (states == 4)
     {
@@ -258,16 +261,28 @@ void pll_set_pattern_weights(pll_partition_t * p, const unsigned int * w)
   for (i = 0; i < p->sites; ++i) p->pattern_weight_sum += w[i];
 }
 
+/* Lewis: lnL - W log(1 - sum_k L_k); Felsenstein: lnL + w log(sum_k L_k), w = sum of the state
+   weights; Stamatakis: lnL + sum_k w_k log(L_k)  (Leache et al. 2015; [libpll-2 knowledge]) */
 int pll_set_asc_bias_type(pll_partition_t * p, int t)
 {
-  (void)p; (void)t;
-  orc_set_error(PLL_ERROR_AB_NOSUPPORT, "Ascertainment bias correction is not supported");
-  return PLL_FAILURE;
+  if (!p->asc_bias_alloc)
+  {
+    orc_set_error(PLL_ERROR_AB_INVALIDMETHOD, "Partition was not created for ascertainment bias correction");
+    return PLL_FAILURE;
+  }
+  if (t != PLL_ATTRIB_AB_LEWIS && t != PLL_ATTRIB_AB_FELSENSTEIN && t != PLL_ATTRIB_AB_STAMATAKIS)
+  {
+    orc_set_error(PLL_ERROR_AB_INVALIDMETHOD, "Illegal ascertainment bias algorithm");
+    return PLL_FAILURE;
+  }
+  p->attributes = (p->attributes & ~(unsigned int)PLL_ATTRIB_AB_MASK) | (unsigned int)t;
+  return PLL_SUCCESS;
 }
 
 void pll_set_asc_state_weights(pll_partition_t * p, const unsigned int * w)
 {
-  (void)p; (void)w;
+  if (!p->asc_bias_alloc) return;
+  memcpy(p->pattern_weights + p->sites, w, sizeof(unsigned int) * p->states);
 }
 
 int pll_set_tip_states(pll_partition_t * p, unsigned int tip,
@@ -322,6 +337,40 @@ int pll_set_tip_states(pll_partition_t * p, unsigned int tip,
               (j < p->states) ? (double)((m >> j) & 1ULL) : 0.0;
     }
   }
+  /* ascertainment-bias columns: pattern sites + k shows state k at every tip */
+  for (n = p->sites; n < orc_salloc(p); ++n)
+  {
+    const pll_state_t m = 1ULL << (n - p->sites);
+    if (p->attributes & PLL_ATTRIB_PATTERN_TIP)
+    {
+      unsigned int code;
+      if (p->states == 4)
+        code = (unsigned int)m;
+      else
+      {
+        for (code = 0; code < p->maxstates; ++code)
+          if (p->tipmap[code] == m) break;
+        if (code == p->maxstates)
+        {
+          if (code >= PLL_ASCII_SIZE)
+          {
+            orc_set_error(PLL_ERROR_TIPDATA_ILLEGALSTATE, "Too many tip codes");
+            return PLL_FAILURE;
+          }
+          p->tipmap[code] = m;
+          p->maxstates++;
+        }
+      }
+      p->tipchars[tip][n] = (unsigned char)code;
+    }
+    else
+    {
+      double * v = p->clv[tip] + (size_t)n * p->rate_cats * p->states_padded;
+      for (r = 0; r < p->rate_cats; ++r)
+        for (j = 0; j < p->states_padded; ++j)
+          v[r * p->states_padded + j] = (j == n - p->sites) ? 1.0 : 0.0;
+    }
+  }
   if ((p->attributes & PLL_ATTRIB_PATTERN_TIP) && (!p->ttlookup || p->maxstates != old_codes))
     return ensure_ttlookup(p);
   return PLL_SUCCESS;
@@ -350,6 +399,13 @@ int pll_set_tip_clv(pll_partition_t * p, unsigned int tip, const double * clv,
       double * dst = p->clv[tip] + ((size_t)n * p->rate_cats + r) * p->states_padded;
       memset(dst, 0, sizeof(double) * p->states_padded);
       memcpy(dst, clv + (size_t)n * in_stride, sizeof(double) * p->states);
+    }
+  for (n = p->sites; n < orc_salloc(p); ++n)        /* ascertainment-bias columns */
+    for (r = 0; r < p->rate_cats; ++r)
+    {
+      double * dst = p->clv[tip] + ((size_t)n * p->rate_cats + r) * p->states_padded;
+      memset(dst, 0, sizeof(double) * p->states_padded);
+      dst[n - p->sites] = 1.0;
     }
   return PLL_SUCCESS;
 }

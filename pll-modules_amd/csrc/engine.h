@@ -29,7 +29,8 @@ constexpr unsigned REDUCE_BLOCKS = 4096; // upper bound of per-block partial sum
 constexpr unsigned REDUCE_QUANTITIES = 16; // sums per launch: up to 8 trial branch lengths x {df, ddf}
 constexpr unsigned MAX_TRIAL_LENGTHS = 8;
 constexpr unsigned REDUCE_COUNTER_WORDS = 8 * 1024 + 1;  // kernels_common.hpp: 8 shard tickets 4 KiB apart + top ticket
-constexpr unsigned RESULT_WORDS = 32;     // mapped result buffer: 16 values, sequence word at RESULT_SEQ_SLOT
+constexpr unsigned RESULT_WORDS = 128;    // mapped result buffer: 16 values, sequence word at RESULT_SEQ_SLOT, AB tail
+constexpr unsigned RESULT_ASC_SLOT = 32;  // log-likelihoods of the <= 64 ascertainment-bias columns
 constexpr unsigned RESULT_SEQ_SLOT = 24;
 constexpr unsigned MAX_SUMTABLES = 4;    // device sumtables kept per partition (LRU)
 
@@ -95,7 +96,10 @@ struct Engine
   int device = 0;
   hipStream_t stream = nullptr;
 
-  unsigned S = 0, Sp = 0, R = 0, N = 0;
+  unsigned S = 0, Sp = 0, R = 0, N = 0;   // N: patterns the arrays hold (alignment + ascertainment-bias columns)
+  unsigned Nreal = 0;                 // alignment patterns (= partition->sites); N - Nreal = S with AB, else 0
+  double * h_asc = nullptr;           // pinned + mapped, AB only: per trial length and state {A, B, C, count}
+  double * d_asc = nullptr;           // device view of h_asc
   unsigned tips = 0, nodes = 0, nscalers = 0, nmat = 0, nrm = 0;
   bool coded_tips = false;
   bool rate_scalers = false;          // PLL_ATTRIB_RATE_SCALERS: one count per (site, rate), scaler[n*R + r]

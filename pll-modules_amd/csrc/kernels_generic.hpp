@@ -529,6 +529,70 @@ __global__ __launch_bounds__(256) void k_node_ancestral(ModelView mv, ParamIdx f
   }
 }
 
+// ---------------------------------------------------------------------------
+// ascertainment-bias correction (PLL_ATTRIB_AB_*): the S constant patterns sit behind the
+// alignment in every per-site array; their share of the likelihood is a closed-form correction
+// the host applies to the sums over the alignment.  Two small kernels hand it what it needs.
+// ---------------------------------------------------------------------------
+// log-likelihoods of the constant patterns (the tail of the per-site output of the lnL kernel
+// that ran before on the same stream) -> mapped host memory, then the sequence word
+__global__ void k_publish_tail(const double * tail, double * dst, unsigned n, unsigned long long * flag,
+                               unsigned long long seq)
+{
+  for (unsigned i = threadIdx.x; i < n; i += blockDim.x) dst[i] = tail[i];
+  __syncthreads();
+  if (threadIdx.x == 0 && flag)
+  {
+    __threadfence_system();
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// A, B, C (likelihood and its first two derivatives by the branch length) and the
+// scaling count of every constant pattern at `ntrial` branch lengths, from the sumtable rows
+// behind the alignment: out[((j * S + k) * 4 + {0, 1, 2, 3}] (mapped host memory).
+// One block; thread = (trial length, pattern).  brows: state rows per blocked unit (0: API layout).
+__global__ __launch_bounds__(256) void k_asc_abc(ModelView mv, ParamIdx params, TrialLengths tl, unsigned ntrial,
+                                                 const double * sumtable, const unsigned * ps, const unsigned * cs,
+                                                 unsigned Nreal, unsigned R, unsigned brows, unsigned rate_scalers,
+                                                 double * out)
+{
+  const unsigned S = mv.S, Sp = mv.Sp;
+  for (unsigned x = threadIdx.x; x < ntrial * S; x += blockDim.x)
+  {
+    const unsigned j = x / S, k0 = x % S;
+    const unsigned long long n = (unsigned long long)Nreal + k0;
+    const unsigned min_cnt = rate_scalers ? rate_min_count(ps, cs, n, R) : 0u;
+    double A = 0.0, B = 0.0, C = 0.0, inv = 0.0;
+    for (unsigned r = 0; r < R; ++r)
+    {
+      const unsigned pi_ = params.v[r];
+      const double pinv = mv.pinv()[pi_];
+      const double wr = mv.weights()[r] * ((pinv > 0.0) ? (1.0 - pinv) : 1.0);
+      double a = 0.0, b = 0.0, c = 0.0;
+      for (unsigned k = 0; k < S; ++k)
+      {
+        const double v = brows ? sumtable[(((n >> 5) * R + r) * brows + k) * 32 + (n & 31)]
+                               : sumtable[(n * R + r) * Sp + k];
+        const double lam = mv.evals(pi_)[k] * mv.rates()[r] / (1.0 - pinv);
+        const double e = wr * exp(lam * tl.t[j]);
+        a += v * e;
+        b += v * e * lam;
+        c += v * e * lam * lam;
+      }
+      const double f = rate_scalers ? rate_factor(ps, cs, n, R, r, min_cnt) : 1.0;
+      A += f * a; B += f * b; C += f * c;
+      if (pinv > 0.0) inv += mv.weights()[r] * pinv * mv.freqs(pi_)[k0];      // a constant pattern IS invariant
+    }
+    const unsigned cnt = rate_scalers ? min_cnt : (ps ? ps[n] : 0u) + (cs ? cs[n] : 0u);
+    if (inv > 0.0) A += (cnt <= 3) ? ldexp(inv, 256 * (int)cnt) : INFINITY;
+    out[(size_t)x * 4] = A;
+    out[(size_t)x * 4 + 1] = B;
+    out[(size_t)x * 4 + 2] = C;
+    out[(size_t)x * 4 + 3] = (double)cnt;
+  }
+}
+
 // expand a coded tip into a 0/1 CLV (host materialisation path)
 __global__ __launch_bounds__(256) void k_expand_codes(const uint8_t * codes,
                                                       const unsigned long long * tipmap,

@@ -112,7 +112,9 @@ Engine * engine_create(pll_partition_t * p)
     return nullptr;
   }
   e->device = dev;
-  e->S = p->states; e->Sp = p->states_padded; e->R = p->rate_cats; e->N = p->sites;
+  e->S = p->states; e->Sp = p->states_padded; e->R = p->rate_cats;
+  e->Nreal = p->sites;
+  e->N = p->sites + (p->asc_bias_alloc ? (unsigned)p->asc_additional_sites : 0u);
   e->tips = p->tips; e->nodes = p->nodes; e->nscalers = p->scale_buffers;
   e->nmat = p->prob_matrices; e->nrm = p->rate_matrices;
   e->coded_tips = (p->attributes & PLL_ATTRIB_PATTERN_TIP) != 0;
@@ -178,6 +180,13 @@ Engine * engine_create(pll_partition_t * p)
   ok = ok && hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->d_result), e->h_result, 0),
                     "hipHostGetDevicePointer");
   if (const char * ff = getenv("PLLHIP_FUSED_FINISH")) e->fused_finish = atoi(ff) != 0;
+  if (p->asc_bias_alloc)
+  {
+    const size_t bytes = sizeof(double) * MAX_TRIAL_LENGTHS * 64 * 4;
+    ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void **>(&e->h_asc), bytes, hipHostMallocMapped), "hipHostMalloc asc");
+    if (ok) memset(e->h_asc, 0, bytes);
+    ok = ok && hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->d_asc), e->h_asc, 0), "map asc");
+  }
   e->pmat_brlen.assign(e->nmat, std::numeric_limits<double>::quiet_NaN());
   e->pmat_params.assign(e->nmat, std::vector<unsigned>());
 
@@ -231,6 +240,7 @@ void engine_destroy(Engine * e)
   (void)hipFree(e->d_persite);
   (void)hipFree(e->d_sum_scratch);
   if (e->h_result) (void)hipHostFree(e->h_result);
+  if (e->h_asc) (void)hipHostFree(e->h_asc);
   (void)hipFree(e->d_counter);
   for (auto & ev : e->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -242,10 +252,16 @@ int upload_weights(pll_partition_t * p)
   Engine * e = engine_of(p);
   if (!e) return PLL_SUCCESS;   // called from the constructor before the engine exists
   PLLHIP_TRY(hipSetDevice(e->device));
+  // the ascertainment-bias columns weigh nothing in the sums over the alignment: their part of
+  // the likelihood is the correction the host applies (the host array keeps their state weights)
   e->weights_shadow.assign(p->pattern_weights, p->pattern_weights + e->N);
+  for (unsigned n = e->Nreal; n < e->N; ++n) e->weights_shadow[n] = 0;
   if (e->N)
-    PLLHIP_TRY(hipMemcpyAsync(e->d_weights, p->pattern_weights, (size_t)e->N * sizeof(unsigned),
+  {
+    PLLHIP_TRY(hipMemcpyAsync(e->d_weights, e->weights_shadow.data(), (size_t)e->N * sizeof(unsigned),
                               hipMemcpyHostToDevice, e->stream));
+    PLLHIP_TRY(hipStreamSynchronize(e->stream));      // the source is this engine's own buffer: keep it simple
+  }
   return PLL_SUCCESS;
 }
 
@@ -499,6 +515,69 @@ static unsigned reduce_grid(const Engine * e)
   static const unsigned env_cap = getenv("PLLHIP_REDUCE_BLOCKS") ? (unsigned)atoi(getenv("PLLHIP_REDUCE_BLOCKS")) : 0u;
   const unsigned cap = env_cap ? env_cap : (e->family == KernelFamily::S4 ? 1024u : 2048u);
   return (unsigned)std::max<unsigned long long>(1ULL, std::min<unsigned long long>(need, std::min(cap, (unsigned)REDUCE_BLOCKS)));
+}
+
+// --- ascertainment-bias correction on the host (same formulas as oracle/orc_kernels.c) ---------
+// from the log-likelihoods l[k] of the S constant patterns:
+//   Lewis  - W log(1 - sum_k L_k);  Felsenstein  + w log(sum_k L_k);  Stamatakis  + sum_k w_k log(L_k)
+static double asc_correction(const pll_partition_t * p, const double * l)
+{
+  const unsigned S = p->states;
+  const unsigned * w = p->pattern_weights + p->sites;
+  unsigned wsum = 0;
+  double mx = l[0], sum = 0.0, corr = 0.0;
+  for (unsigned k = 0; k < S; ++k) { mx = std::max(mx, l[k]); wsum += w[k]; }
+  for (unsigned k = 0; k < S; ++k) sum += exp(l[k] - mx);
+  switch (p->attributes & PLL_ATTRIB_AB_MASK)
+  {
+    case PLL_ATTRIB_AB_LEWIS: return -(double)p->pattern_weight_sum * log1p(-exp(mx) * sum);
+    case PLL_ATTRIB_AB_FELSENSTEIN: return (double)wsum * (mx + log(sum));
+    case PLL_ATTRIB_AB_STAMATAKIS:
+      for (unsigned k = 0; k < S; ++k) corr += (double)w[k] * l[k];
+      return corr;
+    default: return 0.0;
+  }
+}
+
+// first and second derivative of the correction from {A, B, C, count} of the constant patterns
+static void asc_derivatives(const pll_partition_t * p, const double * abc, double * d1, double * d2)
+{
+  const unsigned S = p->states;
+  const unsigned * w = p->pattern_weights + p->sites;
+  unsigned mn = ~0u, wsum = 0;
+  double a = 0.0, b = 0.0, c = 0.0;
+  *d1 = *d2 = 0.0;
+  for (unsigned k = 0; k < S; ++k) { mn = std::min(mn, (unsigned)abc[4 * k + 3]); wsum += w[k]; }
+  for (unsigned k = 0; k < S; ++k)
+  {
+    const unsigned d = (unsigned)abc[4 * k + 3] - mn;
+    const double f = (d == 0) ? 1.0 : (d <= 3) ? ldexp(1.0, -256 * (int)d) : 0.0;
+    a += f * abc[4 * k]; b += f * abc[4 * k + 1]; c += f * abc[4 * k + 2];
+  }
+  switch (p->attributes & PLL_ATTRIB_AB_MASK)
+  {
+    case PLL_ATTRIB_AB_LEWIS:
+    {
+      const double t = (mn == 0) ? 1.0 : (mn <= 3) ? ldexp(1.0, -256 * (int)mn) : 0.0;
+      const double q = t * b / (1.0 - t * a);
+      *d1 = (double)p->pattern_weight_sum * q;
+      *d2 = (double)p->pattern_weight_sum * (t * c / (1.0 - t * a) + q * q);
+      break;
+    }
+    case PLL_ATTRIB_AB_FELSENSTEIN:
+      *d1 = (double)wsum * (b / a);
+      *d2 = (double)wsum * (c / a - (b / a) * (b / a));
+      break;
+    case PLL_ATTRIB_AB_STAMATAKIS:
+      for (unsigned k = 0; k < S; ++k)
+      {
+        const double r1 = abc[4 * k + 1] / abc[4 * k], r2 = abc[4 * k + 2] / abc[4 * k];
+        *d1 += (double)w[k] * r1;
+        *d2 += (double)w[k] * (r2 - r1 * r1);
+      }
+      break;
+    default: break;
+  }
 }
 
 // Scalar results.  A reduction launch leaves its totals in the engine's current sink
@@ -1057,8 +1136,19 @@ double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsigned cc
     if ((unsigned)matrix_index >= e->nmat) { set_error(PLL_ERROR_PARAM_INVALID, "matrix index out of range"); return fail; }
   }
   if (!sync_model(p) || !flush_pmatrices(p) || !ensure_luts(p) || !ensure_invariant(p)) return fail;
-  if (persite_lnl && !e->d_persite)
+  // ascertainment-bias correction: the kernel runs over alignment + constant patterns (the
+  // latter weigh 0 on the device), the per-site values of the constant patterns come back
+  // through the mapped result buffer and the host adds the closed-form correction
+  const bool asc = e->N > e->Nreal;
+  if (asc && deferred)
+  {
+    set_error(PLL_ERROR_PARAM_INVALID, "internal: deferred lnL of an AB partition goes through the blocking form");
+    return fail;
+  }
+  double * const ps_out_req = persite_lnl;
+  if ((persite_lnl || asc) && !e->d_persite)
     if (!dev_alloc(&e->d_persite, (size_t)e->N, "per-site lnL")) return fail;
+  if (asc && !persite_lnl) persite_lnl = e->h_asc;      // any non-null value: "per-site output on"
 
   const unsigned nblocks = reduce_grid(e);
   const ModelView mv = model_view(e);
@@ -1066,6 +1156,8 @@ double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsigned cc
   const NodeRef parent = node_ref(e, pc);
   if (deferred) e->sink = *deferred; else sink_to_host(e);
   e->sink.nq = 1;
+  unsigned long long * const host_flag = e->sink.flag;
+  if (asc) e->sink.flag = nullptr;                      // k_publish_tail tells the host, after the tail
   NodeRef child = {nullptr, nullptr};
   const double * pm = nullptr, * lut = nullptr;
   if (matrix_index >= 0)
@@ -1093,13 +1185,28 @@ double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsigned cc
                                  (matrix_index >= 0) ? scaler_ptr(e, csc) : nullptr,
                                  persite_lnl ? e->d_persite : nullptr, nblocks);
   if (!rc) return fail;
-  if (persite_lnl && e->N)
-    if (!hip_ok(hipMemcpyAsync(persite_lnl, e->d_persite, sizeof(double) * e->N,
-                               hipMemcpyDeviceToHost, e->stream), "persite copy")) return fail;
   double total = 0.0;
   e->counters.lnl_calls++;
   if (deferred) return finish_launch(e, nblocks, 1) ? 0.0 : fail;
-  if (!finish_reduction(e, nblocks, 1, &total)) return fail;
+  if (asc)
+  {
+    if (!finish_launch(e, nblocks, 1)) return fail;
+    hipLaunchKernelGGL(k_publish_tail, dim3(1), dim3(64), 0, e->stream, e->d_persite + e->Nreal,
+                       e->d_result + RESULT_ASC_SLOT, e->S, host_flag, e->sink.seq);
+    if (!hip_ok(hipGetLastError(), "publish tail")) return fail;
+    const volatile unsigned long long * flag =
+        reinterpret_cast<const volatile unsigned long long *>(e->h_result) + RESULT_SEQ_SLOT;
+    if (!wait_sequence(e->stream, flag, e->sink.seq)) return fail;
+    total = e->h_result[0] + asc_correction(p, e->h_result + RESULT_ASC_SLOT);
+  }
+  else if (!finish_reduction(e, nblocks, 1, &total)) return fail;
+  if (ps_out_req && e->Nreal)
+  {
+    // only the alignment patterns go to the caller; wait for the copy (the result flag came first)
+    if (!hip_ok(hipMemcpyAsync(ps_out_req, e->d_persite, sizeof(double) * e->Nreal,
+                               hipMemcpyDeviceToHost, e->stream), "persite copy") ||
+        !hip_ok(hipStreamSynchronize(e->stream), "persite sync")) return fail;
+  }
   return total;
 }
 
@@ -1146,6 +1253,23 @@ int derivatives_impl(pll_partition_t * p, int parent_scaler_index, int child_sca
       return PLL_FAILURE;
     }
   }
+  const bool asc = e->N > e->Nreal;
+  if (asc && deferred)
+  {
+    set_error(PLL_ERROR_PARAM_INVALID, "internal: deferred derivatives of an AB partition go through the blocking form");
+    return PLL_FAILURE;
+  }
+  if (asc)
+  {
+    // {A, B, C, count} of the constant patterns at every trial length, ahead of the scan on the
+    // same stream: when the scan's result flag arrives these are in host memory too
+    TrialLengths all;
+    for (unsigned i = 0; i < MAX_TRIAL_LENGTHS; ++i) all.t[i] = brlens[std::min(i, count - 1)];
+    hipLaunchKernelGGL(k_asc_abc, dim3(1), dim3(256), 0, e->stream, mv, params, all, count, d_sum,
+                       scaler_ptr(e, parent_scaler_index), scaler_ptr(e, child_scaler_index),
+                       e->Nreal, e->R, e->rows, e->rate_scalers ? 1u : 0u, e->d_asc);
+    PLLHIP_TRY(hipGetLastError());
+  }
   Engine::Sink base;
   if (deferred) base = *deferred; else { sink_to_host(e); base = e->sink; }
   for (unsigned first = 0; first < count; first += kmax)
@@ -1178,6 +1302,15 @@ int derivatives_impl(pll_partition_t * p, int parent_scaler_index, int child_sca
       reinterpret_cast<const volatile unsigned long long *>(e->h_result) + RESULT_SEQ_SLOT;
   if (!wait_sequence(e->stream, flag, base.seq)) return PLL_FAILURE;
   for (unsigned i = 0; i < count; ++i) { out_df[i] = e->h_result[2 * i]; out_ddf[i] = e->h_result[2 * i + 1]; }
+  if (asc)
+    for (unsigned i = 0; i < count; ++i)
+    {
+      // d_f, dd_f are derivatives of -lnL: the correction's derivatives come off
+      double d1, d2;
+      asc_derivatives(p, e->h_asc + (size_t)i * e->S * 4, &d1, &d2);
+      out_df[i] -= d1;
+      out_ddf[i] -= d2;
+    }
   return PLL_SUCCESS;
 }
 

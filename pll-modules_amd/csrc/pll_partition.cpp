@@ -83,7 +83,7 @@ unsigned int pll_get_sites_number(const pll_partition_t * p, unsigned int)
 
 unsigned int pll_get_clv_size(const pll_partition_t * p, unsigned int)
 {
-  return p->sites * p->rate_cats * p->states_padded;
+  return (p->sites + (p->asc_bias_alloc ? p->asc_additional_sites : 0)) * p->rate_cats * p->states_padded;
 }
 
 pll_partition_t * pll_partition_create(unsigned int tips,
@@ -101,11 +101,6 @@ pll_partition_t * pll_partition_create(unsigned int tips,
     set_error(PLL_ERROR_PARAM_INVALID,
               "Invalid partition dimensions (2 <= states <= 64, 1 <= rate_cats <= %u)",
               MAX_RATE_CATS);
-    return nullptr;
-  }
-  if (attributes & (PLL_ATTRIB_AB_FLAG | PLL_ATTRIB_AB_MASK))
-  {
-    set_error(PLL_ERROR_AB_NOSUPPORT, "Ascertainment bias correction is not supported");
     return nullptr;
   }
 
@@ -129,6 +124,15 @@ pll_partition_t * pll_partition_create(unsigned int tips,
   p->alignment = PLL_ALIGNMENT_HIP;
   p->states_padded = padded_states(states);
   const unsigned Sp = p->states_padded;
+  // ascertainment-bias correction: one constant pattern per state behind the alignment in every
+  // per-site array (libpll-2's asc_bias_alloc / asc_additional_sites; pll-modules sizes its
+  // sumtables and dumps for it: src/tree/treeinfo.c:333-337, src/binary/binary_io_operations.c)
+  if (attributes & (PLL_ATTRIB_AB_FLAG | PLL_ATTRIB_AB_MASK))
+  {
+    p->asc_bias_alloc = 1;
+    p->asc_additional_sites = static_cast<int>(states);
+  }
+  const unsigned salloc = sites + (p->asc_bias_alloc ? states : 0u);
 
   bool ok = true;
   p->clv = static_cast<double **>(calloc(p->nodes ? p->nodes : 1, sizeof(double *)));
@@ -147,7 +151,7 @@ pll_partition_t * pll_partition_create(unsigned int tips,
   p->rate_weights = static_cast<double *>(calloc(rate_cats, sizeof(double)));
   p->prop_invar = static_cast<double *>(calloc(rate_matrices, sizeof(double)));
   p->eigen_decomp_valid = static_cast<int *>(calloc(rate_matrices, sizeof(int)));
-  p->pattern_weights = static_cast<unsigned int *>(calloc(sites ? sites : 1, sizeof(unsigned int)));
+  p->pattern_weights = static_cast<unsigned int *>(calloc(salloc ? salloc : 1, sizeof(unsigned int)));
   ok = ok && p->rates && p->rate_weights && p->prop_invar && p->eigen_decomp_valid &&
        p->pattern_weights;
   if (ok)
@@ -157,7 +161,7 @@ pll_partition_t * pll_partition_create(unsigned int tips,
       p->rates[i] = 1.0;
       p->rate_weights[i] = 1.0 / rate_cats;
     }
-    for (unsigned i = 0; i < sites; ++i) p->pattern_weights[i] = 1;
+    for (unsigned i = 0; i < salloc; ++i) p->pattern_weights[i] = 1;
   }
   p->subst_params = alloc_table<double>(rate_matrices, static_cast<size_t>(states) * (states - 1) / 2);
   p->frequencies = alloc_table<double>(rate_matrices, Sp);
@@ -168,7 +172,7 @@ pll_partition_t * pll_partition_create(unsigned int tips,
 
   if (ok && (attributes & PLL_ATTRIB_PATTERN_TIP))
   {
-    p->tipchars = alloc_table<unsigned char>(tips, sites);
+    p->tipchars = alloc_table<unsigned char>(tips, salloc);
     p->charmap = static_cast<unsigned char *>(calloc(PLL_ASCII_SIZE, 1));
     p->tipmap = static_cast<pll_state_t *>(calloc(PLL_ASCII_SIZE, sizeof(pll_state_t)));
     ok = p->tipchars && p->charmap && p->tipmap;
@@ -196,13 +200,13 @@ pll_partition_t * pll_partition_create(unsigned int tips,
   {
     // a loader is going to fill these (include/pllhip.h); calloc'ed pages cost nothing
     // until they are written
-    const size_t len = static_cast<size_t>(sites) * rate_cats * Sp;
+    const size_t len = static_cast<size_t>(salloc) * rate_cats * Sp;
     const unsigned first = (attributes & PLL_ATTRIB_PATTERN_TIP) ? tips : 0;
     for (unsigned i = first; ok && i < p->nodes; ++i)
       ok = (p->clv[i] = static_cast<double *>(calloc(len ? len : 1, sizeof(double)))) != nullptr;
     for (unsigned i = 0; ok && i < scale_buffers; ++i)
       ok = (p->scale_buffer[i] = static_cast<unsigned int *>(
-                calloc((sites ? sites : 1) * ((attributes & PLL_ATTRIB_RATE_SCALERS) ? (size_t)rate_cats : 1),
+                calloc((salloc ? salloc : 1) * ((attributes & PLL_ATTRIB_RATE_SCALERS) ? (size_t)rate_cats : 1),
                        sizeof(unsigned int)))) != nullptr;
     if (!ok)
     {
@@ -289,13 +293,30 @@ void pll_set_pattern_weights(pll_partition_t * p, const unsigned int * w)
   upload_weights(p);
 }
 
-int pll_set_asc_bias_type(pll_partition_t *, int)
+// Lewis: lnL - W log(1 - sum_k L_k); Felsenstein: lnL + w log(sum_k L_k), w = sum of the state
+// weights; Stamatakis: lnL + sum_k w_k log(L_k)   (Leache et al. 2015; [libpll-2 knowledge])
+int pll_set_asc_bias_type(pll_partition_t * p, int type)
 {
-  set_error(PLL_ERROR_AB_NOSUPPORT, "Ascertainment bias correction is not supported");
-  return PLL_FAILURE;
+  if (!p->asc_bias_alloc)
+  {
+    set_error(PLL_ERROR_AB_INVALIDMETHOD, "Partition was not created for ascertainment bias correction");
+    return PLL_FAILURE;
+  }
+  if (type != PLL_ATTRIB_AB_LEWIS && type != PLL_ATTRIB_AB_FELSENSTEIN && type != PLL_ATTRIB_AB_STAMATAKIS)
+  {
+    set_error(PLL_ERROR_AB_INVALIDMETHOD, "Illegal ascertainment bias algorithm");
+    return PLL_FAILURE;
+  }
+  p->attributes = (p->attributes & ~static_cast<unsigned>(PLL_ATTRIB_AB_MASK)) | static_cast<unsigned>(type);
+  return PLL_SUCCESS;
 }
 
-void pll_set_asc_state_weights(pll_partition_t *, const unsigned int *) {}
+void pll_set_asc_state_weights(pll_partition_t * p, const unsigned int * w)
+{
+  if (!p->asc_bias_alloc) return;
+  // host-side only: the correction is applied on the host (the device copy of these weights is 0)
+  memcpy(p->pattern_weights + p->sites, w, sizeof(unsigned int) * p->states);
+}
 
 int pll_update_eigen(pll_partition_t * p, unsigned int idx)
 {
@@ -305,6 +326,11 @@ int pll_update_eigen(pll_partition_t * p, unsigned int idx)
     return PLL_FAILURE;
   }
   return update_eigen_host(p, idx);
+}
+
+static unsigned salloc_of(const pll_partition_t * p)
+{
+  return p->sites + (p->asc_bias_alloc ? static_cast<unsigned>(p->asc_additional_sites) : 0u);
 }
 
 int pll_set_tip_states(pll_partition_t * p, unsigned int tip,
@@ -320,7 +346,7 @@ int pll_set_tip_states(pll_partition_t * p, unsigned int tip,
   double * tmp = nullptr;
   if (!coded)
   {
-    tmp = static_cast<double *>(malloc(sizeof(double) * (size_t)p->sites * R * Sp + 8));
+    tmp = static_cast<double *>(malloc(sizeof(double) * (size_t)salloc_of(p) * R * Sp + 8));
     if (!tmp)
     {
       set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate tip staging buffer");
@@ -328,10 +354,12 @@ int pll_set_tip_states(pll_partition_t * p, unsigned int tip,
     }
   }
   unsigned old_codes = p->maxstates;
-  for (unsigned n = 0; n < p->sites; ++n)
+  for (unsigned n = 0; n < salloc_of(p); ++n)
   {
-    unsigned char c = static_cast<unsigned char>(seq[n]);
-    pll_state_t m = map[c];
+    // behind the alignment: the ascertainment-bias column of state n - sites
+    const bool asc = n >= p->sites;
+    unsigned char c = asc ? 0 : static_cast<unsigned char>(seq[n]);
+    pll_state_t m = asc ? (1ULL << (n - p->sites)) : map[c];
     if (!m || (S < 64 && (m >> S)))
     {
       free(tmp);
@@ -358,7 +386,7 @@ int pll_set_tip_states(pll_partition_t * p, unsigned int tip,
           p->maxstates++;
         }
       }
-      p->charmap[c] = static_cast<unsigned char>(code);
+      if (!asc) p->charmap[c] = static_cast<unsigned char>(code);
       p->tipchars[tip][n] = static_cast<unsigned char>(code);
     }
     else
@@ -398,7 +426,7 @@ int pll_set_tip_clv(pll_partition_t * p, unsigned int tip, const double * clv, i
     return PLL_FAILURE;
   }
   const unsigned S = p->states, Sp = p->states_padded, R = p->rate_cats;
-  double * tmp = static_cast<double *>(calloc((size_t)p->sites * R * Sp + 1, sizeof(double)));
+  double * tmp = static_cast<double *>(calloc((size_t)salloc_of(p) * R * Sp + 1, sizeof(double)));
   if (!tmp)
   {
     set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate tip staging buffer");
@@ -409,6 +437,8 @@ int pll_set_tip_clv(pll_partition_t * p, unsigned int tip, const double * clv, i
   for (unsigned n = 0; n < p->sites; ++n)
     for (unsigned r = 0; r < R; ++r)
       memcpy(tmp + ((size_t)n * R + r) * Sp, clv + (size_t)n * in_stride, sizeof(double) * S);
+  for (unsigned n = p->sites; n < salloc_of(p); ++n)       // ascertainment-bias columns
+    for (unsigned r = 0; r < R; ++r) tmp[((size_t)n * R + r) * Sp + (n - p->sites)] = 1.0;
   int rc = upload_tip_clv(p, tip, tmp);
   free(tmp);
   return rc;
@@ -466,7 +496,7 @@ void pll_show_pmatrix(const pll_partition_t * p, unsigned int index, unsigned in
 void pll_show_clv(const pll_partition_t * cp, unsigned int clv_index, int, unsigned int prec)
 {
   pll_partition_t * p = const_cast<pll_partition_t *>(cp);
-  const size_t len = (size_t)p->sites * p->rate_cats * p->states_padded;
+  const size_t len = (size_t)salloc_of(p) * p->rate_cats * p->states_padded;
   double * buf = static_cast<double *>(malloc(sizeof(double) * (len ? len : 1)));
   if (!buf || !pllhip_get_clv(p, clv_index, buf)) { free(buf); return; }
   printf("[ ");

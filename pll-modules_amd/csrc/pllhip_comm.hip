@@ -94,6 +94,33 @@ __global__ void k_fill_results(double * dst, unsigned n, double v)
   for (unsigned i = threadIdx.x; i < n; i += blockDim.x) dst[i] = v;
 }
 
+// values the host already holds (a partition with ascertainment-bias correction computes its
+// scalars in the blocking form: the correction is host arithmetic) -> a slot, and its sequence word
+struct HostValues { double v[2 * MAX_TRIAL_LENGTHS]; };
+
+__global__ void k_deposit_values(double * dst, HostValues hv, unsigned n, unsigned long long * flag,
+                                 unsigned long long seq)
+{
+  for (unsigned i = threadIdx.x; i < n; i += blockDim.x) dst[i] = hv.v[i];
+  __syncthreads();
+  if (threadIdx.x == 0 && flag)
+  {
+    __threadfence_system();
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+static int deposit_host_values(pll_partition_t * p, const Engine::Sink & sink, const double * v, unsigned n)
+{
+  Engine * e = engine_of(p);
+  HostValues hv;
+  memset(&hv, 0, sizeof(hv));
+  for (unsigned i = 0; i < n; ++i) hv.v[i] = v[i];
+  hipLaunchKernelGGL(k_deposit_values, dim3(1), dim3(64), 0, e->stream, sink.dst, hv, n, sink.flag, sink.seq);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
 extern "C" {
 
 int pllhip_comm_get_unique_id(unsigned char id[PLLHIP_COMM_ID_BYTES])
@@ -261,6 +288,13 @@ int pllhip_results_edge_loglikelihood(pllhip_results_t * rs, unsigned int slot, 
 {
   Engine::Sink sink;
   if (!results_sink(rs, p, slot, 1, &sink)) return PLL_FAILURE;
+  if (p->asc_bias_alloc)
+  {
+    const double v = loglikelihood_impl(p, parent_clv_index, parent_scaler_index, child_clv_index,
+                                        child_scaler_index, (int)matrix_index, freqs_indices, nullptr, nullptr);
+    if (!std::isfinite(v) && pll_errno) return PLL_FAILURE;
+    return deposit_host_values(p, sink, &v, 1);
+  }
   const double v = loglikelihood_impl(p, parent_clv_index, parent_scaler_index, child_clv_index,
                                       child_scaler_index, (int)matrix_index, freqs_indices, nullptr, &sink);
   return (v == 0.0) ? PLL_SUCCESS : PLL_FAILURE;
@@ -272,7 +306,16 @@ int pllhip_results_derivatives(pllhip_results_t * rs, unsigned int slot, pll_par
                                const unsigned int * params_indices, const double * sumtable)
 {
   Engine::Sink sink;
-  if (!results_sink(rs, p, slot, 2 * count, &sink)) return PLL_FAILURE;
+  if (count > MAX_TRIAL_LENGTHS || !results_sink(rs, p, slot, 2 * count, &sink)) return PLL_FAILURE;
+  if (p->asc_bias_alloc)
+  {
+    double df[MAX_TRIAL_LENGTHS], ddf[MAX_TRIAL_LENGTHS], v[2 * MAX_TRIAL_LENGTHS];
+    if (!derivatives_impl(p, parent_scaler_index, child_scaler_index, branch_lengths, count, params_indices,
+                          sumtable, nullptr, df, ddf))
+      return PLL_FAILURE;
+    for (unsigned i = 0; i < count; ++i) { v[2 * i] = df[i]; v[2 * i + 1] = ddf[i]; }
+    return deposit_host_values(p, sink, v, 2 * count);
+  }
   return derivatives_impl(p, parent_scaler_index, child_scaler_index, branch_lengths, count, params_indices,
                           sumtable, &sink, nullptr, nullptr);
 }

@@ -165,6 +165,9 @@ class PllLib:
         L.pll_set_tip_states.argtypes = [pp, C.c_uint, C.POINTER(C.c_ulonglong), C.c_char_p]
         L.pll_set_tip_clv.argtypes = [pp, C.c_uint, c_double_p, C.c_int]
         L.pll_set_pattern_weights.argtypes = [pp, c_uint_p]
+        L.pll_set_asc_bias_type.argtypes = [pp, C.c_int]
+        L.pll_set_asc_state_weights.argtypes = [pp, c_uint_p]
+        L.pll_set_asc_state_weights.restype = None
         L.pll_set_subst_params.argtypes = [pp, C.c_uint, c_double_p]
         L.pll_set_frequencies.argtypes = [pp, C.c_uint, c_double_p]
         L.pll_set_category_rates.argtypes = [pp, c_double_p]
@@ -317,6 +320,8 @@ class Instance:
             raise RuntimeError(f"pll_partition_create failed: [{lib.errno}] {lib.errmsg}")
         self.Sp = self.p.contents.states_padded
         self.rate_scalers = bool(attributes & PLL_ATTRIB_RATE_SCALERS)
+        # with ascertainment-bias correction every per-site array carries `states` extra patterns
+        self.Nalloc = sites + (states if attributes & (PLL_ATTRIB_AB_FLAG | (7 << 5)) else 0)
         self.params = _u32(np.zeros(rate_cats))
         self._keep = []
 
@@ -358,6 +363,13 @@ class Instance:
     def set_pattern_weights(self, w):
         a = _u32(w)
         self.L.pll_set_pattern_weights(self.p, a.ctypes.data_as(c_uint_p))
+
+    def set_asc(self, asc_type, state_weights=None):
+        if not self.L.pll_set_asc_bias_type(self.p, asc_type):
+            raise RuntimeError(self.lib.errmsg)
+        if state_weights is not None:
+            w = _u32(state_weights)
+            self.L.pll_set_asc_state_weights(self.p, w.ctypes.data_as(c_uint_p))
 
     def set_pinv(self, pinv, idx=0):
         if not self.L.pll_update_invariant_sites_proportion(self.p, idx, pinv):
@@ -419,7 +431,7 @@ class Instance:
 
     def alloc_sumtable(self):
         """caller-owned buffer exactly as src/tree/treeinfo.c:336-340 allocates it"""
-        n = self.N * self.R * self.Sp
+        n = self.Nalloc * self.R * self.Sp          # src/tree/treeinfo.c:333-337 adds the AB patterns too
         ptr = self.L.pll_aligned_alloc(max(1, n) * 8, self.p.contents.alignment)
         return C.cast(ptr, c_double_p)
 
@@ -449,7 +461,7 @@ class Instance:
 
     # --- read-back (works for both libraries) -------------------------------
     def get_clv(self, idx):
-        n = self.N * self.R * self.Sp
+        n = self.Nalloc * self.R * self.Sp
         out = np.zeros(n)
         if self.lib.is_product:
             if not self.L.pllhip_get_clv(self.p, idx, out.ctypes.data_as(c_double_p)):
@@ -457,18 +469,18 @@ class Instance:
         else:
             ptr = self.p.contents.clv[idx]
             out[:] = np.ctypeslib.as_array(ptr, shape=(n,))
-        return out.reshape(self.N, self.R, self.Sp)[:, :, :self.S]
+        return out.reshape(self.Nalloc, self.R, self.Sp)[:self.N, :, :self.S]
 
     def get_scaler(self, idx):
         """scaler counts: [site], or [site][rate] with PLL_ATTRIB_RATE_SCALERS"""
-        n = self.N * (self.R if self.rate_scalers else 1)
+        n = self.Nalloc * (self.R if self.rate_scalers else 1)
         out = np.zeros(n, dtype=np.uint32)
         if self.lib.is_product:
             if not self.L.pllhip_get_scaler(self.p, idx, out.ctypes.data_as(c_uint_p)):
                 raise RuntimeError(self.lib.errmsg)
         else:
             out[:] = np.ctypeslib.as_array(self.p.contents.scale_buffer[idx], shape=(n,))
-        return out
+        return out[:self.N * (self.R if self.rate_scalers else 1)]
 
     def get_pmatrix(self, idx):
         if self.lib.is_product:
@@ -478,14 +490,14 @@ class Instance:
         return a.reshape(self.R, self.S, self.Sp)[:, :, :self.S]
 
     def get_sumtable(self, st):
-        n = self.N * self.R * self.Sp
+        n = self.Nalloc * self.R * self.Sp
         out = np.zeros(n)
         if self.lib.is_product:
             if not self.L.pllhip_get_sumtable(self.p, st, out.ctypes.data_as(c_double_p)):
                 raise RuntimeError(self.lib.errmsg)
         else:
             out[:] = np.ctypeslib.as_array(st, shape=(n,))
-        return out.reshape(self.N, self.R, self.Sp)[:, :, :self.S]
+        return out.reshape(self.Nalloc, self.R, self.Sp)[:self.N, :, :self.S]
 
     def counters(self):
         c = Counters()

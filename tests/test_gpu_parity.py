@@ -654,3 +654,54 @@ def test_per_rate_scalers(product, oracle, states, ntips, rate_cats):
         assert product.lib.pllhip_sync_to_host(a.p, pc.PLLHIP_SYNC_SCALERS)        # mirrors hold sites x rates counts
         m = np.ctypeslib.as_array(a.p.contents.scale_buffer[t.scaler_of(t.root_a)], shape=(a.N * a.R,))
         assert np.array_equal(m, a.get_scaler(t.scaler_of(t.root_a)))
+
+
+@pytest.mark.parametrize("asc_type", [pc.PLL_ATTRIB_AB_LEWIS, pc.PLL_ATTRIB_AB_FELSENSTEIN, pc.PLL_ATTRIB_AB_STAMATAKIS])
+@pytest.mark.parametrize("states,coded,pinv", [(4, True, 0.0), (4, False, 0.0), (7, True, 0.0), (20, True, 0.1),
+                                               (61, True, 0.0), (17, True, 0.0), (2, True, 0.0)])
+def test_ascertainment_bias_correction(product, oracle, states, coded, pinv, asc_type):
+    """PLL_ATTRIB_AB_*: the S constant patterns behind the alignment, the closed-form correction of
+    lnL and of its derivatives.  Checked against the engine's own ordinary primitives and finite
+    differences (tests/test_oracle_properties.py::check_asc_bias), and against the oracle."""
+    from test_oracle_properties import check_asc_bias
+    tol = 1e-9 if states <= 20 else 1e-7
+    g = check_asc_bias(product, states, asc_type, coded, pinv, tol)
+    c = check_asc_bias(oracle, states, asc_type, coded, pinv, tol)
+    for x, y in zip(g, c):
+        assert abs(x - y) <= (1e-9 if states <= 20 else 2e-6) * max(1.0, abs(y)), (g, c)
+
+
+def test_ascertainment_bias_through_deferred_results(product):
+    """an AB partition inside a result group (the evaluation driver on deferred results): the
+    host-side correction still reaches the slot"""
+    t = pc.Tree(8, 42, 43)
+    ev = pc.Evaluation(product, t.newick(), nparts=2)
+    with ev:
+        for k, attrs in enumerate((pc.PLL_ATTRIB_AB_FLAG | pc.PLL_ATTRIB_AB_LEWIS, 0)):
+            inst = pc.Instance(product, 8, 4, 300, 4, attributes=pc.PLL_ATTRIB_PATTERN_TIP | attrs)
+            inst.set_model(pc.DNA_GTR_RATES, pc.DNA_FREQS, product.gamma_cats(0.8, 4))
+            codes = pc.simulated_codes(t, 300, 4, seed=45 + k)
+            cmap = pc.state_charmap(4)
+            for tip in range(8):
+                inst.set_tip_states(ev.tip_clv[tip], cmap, (codes[tip] + 48).tobytes())
+            if attrs:
+                inst.set_asc(pc.PLL_ATTRIB_AB_LEWIS)
+            assert product.lib.pllhip_eval_set_partition(ev.ev, k, inst.p, inst.params_p)
+            ev.parts.append(inst)
+        plain = (ev.loglh(), ev.optimize_branches(1e-4, 10.0, 0.01, 4, -1))
+    ev = pc.Evaluation(product, t.newick(), nparts=2)
+    with ev:
+        for k, attrs in enumerate((pc.PLL_ATTRIB_AB_FLAG | pc.PLL_ATTRIB_AB_LEWIS, 0)):
+            inst = pc.Instance(product, 8, 4, 300, 4, attributes=pc.PLL_ATTRIB_PATTERN_TIP | attrs)
+            inst.set_model(pc.DNA_GTR_RATES, pc.DNA_FREQS, product.gamma_cats(0.8, 4))
+            codes = pc.simulated_codes(t, 300, 4, seed=45 + k)
+            cmap = pc.state_charmap(4)
+            for tip in range(8):
+                inst.set_tip_states(ev.tip_clv[tip], cmap, (codes[tip] + 48).tobytes())
+            if attrs:
+                inst.set_asc(pc.PLL_ATTRIB_AB_LEWIS)
+            assert product.lib.pllhip_eval_set_partition(ev.ev, k, inst.p, inst.params_p)
+            ev.parts.append(inst)
+        ev.attach_comm(None)
+        fused = (ev.loglh(), ev.optimize_branches(1e-4, 10.0, 0.01, 4, -1))
+    assert plain == fused

@@ -211,3 +211,72 @@ def test_per_rate_scalers_agree_with_per_site_scalers(oracle, states, ntips):
         ra = a.root_lnl(t.root_a, t.scaler_of(t.root_a))
         rb = b.root_lnl(t.root_a, t.scaler_of(t.root_a))
         assert abs(ra - rb) < 1e-9 * abs(ra)
+
+
+def check_asc_bias(lib, states, asc_type, coded, pinv=0.0, tol=1e-9):
+    """ascertainment-bias correction against the same library's ordinary primitives: the
+    corrected lnL must equal lnL(alignment) + f(likelihoods of the S constant patterns), the
+    latter taken from an ordinary partition that holds just those S columns; derivatives
+    against finite differences of the corrected lnL"""
+    ntips, nsites, R = 9, 150, 4
+    tree = pc.Tree(ntips, 42, 43)
+    ab = pc.build_instance(lib, states=states, rate_cats=R, ntips=ntips, nsites=nsites, coded=coded, tree=tree,
+                           attributes=pc.PLL_ATTRIB_AB_FLAG | asc_type, pinv=pinv)
+    plain = pc.build_instance(lib, states=states, rate_cats=R, ntips=ntips, nsites=nsites, coded=coded, tree=tree,
+                              pinv=pinv)
+    const = pc.build_instance(lib, states=states, rate_cats=R, ntips=ntips, nsites=states, coded=coded, tree=tree,
+                              pinv=pinv)
+    with ab, plain, const:
+        rng = np.random.RandomState(3)
+        w = rng.randint(1, 5, size=nsites).astype(np.uint32)
+        sw = rng.randint(0, 7, size=states).astype(np.uint32)
+        sw[0] = max(1, sw[0])
+        for inst in (ab, plain):
+            inst.set_pattern_weights(w)
+        ab.set_asc(asc_type, sw)
+        cmap = pc.state_charmap(states)
+        for t in range(ntips):
+            const.set_tip_states(t, cmap, (np.arange(states, dtype=np.uint8) + 48).tobytes())
+        if pinv > 0:
+            for inst in (ab, plain, const):
+                assert inst.L.pll_update_invariant_sites(inst.p)
+        l_ab, l_plain = pc.full_traversal(ab), pc.full_traversal(plain)
+        pc.full_traversal(const)
+        sa, sb = tree.scaler_of(tree.root_a), tree.scaler_of(tree.root_b)
+        _, lk = const.edge_lnl(tree.root_a, sa, tree.root_b, sb, tree.root_matrix, persite=True)
+        W = float(w.sum())
+        want = {pc.PLL_ATTRIB_AB_LEWIS: -W * np.log1p(-np.exp(lk).sum()),
+                pc.PLL_ATTRIB_AB_FELSENSTEIN: float(sw.sum()) * np.log(np.exp(lk).sum()),
+                pc.PLL_ATTRIB_AB_STAMATAKIS: float((sw * lk).sum())}[asc_type]
+        assert abs(l_ab - (l_plain + want)) <= tol * abs(l_ab), (l_ab, l_plain, want)
+        assert abs(want) > 1e-3                          # the correction is not a no-op
+        # per-site values are those of the alignment patterns
+        _, ps_ab = ab.edge_lnl(tree.root_a, sa, tree.root_b, sb, tree.root_matrix, persite=True)
+        _, ps_pl = plain.edge_lnl(tree.root_a, sa, tree.root_b, sb, tree.root_matrix, persite=True)
+        assert np.allclose(ps_ab, ps_pl, rtol=1e-12, atol=0)
+        # derivatives of the corrected -lnL
+        st = ab.alloc_sumtable()
+        ab.update_sumtable(tree.root_a, tree.root_b, sa, sb, st)
+        x, h = float(tree.brlens[tree.root_matrix]), 1e-5
+
+        def neg_lnl(bl):
+            ab.update_pmatrices([tree.root_matrix], [bl])
+            return -ab.edge_lnl(tree.root_a, sa, tree.root_b, sb, tree.root_matrix)
+        df, ddf = ab.derivatives(sa, sb, x, st)
+        f0, fp, fm = neg_lnl(x), neg_lnl(x + h), neg_lnl(x - h)
+        assert abs(df - (fp - fm) / (2 * h)) < 1e-5 * max(1.0, abs(df)), (df, (fp - fm) / (2 * h))
+        assert abs(ddf - (fp - 2 * f0 + fm) / (h * h)) < 5e-3 * max(1.0, abs(ddf))
+        ab.free_sumtable(st)
+        return l_ab, df, ddf
+
+
+@pytest.mark.parametrize("asc_type", [pc.PLL_ATTRIB_AB_LEWIS, pc.PLL_ATTRIB_AB_FELSENSTEIN, pc.PLL_ATTRIB_AB_STAMATAKIS])
+@pytest.mark.parametrize("states,coded,pinv", [(4, True, 0.0), (4, False, 0.0), (7, True, 0.0), (20, True, 0.1)])
+def test_ascertainment_bias_correction_on_oracle(oracle, states, coded, pinv, asc_type):
+    check_asc_bias(oracle, states, asc_type, coded, pinv)
+
+
+def test_asc_needs_a_partition_created_for_it(oracle):
+    with pc.Instance(oracle, 3, 4, 8, 4) as a:
+        assert not oracle.lib.pll_set_asc_bias_type(a.p, pc.PLL_ATTRIB_AB_LEWIS)
+        assert oracle.errno == 121          # PLL_ERROR_AB_INVALIDMETHOD
