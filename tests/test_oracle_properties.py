@@ -139,8 +139,8 @@ def test_tiled_alignment_scales_linearly(oracle):
 
 def test_error_reporting(oracle):
     L = oracle.lib
-    assert not L.pll_partition_create(3, 1, 4, 4, 1, 3, 4, 0, 1 << 8)        # ascertainment bias
-    assert oracle.errno == 122
+    assert not L.pll_partition_create(3, 1, 1, 4, 1, 3, 4, 0, 0)             # one state
+    assert oracle.errno == 113
     with pc.Instance(oracle, 3, 4, 4, 4, scalers=False, clv_buffers=1, prob_matrices=3) as a:
         with pytest.raises(RuntimeError):
             a.set_tip_states(0, pc.state_charmap(4), b"01Z3")                   # illegal character
