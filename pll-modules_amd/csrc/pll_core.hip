@@ -285,6 +285,13 @@ int upload_tip_codes(pll_partition_t * p, unsigned tip)
   return upload_tipmap(p);
 }
 
+// device staging buffer that frees itself on every exit path
+struct DevTmp
+{
+  double * ptr = nullptr;
+  ~DevTmp() { if (ptr) (void)hipFree(ptr); }
+};
+
 // API layout [site][rate][Sp] on the host -> device layout of the family
 static int store_clv(Engine * e, double * d_dst, const double * host_clv)
 {
@@ -296,14 +303,13 @@ static int store_clv(Engine * e, double * d_dst, const double * host_clv)
     PLLHIP_TRY(hipStreamSynchronize(e->stream));
     return PLL_SUCCESS;
   }
-  double * tmp = nullptr;
-  if (!dev_alloc(&tmp, len, "layout staging")) return PLL_FAILURE;
-  PLLHIP_TRY(hipMemcpyAsync(tmp, host_clv, len * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  DevTmp tmp;
+  if (!dev_alloc(&tmp.ptr, len, "layout staging")) return PLL_FAILURE;
+  PLLHIP_TRY(hipMemcpyAsync(tmp.ptr, host_clv, len * sizeof(double), hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(k_s20_to_blocked, dim3(e->cu_count * 8), dim3(256), 0, e->stream,
-                     tmp, d_dst, e->N, e->nblk, e->R, e->Sp, e->rows);
+                     tmp.ptr, d_dst, e->N, e->nblk, e->R, e->Sp, e->rows);
   PLLHIP_TRY(hipGetLastError());
   PLLHIP_TRY(hipStreamSynchronize(e->stream));
-  (void)hipFree(tmp);
   return PLL_SUCCESS;
 }
 
@@ -318,14 +324,13 @@ static int fetch_clv(Engine * e, const double * d_src, double * host_out)
     PLLHIP_TRY(hipStreamSynchronize(e->stream));
     return PLL_SUCCESS;
   }
-  double * tmp = nullptr;
-  if (!dev_alloc(&tmp, len, "layout staging")) return PLL_FAILURE;
+  DevTmp tmp;
+  if (!dev_alloc(&tmp.ptr, len, "layout staging")) return PLL_FAILURE;
   hipLaunchKernelGGL(k_s20_from_blocked, dim3(e->cu_count * 8), dim3(256), 0, e->stream,
-                     d_src, tmp, e->N, e->R, e->Sp, e->rows);
+                     d_src, tmp.ptr, e->N, e->R, e->Sp, e->rows);
   PLLHIP_TRY(hipGetLastError());
-  PLLHIP_TRY(hipMemcpyAsync(host_out, tmp, len * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  PLLHIP_TRY(hipMemcpyAsync(host_out, tmp.ptr, len * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   PLLHIP_TRY(hipStreamSynchronize(e->stream));
-  (void)hipFree(tmp);
   return PLL_SUCCESS;
 }
 

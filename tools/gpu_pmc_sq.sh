@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the bench kernels (MFMA busy cycles, LDS bank conflicts, wave/wait cycles):
-# tools/gpu_pmc_sq.sh <cfg>; raw output in gpurun_out/pmc_sq_<cfg>, condensed by
+# tools/gpu_pmc_sq.sh <cfg>; raw output in gpurun_out/pmc_sq_<cfg>, condensed into profiles/ by
 # tools/summarize_sq.py.  One --pmc pass (8 SQ slots), no tracing domains.
 CFG=${1:-c3}
 R=$GRAFT_REPO_ROOT
