@@ -180,6 +180,7 @@ __device__ inline void s20_op_body(const OpDesc & op, unsigned nblk, unsigned Rr
                                    unsigned lut_codes, unsigned flags, double * frag)
 {
   const bool nt_ld = flags & 1u, nt_st = flags & 2u;
+  const bool rate_scalers = flags & 4u;      // PLL_ATTRIB_RATE_SCALERS: the vote covers one unit, scaler[n*R + r]
   const unsigned R = RT ? RT : Rrt;
   // each child owns R * S20_FRAGS doubles of LDS: the A fragments of its P-matrix,
   // or -- for a coded tip -- its lookup table (fits while lut_codes <= 30, rows padded to 21); LUT
@@ -224,17 +225,38 @@ __device__ inline void s20_op_body(const OpDesc & op, unsigned nblk, unsigned Rr
         if (!op.codes2) s20_child_inner(op.clv2 + ubase, frag2 + r * S20_FRAGS, lane, t2, nt_ld);
         else if (lut_lds) s20_child_tip(frag2 + r * lut_codes * S20_LUT_RS, c2e, c2o, q, t2, S20_LUT_RS);
         else s20_child_tip(op.lut2 + (size_t)r * lut_codes * 20, c2e, c2o, q, t2);
+        int re = 1, ro = 1;
 #pragma unroll
         for (int k = 0; k < 5; ++k)
         {
           out[r][k].x *= t2[k].x;
           out[r][k].y *= t2[k].y;
-          small_e &= (out[r][k].x < SCALE_THRESHOLD);
-          small_o &= (out[r][k].y < SCALE_THRESHOLD);
+          re &= (out[r][k].x < SCALE_THRESHOLD);
+          ro &= (out[r][k].y < SCALE_THRESHOLD);
         }
+        if (scaling && rate_scalers)
+        {
+          // per-rate scalers: decide, scale and count this unit now
+          re = s20_and_q(re);
+          ro = s20_and_q(ro);
+          const double ue = re ? SCALE_FACTOR : 1.0, uo = ro ? SCALE_FACTOR : 1.0;
+#pragma unroll
+          for (int k = 0; k < 5; ++k) { out[r][k].x *= ue; out[r][k].y *= uo; }
+          if (q == 0)
+          {
+            const size_t xe = site0 * RT + r, xo = (site0 + 1) * RT + r;
+            unsigned ce = re ? 1u : 0u, co = ro ? 1u : 0u;
+            if (op.scaler1) { ce += op.scaler1[xe]; co += op.scaler1[xo]; }
+            if (op.scaler2) { ce += op.scaler2[xe]; co += op.scaler2[xo]; }
+            op.parent_scaler[xe] = ce;
+            op.parent_scaler[xo] = co;
+          }
+        }
+        small_e &= re;
+        small_o &= ro;
       }
       double fe = 1.0, fo = 1.0;
-      if (scaling)
+      if (scaling && !rate_scalers)
       {
         small_e = s20_and_q(small_e);
         small_o = s20_and_q(small_o);
@@ -248,7 +270,7 @@ __device__ inline void s20_op_body(const OpDesc & op, unsigned nblk, unsigned Rr
         for (int k = 0; k < 5; ++k) { out[r][k].x *= fe; out[r][k].y *= fo; }
         s20_store_d(op.parent + ((size_t)blk * RT + r) * S20_UNIT, lane, out[r], nt_st);
       }
-      if (scaling && q == 0)
+      if (scaling && !rate_scalers && q == 0)
       {
         unsigned ce = small_e ? 1u : 0u, co = small_o ? 1u : 0u;
         if (op.scaler1) { ce += op.scaler1[site0]; co += op.scaler1[site0 + 1]; }
@@ -269,18 +291,38 @@ __device__ inline void s20_op_body(const OpDesc & op, unsigned nblk, unsigned Rr
       if (!op.codes2) s20_child_inner(op.clv2 + ubase, frag2 + r * S20_FRAGS, lane, t2, nt_ld);
       else if (lut_lds) s20_child_tip(frag2 + r * lut_codes * S20_LUT_RS, c2e, c2o, q, t2, S20_LUT_RS);
       else s20_child_tip(op.lut2 + (size_t)r * lut_codes * 20, c2e, c2o, q, t2);
+      int re = 1, ro = 1;
 #pragma unroll
       for (int k = 0; k < 5; ++k)
       {
         t1[k].x *= t2[k].x;
         t1[k].y *= t2[k].y;
-        small_e &= (t1[k].x < SCALE_THRESHOLD);
-        small_o &= (t1[k].y < SCALE_THRESHOLD);
+        re &= (t1[k].x < SCALE_THRESHOLD);
+        ro &= (t1[k].y < SCALE_THRESHOLD);
       }
+      if (scaling && rate_scalers)
+      {
+        re = s20_and_q(re);
+        ro = s20_and_q(ro);
+        const double ue = re ? SCALE_FACTOR : 1.0, uo = ro ? SCALE_FACTOR : 1.0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { t1[k].x *= ue; t1[k].y *= uo; }
+        if (q == 0)
+        {
+          const size_t xe = site0 * R + r, xo = (site0 + 1) * R + r;
+          unsigned ce = re ? 1u : 0u, co = ro ? 1u : 0u;
+          if (op.scaler1) { ce += op.scaler1[xe]; co += op.scaler1[xo]; }
+          if (op.scaler2) { ce += op.scaler2[xe]; co += op.scaler2[xo]; }
+          op.parent_scaler[xe] = ce;
+          op.parent_scaler[xo] = co;
+        }
+      }
+      small_e &= re;
+      small_o &= ro;
       s20_store_d(op.parent + ubase, lane, t1, nt_st);
     }
 
-    if (scaling)
+    if (scaling && !rate_scalers)
     {
       small_e = s20_and_q(small_e);
       small_o = s20_and_q(small_o);
@@ -547,7 +589,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_lnl_s20(ModelView mv, ParamIdx 
                                                          const unsigned * weights, const int * invariant,
                                                          const unsigned long long * tipmap,
                                                          unsigned N, unsigned nblk, unsigned R,
-                                                         double * persite, ReduceOut block_out)
+                                                         double * persite, ReduceOut block_out,
+                                                         unsigned rate_scalers)
 {
   extern __shared__ double frag[];
   __shared__ double scratch[4];
@@ -562,7 +605,13 @@ __global__ __launch_bounds__(256, 2) void k_edge_lnl_s20(ModelView mv, ParamIdx 
   for (unsigned blk = blockIdx.x * 4 + wave; blk < nblk; blk += wstride)
   {
     const size_t site0 = (size_t)blk * S20_BS + 2 * n;
-    const SiteSide sd = load_site_side(ps, cs, weights, site0, N, q == 0 && blk < nblk);
+    SiteSide sd = load_site_side(rate_scalers ? nullptr : ps, rate_scalers ? nullptr : cs, weights, site0, N,
+                                 q == 0 && blk < nblk);
+    if (rate_scalers)
+    {
+      sd.cnt_e = rate_min_count(ps, cs, site0, R);
+      sd.cnt_o = rate_min_count(ps, cs, site0 + 1, R);
+    }
     unsigned cce = 0, cco = 0;
     unsigned long long pme = 0, pmo = 0;
     if (child.codes) { cce = child.codes[site0]; cco = child.codes[site0 + 1]; }
@@ -600,6 +649,11 @@ __global__ __launch_bounds__(256, 2) void k_edge_lnl_s20(ModelView mv, ParamIdx 
       }
       le = s20_sum_q(le);
       lo = s20_sum_q(lo);
+      if (rate_scalers)
+      {
+        le *= rate_factor(ps, cs, site0, R, r, sd.cnt_e);
+        lo *= rate_factor(ps, cs, site0 + 1, R, r, sd.cnt_o);
+      }
       const double pinv = mv.pinv()[fi], w = mv.weights()[r];
       if (pinv > 0.0)
       {
@@ -883,7 +937,8 @@ static int launch_partials_s20(Engine * e, const OpBatch & batch, unsigned nops)
 {
   const size_t lds = sizeof(double) * 2 * e->R * S20_FRAGS;
   static const int unroll = getenv("PLLHIP_S20_UNROLL") ? atoi(getenv("PLLHIP_S20_UNROLL")) : 0;
-  static const unsigned flags = getenv("PLLHIP_S20_NT") ? (unsigned)atoi(getenv("PLLHIP_S20_NT")) : 0u;
+  static const unsigned env_flags = getenv("PLLHIP_S20_NT") ? (unsigned)atoi(getenv("PLLHIP_S20_NT")) & 3u : 0u;
+  const unsigned flags = env_flags | (e->rate_scalers ? 4u : 0u);
   if (e->R == 4 && !unroll)    // PLLHIP_S20_UNROLL=1 selects the runtime-R variant for A/B runs
     hipLaunchKernelGGL(k_partials_s20<4>, dim3(s20_grid(e, 4), nops), dim3(256), lds, e->stream,
                        batch, e->nblk, e->R, e->lut_codes, flags);
@@ -894,7 +949,8 @@ static int launch_partials_s20(Engine * e, const OpBatch & batch, unsigned nops)
   return PLL_SUCCESS;
 }
 
-static bool chains_supported_s20(const Engine * e) { return e->R == 4 || e->R == 2 || e->R == 1; }
+// (per-rate scalers: the chain kernel votes per site; such partitions keep the level schedule)
+static bool chains_supported_s20(const Engine * e) { return !e->rate_scalers && (e->R == 4 || e->R == 2 || e->R == 1); }
 
 // LDS doubles of the two children's tables of an operation in a chain (0: read from global)
 static bool s20_chain_lut_lds(const Engine * e, unsigned lut_used)
@@ -956,7 +1012,7 @@ static int launch_edge_lnl_s20(Engine * e, const ModelView & mv, const ParamIdx 
   hipLaunchKernelGGL(k_edge_lnl_s20, dim3(nblocks), dim3(256), lds, e->stream,
                      mv, fidx, parent, child, pm, lut, e->lut_codes, ps, cs,
                      e->d_weights, e->d_invariant, e->d_tipmap, e->N, e->nblk, e->R,
-                     persite, reduce_out(e));
+                     persite, reduce_out(e), e->rate_scalers ? 1u : 0u);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }
@@ -998,7 +1054,8 @@ static int launch_derivatives_s20(Engine * e, const ModelView & mv, const ParamI
                                   unsigned nblocks)
 {
   hipLaunchKernelGGL((k_derivatives_mfma<5, 20>), dim3(nblocks), dim3(256), sizeof(double) * e->R * 5 * 64, e->stream,
-                     mv, params, tl, count, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, reduce_out(e), 0u);
+                     mv, params, tl, count, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, reduce_out(e),
+                     e->rate_scalers ? 1u : 0u);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

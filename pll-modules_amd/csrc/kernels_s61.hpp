@@ -217,6 +217,45 @@ __device__ inline void s61_finish_unit(double * dst, unsigned lane, unsigned q, 
   s61_store_d(dst, lane, t1);
 }
 
+// PLL_ATTRIB_RATE_SCALERS: the vote covers this unit alone -- decide (all four lane groups),
+// scale, store, and write the count of (site, rate): no votes, no prediction, no fix-up kernel
+__device__ inline void s61_finish_unit_rs(const OpDesc & op, unsigned blk, unsigned r, unsigned R,
+                                          double * dst, unsigned lane, double2 t1[S61_KS], const double2 t2[S61_KS])
+{
+  const unsigned q = lane >> 4, n = lane & 15;
+  int se = 1, so = 1;
+#pragma unroll
+  for (unsigned k = 0; k < S61_KS; ++k)
+  {
+    t1[k].x *= t2[k].x;
+    t1[k].y *= t2[k].y;
+    if (4 * k + q < S61_S)
+    {
+      se &= (t1[k].x < SCALE_THRESHOLD);
+      so &= (t1[k].y < SCALE_THRESHOLD);
+    }
+  }
+  if (op.parent_scaler)
+  {
+    se = s20_and_q(se);
+    so = s20_and_q(so);
+    const double fe = se ? SCALE_FACTOR : 1.0, fo = so ? SCALE_FACTOR : 1.0;
+#pragma unroll
+    for (unsigned k = 0; k < S61_KS; ++k) { t1[k].x *= fe; t1[k].y *= fo; }
+    if (q == 0)
+    {
+      const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+      const size_t xe = site0 * R + r, xo = (site0 + 1) * R + r;
+      unsigned ce = se ? 1u : 0u, co = so ? 1u : 0u;
+      if (op.scaler1) { ce += op.scaler1[xe]; co += op.scaler1[xo]; }
+      if (op.scaler2) { ce += op.scaler2[xe]; co += op.scaler2[xo]; }
+      op.parent_scaler[xe] = ce;
+      op.parent_scaler[xo] = co;
+    }
+  }
+  s61_store_d(dst, lane, t1);
+}
+
 __device__ inline void s61_pred_factors(const uint8_t * pred, unsigned blk, unsigned lane, double & fe, double & fo)
 {
   fe = fo = 1.0;
@@ -240,7 +279,7 @@ __device__ inline void s61_acc_to_t(const v4d acc[S61_MT][2], double2 t[S61_KS])
 // one rate of a wave's blocks (first, first + 4, ...: nb of them), both children inner
 __device__ inline void s61_rate_ii(const OpDesc & op, const double * frag, const double * frag2,
                                    unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
-                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred)
+                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred, bool rs)
 {
   const double2 * f1 = reinterpret_cast<const double2 *>(frag);
   const double2 * f2 = reinterpret_cast<const double2 *>(frag2);
@@ -273,6 +312,7 @@ __device__ inline void s61_rate_ii(const OpDesc & op, const double * frag, const
     s61_mfma_half<1>(bB, f2, lane, acc);
     S61_SCHED_FENCE();
     s61_acc_to_t(acc, t2);
+    if (rs) { s61_finish_unit_rs(op, first + 4 * i, r, R, op.parent + ub, lane, t1, t2); continue; }
     double fe, fo;
     s61_pred_factors(pred, first + 4 * i, lane, fe, fo);
     s61_finish_unit(op.parent + ub, lane, q, t1, t2, 1u << i, small_e, small_o, fe, fo);
@@ -283,7 +323,7 @@ __device__ inline void s61_rate_ii(const OpDesc & op, const double * frag, const
 __device__ inline void s61_rate_ti(const OpDesc & op, const double * clv, const double * fragi,
                                    const unsigned char * codes, const double * lut_r,
                                    unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
-                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred)
+                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred, bool rs)
 {
   const double2 * f1 = reinterpret_cast<const double2 *>(fragi);
   const unsigned q = lane >> 4, n = lane & 15;
@@ -309,6 +349,7 @@ __device__ inline void s61_rate_ti(const OpDesc & op, const double * clv, const 
     S61_SCHED_FENCE();
     s61_acc_to_t(acc, t1);
     s61_child_tip(lut_r, ce, co, q, t2);
+    if (rs) { s61_finish_unit_rs(op, blk, r, R, op.parent + ub, lane, t1, t2); continue; }
     double fe, fo;
     s61_pred_factors(pred, blk, lane, fe, fo);
     s61_finish_unit(op.parent + ub, lane, q, t1, t2, 1u << i, small_e, small_o, fe, fo);
@@ -317,7 +358,7 @@ __device__ inline void s61_rate_ti(const OpDesc & op, const double * clv, const 
 
 __device__ inline void s61_rate_tt(const OpDesc & op, const double * lut1_r, const double * lut2_r,
                                    unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
-                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred)
+                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred, bool rs)
 {
   const unsigned q = lane >> 4, n = lane & 15;
   // the tip codes of block i+1 are fetched while block i is looked up and stored
@@ -333,10 +374,14 @@ __device__ inline void s61_rate_tt(const OpDesc & op, const double * lut1_r, con
     double2 t1[S61_KS], t2[S61_KS];
     s61_child_tip(lut1_r, c1e, c1o, q, t1);
     s61_child_tip(lut2_r, c2e, c2o, q, t2);
-    double fe, fo;
-    s61_pred_factors(pred, blk, lane, fe, fo);
-    s61_finish_unit(op.parent + ((size_t)blk * R + r) * S61_UNIT, lane, q, t1, t2, 1u << i,
-                    small_e, small_o, fe, fo);
+    if (rs) s61_finish_unit_rs(op, blk, r, R, op.parent + ((size_t)blk * R + r) * S61_UNIT, lane, t1, t2);
+    else
+    {
+      double fe, fo;
+      s61_pred_factors(pred, blk, lane, fe, fo);
+      s61_finish_unit(op.parent + ((size_t)blk * R + r) * S61_UNIT, lane, q, t1, t2, 1u << i,
+                      small_e, small_o, fe, fo);
+    }
     c1e = n1e; c1o = n1o; c2e = n2e; c2o = n2o;
   }
 }
@@ -345,14 +390,16 @@ __device__ inline void s61_rate_tt(const OpDesc & op, const double * lut1_r, con
 // a workgroup handles ONE rate, writes its per-site "all entries small" vote to
 // votes[(op*R + r)*Nalloc + site], and k_s61_scale_fixup combines the votes.
 __global__ __launch_bounds__(256, 2) void k_partials_s61v3(OpBatch batch, unsigned nblk, unsigned R,
-                                                           unsigned lut_codes, uint8_t * votes, PredBatch preds)
+                                                           unsigned lut_codes, uint8_t * votes, PredBatch preds,
+                                                           unsigned rate_scalers)
 {
+  const bool rs = rate_scalers != 0;
   extern __shared__ double frag[];
   double * const frag2 = frag + S61_FRAGS;
   const OpDesc & op = batch.op[blockIdx.y];
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned q = lane >> 4, n = lane & 15;
-  const bool scaling = op.parent_scaler != nullptr;
+  const bool scaling = op.parent_scaler != nullptr && !rs;     // per-rate scalers are settled unit by unit
   const bool lut_lds = lut_codes * S61_S <= S61_FRAGS;
   const bool tip1 = op.codes1 != nullptr, tip2 = op.codes2 != nullptr;
   const unsigned beg = (unsigned)(((unsigned long long)nblk * blockIdx.x) / gridDim.x);
@@ -385,10 +432,10 @@ __global__ __launch_bounds__(256, 2) void k_partials_s61v3(OpBatch batch, unsign
       if (nb == 0) continue;
       const double * l1 = lut_lds ? frag : op.lut1 + (size_t)r * lut_codes * S61_S;
       const double * l2 = lut_lds ? frag2 : op.lut2 + (size_t)r * lut_codes * S61_S;
-      if (tip1 && tip2) s61_rate_tt(op, l1, l2, r, R, first, nb, lane, small_e, small_o, pred);
-      else if (!tip1 && !tip2) s61_rate_ii(op, frag, frag2, r, R, first, nb, lane, small_e, small_o, pred);
-      else if (tip1) s61_rate_ti(op, op.clv2, frag2, op.codes1, l1, r, R, first, nb, lane, small_e, small_o, pred);
-      else s61_rate_ti(op, op.clv1, frag, op.codes2, l2, r, R, first, nb, lane, small_e, small_o, pred);
+      if (tip1 && tip2) s61_rate_tt(op, l1, l2, r, R, first, nb, lane, small_e, small_o, pred, rs);
+      else if (!tip1 && !tip2) s61_rate_ii(op, frag, frag2, r, R, first, nb, lane, small_e, small_o, pred, rs);
+      else if (tip1) s61_rate_ti(op, op.clv2, frag2, op.codes1, l1, r, R, first, nb, lane, small_e, small_o, pred, rs);
+      else s61_rate_ti(op, op.clv1, frag, op.codes2, l2, r, R, first, nb, lane, small_e, small_o, pred, rs);
     }
 
     if (scaling && rate_parallel)
@@ -501,7 +548,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_lnl_s61(ModelView mv, ParamIdx 
                                                          const unsigned * weights, const int * invariant,
                                                          const unsigned long long * tipmap,
                                                          unsigned N, unsigned nblk, unsigned R,
-                                                         double * persite, ReduceOut block_out)
+                                                         double * persite, ReduceOut block_out,
+                                                         unsigned rate_scalers)
 {
   extern __shared__ double frag[];
   __shared__ double scratch[4];
@@ -515,7 +563,13 @@ __global__ __launch_bounds__(256, 2) void k_edge_lnl_s61(ModelView mv, ParamIdx 
     const unsigned blk = tile * 4 + wave;
     const bool live = blk < nblk;
     const size_t site0 = (size_t)blk * S20_BS + 2 * n;
-    const SiteSide sd = load_site_side(ps, cs, weights, site0, N, q == 0 && blk < nblk);
+    SiteSide sd = load_site_side(rate_scalers ? nullptr : ps, rate_scalers ? nullptr : cs, weights, site0, N,
+                                 q == 0 && blk < nblk);
+    if (rate_scalers && live)
+    {
+      sd.cnt_e = rate_min_count(ps, cs, site0, R);
+      sd.cnt_o = rate_min_count(ps, cs, site0 + 1, R);
+    }
     unsigned cce = 0, cco = 0;
     unsigned long long pme = 0, pmo = 0;
     int inv_e = -1, inv_o = -1;
@@ -560,6 +614,11 @@ __global__ __launch_bounds__(256, 2) void k_edge_lnl_s61(ModelView mv, ParamIdx 
       }
       le = s20_sum_q(le);
       lo = s20_sum_q(lo);
+      if (rate_scalers)
+      {
+        le *= rate_factor(ps, cs, site0, R, r, sd.cnt_e);
+        lo *= rate_factor(ps, cs, site0 + 1, R, r, sd.cnt_o);
+      }
       const double pinv = mv.pinv()[fi], w = mv.weights()[r];
       if (pinv > 0.0)
       {
@@ -766,6 +825,7 @@ static int launch_partials_s61(Engine * e, const OpBatch & batch, unsigned nops)
   const bool rate_parallel = e->R > 1 && (env_rp >= 0 ? env_rp != 0 : e->nblk < slots * 4u * 8u);
   bool scaling = false;
   for (unsigned i = 0; i < nops; ++i) scaling |= batch.op[i].parent_scaler != nullptr;
+  if (e->rate_scalers) scaling = false;      // per-rate scalers: no votes, no predictions, no fix-up kernel
   if (rate_parallel && scaling && !e->d_s61_votes)
     PLLHIP_TRY(hipMalloc((void **)&e->d_s61_votes,
                          (size_t)MAX_OPS_PER_LAUNCH * e->R * e->nblk * S20_BS));
@@ -809,7 +869,8 @@ static int launch_partials_s61(Engine * e, const OpBatch & batch, unsigned nops)
   const unsigned per = (rate_parallel ? std::max(1u, slots / e->R) : slots) * (unsigned)std::max(1, env_mul);
   const unsigned gx = std::max(1u, std::min((e->nblk + 3) / 4, per));
   hipLaunchKernelGGL(k_partials_s61v3, dim3(gx, nops, rate_parallel ? e->R : 1u), dim3(256), lds, e->stream,
-                     batch, e->nblk, e->R, e->lut_codes, rate_parallel ? e->d_s61_votes : (uint8_t *)nullptr, preds);
+                     batch, e->nblk, e->R, e->lut_codes, rate_parallel ? e->d_s61_votes : (uint8_t *)nullptr, preds,
+                     e->rate_scalers ? 1u : 0u);
   PLLHIP_TRY(hipGetLastError());
   if (rate_parallel && scaling)
   {
@@ -827,7 +888,7 @@ static int launch_edge_lnl_s61(Engine * e, const ModelView & mv, const ParamIdx 
                                double * persite, unsigned nblocks)
 {
   static const int env_r4 = getenv("PLLHIP_S61_LNL_R4") ? atoi(getenv("PLLHIP_S61_LNL_R4")) : 1;
-  if (env_r4 && pm && !child.codes && e->R <= 4 && e->nblk)
+  if (env_r4 && pm && !child.codes && e->R <= 4 && e->nblk && !e->rate_scalers)
   {
     const size_t lds = sizeof(double) * ((size_t)e->R * S61_FRAGS + (size_t)e->R * 64);
     static bool attr_set_dev[64] = {false};        // per device: one process may drive several GPUs
@@ -850,7 +911,7 @@ static int launch_edge_lnl_s61(Engine * e, const ModelView & mv, const ParamIdx 
   hipLaunchKernelGGL(k_edge_lnl_s61, dim3(nblocks), dim3(256), lds, e->stream,
                      mv, fidx, parent, child, pm, lut, e->lut_codes, ps, cs,
                      e->d_weights, e->d_invariant, e->d_tipmap, e->N, e->nblk, e->R,
-                     persite, reduce_out(e));
+                     persite, reduce_out(e), e->rate_scalers ? 1u : 0u);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }
@@ -907,7 +968,8 @@ static int launch_derivatives_s61(Engine * e, const ModelView & mv, const ParamI
     }
   }
   hipLaunchKernelGGL((k_derivatives_mfma<S61_KS, S61_S>), dim3(nblocks), dim3(256), lds, e->stream,
-                     mv, params, tl, count, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, reduce_out(e), 0u);
+                     mv, params, tl, count, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, reduce_out(e),
+                     e->rate_scalers ? 1u : 0u);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

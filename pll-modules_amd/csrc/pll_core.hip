@@ -125,9 +125,9 @@ Engine * engine_create(pll_partition_t * p)
   const char * force = getenv("PLLHIP_FORCE_GENERIC");
   static const int no_s16 = getenv("PLLHIP_NO_S16") ? atoi(getenv("PLLHIP_NO_S16")) : 0;
   if (force && atoi(force)) e->family = KernelFamily::Generic;
-  // per-rate scalers: the 2..16-state family and the generic kernels carry them (the 4-, 20- and
-  // 61-state families vote per site)
-  else if (e->rate_scalers) e->family = (e->S <= 16 && !no_s16) ? KernelFamily::S16 : KernelFamily::Generic;
+  // per-rate scalers: every matrix-core family carries them (4 states go to the 2..16-state
+  // family: the VALU 4-state kernels vote per site)
+  else if (e->rate_scalers && e->S <= 16) e->family = no_s16 ? KernelFamily::Generic : KernelFamily::S16;
   else if (e->S == 4 && (e->R & (e->R - 1)) == 0) e->family = KernelFamily::S4;
   else if (e->S == 20 && e->R <= 8) e->family = KernelFamily::S20;
   else if (e->S == 61) e->family = KernelFamily::S61;
