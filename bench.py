@@ -54,9 +54,15 @@ def parse_args():
     ap.add_argument("--sites", type=int, default=0, help="override the per-configuration site count")
     ap.add_argument("--taxa", type=int, default=0)
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
+    ap.add_argument("--topology", default="ranks", choices=["ranks", "internal"],
+                    help="ranks: one process per GPU, lnL all-reduced over RCCL (the contract's launch); "
+                         "internal: ONE process, every partition spread over --gpus devices inside the engine "
+                         "(pllhip_set_sharding: what an unmodified single-treeinfo client gets)")
     ap.add_argument("--pmatrix-calls", default="per-branch", choices=["per-branch", "batched"],
                     help="per-branch = one pll_update_prob_matrices call per branch, as treeinfo issues "
                          "them (src/tree/treeinfo.c:845-865); batched = one call with count = 2n-3")
+    ap.add_argument("--rate-scalers", action="store_true",
+                    help="PLL_ATTRIB_RATE_SCALERS: one scaling count per (site, rate) instead of per site")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sites", type=int, default=0, help="sites of the CPU baseline sample")
     return ap.parse_args()
@@ -83,6 +89,9 @@ def partition_plan(config, states, nsites):
     return [(s, max(1, int(round(nsites * f)))) for s, f in C4_PARTS]
 
 
+ATTRIBUTES = 0      # extra pll_partition_create attributes of every partition (--rate-scalers)
+
+
 def make_evaluation(pc, lib, tree, plan, rate_cats, seed, per_branch, first_sites=None):
     """one Evaluation (C driver) over the partitions of `plan` = [(states, sites), ...];
     partition k holds sites first_sites[k] .. of the alignment that seed + 101 k defines"""
@@ -92,7 +101,8 @@ def make_evaluation(pc, lib, tree, plan, rate_cats, seed, per_branch, first_site
         subst, freqs, alpha = model_of(pc, states)
         codes = pc.random_codes(tree.ntips, nsites, states, seed + 101 * k,
                                 first_site=first_sites[k] if first_sites else 0)
-        insts.append(ev.add_partition(k, states, nsites, rate_cats, codes, subst, freqs, alpha, coded=True))
+        insts.append(ev.add_partition(k, states, nsites, rate_cats, codes, subst, freqs, alpha, coded=True,
+                                      attributes=ATTRIBUTES))
     return ev, insts
 
 
@@ -215,18 +225,28 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     in_rank_env = "RANK" in os.environ and "WORLD_SIZE" in os.environ
-    if args.gpus > 1 and not in_rank_env:
+    internal = args.topology == "internal" and args.gpus > 1
+    if internal:
+        import torch
+        if torch.cuda.device_count() < args.gpus and os.environ.get("PLLHIP_ALLOW_DEVICE_WRAP") != "1":
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible")
+    elif args.gpus > 1 and not in_rank_env:
         launch_ranks(args)                      # never returns
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    if internal:
+        rank, world, local_rank = 0, 1, 0
+    elif world != args.gpus:
         # never report a run of `world` ranks as a run of --gpus ranks
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if os.environ.get("PLLHIP_BENCH_LAUNCH_PROBE") == "1":
         return launch_probe(args, rank, world)
 
     import pllhip_ctypes as pc
+    global ATTRIBUTES
+    if args.rate_scalers:
+        ATTRIBUTES = pc.PLL_ATTRIB_RATE_SCALERS
     product = pc.PllLib(pc.PRODUCT_LIB)
     if product.lib.pllhip_device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible; the engine has no CPU fallback")
@@ -239,6 +259,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not product.lib.pllhip_set_device(local_rank):
+        raise SystemExit(product.errmsg)
+    if internal and not product.lib.pllhip_set_sharding(args.gpus, None):
         raise SystemExit(product.errmsg)
 
     states, rate_cats, ntips, nsites = pc.CONFIGS[args.config]
@@ -377,7 +399,9 @@ def main():
         product.lib.pllhip_comm_destroy(comm)
 
     cpu = parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if internal:
+        product.lib.pllhip_set_sharding(0, None)
+    if rank == 0 and world == 1 and not internal and not args.no_cpu_baseline:
         cpu, parity = cpu_baseline(pc, product, tree, args.config, states, rate_cats, local_sites,
                                    args.cpu_sites, per_branch)
 
@@ -393,7 +417,7 @@ def main():
         out = {
             "metric": "CLV site-updates/sec (sites x rates x edges); |dlnL| vs ref",
             "value": value, "unit": "CLV site-updates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": args.gpus if internal else world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
@@ -405,11 +429,14 @@ def main():
                 "config": args.config, "states": states, "rate_cats": rate_cats, "taxa": ntips,
                 "sites_total": total_sites, "sites_per_gpu": local_sites, "ops_per_step": nops,
                 "partitions": [{"states": s, "sites_per_gpu": n} for s, n in plan],
-                "tips": "1-byte codes", "scalers": "per-site, one per inner node",
+                "tips": "1-byte codes",
+                "scalers": ("per (site, rate)" if args.rate_scalers else "per-site") + ", one buffer per inner node",
                 "pmatrix_calls": args.pmatrix_calls,
                 "pmatrix_launches_per_step": counters.pmatrix_launches // evals,
                 "partial_launches_per_step": counters.partial_launches // evals,
-                "parallelism": f"sites sharded over {world} GPU(s), lnL all-reduced" if world > 1 else "1 GPU",
+                "parallelism": (f"one process, every partition spread over {args.gpus} devices inside the engine, "
+                                f"lnL summed on the host" if internal else
+                                f"sites sharded over {world} GPU(s), lnL all-reduced" if world > 1 else "1 GPU"),
             },
             # the same alignment at every N: the summed lnL must not depend on n_gpus
             "lnl": lnl, "lnl_per_site": lnl / total_sites,

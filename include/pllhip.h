@@ -52,6 +52,20 @@ PLL_EXPORT int pllhip_device_count(void);
 PLL_EXPORT int pllhip_set_device(int device);
 PLL_EXPORT int pllhip_get_device(void);
 
+/* ---- one partition over several GPUs (engine-internal sharding, SURVEY.md 8e topology i) ----
+ * Partitions created afterwards on this thread are split into `count` contiguous site ranges,
+ * one per device (devices[i]; NULL: device i modulo the visible ones): every device holds all
+ * nodes' CLVs of its range and a replica of the model; pll_update_partials /
+ * pll_update_prob_matrices / pll_update_sumtable fan out without communication, the scalar
+ * calls add the devices' sums on the host in a fixed order.  The caller -- an unmodified
+ * pll-modules client with ONE treeinfo and no parallel_reduce_cb -- sees one pll_partition_t.
+ * count <= 1 switches it off.  The environment variable PLLHIP_SHARD_DEVICES="0,1,2,3" does the
+ * same for clients that cannot call this.  Partitions with fewer than 64 sites per device, and
+ * partitions with ascertainment-bias correction, stay on one device. */
+PLL_EXPORT int pllhip_set_sharding(unsigned int count, const int * devices);
+/* number of devices `partition` is spread over (1: an ordinary partition) */
+PLL_EXPORT unsigned int pllhip_shard_count(const pll_partition_t * partition);
+
 /* gfx architecture name of a device, e.g. "gfx950" */
 PLL_EXPORT int pllhip_device_arch(int device, char * out, size_t out_len);
 

@@ -95,6 +95,11 @@ struct Engine
 {
   int device = 0;
   hipStream_t stream = nullptr;
+  // engine-internal sharding (include/pllhip.h, pllhip_set_sharding): a ROUTER owns no device
+  // memory; it forwards every call to its shards, ordinary partitions that each hold a
+  // contiguous site range on their own device
+  std::vector<pll_partition_t *> shards;
+  std::vector<unsigned> shard_first;   // first site of every shard (+ the total at the end)
 
   unsigned S = 0, Sp = 0, R = 0, N = 0;   // N: patterns the arrays hold (alignment + ascertainment-bias columns)
   unsigned Nreal = 0;                 // alignment patterns (= partition->sites); N - Nreal = S with AB, else 0
@@ -186,6 +191,13 @@ struct Engine
 };
 
 inline Engine * engine_of(const pll_partition_t * p) { return static_cast<Engine *>(p->engine); }
+inline bool is_router(const pll_partition_t * p) { return !engine_of(p)->shards.empty(); }
+// the engine that executes for `p`: its own, or the first shard's
+inline Engine * exec_engine(const pll_partition_t * p)
+{
+  Engine * e = engine_of(p);
+  return e->shards.empty() ? e : engine_of(e->shards[0]);
+}
 
 // --- host side model code (pll_model.cpp) ---
 int update_eigen_host(pll_partition_t * p, unsigned params_index);

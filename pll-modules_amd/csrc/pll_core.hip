@@ -56,6 +56,31 @@ static int current_device()
 int flush_pmatrices(pll_partition_t * p);
 static int ensure_luts(pll_partition_t * p);
 
+// ---------------------------------------------------------------------------
+// engine-internal sharding: which devices the partitions created next are spread over
+// ---------------------------------------------------------------------------
+static thread_local std::vector<int> g_shard_devices;
+static thread_local bool g_shard_devices_set = false;
+static thread_local bool g_building_shards = false;
+
+static std::vector<int> shard_devices()
+{
+  if (!g_shard_devices_set)
+  {
+    g_shard_devices_set = true;
+    if (const char * env = getenv("PLLHIP_SHARD_DEVICES"))
+      for (const char * c = env; *c; )
+      {
+        char * end = nullptr;
+        const long v = strtol(c, &end, 10);
+        if (end == c) break;
+        g_shard_devices.push_back((int)v);
+        c = (*end == ',') ? end + 1 : end;
+      }
+  }
+  return g_shard_devices;
+}
+
 static ModelView model_view(const Engine * e)
 {
   ModelView mv;
@@ -102,6 +127,52 @@ Engine * engine_create(pll_partition_t * p)
   {
     set_error(PLL_ERROR_HIP_NODEVICE, "HIP device %d requested, %d visible", dev, ndev);
     return nullptr;
+  }
+  // spread over several devices?  (not for the shards themselves, tiny partitions, or AB partitions:
+  // their correction needs the constant patterns and the total pattern weight in one place)
+  const std::vector<int> devs = g_building_shards ? std::vector<int>() : shard_devices();
+  if (devs.size() >= 2 && !p->asc_bias_alloc && p->sites >= 64u * devs.size())
+  {
+    Engine * r = new (std::nothrow) Engine();
+    if (!r) { set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate engine state"); return nullptr; }
+    r->device = dev;
+    r->S = p->states; r->Sp = p->states_padded; r->R = p->rate_cats; r->N = r->Nreal = p->sites;
+    r->tips = p->tips; r->nodes = p->nodes; r->nscalers = p->scale_buffers;
+    r->nmat = p->prob_matrices; r->nrm = p->rate_matrices;
+    r->coded_tips = (p->attributes & PLL_ATTRIB_PATTERN_TIP) != 0;
+    r->rate_scalers = (p->attributes & PLL_ATTRIB_RATE_SCALERS) != 0;
+    const unsigned K = (unsigned)devs.size();
+    const unsigned chunk = ((p->sites + K - 1) / K + S20_BS - 1) / S20_BS * S20_BS;   // whole 32-site blocks
+    const int saved = g_device;
+    g_building_shards = true;
+    bool ok = true;
+    for (unsigned k = 0; ok && k < K; ++k)
+    {
+      const unsigned first = std::min(p->sites, k * chunk), last = std::min(p->sites, (k + 1) * chunk);
+      if (first == last) break;
+      if (devs[k] < 0 || devs[k] % ndev != devs[k]) { /* wrap: lets a test shard over one visible device */ }
+      g_device = ((devs[k] % ndev) + ndev) % ndev;
+      pll_partition_t * c = pll_partition_create(p->tips, p->clv_buffers, p->states, last - first, p->rate_matrices,
+                                                 p->prob_matrices, p->rate_cats, p->scale_buffers,
+                                                 p->attributes & ~PLLHIP_ATTRIB_HOST_MIRRORS);
+      ok = c != nullptr;
+      if (ok) { r->shards.push_back(c); r->shard_first.push_back(first); }
+    }
+    g_building_shards = false;
+    g_device = saved;
+    if (!ok || r->shards.size() < 2)
+    {
+      for (pll_partition_t * c : r->shards) pll_partition_destroy(c);
+      delete r;
+      if (!ok) return nullptr;
+    }
+    else
+    {
+      r->shard_first.push_back(p->sites);
+      r->family = engine_of(r->shards[0])->family;
+      p->engine = r;
+      return r;
+    }
   }
   if (!hip_ok(hipSetDevice(dev), "hipSetDevice")) return nullptr;
 
@@ -221,6 +292,12 @@ Engine * engine_create(pll_partition_t * p)
 void engine_destroy(Engine * e)
 {
   if (!e) return;
+  if (!e->shards.empty())
+  {
+    for (pll_partition_t * c : e->shards) pll_partition_destroy(c);
+    delete e;
+    return;
+  }
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (double * ptr : e->d_clv) if (ptr) (void)hipFree(ptr);
@@ -247,10 +324,35 @@ void engine_destroy(Engine * e)
   delete e;
 }
 
+// the small model arrays of a sharded partition live in the parent (the caller writes them
+// there); every routed call that depends on them copies them to the shards first
+static void push_model(const pll_partition_t * p, pll_partition_t * c)
+{
+  const size_t S = p->states, Sp = p->states_padded;
+  memcpy(c->rates, p->rates, sizeof(double) * p->rate_cats);
+  memcpy(c->rate_weights, p->rate_weights, sizeof(double) * p->rate_cats);
+  memcpy(c->prop_invar, p->prop_invar, sizeof(double) * p->rate_matrices);
+  memcpy(c->eigen_decomp_valid, p->eigen_decomp_valid, sizeof(int) * p->rate_matrices);
+  for (unsigned m = 0; m < p->rate_matrices; ++m)
+  {
+    memcpy(c->frequencies[m], p->frequencies[m], sizeof(double) * Sp);
+    memcpy(c->subst_params[m], p->subst_params[m], sizeof(double) * S * (S - 1) / 2);
+    memcpy(c->eigenvals[m], p->eigenvals[m], sizeof(double) * Sp);
+    memcpy(c->eigenvecs[m], p->eigenvecs[m], sizeof(double) * S * Sp);
+    memcpy(c->inv_eigenvecs[m], p->inv_eigenvecs[m], sizeof(double) * S * Sp);
+  }
+}
+
 int upload_weights(pll_partition_t * p)
 {
   Engine * e = engine_of(p);
   if (!e) return PLL_SUCCESS;   // called from the constructor before the engine exists
+  if (!e->shards.empty())
+  {
+    for (size_t k = 0; k < e->shards.size(); ++k)
+      pll_set_pattern_weights(e->shards[k], p->pattern_weights + e->shard_first[k]);
+    return PLL_SUCCESS;
+  }
   PLLHIP_TRY(hipSetDevice(e->device));
   // the ascertainment-bias columns weigh nothing in the sums over the alignment: their part of
   // the likelihood is the correction the host applies (the host array keeps their state weights)
@@ -278,6 +380,21 @@ static int upload_tipmap(pll_partition_t * p)
 int upload_tip_codes(pll_partition_t * p, unsigned tip)
 {
   Engine * e = engine_of(p);
+  if (!e->shards.empty())
+  {
+    // the shards take the parent's codes and code table as they are (a checkpoint loader wrote them)
+    for (size_t k = 0; k < e->shards.size(); ++k)
+    {
+      pll_partition_t * c = e->shards[k];
+      memcpy(c->tipchars[tip], p->tipchars[tip] + e->shard_first[k], c->sites);
+      memcpy(c->tipmap, p->tipmap, sizeof(pll_state_t) * PLL_ASCII_SIZE);
+      memcpy(c->charmap, p->charmap, PLL_ASCII_SIZE);
+      if (c->maxstates != p->maxstates) { c->maxstates = p->maxstates; invalidate_luts(c); }
+      engine_of(c)->tipmap_codes_uploaded = ~0u;
+      if (!upload_tip_codes(c, tip)) return PLL_FAILURE;
+    }
+    return PLL_SUCCESS;
+  }
   PLLHIP_TRY(hipSetDevice(e->device));
   if (e->N)
     PLLHIP_TRY(hipMemcpyAsync(e->d_codes[tip], p->tipchars[tip], (size_t)e->N,
@@ -337,6 +454,12 @@ static int fetch_clv(Engine * e, const double * d_src, double * host_out)
 int upload_tip_clv(pll_partition_t * p, unsigned tip, const double * host_clv)
 {
   Engine * e = engine_of(p);
+  if (!e->shards.empty())
+  {
+    for (size_t k = 0; k < e->shards.size(); ++k)
+      if (!upload_tip_clv(e->shards[k], tip, host_clv + (size_t)e->shard_first[k] * e->R * e->Sp)) return PLL_FAILURE;
+    return PLL_SUCCESS;
+  }
   PLLHIP_TRY(hipSetDevice(e->device));
   return store_clv(e, e->d_clv[tip], host_clv);
 }
@@ -345,6 +468,7 @@ void invalidate_luts(pll_partition_t * p)
 {
   Engine * e = engine_of(p);
   if (e) e->lut_stale = true;
+  if (e) for (pll_partition_t * c : e->shards) invalidate_luts(c);
 }
 
 // host model arrays -> device if anything changed since the last call
@@ -1064,6 +1188,86 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
 
 } // namespace pllhip
 
+namespace pllhip {
+
+// ---------------------------------------------------------------------------
+// router: a partition spread over several devices (Engine::shards)
+// ---------------------------------------------------------------------------
+// where a shard's next reduction leaves its totals: its own mapped result buffer
+static Engine::Sink shard_sink(Engine * c)
+{
+  Engine::Sink sk;
+  sk.dst = c->d_result;
+  sk.flag = reinterpret_cast<unsigned long long *>(c->d_result) + RESULT_SEQ_SLOT;
+  sk.seq = ++c->result_seq;
+  sk.nq = 0;
+  return sk;
+}
+
+static int shard_wait(Engine * c, unsigned long long seq)
+{
+  const volatile unsigned long long * flag =
+      reinterpret_cast<const volatile unsigned long long *>(c->h_result) + RESULT_SEQ_SLOT;
+  return wait_sequence(c->stream, flag, seq);
+}
+
+// every shard's kernel is enqueued (all devices run at once), then the totals are collected and
+// added in shard order: bit-reproducible, whatever the devices' finishing order
+static double router_loglikelihood(pll_partition_t * p, unsigned pc, int psc, unsigned cc, int csc,
+                                   int matrix_index, const unsigned * freqs_indices, double * persite_lnl)
+{
+  Engine * r = engine_of(p);
+  const double fail = -std::numeric_limits<double>::infinity();
+  std::vector<unsigned long long> seq(r->shards.size());
+  for (size_t k = 0; k < r->shards.size(); ++k)
+  {
+    pll_partition_t * c = r->shards[k];
+    push_model(p, c);
+    Engine::Sink sk = shard_sink(engine_of(c));
+    seq[k] = sk.seq;
+    const double v = loglikelihood_impl(c, pc, psc, cc, csc, matrix_index, freqs_indices,
+                                        persite_lnl ? persite_lnl + r->shard_first[k] : nullptr, &sk);
+    if (v != 0.0) return fail;
+  }
+  double total = 0.0;
+  for (size_t k = 0; k < r->shards.size(); ++k)
+  {
+    Engine * c = engine_of(r->shards[k]);
+    if (hipSetDevice(c->device) != hipSuccess || !shard_wait(c, seq[k])) return fail;
+    if (persite_lnl && !hip_ok(hipStreamSynchronize(c->stream), "persite sync")) return fail;
+    total += c->h_result[0];
+  }
+  return total;
+}
+
+static int router_derivatives(pll_partition_t * p, int psc, int csc, const double * brlens, unsigned count,
+                              const unsigned * params_indices, const double * sumtable,
+                              double * out_df, double * out_ddf)
+{
+  Engine * r = engine_of(p);
+  std::vector<unsigned long long> seq(r->shards.size());
+  for (size_t k = 0; k < r->shards.size(); ++k)
+  {
+    pll_partition_t * c = r->shards[k];
+    push_model(p, c);
+    Engine::Sink sk = shard_sink(engine_of(c));
+    seq[k] = sk.seq;
+    if (!derivatives_impl(c, psc, csc, brlens, count, params_indices, sumtable, &sk, nullptr, nullptr))
+      return PLL_FAILURE;
+  }
+  for (unsigned i = 0; i < count; ++i) out_df[i] = out_ddf[i] = 0.0;
+  for (size_t k = 0; k < r->shards.size(); ++k)
+  {
+    Engine * c = engine_of(r->shards[k]);
+    PLLHIP_TRY(hipSetDevice(c->device));
+    if (!shard_wait(c, seq[k])) return PLL_FAILURE;
+    for (unsigned i = 0; i < count; ++i) { out_df[i] += c->h_result[2 * i]; out_ddf[i] += c->h_result[2 * i + 1]; }
+  }
+  return PLL_SUCCESS;
+}
+
+} // namespace pllhip
+
 using namespace pllhip;
 
 // ===========================================================================
@@ -1078,6 +1282,17 @@ int pll_update_prob_matrices(pll_partition_t * p,
                              unsigned int count)
 {
   Engine * e = engine_of(p);
+  if (!e->shards.empty())
+  {
+    // the decomposition runs once, on the parent's arrays; every shard builds the (tiny) matrices itself
+    if (!ensure_eigen(p, params_indices)) return PLL_FAILURE;
+    for (pll_partition_t * c : e->shards)
+    {
+      push_model(p, c);
+      if (!pll_update_prob_matrices(c, params_indices, matrix_indices, branch_lengths, count)) return PLL_FAILURE;
+    }
+    return PLL_SUCCESS;
+  }
   PLLHIP_TRY(hipSetDevice(e->device));
   if (!ensure_eigen(p, params_indices)) return PLL_FAILURE;
   if (!sync_model(p)) return PLL_FAILURE;
@@ -1116,6 +1331,11 @@ void pll_update_partials(pll_partition_t * p, const pll_operation_t * ops, unsig
 {
   if (!count) return;
   // void in the reference interface: errors are reported through pll_errno
+  if (is_router(p))
+  {
+    for (pll_partition_t * c : engine_of(p)->shards) (void)update_partials_impl(c, ops, count);
+    return;
+  }
   (void)update_partials_impl(p, ops, count);
 }
 
@@ -1192,7 +1412,15 @@ double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsigned cc
   if (!rc) return fail;
   double total = 0.0;
   e->counters.lnl_calls++;
-  if (deferred) return finish_launch(e, nblocks, 1) ? 0.0 : fail;
+  if (deferred)
+  {
+    if (!finish_launch(e, nblocks, 1)) return fail;
+    // (the caller waits for the stream before it reads a per-site buffer)
+    if (ps_out_req && e->Nreal &&
+        !hip_ok(hipMemcpyAsync(ps_out_req, e->d_persite, sizeof(double) * e->Nreal, hipMemcpyDeviceToHost, e->stream),
+                "persite copy")) return fail;
+    return 0.0;
+  }
   if (asc)
   {
     if (!finish_launch(e, nblocks, 1)) return fail;
@@ -1330,6 +1558,9 @@ double pll_compute_edge_loglikelihood(pll_partition_t * p,
                                       const unsigned int * freqs_indices,
                                       double * persite_lnl)
 {
+  if (is_router(p))
+    return router_loglikelihood(p, parent_clv_index, parent_scaler_index, child_clv_index,
+                                child_scaler_index, (int)matrix_index, freqs_indices, persite_lnl);
   return loglikelihood_impl(p, parent_clv_index, parent_scaler_index, child_clv_index,
                             child_scaler_index, (int)matrix_index, freqs_indices, persite_lnl, nullptr);
 }
@@ -1337,6 +1568,8 @@ double pll_compute_edge_loglikelihood(pll_partition_t * p,
 double pll_compute_root_loglikelihood(pll_partition_t * p, unsigned int clv_index, int scaler_index,
                                       const unsigned int * freqs_indices, double * persite_lnl)
 {
+  if (is_router(p))
+    return router_loglikelihood(p, clv_index, scaler_index, 0, PLL_SCALE_BUFFER_NONE, -1, freqs_indices, persite_lnl);
   return loglikelihood_impl(p, clv_index, scaler_index, 0, PLL_SCALE_BUFFER_NONE, -1,
                             freqs_indices, persite_lnl, nullptr);
 }
@@ -1347,6 +1580,18 @@ int pll_update_sumtable(pll_partition_t * p,
                         const unsigned int * params_indices, double * sumtable)
 {
   Engine * e = engine_of(p);
+  if (!e->shards.empty())
+  {
+    if (!ensure_eigen(p, params_indices)) return PLL_FAILURE;
+    for (pll_partition_t * c : e->shards)
+    {
+      push_model(p, c);
+      if (!pll_update_sumtable(c, parent_clv_index, child_clv_index, parent_scaler_index, child_scaler_index,
+                               params_indices, sumtable))
+        return PLL_FAILURE;
+    }
+    return PLL_SUCCESS;
+  }
   PLLHIP_TRY(hipSetDevice(e->device));
   if (!check_clv_index(e, parent_clv_index, "parent") || !check_clv_index(e, child_clv_index, "child") ||
       !check_scaler_index(e, parent_scaler_index) || !check_scaler_index(e, child_scaler_index))
@@ -1385,13 +1630,36 @@ int pll_compute_likelihood_derivatives(pll_partition_t * p,
                                        const unsigned int * params_indices,
                                        const double * sumtable, double * d_f, double * dd_f)
 {
+  if (is_router(p))
+    return router_derivatives(p, parent_scaler_index, child_scaler_index, &branch_length, 1, params_indices,
+                              sumtable, d_f, dd_f);
   return derivatives_impl(p, parent_scaler_index, child_scaler_index, &branch_length, 1, params_indices,
                           sumtable, nullptr, d_f, dd_f);
 }
 
 unsigned int pllhip_free_trial_lengths(const pll_partition_t * p)
 {
-  return engine_of(p)->blocked ? 4u : 1u;
+  return exec_engine(p)->blocked ? 4u : 1u;
+}
+
+int pllhip_set_sharding(unsigned int count, const int * devices)
+{
+  g_shard_devices.clear();
+  g_shard_devices_set = true;
+  if (count <= 1) return PLL_SUCCESS;
+  const int n = pllhip_device_count();
+  if (n < 1)
+  {
+    set_error(PLL_ERROR_HIP_NODEVICE, "No HIP device available");
+    return PLL_FAILURE;
+  }
+  for (unsigned k = 0; k < count; ++k) g_shard_devices.push_back(devices ? devices[k] : (int)(k % (unsigned)n));
+  return PLL_SUCCESS;
+}
+
+unsigned int pllhip_shard_count(const pll_partition_t * p)
+{
+  return is_router(p) ? (unsigned)engine_of(p)->shards.size() : 1u;
 }
 
 int pllhip_compute_likelihood_derivatives_multi(pll_partition_t * p,
@@ -1400,6 +1668,16 @@ int pllhip_compute_likelihood_derivatives_multi(pll_partition_t * p,
                                                 const unsigned int * params_indices,
                                                 const double * sumtable, double * d_f, double * dd_f)
 {
+  if (is_router(p))
+  {
+    if (!count || count > MAX_TRIAL_LENGTHS)
+    {
+      set_error(PLL_ERROR_PARAM_INVALID, "1 to %u trial branch lengths per call", MAX_TRIAL_LENGTHS);
+      return PLL_FAILURE;
+    }
+    return router_derivatives(p, parent_scaler_index, child_scaler_index, branch_lengths, count, params_indices,
+                              sumtable, d_f, dd_f);
+  }
   return derivatives_impl(p, parent_scaler_index, child_scaler_index, branch_lengths, count, params_indices,
                           sumtable, nullptr, d_f, dd_f);
 }
@@ -1407,6 +1685,17 @@ int pllhip_compute_likelihood_derivatives_multi(pll_partition_t * p,
 int pll_update_invariant_sites(pll_partition_t * p)
 {
   Engine * e = engine_of(p);
+  if (!e->shards.empty())
+  {
+    if (!p->invariant) p->invariant = static_cast<int *>(malloc(sizeof(int) * (p->sites ? p->sites : 1)));
+    if (!p->invariant) { set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate invariant sites array"); return PLL_FAILURE; }
+    for (size_t k = 0; k < e->shards.size(); ++k)
+    {
+      if (!pll_update_invariant_sites(e->shards[k])) return PLL_FAILURE;
+      memcpy(p->invariant + e->shard_first[k], e->shards[k]->invariant, sizeof(int) * e->shards[k]->sites);
+    }
+    return PLL_SUCCESS;
+  }
   PLLHIP_TRY(hipSetDevice(e->device));
   if (!upload_tipmap(p)) return PLL_FAILURE;
   if (!p->invariant)
@@ -1446,6 +1735,18 @@ int pll_compute_node_ancestral(pll_partition_t * p, unsigned int node_clv_index,
                                double * ancestral)
 {
   Engine * e = engine_of(p);
+  if (!e->shards.empty())
+  {
+    for (size_t k = 0; k < e->shards.size(); ++k)
+    {
+      push_model(p, e->shards[k]);
+      if (!pll_compute_node_ancestral(e->shards[k], node_clv_index, node_scaler_index, other_clv_index,
+                                      other_scaler_index, matrix_index, freqs_indices,
+                                      ancestral + (size_t)e->shard_first[k] * e->S))
+        return PLL_FAILURE;
+    }
+    return PLL_SUCCESS;
+  }
   PLLHIP_TRY(hipSetDevice(e->device));
   if (!check_clv_index(e, node_clv_index, "node") || !check_clv_index(e, other_clv_index, "other") ||
       !check_scaler_index(e, node_scaler_index) || !check_scaler_index(e, other_scaler_index))
@@ -1509,16 +1810,28 @@ int pllhip_device_arch(int device, char * out, size_t out_len)
 int pllhip_synchronize(pll_partition_t * p)
 {
   Engine * e = engine_of(p);
+  if (!e->shards.empty())
+  {
+    for (pll_partition_t * c : e->shards) if (!pllhip_synchronize(c)) return PLL_FAILURE;
+    return PLL_SUCCESS;
+  }
   PLLHIP_TRY(hipSetDevice(e->device));
   PLLHIP_TRY(hipStreamSynchronize(e->stream));
   return PLL_SUCCESS;
 }
 
-void * pllhip_stream(pll_partition_t * p) { return engine_of(p)->stream; }
+void * pllhip_stream(pll_partition_t * p) { return exec_engine(p)->stream; }
 
 int pllhip_get_clv(pll_partition_t * p, unsigned int clv_index, double * out)
 {
   Engine * e = engine_of(p);
+  if (!e->shards.empty())
+  {
+    // API layout is site-major: a shard's vector is a contiguous piece of the whole
+    for (size_t k = 0; k < e->shards.size(); ++k)
+      if (!pllhip_get_clv(e->shards[k], clv_index, out + (size_t)e->shard_first[k] * e->R * e->Sp)) return PLL_FAILURE;
+    return PLL_SUCCESS;
+  }
   PLLHIP_TRY(hipSetDevice(e->device));
   if (!check_clv_index(e, clv_index, "requested")) return PLL_FAILURE;
   const size_t len = (size_t)e->N * e->R * e->Sp;
@@ -1541,6 +1854,12 @@ int pllhip_get_clv(pll_partition_t * p, unsigned int clv_index, double * out)
 int pllhip_set_clv(pll_partition_t * p, unsigned int clv_index, const double * clv)
 {
   Engine * e = engine_of(p);
+  if (!e->shards.empty())
+  {
+    for (size_t k = 0; k < e->shards.size(); ++k)
+      if (!pllhip_set_clv(e->shards[k], clv_index, clv + (size_t)e->shard_first[k] * e->R * e->Sp)) return PLL_FAILURE;
+    return PLL_SUCCESS;
+  }
   PLLHIP_TRY(hipSetDevice(e->device));
   if (!check_clv_index(e, clv_index, "target")) return PLL_FAILURE;
   if (clv_index < e->tips && e->coded_tips)
@@ -1554,6 +1873,13 @@ int pllhip_set_clv(pll_partition_t * p, unsigned int clv_index, const double * c
 int pllhip_get_scaler(pll_partition_t * p, unsigned int idx, unsigned int * out)
 {
   Engine * e = engine_of(p);
+  if (!e->shards.empty())
+  {
+    const size_t per = e->rate_scalers ? e->R : 1;
+    for (size_t k = 0; k < e->shards.size(); ++k)
+      if (!pllhip_get_scaler(e->shards[k], idx, out + (size_t)e->shard_first[k] * per)) return PLL_FAILURE;
+    return PLL_SUCCESS;
+  }
   PLLHIP_TRY(hipSetDevice(e->device));
   if (idx >= e->nscalers) { set_error(PLL_ERROR_PARAM_INVALID, "scaler index out of range"); return PLL_FAILURE; }
   if (!e->N) return PLL_SUCCESS;
@@ -1567,6 +1893,13 @@ int pllhip_get_scaler(pll_partition_t * p, unsigned int idx, unsigned int * out)
 int pllhip_set_scaler(pll_partition_t * p, unsigned int idx, const unsigned int * in)
 {
   Engine * e = engine_of(p);
+  if (!e->shards.empty())
+  {
+    const size_t per = e->rate_scalers ? e->R : 1;
+    for (size_t k = 0; k < e->shards.size(); ++k)
+      if (!pllhip_set_scaler(e->shards[k], idx, in + (size_t)e->shard_first[k] * per)) return PLL_FAILURE;
+    return PLL_SUCCESS;
+  }
   PLLHIP_TRY(hipSetDevice(e->device));
   if (idx >= e->nscalers) { set_error(PLL_ERROR_PARAM_INVALID, "scaler index out of range"); return PLL_FAILURE; }
   if (!e->N) return PLL_SUCCESS;
@@ -1580,6 +1913,12 @@ int pllhip_set_scaler(pll_partition_t * p, unsigned int idx, const unsigned int 
 int pllhip_get_sumtable(pll_partition_t * p, const double * key, double * out)
 {
   Engine * e = engine_of(p);
+  if (!e->shards.empty())
+  {
+    for (size_t k = 0; k < e->shards.size(); ++k)
+      if (!pllhip_get_sumtable(e->shards[k], key, out + (size_t)e->shard_first[k] * e->R * e->Sp)) return PLL_FAILURE;
+    return PLL_SUCCESS;
+  }
   PLLHIP_TRY(hipSetDevice(e->device));
   double * d_sum = sumtable_device(e, key, false);
   if (!d_sum) { set_error(PLL_ERROR_PARAM_INVALID, "unknown sumtable key"); return PLL_FAILURE; }
@@ -1589,7 +1928,15 @@ int pllhip_get_sumtable(pll_partition_t * p, const double * key, double * out)
 int pllhip_sync_to_host(pll_partition_t * p, unsigned int what)
 {
   Engine * e = engine_of(p);
-  PLLHIP_TRY(hipSetDevice(e->device));
+  if (!e->shards.empty() && (what & PLLHIP_SYNC_PMATRIX) && e->nmat)
+  {
+    // every shard holds the same matrices: the first one's mirror is the partition's
+    pll_partition_t * c = e->shards[0];
+    if (!pllhip_sync_to_host(c, PLLHIP_SYNC_PMATRIX)) return PLL_FAILURE;
+    memcpy(p->pmatrix[0], c->pmatrix[0], sizeof(double) * (size_t)e->nmat * e->R * e->S * e->Sp);
+    what &= ~(unsigned)PLLHIP_SYNC_PMATRIX;
+  }
+  if (e->shards.empty()) PLLHIP_TRY(hipSetDevice(e->device));
   if ((what & PLLHIP_SYNC_PMATRIX) && e->pmat_host_dirty && e->nmat)
   {
     if (!flush_pmatrices(p)) return PLL_FAILURE;
@@ -1627,7 +1974,18 @@ int pllhip_sync_to_host(pll_partition_t * p, unsigned int what)
 int pllhip_sync_to_device(pll_partition_t * p, unsigned int what)
 {
   Engine * e = engine_of(p);
-  PLLHIP_TRY(hipSetDevice(e->device));
+  if (!e->shards.empty() && (what & PLLHIP_SYNC_PMATRIX) && e->nmat)
+  {
+    for (pll_partition_t * c : e->shards)
+    {
+      memcpy(c->pmatrix[0], p->pmatrix[0], sizeof(double) * (size_t)e->nmat * e->R * e->S * e->Sp);
+      if (!pllhip_sync_to_device(c, PLLHIP_SYNC_PMATRIX)) return PLL_FAILURE;
+    }
+    what &= ~(unsigned)PLLHIP_SYNC_PMATRIX;
+  }
+  if (!e->shards.empty())
+    for (pll_partition_t * c : e->shards) push_model(p, c);     // a loader filled the parent's model arrays
+  if (e->shards.empty()) PLLHIP_TRY(hipSetDevice(e->device));
   if (what & PLLHIP_SYNC_TIPS)
   {
     if (e->coded_tips)
@@ -1674,18 +2032,21 @@ int pllhip_sync_to_device(pll_partition_t * p, unsigned int what)
 
 int pllhip_get_counters(const pll_partition_t * p, pllhip_counters_t * out)
 {
-  *out = engine_of(p)->counters;
+  // a sharded partition reports its first shard: every shard does the same calls on its share of the sites
+  *out = exec_engine(p)->counters;
   return PLL_SUCCESS;
 }
 
 void pllhip_reset_counters(pll_partition_t * p)
 {
   engine_of(p)->counters = pllhip_counters_t{};
+  for (pll_partition_t * c : engine_of(p)->shards) engine_of(c)->counters = pllhip_counters_t{};
 }
 
 int pllhip_profile_partials(pll_partition_t * p, int enable)
 {
   Engine * e = engine_of(p);
+  for (pll_partition_t * c : e->shards) (void)pllhip_profile_partials(c, enable);
   e->profiling = enable != 0;
   e->prof_used = 0;
   e->prof_bytes = 0.0;
@@ -1697,6 +2058,22 @@ int pllhip_profile_partials(pll_partition_t * p, int enable)
 int pllhip_profile_read(pll_partition_t * p, pllhip_profile_t * out)
 {
   Engine * e = engine_of(p);
+  if (!e->shards.empty())
+  {
+    // bytes and flops add up over the shards; the devices run side by side, so the time is the slowest shard's
+    memset(out, 0, sizeof(*out));
+    for (pll_partition_t * c : e->shards)
+    {
+      pllhip_profile_t one;
+      if (!pllhip_profile_read(c, &one)) return PLL_FAILURE;
+      out->launches = one.launches;
+      out->ops = one.ops;
+      out->kernel_ms = std::max(out->kernel_ms, one.kernel_ms);
+      out->algorithmic_bytes += one.algorithmic_bytes;
+      out->algorithmic_flops += one.algorithmic_flops;
+    }
+    return PLL_SUCCESS;
+  }
   PLLHIP_TRY(hipSetDevice(e->device));
   PLLHIP_TRY(hipStreamSynchronize(e->stream));
   double ms = 0.0;
@@ -1720,7 +2097,7 @@ int pllhip_profile_read(pll_partition_t * p, pllhip_profile_t * out)
 
 const char * pllhip_partials_kernel_name(const pll_partition_t * p)
 {
-  switch (engine_of(p)->family)
+  switch (exec_engine(p)->family)
   {
     case KernelFamily::S4: return "s4-valu";
     case KernelFamily::S20: return "s20-mfma";

@@ -112,7 +112,8 @@ __global__ void k_deposit_values(double * dst, HostValues hv, unsigned n, unsign
 
 static int deposit_host_values(pll_partition_t * p, const Engine::Sink & sink, const double * v, unsigned n)
 {
-  Engine * e = engine_of(p);
+  Engine * e = exec_engine(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
   HostValues hv;
   memset(&hv, 0, sizeof(hv));
   for (unsigned i = 0; i < n; ++i) hv.v[i] = v[i];
@@ -247,7 +248,7 @@ static int results_sink(pllhip_results_t * rs, pll_partition_t * p, unsigned slo
     set_error(PLL_ERROR_PARAM_INVALID, "result slots %u..%u out of range (%u)", slot, slot + n, rs->nslots);
     return PLL_FAILURE;
   }
-  Engine * e = engine_of(p);
+  Engine * e = exec_engine(p);
   if (e->device != rs->device)
   {
     set_error(PLL_ERROR_PARAM_INVALID, "partition on device %d, result group on device %d", e->device, rs->device);
@@ -288,10 +289,12 @@ int pllhip_results_edge_loglikelihood(pllhip_results_t * rs, unsigned int slot, 
 {
   Engine::Sink sink;
   if (!results_sink(rs, p, slot, 1, &sink)) return PLL_FAILURE;
-  if (p->asc_bias_alloc)
+  if (p->asc_bias_alloc || is_router(p))
   {
-    const double v = loglikelihood_impl(p, parent_clv_index, parent_scaler_index, child_clv_index,
-                                        child_scaler_index, (int)matrix_index, freqs_indices, nullptr, nullptr);
+    // the scalar is host arithmetic here (ascertainment-bias correction; sum over the shards of
+    // a partition spread over several devices): the blocking form, then the value into the slot
+    const double v = pll_compute_edge_loglikelihood(p, parent_clv_index, parent_scaler_index, child_clv_index,
+                                                    child_scaler_index, matrix_index, freqs_indices, nullptr);
     if (!std::isfinite(v) && pll_errno) return PLL_FAILURE;
     return deposit_host_values(p, sink, &v, 1);
   }
@@ -307,11 +310,11 @@ int pllhip_results_derivatives(pllhip_results_t * rs, unsigned int slot, pll_par
 {
   Engine::Sink sink;
   if (count > MAX_TRIAL_LENGTHS || !results_sink(rs, p, slot, 2 * count, &sink)) return PLL_FAILURE;
-  if (p->asc_bias_alloc)
+  if (p->asc_bias_alloc || is_router(p))
   {
     double df[MAX_TRIAL_LENGTHS], ddf[MAX_TRIAL_LENGTHS], v[2 * MAX_TRIAL_LENGTHS];
-    if (!derivatives_impl(p, parent_scaler_index, child_scaler_index, branch_lengths, count, params_indices,
-                          sumtable, nullptr, df, ddf))
+    if (!pllhip_compute_likelihood_derivatives_multi(p, parent_scaler_index, child_scaler_index, branch_lengths,
+                                                     count, params_indices, sumtable, df, ddf))
       return PLL_FAILURE;
     for (unsigned i = 0; i < count; ++i) { v[2 * i] = df[i]; v[2 * i + 1] = ddf[i]; }
     return deposit_host_values(p, sink, v, 2 * count);

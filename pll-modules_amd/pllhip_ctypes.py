@@ -135,7 +135,8 @@ pllhip_get_scaler pllhip_get_sumtable pllhip_set_clv pllhip_set_scaler pllhip_sy
 pllhip_stream pllhip_get_counters pllhip_reset_counters pllhip_partials_kernel_name
 pllhip_comm_get_unique_id pllhip_comm_create pllhip_comm_destroy pllhip_reduce_cb
 pllhip_profile_partials pllhip_profile_read pllhip_comm_rank pllhip_comm_size
-pllhip_compute_likelihood_derivatives_multi pllhip_free_trial_lengths pllhip_results_create pllhip_results_destroy
+pllhip_compute_likelihood_derivatives_multi pllhip_free_trial_lengths pllhip_set_sharding
+pllhip_shard_count pllhip_results_create pllhip_results_destroy
 pllhip_results_edge_loglikelihood pllhip_results_derivatives pllhip_results_fetch
 pllhip_eval_attach_comm""".split()
 
@@ -269,6 +270,9 @@ class PllLib:
             L.pllhip_comm_destroy.argtypes = [C.c_void_p]
             L.pllhip_reduce_cb.restype = None
             L.pllhip_reduce_cb.argtypes = [C.c_void_p, c_double_p, C.c_size_t, C.c_int]
+            L.pllhip_set_sharding.argtypes = [C.c_uint, C.POINTER(C.c_int)]
+            L.pllhip_shard_count.argtypes = [pp]
+            L.pllhip_shard_count.restype = C.c_uint
             L.pllhip_comm_rank.argtypes = [C.c_void_p]
             L.pllhip_comm_size.argtypes = [C.c_void_p]
             L.pllhip_eval_attach_comm.argtypes = [C.c_void_p, C.c_void_p]
@@ -740,9 +744,10 @@ class Evaluation:
             raise RuntimeError(lib.errmsg)
         self.parts = []
 
-    def add_partition(self, index, states, nsites, rate_cats, codes, subst, freqs, alpha, coded=True):
+    def add_partition(self, index, states, nsites, rate_cats, codes, subst, freqs, alpha, coded=True,
+                      attributes=0):
         inst = Instance(self.lib, self.ntips, states, nsites, rate_cats,
-                        attributes=PLL_ATTRIB_PATTERN_TIP if coded else 0)
+                        attributes=(PLL_ATTRIB_PATTERN_TIP if coded else 0) | attributes)
         rates = self.lib.gamma_cats(alpha, rate_cats) if rate_cats > 1 else np.ones(1)
         inst.set_model(subst, freqs, rates)
         cmap = state_charmap(states)

@@ -207,3 +207,80 @@ def test_c_driver_across_two_processes_on_one_gpu(tmp_path):
         d = tmp_path / mode
         d.mkdir()
         check_driver_ranks(_run_driver_workers("product", mode, d))
+
+
+@pytest.mark.parametrize("states,nshards", [(20, 3), (4, 2), (61, 2), (10, 4)])
+def test_partition_spread_over_devices(product, states, nshards):
+    """engine-internal sharding (include/pllhip.h: pllhip_set_sharding; SURVEY.md 8e topology i): ONE
+    pll_partition_t whose sites are split into contiguous ranges, one engine per range -- on a node
+    with several GPUs one per device, here all on device 0.  Everything a caller can observe must
+    be what the unsharded partition gives (sums differ in their grouping only)."""
+    L = product.lib
+    nsites = 1000 if states <= 20 else 400
+    kw = dict(states=states, rate_cats=4, ntips=9, nsites=nsites, coded=True, pinv=0.1)
+    plain = pc.build_instance(product, **kw)
+    assert L.pllhip_set_sharding(nshards, None)
+    try:
+        shard = pc.build_instance(product, **kw, tree=plain.tree)
+    finally:
+        assert L.pllhip_set_sharding(0, None)
+    with plain, shard:
+        assert L.pllhip_shard_count(shard.p) == nshards and L.pllhip_shard_count(plain.p) == 1
+        w = (pc.splitmix64(5, nsites) % np.uint64(4)).astype(np.uint32) + 1
+        for inst in (plain, shard):
+            inst.set_pattern_weights(w)
+            assert inst.L.pll_update_invariant_sites(inst.p)
+        inv_a = np.ctypeslib.as_array(plain.p.contents.invariant, shape=(nsites,))
+        inv_b = np.ctypeslib.as_array(shard.p.contents.invariant, shape=(nsites,))
+        assert np.array_equal(inv_a, inv_b)
+        la, lb = pc.full_traversal(plain), pc.full_traversal(shard)
+        assert abs(la - lb) <= 1e-12 * abs(la)
+        t = plain.tree
+        edge = (t.root_a, t.scaler_of(t.root_a), t.root_b, t.scaler_of(t.root_b), t.root_matrix)
+        (_, pa), (_, pb) = plain.edge_lnl(*edge, persite=True), shard.edge_lnl(*edge, persite=True)
+        assert np.array_equal(pa, pb)                       # per-site values are computed site by site
+        for op in t.ops[-3:]:
+            assert np.array_equal(plain.get_clv(op[0]), shard.get_clv(op[0]))
+            assert np.array_equal(plain.get_scaler(op[1]), shard.get_scaler(op[1]))
+        assert np.array_equal(plain.get_pmatrix(3), shard.get_pmatrix(3))
+        sa, sb = plain.alloc_sumtable(), shard.alloc_sumtable()
+        args = (t.root_a, t.root_b, t.scaler_of(t.root_a), t.scaler_of(t.root_b))
+        plain.update_sumtable(*args, sa)
+        shard.update_sumtable(*args, sb)
+        assert np.array_equal(plain.get_sumtable(sa), shard.get_sumtable(sb))
+        for x in (0.01, 0.4):
+            da, db = plain.derivatives(args[2], args[3], x, sa), shard.derivatives(args[2], args[3], x, sb)
+            assert np.allclose(da, db, rtol=1e-12)
+        ma, mb = plain.derivatives_multi(args[2], args[3], [0.3, 0.02, 1.0], sa), \
+            shard.derivatives_multi(args[2], args[3], [0.3, 0.02, 1.0], sb)
+        assert np.allclose(ma, mb, rtol=1e-12)
+        # the caller pokes the model arrays of the ONE partition it sees
+        for inst in (plain, shard):
+            r = np.ctypeslib.as_array(inst.p.contents.rates, shape=(4,))
+            r[:] = r * 1.3
+        la2, lb2 = pc.full_traversal(plain), pc.full_traversal(shard)
+        assert abs(la2 - la) > 1.0 and abs(la2 - lb2) <= 1e-12 * abs(la2)
+        assert np.allclose(plain.node_ancestral(*edge), shard.node_ancestral(*edge), rtol=1e-12, atol=1e-300)
+        plain.free_sumtable(sa)
+        shard.free_sumtable(sb)
+
+
+def test_driver_on_a_partition_spread_over_devices(product):
+    """the evaluation driver (branch-length optimisation, deferred results) on sharded partitions:
+    same path, same numbers to rounding"""
+    L = product.lib
+    out = []
+    for shards in (0, 3):
+        assert L.pllhip_set_sharding(shards, None)
+        try:
+            with build(product, ntips=12, sizes=(700, 300)) as ev:
+                if shards:
+                    assert all(L.pllhip_shard_count(i.p) == 3 for i in ev.parts)
+                    ev.attach_comm(None)
+                lnl = ev.loglh()
+                opt = ev.optimize_branches(1e-4, 10.0, 0.01, 4, -1)
+                out.append((lnl, opt, ev.newton_iterations()))
+        finally:
+            assert L.pllhip_set_sharding(0, None)
+    assert abs(out[0][0] - out[1][0]) < 1e-11 * abs(out[0][0])
+    assert abs(out[0][1] - out[1][1]) < 1e-8 * abs(out[0][1]) and out[0][2] == out[1][2]

@@ -199,10 +199,39 @@ def spr(lib, out, nsites=None, ntips=None, radius_max=5, thorough=False):
                     "branch-length optimisation of the remembered topologies"}
 
 
+def alphabets(lib, out):
+    """full traversals at the state counts of pll-modules' other model families (binary, genotype
+    10 / 16 states: src/util/models_gt.c, multistate: src/util/models_mult.c): the 2..16-state
+    matrix-core family.  PLLHIP_NO_S16=1 in the environment selects the generic kernels instead
+    (one thread per output element), for the comparison."""
+    for S, N in ((2, 1_000_000), (10, 500_000), (16, 500_000), (7, 500_000)):
+        inst = pc.build_instance(lib, states=S, rate_cats=4, ntips=50, nsites=N, coded=True)
+        with inst:
+            pc.full_traversal(inst)
+            lib.lib.pllhip_synchronize(inst.p)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                lnl = pc.full_traversal(inst)
+            dt = (time.perf_counter() - t0) / 5
+            name = lib.lib.pllhip_partials_kernel_name(inst.p).decode()
+            # algorithmic bytes as SURVEY.md 8d counts them: 3 vectors of 8*S per (site, rate) and inner x inner op;
+            # a coded tip child is 1 byte per site
+            t = inst.tree
+            nb = 0.0
+            for op in t.ops:
+                tips = (op[2] < t.ntips) + (op[5] < t.ntips)
+                nb += N * 4 * 8.0 * S * (3 - tips) + N * tips + 12.0 * N
+            out[f"ALPHABET_{S}states_{N}"] = {"kernel": name, "ms_per_traversal": dt * 1e3, "lnl": lnl,
+                                              "site_updates_per_s": len(t.ops) * N * 4 / dt,
+                                              "algorithmic_GBps": nb / dt / 1e9}
+
+
 def main():
     lib = pc.PllLib(pc.PRODUCT_LIB)
     out = {}
     which = sys.argv[1:] or ["w2", "w3", "c4", "blo"]
+    if "alphabets" in which:
+        alphabets(lib, out)
     if "blo125" in which:
         blo(lib, "c3", out, nsites=125_000)
     if "blo_c2" in which:
