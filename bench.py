@@ -354,7 +354,7 @@ def main():
     traffic = None
     traffic_source = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and world == 1 and not args.sites and not args.taxa:
+    if os.path.exists(tpath) and world == 1 and not args.sites and not args.taxa and not args.rate_scalers:
         try:
             traffic = json.load(open(tpath)).get(f"{args.config}:{kernel}")
             traffic_source = ("profiles/traffic.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
