@@ -89,6 +89,36 @@ struct ChainBatch
   unsigned short slot2[MAX_OPS_PER_LAUNCH];      // start of its chain's area, of the two children's tables
 };
 
+// Whole traversals in ONE launch.  Felsenstein pruning never mixes sites, so a wave that keeps
+// the same site blocks through every operation of a traversal depends on nobody else: the
+// schedule (chains in dependency order) lives in device memory, a workgroup walks ALL its chains
+// -- re-staging its LDS tables between two chains -- and no kernel boundary (launch gap, L2
+// write-back, refill of every CU) separates the rounds of chains any more.
+struct PlanOp
+{
+  OpDesc d;
+  unsigned carried;      // 0 = both children from memory, 1 / 2 = child 1 / 2 is the previous op's parent
+  unsigned slot1, slot2; // 20 states: LDS offsets (doubles) of the two children's tables
+  unsigned pad;
+};
+struct PlanChain { unsigned first, len; };       // operations [first, first + len) of PlanOp[]
+struct PlanView { const PlanOp * ops; const PlanChain * chains; unsigned nchains; };
+
+struct DevicePlan                                 // the schedule resident on the device
+{
+  unsigned char * d_buf = nullptr;                // [PlanOp x nops][PlanChain x nchains]
+  size_t cap = 0;
+  unsigned char * h_stage = nullptr;              // pinned staging of the upload
+  size_t h_cap = 0;
+  hipEvent_t copied = nullptr;                    // the last upload has left h_stage
+  std::vector<unsigned char> resident;            // what d_buf holds (an unchanged schedule is not uploaded again)
+  // the schedule of the last traversal, kept so that a repeated operation list is not planned again
+  std::vector<unsigned char> key;                 // operation list + settings it was built from
+  std::vector<unsigned char> bytes;               // serialised [PlanOp ...][PlanChain ...]
+  unsigned nops = 0, nchains = 0, lds_doubles = 0;
+  double algo_bytes = 0.0, algo_flops = 0.0;      // algorithmic traffic / work of the traversal
+};
+
 enum class KernelFamily { Generic, S4, S16, S20, S61 };
 
 struct Engine
@@ -180,6 +210,8 @@ struct Engine
   bool pmat_host_dirty = false;
 
   pllhip_counters_t counters = {};
+
+  DevicePlan plan;                    // schedule of the last whole-traversal launch
 
   // optional timing of the partials launches with HIP events on `stream`
   bool profiling = false;

@@ -315,4 +315,47 @@ __device__ inline double site_loglh(double x, unsigned cnt, double inv)
   return log(x + inv) - (double)cnt * LN_SCALE;
 }
 
+// ---------------------------------------------------------------------------
+// device-resident schedules (PlanOp / PlanChain, engine.h): entries are fetched through the
+// constant address space, i.e. with scalar loads into SGPRs -- the index is wave-uniform and the
+// buffer is written by a copy that precedes the launch
+// ---------------------------------------------------------------------------
+template <class T>
+__device__ inline T plan_fetch(const T * p)
+{
+  static_assert(sizeof(T) % 8 == 0, "plan entries are whole 64-bit words");
+  constexpr unsigned W = sizeof(T) / 8;
+  typedef const unsigned long long __attribute__((address_space(4))) * const_words;
+  const_words c = (const_words)(unsigned long long)p;
+  unsigned long long w[W];
+#pragma unroll
+  for (unsigned k = 0; k < W; ++k) w[k] = c[k];
+  T out;
+  __builtin_memcpy(&out, w, sizeof(T));
+  return out;
+}
+
+// A pointer that came out of a fetched plan entry has lost its address space (the compiler would
+// use flat loads / stores, which also count against LDS traffic): say that it is global memory.
+template <class T>
+__device__ inline T * as_global(T * p)
+{
+  typedef __attribute__((address_space(1))) T * global_ptr;
+  return (T *)(global_ptr)(unsigned long long)p;
+}
+
+__device__ inline PlanOp plan_fetch_op(const PlanOp * p)
+{
+  PlanOp po = plan_fetch(p);
+  OpDesc & d = po.d;
+  d.clv1 = as_global(d.clv1);       d.codes1 = as_global(d.codes1);
+  d.pmat1 = as_global(d.pmat1);     d.lut1 = as_global(d.lut1);
+  d.clv2 = as_global(d.clv2);       d.codes2 = as_global(d.codes2);
+  d.pmat2 = as_global(d.pmat2);     d.lut2 = as_global(d.lut2);
+  d.scaler1 = as_global(d.scaler1); d.scaler2 = as_global(d.scaler2);
+  d.parent = as_global(d.parent);   d.parent_scaler = as_global(d.parent_scaler);
+  d.pfrag1 = as_global(d.pfrag1);   d.pfrag2 = as_global(d.pfrag2);
+  return po;
+}
+
 } // namespace pllhip

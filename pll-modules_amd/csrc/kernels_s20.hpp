@@ -577,6 +577,48 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_chain_s20(ChainBatc
   }
 }
 
+// A whole traversal in one launch (PlanView, engine.h): the workgroup walks every chain of the
+// schedule in dependency order.  A wave keeps the SAME site blocks in every chain, so all it
+// reads from an earlier chain it has written itself -- there is nothing to wait for but the
+// workgroup's own barrier around the re-staging of the LDS tables.
+// grid = gx, block = 512, dynamic LDS = the largest chain area of the schedule.
+template <unsigned RT>
+__global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanView plan, unsigned nblk,
+                                                                           unsigned lut_codes, unsigned lut_used,
+                                                                           unsigned flags)
+{
+  extern __shared__ double lds[];
+  const bool nt_ld = flags & 1u, nt_st = flags & 2u;
+  const bool lut_lds = (flags & 8u) != 0;
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned wstride = gridDim.x * S20_CHAIN_WAVES;
+  for (unsigned c = 0; c < plan.nchains; ++c)
+  {
+    const PlanChain ch = plan_fetch(plan.chains + c);
+    if (c) __syncthreads();                           // every wave has left the previous chain's tables
+    for (unsigned i = 0; i < ch.len; ++i)
+    {
+      const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
+      s20_fill_slot(lds + po.slot1, po.d.pmat1, po.d.pfrag1, po.d.codes1 ? po.d.lut1 : nullptr, RT, lut_codes, lut_used, lut_lds);
+      s20_fill_slot(lds + po.slot2, po.d.pmat2, po.d.pfrag2, po.d.codes2 ? po.d.lut2 : nullptr, RT, lut_codes, lut_used, lut_lds);
+    }
+    __syncthreads();
+
+    for (unsigned blk = blockIdx.x * S20_CHAIN_WAVES + wave; blk < nblk; blk += wstride)
+    {
+      double2 X[RT][5];
+      unsigned xe = 0, xo = 0;
+#pragma unroll 1
+      for (unsigned i = 0; i < ch.len; ++i)
+      {
+        const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
+        s20_chain_op<RT>(po.d, i ? po.carried : 0u, X, lds + po.slot1, lds + po.slot2,
+                         lut_codes, lut_used, lut_lds, blk, lane, nt_ld, nt_st, xe, xo);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // edge / root log-likelihood.  grid = nblocks (<= REDUCE_BLOCKS), block = 256
 // dynamic LDS = R * S20_FRAGS doubles (unused for the root form)
@@ -998,6 +1040,37 @@ static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned ncha
     hipLaunchKernelGGL(k_chain_s20<2>, grid, block, lds, e->stream, batch, e->nblk, e->lut_codes, lut_used, flags);
   else
     hipLaunchKernelGGL(k_chain_s20<1>, grid, block, lds, e->stream, batch, e->nblk, e->lut_codes, lut_used, flags);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+static int launch_traverse_s20(Engine * e, const PlanView & plan, unsigned lds_doubles, unsigned lut_used)
+{
+  const size_t lds = sizeof(double) * lds_doubles;
+  const unsigned env_flags = []() { const char * v = getenv("PLLHIP_S20_NT"); return v ? (unsigned)atoi(v) & 3u : 0u; }();
+  const unsigned flags = env_flags | (s20_chain_lut_lds(e, lut_used) ? 8u : 0u);
+  static bool attr_set_dev[64] = {false};
+  bool & attr_set = attr_set_dev[e->device & 63];
+  if (!attr_set)
+  {
+    const int cap = (int)(sizeof(double) * S20_CHAIN_LDS);
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_traverse_s20<4>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_traverse_s20<2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_traverse_s20<1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    attr_set = true;
+  }
+  const unsigned need = (e->nblk + S20_CHAIN_WAVES - 1) / S20_CHAIN_WAVES;
+  const unsigned gx = std::max(1u, std::min(need, e->cu_count));
+  const dim3 grid(gx), block(64 * S20_CHAIN_WAVES);
+  if (e->R == 4)
+    hipLaunchKernelGGL(k_traverse_s20<4>, grid, block, lds, e->stream, plan, e->nblk, e->lut_codes, lut_used, flags);
+  else if (e->R == 2)
+    hipLaunchKernelGGL(k_traverse_s20<2>, grid, block, lds, e->stream, plan, e->nblk, e->lut_codes, lut_used, flags);
+  else
+    hipLaunchKernelGGL(k_traverse_s20<1>, grid, block, lds, e->stream, plan, e->nblk, e->lut_codes, lut_used, flags);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

@@ -319,6 +319,9 @@ void engine_destroy(Engine * e)
   if (e->h_result) (void)hipHostFree(e->h_result);
   if (e->h_asc) (void)hipHostFree(e->h_asc);
   (void)hipFree(e->d_counter);
+  (void)hipFree(e->plan.d_buf);
+  if (e->plan.h_stage) (void)hipHostFree(e->plan.h_stage);
+  if (e->plan.copied) (void)hipEventDestroy(e->plan.copied);
   for (auto & ev : e->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -587,6 +590,7 @@ static int ensure_luts(pll_partition_t * p)
     if (e->family == KernelFamily::S61 && want <= 67u) cap = std::min(cap, 67u);
     if (e->family == KernelFamily::S20 && want <= 30u) cap = std::min(cap, 30u);
     if (e->d_lut) { PLLHIP_TRY(hipStreamSynchronize(e->stream)); (void)hipFree(e->d_lut); e->d_lut = nullptr; }
+    e->plan.key.clear();                            // cached schedules point into the old tables
     if (!dev_alloc(&e->d_lut, (size_t)e->nmat * e->R * cap * e->S, "tip lookup tables")) return PLL_FAILURE;
     e->lut_codes = cap;
     e->lut_stale = true;
@@ -926,6 +930,46 @@ static bool plan_chains(const Engine * e, const pll_operation_t * ops, unsigned 
   return true;
 }
 
+// make DevicePlan::bytes resident on the device (stream-ordered; nothing is copied when the
+// device already holds exactly these bytes) and point `view` at it
+static int upload_plan(Engine * e, PlanView & view)
+{
+  DevicePlan & dp = e->plan;
+  const size_t len = dp.bytes.size();
+  if (dp.resident != dp.bytes)
+  {
+    if (len > dp.cap)
+    {
+      PLLHIP_TRY(hipStreamSynchronize(e->stream));    // a running traversal may still read the old buffer
+      (void)hipFree(dp.d_buf);
+      dp.d_buf = nullptr;
+      dp.cap = 0;
+      const size_t cap = std::max<size_t>(2 * len, 65536);
+      if (!dev_alloc(&dp.d_buf, cap, "traversal schedule")) return PLL_FAILURE;
+      dp.cap = cap;
+    }
+    if (!dp.copied) PLLHIP_TRY(hipEventCreateWithFlags(&dp.copied, hipEventDisableTiming));
+    else PLLHIP_TRY(hipEventSynchronize(dp.copied));  // the previous upload has left the staging buffer
+    if (len > dp.h_cap)
+    {
+      if (dp.h_stage) (void)hipHostFree(dp.h_stage);
+      dp.h_stage = nullptr;
+      dp.h_cap = 0;
+      const size_t cap = std::max<size_t>(2 * len, 65536);
+      PLLHIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&dp.h_stage), cap, hipHostMallocDefault));
+      dp.h_cap = cap;
+    }
+    memcpy(dp.h_stage, dp.bytes.data(), len);
+    PLLHIP_TRY(hipMemcpyAsync(dp.d_buf, dp.h_stage, len, hipMemcpyHostToDevice, e->stream));
+    PLLHIP_TRY(hipEventRecord(dp.copied, e->stream));
+    dp.resident = dp.bytes;
+  }
+  view.ops = reinterpret_cast<const PlanOp *>(dp.d_buf);
+  view.chains = reinterpret_cast<const PlanChain *>(dp.d_buf + (size_t)dp.nops * sizeof(PlanOp));
+  view.nchains = dp.nchains;
+  return PLL_SUCCESS;
+}
+
 static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops, unsigned count)
 {
   Engine * e = engine_of(p);
@@ -1051,6 +1095,73 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     ChainPlan plan;
     // tip tables are staged with the codes in use (at least one: an untouched partition)
     const unsigned lut_used = std::max(1u, std::min(p->maxstates, e->lut_codes));
+    // the whole traversal in one launch (PLLHIP_TRAVERSE=0: one launch per round of chains)
+    static const int use_traverse = getenv("PLLHIP_TRAVERSE") ? atoi(getenv("PLLHIP_TRAVERSE")) : 1;
+    if (use_traverse && chains20)
+    {
+      DevicePlan & dp = e->plan;
+      std::vector<unsigned char> key(2 * sizeof(unsigned) + (size_t)count * sizeof(pll_operation_t));
+      memcpy(key.data(), &count, sizeof(unsigned));
+      memcpy(key.data() + sizeof(unsigned), &lut_used, sizeof(unsigned));
+      memcpy(key.data() + 2 * sizeof(unsigned), ops, (size_t)count * sizeof(pll_operation_t));
+      bool have = !dp.key.empty() && dp.key == key;
+      if (!have && plan_chains(e, ops, count, S20_CHAIN_MAX, S20_CHAIN_LDS, lut_used, plan))
+      {
+        std::vector<size_t> order(plan.chains.size());
+        for (size_t c = 0; c < order.size(); ++c) order[c] = c;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return plan.launch[a] < plan.launch[b]; });
+        std::vector<PlanOp> pops(count);
+        std::vector<PlanChain> pchains;
+        unsigned nops = 0, lds_max = 0;
+        dp.algo_bytes = dp.algo_flops = 0.0;
+        for (size_t c : order)
+        {
+          const std::vector<unsigned> & ch = plan.chains[c];
+          PlanChain pc;
+          pc.first = nops;
+          pc.len = (unsigned)ch.size();
+          pchains.push_back(pc);
+          unsigned off = 0;
+          for (size_t i = 0; i < ch.size(); ++i)
+          {
+            const pll_operation_t & o = ops[ch[i]];
+            PlanOp & po = pops[nops++];
+            memset(&po, 0, sizeof(po));
+            fill_desc(o, po.d, dp.algo_bytes, dp.algo_flops);
+            po.carried = i ? plan.carried[ch[i]] : 0;
+            const bool t1 = e->coded_tips && o.child1_clv_index < e->tips;
+            const bool t2 = e->coded_tips && o.child2_clv_index < e->tips;
+            po.slot1 = off;
+            off += s20_chain_slot(e, t1, lut_used);
+            po.slot2 = off;
+            off += s20_chain_slot(e, t2, lut_used);
+          }
+          lds_max = std::max(lds_max, off);
+        }
+        dp.bytes.resize(pops.size() * sizeof(PlanOp) + pchains.size() * sizeof(PlanChain));
+        memcpy(dp.bytes.data(), pops.data(), pops.size() * sizeof(PlanOp));
+        memcpy(dp.bytes.data() + pops.size() * sizeof(PlanOp), pchains.data(), pchains.size() * sizeof(PlanChain));
+        dp.nops = nops;
+        dp.nchains = (unsigned)pchains.size();
+        dp.lds_doubles = lds_max;
+        dp.key.swap(key);
+        have = true;
+      }
+      if (have)
+      {
+        PlanView view;
+        if (!upload_plan(e, view)) return PLL_FAILURE;
+        hipEvent_t ev1;
+        if (!prof_begin(ev1)) return PLL_FAILURE;
+        if (!launch_traverse_s20(e, view, dp.lds_doubles, lut_used)) return PLL_FAILURE;
+        if (!prof_end(ev1, dp.algo_bytes, dp.algo_flops, count)) return PLL_FAILURE;
+        e->counters.partial_launches++;
+        e->counters.partial_ops += count;
+        e->counters.site_updates += (unsigned long long)count * e->N * e->R;
+        return PLL_SUCCESS;
+      }
+      plan = ChainPlan();
+    }
     if (plan_chains(e, ops, count, chains20 ? S20_CHAIN_MAX : S4_CHAIN_MAX,
                     chains20 ? S20_CHAIN_LDS : ~0u, lut_used, plan))
     {
