@@ -159,6 +159,8 @@ struct Engine
   double * d_lut = nullptr;           // [nmat][R][lut_codes][S]   (coded tips only)
   unsigned long long result_seq = 0;  // sequence word of the mapped result buffer (finish_reduction)
   uint8_t * d_s61_votes = nullptr;
+  uint8_t * d_s61_ttscale = nullptr;  // per folded cherry: [codes][codes] scaling decision per pair of tip codes
+  size_t s61_ttscale_cap = 0;
   // last scaling decisions of the 61-state rate-parallel launches: per parent vector up to
   // three orientations (an inner node's slot is computed from any two of its three
   // neighbours), each double-buffered

@@ -276,10 +276,10 @@ __device__ inline void s61_acc_to_t(const v4d acc[S61_MT][2], double2 t[S61_KS])
       t[mt * 4 + v] = make_double2(acc[mt][0][v], acc[mt][1][v]);
 }
 
-// one rate of a wave's blocks (first, first + 4, ...: nb of them), both children inner
+// one rate of a wave's blocks (first, first + W, ...: nb of them; W = waves of the workgroup), both children inner
 __device__ inline void s61_rate_ii(const OpDesc & op, const double * frag, const double * frag2,
                                    unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
-                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred, bool rs)
+                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred, bool rs, unsigned W = 4)
 {
   const double2 * f1 = reinterpret_cast<const double2 *>(frag);
   const double2 * f2 = reinterpret_cast<const double2 *>(frag2);
@@ -288,8 +288,8 @@ __device__ inline void s61_rate_ii(const OpDesc & op, const double * frag, const
   s61_issue_half<0>(op.clv1 + ((size_t)first * R + r) * S61_UNIT, lane, bA);
   for (unsigned i = 0; i < nb; ++i)
   {
-    const size_t ub = ((size_t)(first + 4 * i) * R + r) * S61_UNIT;
-    const size_t ubn = ((size_t)(first + 4 * (i + 1 < nb ? i + 1 : i)) * R + r) * S61_UNIT;
+    const size_t ub = ((size_t)(first + W * i) * R + r) * S61_UNIT;
+    const size_t ubn = ((size_t)(first + W * (i + 1 < nb ? i + 1 : i)) * R + r) * S61_UNIT;
     v4d acc[S61_MT][2];
     double2 t1[S61_KS], t2[S61_KS];
     s61_acc_zero(acc);
@@ -312,9 +312,9 @@ __device__ inline void s61_rate_ii(const OpDesc & op, const double * frag, const
     s61_mfma_half<1>(bB, f2, lane, acc);
     S61_SCHED_FENCE();
     s61_acc_to_t(acc, t2);
-    if (rs) { s61_finish_unit_rs(op, first + 4 * i, r, R, op.parent + ub, lane, t1, t2); continue; }
+    if (rs) { s61_finish_unit_rs(op, first + W * i, r, R, op.parent + ub, lane, t1, t2); continue; }
     double fe, fo;
-    s61_pred_factors(pred, first + 4 * i, lane, fe, fo);
+    s61_pred_factors(pred, first + W * i, lane, fe, fo);
     s61_finish_unit(op.parent + ub, lane, q, t1, t2, 1u << i, small_e, small_o, fe, fo);
   }
 }
@@ -323,7 +323,7 @@ __device__ inline void s61_rate_ii(const OpDesc & op, const double * frag, const
 __device__ inline void s61_rate_ti(const OpDesc & op, const double * clv, const double * fragi,
                                    const unsigned char * codes, const double * lut_r,
                                    unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
-                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred, bool rs)
+                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred, bool rs, unsigned W = 4)
 {
   const double2 * f1 = reinterpret_cast<const double2 *>(fragi);
   const unsigned q = lane >> 4, n = lane & 15;
@@ -331,9 +331,9 @@ __device__ inline void s61_rate_ti(const OpDesc & op, const double * clv, const 
   s61_issue_half<0>(clv + ((size_t)first * R + r) * S61_UNIT, lane, bA);
   for (unsigned i = 0; i < nb; ++i)
   {
-    const unsigned blk = first + 4 * i;
+    const unsigned blk = first + W * i;
     const size_t ub = ((size_t)blk * R + r) * S61_UNIT;
-    const size_t ubn = ((size_t)(first + 4 * (i + 1 < nb ? i + 1 : i)) * R + r) * S61_UNIT;
+    const size_t ubn = ((size_t)(first + W * (i + 1 < nb ? i + 1 : i)) * R + r) * S61_UNIT;
     const size_t site0 = (size_t)blk * S20_BS + 2 * n;
     const unsigned ce = codes[site0], co = codes[site0 + 1];
     v4d acc[S61_MT][2];
@@ -358,7 +358,7 @@ __device__ inline void s61_rate_ti(const OpDesc & op, const double * clv, const 
 
 __device__ inline void s61_rate_tt(const OpDesc & op, const double * lut1_r, const double * lut2_r,
                                    unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
-                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred, bool rs)
+                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred, bool rs, unsigned W = 4)
 {
   const unsigned q = lane >> 4, n = lane & 15;
   // the tip codes of block i+1 are fetched while block i is looked up and stored
@@ -367,8 +367,8 @@ __device__ inline void s61_rate_tt(const OpDesc & op, const double * lut1_r, con
   unsigned c2e = op.codes2[site0], c2o = op.codes2[site0 + 1];
   for (unsigned i = 0; i < nb; ++i)
   {
-    const unsigned blk = first + 4 * i;
-    const size_t siten = (size_t)(first + 4 * (i + 1 < nb ? i + 1 : i)) * S20_BS + 2 * n;
+    const unsigned blk = first + W * i;
+    const size_t siten = (size_t)(first + W * (i + 1 < nb ? i + 1 : i)) * S20_BS + 2 * n;
     const unsigned n1e = op.codes1[siten], n1o = op.codes1[siten + 1];
     const unsigned n2e = op.codes2[siten], n2o = op.codes2[siten + 1];
     double2 t1[S61_KS], t2[S61_KS];
@@ -479,6 +479,222 @@ __global__ __launch_bounds__(256, 2) void k_partials_s61v3(OpBatch batch, unsign
           if (op.scaler2) { ce += op.scaler2[site0]; co += op.scaler2[site0 + 1]; }
           op.parent_scaler[site0] = ce;
           op.parent_scaler[site0 + 1] = co;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Cherries folded into their consumer.  A tip x tip operation ("cherry") does no matrix work: it
+// looks two table rows up per site and streams one vector out, at HBM-write speed, while the
+// matrix cores idle (1.4 of the 8.8 ms of a 50-taxon codon traversal).  Its only reader is the
+// operation above it, which is bound by the matrix pipe -- so that operation computes the cherry
+// itself: the B operand of its first matrix product is the product of the two tips' table rows,
+// built in registers from LDS, and the same registers are stored to the cherry's vector (later
+// partial traversals read it) while the MFMAs run.  The cherry's launch, its HBM-bound time and
+// the re-read of its vector disappear.
+//
+// Scaling stays exact without a vote: whether a cherry site is scaled depends on its pair of tip
+// codes only, so k_s61_cherry_scale tabulates the decision per code pair before the traversal
+// and both the stored vector and the operand carry the right factor from the start.
+//
+// One 512-thread workgroup per CU (four tables: P fragments of the cherry's branch, the other
+// child's fragments or table, the two tips' tables = 128 KiB of LDS), always rate-parallel.
+// ---------------------------------------------------------------------------
+constexpr unsigned S61_V4_OPS = 12;
+constexpr unsigned S61_V4_WAVES = 8;
+
+struct S61Batch
+{
+  OpDesc op[S61_V4_OPS];                 // child 1 is the folded cherry's vector when tt[i].parent != nullptr
+  OpDesc tt[S61_V4_OPS];                 // the folded cherry: codes1/2, lut1/2, parent, scalers
+  const uint8_t * ttscale[S61_V4_OPS];   // [codes][codes] "every entry of every rate is small" per code pair (null: unscaled)
+  const uint8_t * pred_in[S61_V4_OPS];   // predicted scaling of op[i] (see k_partials_s61v3)
+};
+
+struct CherryScaleBatch
+{
+  const double * lut1[32];
+  const double * lut2[32];
+  uint8_t * out[32];
+};
+
+// grid = (codes, cherries), block = 64
+__global__ __launch_bounds__(64) void k_s61_cherry_scale(CherryScaleBatch batch, unsigned lut_codes, unsigned R)
+{
+  const double * l1 = batch.lut1[blockIdx.y], * l2 = batch.lut2[blockIdx.y];
+  const unsigned ca = blockIdx.x;
+  for (unsigned cb = threadIdx.x; cb < lut_codes; cb += blockDim.x)
+  {
+    int small = 1;
+    for (unsigned r = 0; r < R; ++r)
+    {
+      const double * ra = l1 + ((size_t)r * lut_codes + ca) * S61_S, * rb = l2 + ((size_t)r * lut_codes + cb) * S61_S;
+      for (unsigned i = 0; i < S61_S; ++i) small &= (ra[i] * rb[i] < SCALE_THRESHOLD);
+    }
+    batch.out[blockIdx.y][(size_t)ca * lut_codes + cb] = (uint8_t)small;
+  }
+}
+
+// k-steps 8 HALF .. 8 HALF + 7 of a cherry's unit: product of the two tips' rows with the cherry's
+// scaling factor, stored to the cherry's vector and kept as B operand
+template <unsigned HALF>
+__device__ inline void s61_cherry_half(const double * ae, const double * ao, const double * be, const double * bo,
+                                       unsigned q, double fe, double fo, double * unit, unsigned lane, double2 b[8])
+{
+#pragma unroll
+  for (unsigned k = 0; k < 8; ++k)
+  {
+    const unsigned i = 4 * (HALF * 8 + k) + q;
+    double2 v = make_double2(0.0, 0.0);
+    if (i < S61_S)
+    {
+      v.x = ae[i] * be[i];
+      v.y = ao[i] * bo[i];
+      v.x *= fe;
+      v.y *= fo;
+    }
+    b[k] = v;
+    *reinterpret_cast<double2 *>(unit + (HALF * 8 + k) * 128 + lane * 2) = v;
+  }
+}
+
+// one rate of a wave's blocks: child 1 is a folded cherry, child 2 an inner vector (tip2 == false)
+// or a coded tip (its table at lut2_r)
+__device__ inline void s61_rate_cherry(const OpDesc & op, const OpDesc & tt, const uint8_t * ttscale, unsigned lut_codes,
+                                       const double * frag1, const double * frag2, const double * lut2_r,
+                                       const double * luta_r, const double * lutb_r, bool tip2,
+                                       unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
+                                       unsigned & small_e, unsigned & small_o, const uint8_t * pred, unsigned W)
+{
+  const double2 * f1 = reinterpret_cast<const double2 *>(frag1);
+  const double2 * f2 = reinterpret_cast<const double2 *>(frag2);
+  const unsigned q = lane >> 4, n = lane & 15;
+  double2 bA[8], bB[8], bC[8];
+  if (!tip2) s61_issue_half<0>(op.clv2 + ((size_t)first * R + r) * S61_UNIT, lane, bA);
+  size_t site0 = (size_t)first * S20_BS + 2 * n;
+  unsigned cae = tt.codes1[site0], cao = tt.codes1[site0 + 1];
+  unsigned cbe = tt.codes2[site0], cbo = tt.codes2[site0 + 1];
+  for (unsigned i = 0; i < nb; ++i)
+  {
+    const unsigned blk = first + W * i;
+    const unsigned blkn = first + W * (i + 1 < nb ? i + 1 : i);
+    const size_t ub = ((size_t)blk * R + r) * S61_UNIT, ubn = ((size_t)blkn * R + r) * S61_UNIT;
+    site0 = (size_t)blk * S20_BS + 2 * n;
+    const size_t siten = (size_t)blkn * S20_BS + 2 * n;
+    const unsigned nae = tt.codes1[siten], nao = tt.codes1[siten + 1];
+    const unsigned nbe = tt.codes2[siten], nbo = tt.codes2[siten + 1];
+    unsigned c2e = 0, c2o = 0;
+    if (tip2) { c2e = op.codes2[site0]; c2o = op.codes2[site0 + 1]; }
+    // the cherry's own scaling: a function of the code pair
+    unsigned de = 0, dd = 0;
+    if (ttscale)
+    {
+      de = ttscale[(size_t)cae * lut_codes + cbe];
+      dd = ttscale[(size_t)cao * lut_codes + cbo];
+    }
+    if (tt.parent_scaler && r == 0 && q == 0)
+    {
+      unsigned ce = de, co = dd;
+      if (tt.scaler1) { ce += tt.scaler1[site0]; co += tt.scaler1[site0 + 1]; }
+      if (tt.scaler2) { ce += tt.scaler2[site0]; co += tt.scaler2[site0 + 1]; }
+      tt.parent_scaler[site0] = ce;
+      tt.parent_scaler[site0 + 1] = co;
+    }
+    const double tfe = de ? SCALE_FACTOR : 1.0, tfo = dd ? SCALE_FACTOR : 1.0;
+    const double * ae = luta_r + cae * S61_S, * ao = luta_r + cao * S61_S;
+    const double * be = lutb_r + cbe * S61_S, * bo = lutb_r + cbo * S61_S;
+
+    v4d acc[S61_MT][2];
+    double2 t1[S61_KS], t2[S61_KS];
+    s61_acc_zero(acc);
+    if (!tip2) s61_issue_half<1>(op.clv2 + ub, lane, bB);
+    s61_cherry_half<0>(ae, ao, be, bo, q, tfe, tfo, tt.parent + ub, lane, bC);
+    S61_SCHED_FENCE();
+    s61_mfma_half<0>(bC, f1, lane, acc);
+    S61_SCHED_FENCE();
+    s61_cherry_half<1>(ae, ao, be, bo, q, tfe, tfo, tt.parent + ub, lane, bC);
+    S61_SCHED_FENCE();
+    s61_mfma_half<1>(bC, f1, lane, acc);
+    S61_SCHED_FENCE();
+    s61_acc_to_t(acc, t1);
+    if (!tip2)
+    {
+      s61_acc_zero(acc);
+      s61_mfma_half<0>(bA, f2, lane, acc);
+      S61_SCHED_FENCE();
+      s61_issue_half<0>(op.clv2 + ubn, lane, bA);      // next block (the last one re-reads itself)
+      S61_SCHED_FENCE();
+      s61_mfma_half<1>(bB, f2, lane, acc);
+      S61_SCHED_FENCE();
+      s61_acc_to_t(acc, t2);
+    }
+    else s61_child_tip(lut2_r, c2e, c2o, q, t2);
+    double fe, fo;
+    s61_pred_factors(pred, blk, lane, fe, fo);
+    s61_finish_unit(op.parent + ub, lane, q, t1, t2, 1u << i, small_e, small_o, fe, fo);
+    cae = nae; cao = nao; cbe = nbe; cbo = nbo;
+  }
+}
+
+// grid = (<= CUs / R, ops, R), block = 512, dynamic LDS = 4 x 32 KiB
+__global__ __launch_bounds__(64 * S61_V4_WAVES, 1) void k_partials_s61v4(S61Batch batch, unsigned nblk, unsigned R,
+                                                                         unsigned lut_codes, uint8_t * votes)
+{
+  extern __shared__ double frag[];
+  double * const frag2 = frag + S61_FRAGS, * const luta = frag + 2 * S61_FRAGS, * const lutb = frag + 3 * S61_FRAGS;
+  const OpDesc & op = batch.op[blockIdx.y];
+  const OpDesc & tt = batch.tt[blockIdx.y];
+  const bool cherry = tt.parent != nullptr;
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, n = lane & 15;
+  const bool scaling = op.parent_scaler != nullptr;
+  const bool tip1 = op.codes1 != nullptr, tip2 = op.codes2 != nullptr;
+  const unsigned beg = (unsigned)(((unsigned long long)nblk * blockIdx.x) / gridDim.x);
+  const unsigned end = (unsigned)(((unsigned long long)nblk * (blockIdx.x + 1)) / gridDim.x);
+  const uint8_t * pred = scaling ? batch.pred_in[blockIdx.y] : nullptr;
+  const unsigned r = blockIdx.z;
+  const size_t lut_len = (size_t)lut_codes * S61_S;
+
+  if (!tip1) s61_fill_frags_v3(frag, op.pmat1, r);
+  else for (unsigned e = threadIdx.x; e < lut_len; e += blockDim.x) frag[e] = op.lut1[r * lut_len + e];
+  if (!tip2) s61_fill_frags_v3(frag2, op.pmat2, r);
+  else for (unsigned e = threadIdx.x; e < lut_len; e += blockDim.x) frag2[e] = op.lut2[r * lut_len + e];
+  if (cherry)
+    for (unsigned e = threadIdx.x; e < lut_len; e += blockDim.x)
+    {
+      luta[e] = tt.lut1[r * lut_len + e];
+      lutb[e] = tt.lut2[r * lut_len + e];
+    }
+  __syncthreads();
+
+  constexpr unsigned W = S61_V4_WAVES;
+  for (unsigned c0 = beg; c0 < end; c0 += S61_CHUNK)
+  {
+    const unsigned c1 = min(end, c0 + S61_CHUNK);
+    const unsigned first = c0 + wave;
+    const unsigned nb = first < c1 ? (c1 - first + W - 1) / W : 0;
+    unsigned small_e = ~0u, small_o = ~0u;
+    if (nb == 0) continue;
+    if (cherry) s61_rate_cherry(op, tt, batch.ttscale[blockIdx.y], lut_codes, frag, frag2, frag2, luta, lutb, tip2,
+                                r, R, first, nb, lane, small_e, small_o, pred, W);
+    else if (tip1 && tip2) s61_rate_tt(op, frag, frag2, r, R, first, nb, lane, small_e, small_o, pred, false, W);
+    else if (!tip1 && !tip2) s61_rate_ii(op, frag, frag2, r, R, first, nb, lane, small_e, small_o, pred, false, W);
+    else if (tip1) s61_rate_ti(op, op.clv2, frag2, op.codes1, frag, r, R, first, nb, lane, small_e, small_o, pred, false, W);
+    else s61_rate_ti(op, op.clv1, frag, op.codes2, frag2, r, R, first, nb, lane, small_e, small_o, pred, false, W);
+
+    if (scaling)
+    {
+      uint8_t * v = votes + ((size_t)blockIdx.y * R + r) * ((size_t)nblk * S20_BS);
+      for (unsigned i = 0; i < nb; ++i)
+      {
+        const int se = s20_and_q((int)((small_e >> i) & 1u)), so = s20_and_q((int)((small_o >> i) & 1u));
+        if (q == 0)
+        {
+          const size_t site0 = (size_t)(first + W * i) * S20_BS + 2 * n;
+          v[site0] = (uint8_t)se;
+          v[site0 + 1] = (uint8_t)so;
         }
       }
     }
@@ -815,56 +1031,72 @@ __global__ __launch_bounds__(256) void k_sumtable_prep_s61(ModelView mv, ParamId
 
 // --- launchers -------------------------------------------------------------
 
+// rate-parallel launches are used when a GPU has few blocks per wave: one workgroup per (range,
+// rate) balances the matrix pipes better and quarters the critical path of small slices; the
+// scaling votes then meet in a second kernel
+static bool s61_rate_parallel(const Engine * e)
+{
+  static const int env_rp = getenv("PLLHIP_S61_RATEPAR") ? atoi(getenv("PLLHIP_S61_RATEPAR")) : -1;
+  const unsigned slots = e->cu_count * 2u;
+  return e->R > 1 && (env_rp >= 0 ? env_rp != 0 : e->nblk < slots * 4u * 8u);
+}
+
+// cherries can be folded into their consumers (k_partials_s61v4)
+static bool s61_cherries_supported(const Engine * e)
+{
+  static const int env = getenv("PLLHIP_S61_CHERRIES") ? atoi(getenv("PLLHIP_S61_CHERRIES")) : 1;
+  return env && e->coded_tips && !e->rate_scalers && s61_rate_parallel(e) && e->lut_codes * S61_S <= S61_FRAGS;
+}
+
+// last scaling decisions per parent vector, double-buffered (the fix-up kernel reads the
+// old one in all its rate slices while one of them writes the new one)
+static int s61_prepare_preds(Engine * e, const OpBatch & batch, unsigned nops, PredBatch & preds)
+{
+  if (!e->d_s61_votes)
+    PLLHIP_TRY(hipMalloc((void **)&e->d_s61_votes, (size_t)MAX_OPS_PER_LAUNCH * e->R * e->nblk * S20_BS));
+  if (e->s61_pred.empty()) e->s61_pred.resize(3 * (size_t)e->nodes);
+  const size_t bytes = (size_t)e->nblk * S20_BS;
+  for (unsigned i = 0; i < nops; ++i)
+  {
+    const OpDesc & d = batch.op[i];
+    if (!d.parent_scaler) continue;
+    const unsigned long long lo = std::min(d.child1_index, d.child2_index), hi = std::max(d.child1_index, d.child2_index);
+    const unsigned long long key = (hi << 32) | lo;
+    Engine::PredSlot * slot = nullptr, * victim = &e->s61_pred[3 * (size_t)d.parent_index];
+    for (int w = 0; w < 3; ++w)
+    {
+      Engine::PredSlot & c = e->s61_pred[3 * (size_t)d.parent_index + w];
+      if (c.key == key) { slot = &c; break; }
+      if (c.used < victim->used) victim = &c;
+    }
+    if (!slot)
+    {
+      slot = victim;                      // new orientation (or topology): start from "no site scales"
+      slot->key = key;
+      slot->cur = 0;
+      for (int w = 0; w < 2; ++w)
+        if (!slot->buf[w]) PLLHIP_TRY(hipMalloc((void **)&slot->buf[w], bytes));
+      PLLHIP_TRY(hipMemsetAsync(slot->buf[0], 0, bytes, e->stream));
+    }
+    slot->used = ++e->s61_pred_clock;
+    preds.in[i] = slot->buf[slot->cur];
+    preds.out[i] = slot->buf[slot->cur ^ 1u];
+    slot->cur ^= 1u;
+  }
+  return PLL_SUCCESS;
+}
+
 static int launch_partials_s61(Engine * e, const OpBatch & batch, unsigned nops)
 {
-  // few blocks per wave: one workgroup per (range, rate) balances the matrix pipes better and
-  // quarters the critical path of small slices; the scaling votes then meet in a second kernel
-  static const int env_rp = getenv("PLLHIP_S61_RATEPAR") ? atoi(getenv("PLLHIP_S61_RATEPAR")) : -1;
   const size_t lds = sizeof(double) * 2 * S61_FRAGS;
   const unsigned slots = e->cu_count * 2u;
-  const bool rate_parallel = e->R > 1 && (env_rp >= 0 ? env_rp != 0 : e->nblk < slots * 4u * 8u);
+  const bool rate_parallel = s61_rate_parallel(e);
   bool scaling = false;
   for (unsigned i = 0; i < nops; ++i) scaling |= batch.op[i].parent_scaler != nullptr;
   if (e->rate_scalers) scaling = false;      // per-rate scalers: no votes, no predictions, no fix-up kernel
-  if (rate_parallel && scaling && !e->d_s61_votes)
-    PLLHIP_TRY(hipMalloc((void **)&e->d_s61_votes,
-                         (size_t)MAX_OPS_PER_LAUNCH * e->R * e->nblk * S20_BS));
   PredBatch preds;
   memset(&preds, 0, sizeof(preds));
-  if (rate_parallel && scaling)
-  {
-    // last scaling decisions per parent vector, double-buffered (the fix-up kernel reads the
-    // old one in all its rate slices while one of them writes the new one)
-    if (e->s61_pred.empty()) e->s61_pred.resize(3 * (size_t)e->nodes);
-    const size_t bytes = (size_t)e->nblk * S20_BS;
-    for (unsigned i = 0; i < nops; ++i)
-    {
-      const OpDesc & d = batch.op[i];
-      if (!d.parent_scaler) continue;
-      const unsigned long long lo = std::min(d.child1_index, d.child2_index), hi = std::max(d.child1_index, d.child2_index);
-      const unsigned long long key = (hi << 32) | lo;
-      Engine::PredSlot * slot = nullptr, * victim = &e->s61_pred[3 * (size_t)d.parent_index];
-      for (int w = 0; w < 3; ++w)
-      {
-        Engine::PredSlot & c = e->s61_pred[3 * (size_t)d.parent_index + w];
-        if (c.key == key) { slot = &c; break; }
-        if (c.used < victim->used) victim = &c;
-      }
-      if (!slot)
-      {
-        slot = victim;                      // new orientation (or topology): start from "no site scales"
-        slot->key = key;
-        slot->cur = 0;
-        for (int w = 0; w < 2; ++w)
-          if (!slot->buf[w]) PLLHIP_TRY(hipMalloc((void **)&slot->buf[w], bytes));
-        PLLHIP_TRY(hipMemsetAsync(slot->buf[0], 0, bytes, e->stream));
-      }
-      slot->used = ++e->s61_pred_clock;
-      preds.in[i] = slot->buf[slot->cur];
-      preds.out[i] = slot->buf[slot->cur ^ 1u];
-      slot->cur ^= 1u;
-    }
-  }
+  if (rate_parallel && scaling && !s61_prepare_preds(e, batch, nops, preds)) return PLL_FAILURE;
   static const int env_mul = getenv("PLLHIP_S61_GXMUL") ? atoi(getenv("PLLHIP_S61_GXMUL")) : 1;
   const unsigned per = (rate_parallel ? std::max(1u, slots / e->R) : slots) * (unsigned)std::max(1, env_mul);
   const unsigned gx = std::max(1u, std::min((e->nblk + 3) / 4, per));
@@ -878,6 +1110,57 @@ static int launch_partials_s61(Engine * e, const OpBatch & batch, unsigned nops)
                        batch, e->nblk, e->R, (const uint8_t *)e->d_s61_votes, preds);
     PLLHIP_TRY(hipGetLastError());
   }
+  return PLL_SUCCESS;
+}
+
+// a launch of the cherry-folding kernel: batch.op[i] with the cherry cherries.op[i] folded in
+// (cherries.op[i].parent == nullptr: none), ttscale[i] its per-code-pair scaling table
+static int launch_partials_s61_cherries(Engine * e, const OpBatch & batch, const OpBatch & cherries,
+                                        const uint8_t * const * ttscale, unsigned nops)
+{
+  if (nops > S61_V4_OPS) { set_error(PLL_ERROR_PARAM_INVALID, "cherry launch of %u operations", nops); return PLL_FAILURE; }
+  const size_t lds = sizeof(double) * 4 * S61_FRAGS;
+  static bool attr_set_dev[64] = {false};
+  bool & attr_set = attr_set_dev[e->device & 63];
+  if (!attr_set)
+  {
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_partials_s61v4),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  bool scaling = false;
+  for (unsigned i = 0; i < nops; ++i) scaling |= batch.op[i].parent_scaler != nullptr;
+  PredBatch preds;
+  memset(&preds, 0, sizeof(preds));
+  if (scaling && !s61_prepare_preds(e, batch, nops, preds)) return PLL_FAILURE;
+  S61Batch sb;
+  memset(&sb, 0, sizeof(sb));
+  for (unsigned i = 0; i < nops; ++i)
+  {
+    sb.op[i] = batch.op[i];
+    sb.tt[i] = cherries.op[i];
+    sb.ttscale[i] = ttscale[i];
+    sb.pred_in[i] = preds.in[i];
+  }
+  const unsigned per = std::max(1u, e->cu_count / e->R);
+  const unsigned gx = std::max(1u, std::min((e->nblk + S61_V4_WAVES - 1) / S61_V4_WAVES, per));
+  hipLaunchKernelGGL(k_partials_s61v4, dim3(gx, nops, e->R), dim3(64 * S61_V4_WAVES), lds, e->stream,
+                     sb, e->nblk, e->R, e->lut_codes, e->d_s61_votes);
+  PLLHIP_TRY(hipGetLastError());
+  if (scaling)
+  {
+    hipLaunchKernelGGL(k_s61_scale_fixup, dim3((e->nblk + 3) / 4, nops), dim3(256), 0, e->stream,
+                       batch, e->nblk, e->R, (const uint8_t *)e->d_s61_votes, preds);
+    PLLHIP_TRY(hipGetLastError());
+  }
+  return PLL_SUCCESS;
+}
+
+// scaling tables of `count` cherries (CherryScaleBatch): out[i] = [codes][codes]
+static int launch_cherry_scale_s61(Engine * e, const CherryScaleBatch & batch, unsigned count)
+{
+  hipLaunchKernelGGL(k_s61_cherry_scale, dim3(e->lut_codes, count), dim3(64), 0, e->stream, batch, e->lut_codes, e->R);
+  PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }
 

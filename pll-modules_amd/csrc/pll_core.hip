@@ -308,6 +308,7 @@ void engine_destroy(Engine * e)
   (void)hipFree(e->d_pfrag);
   (void)hipFree(e->d_lut);
   (void)hipFree(e->d_s61_votes);
+  (void)hipFree(e->d_s61_ttscale);
   for (auto & slot : e->s61_pred) { if (slot.buf[0]) (void)hipFree(slot.buf[0]); if (slot.buf[1]) (void)hipFree(slot.buf[1]); }
   (void)hipFree(e->d_weights);
   (void)hipFree(e->d_invariant);
@@ -1233,60 +1234,142 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     }
   }
 
-  // 61 states: operations with matrix work are bound by the FP64 matrix pipe, tip x tip
-  // operations (two table look-ups, one vector out) by HBM.  In the plain level schedule all
-  // tip x tip operations of a traversal share launch 0 and leave the matrix cores idle; run
-  // as LATE as their consumer allows, they share a launch with matrix-bound operations and
-  // the two pipes overlap.  Only for lists with the shape of a tree traversal (plan_chains'
-  // test); PLLHIP_S61_ALAP=0 keeps the plain schedule.
+  // 61 states.  (1) Cherries -- tip x tip operations, bound by HBM writes while the matrix cores
+  // idle -- are folded into the operation that consumes them (kernels_s61.hpp, k_partials_s61v4).
+  // (2) Those that stay (their consumer already folds its other child) run as LATE as the consumer
+  // allows, so that they share a launch with matrix-bound operations.  Both only for lists with the
+  // shape of a tree traversal (plan_chains' test); PLLHIP_S61_CHERRIES=0 / PLLHIP_S61_ALAP=0 switch
+  // them off.
   static const int use_alap = getenv("PLLHIP_S61_ALAP") ? atoi(getenv("PLLHIP_S61_ALAP")) : 1;
   std::vector<char> light(count, 0);
-  if (use_alap && e->family == KernelFamily::S61 && e->coded_tips && count >= 3)
+  std::vector<int> cherry_of(count, -1);          // consumer -> the cherry folded into it
+  std::vector<const uint8_t *> cherry_table(count, nullptr);
+  bool folding = false;
+  if (e->family == KernelFamily::S61 && e->coded_tips && count >= 2)
   {
     ChainPlan shape;
     if (plan_chains(e, ops, count, 1, ~0u, 1u, shape))
     {
-      std::vector<int> producer(e->nodes, -1), consumer(count, -1);
+      std::vector<int> producer(e->nodes, -1), consumer(count, -1), prod1(count, -1), prod2(count, -1);
       for (unsigned k = 0; k < count; ++k)
       {
-        const int p1 = producer[ops[k].child1_clv_index], p2 = producer[ops[k].child2_clv_index];
-        if (p1 >= 0) consumer[p1] = (int)k;
-        if (p2 >= 0) consumer[p2] = (int)k;
+        prod1[k] = producer[ops[k].child1_clv_index];
+        prod2[k] = producer[ops[k].child2_clv_index];
+        if (prod1[k] >= 0) consumer[prod1[k]] = (int)k;
+        if (prod2[k] >= 0) consumer[prod2[k]] = (int)k;
         producer[ops[k].parent_clv_index] = (int)k;
       }
-      for (unsigned k = 0; k < count; ++k)
+      auto is_cherry = [&](unsigned k) { return ops[k].child1_clv_index < e->tips && ops[k].child2_clv_index < e->tips; };
+      std::vector<char> folded(count, 0);
+      if (s61_cherries_supported(e))
       {
-        const bool tt = ops[k].child1_clv_index < e->tips && ops[k].child2_clv_index < e->tips;
-        if (tt && consumer[k] >= 0 && level[consumer[k]] - 1 > level[k])
+        for (unsigned k = 0; k < count; ++k)
+          if (is_cherry(k) && consumer[k] >= 0 && cherry_of[consumer[k]] < 0)
+          {
+            cherry_of[consumer[k]] = (int)k;
+            folded[k] = 1;
+            folding = true;
+          }
+      }
+      if (folding)
+      {
+        // levels from the remaining dependencies alone (the list is a tree traversal: every vector
+        // is written once and read by one later operation)
+        max_level = 0;
+        for (unsigned k = 0; k < count; ++k)
         {
-          level[k] = level[consumer[k]] - 1;
+          if (folded[k]) { level[k] = -1; continue; }
+          int l = 0;
+          if (prod1[k] >= 0 && !folded[prod1[k]]) l = std::max(l, level[prod1[k]] + 1);
+          if (prod2[k] >= 0 && !folded[prod2[k]]) l = std::max(l, level[prod2[k]] + 1);
+          level[k] = l;
+          max_level = std::max(max_level, l);
+        }
+        // scaling decision of every folded cherry per pair of tip codes
+        std::vector<unsigned> need;
+        for (unsigned k = 0; k < count; ++k)
+          if (folded[k] && ops[k].parent_scaler_index != PLL_SCALE_BUFFER_NONE) need.push_back(k);
+        const size_t tab = (size_t)e->lut_codes * e->lut_codes;
+        if (need.size() * tab > e->s61_ttscale_cap)
+        {
+          PLLHIP_TRY(hipStreamSynchronize(e->stream));
+          (void)hipFree(e->d_s61_ttscale);
+          e->d_s61_ttscale = nullptr;
+          e->s61_ttscale_cap = 0;
+          if (!dev_alloc(&e->d_s61_ttscale, 2 * need.size() * tab, "cherry scaling tables")) return PLL_FAILURE;
+          e->s61_ttscale_cap = 2 * need.size() * tab;
+        }
+        for (size_t i0 = 0; i0 < need.size(); i0 += 32)
+        {
+          CherryScaleBatch cs;
+          memset(&cs, 0, sizeof(cs));
+          const unsigned nc = (unsigned)std::min<size_t>(32, need.size() - i0);
+          for (unsigned i = 0; i < nc; ++i)
+          {
+            const pll_operation_t & o = ops[need[i0 + i]];
+            cs.lut1[i] = e->d_lut + lut_stride * o.child1_matrix_index;
+            cs.lut2[i] = e->d_lut + lut_stride * o.child2_matrix_index;
+            cs.out[i] = e->d_s61_ttscale + (i0 + i) * tab;
+            cherry_table[need[i0 + i]] = cs.out[i];
+          }
+          if (!launch_cherry_scale_s61(e, cs, nc)) return PLL_FAILURE;
+        }
+      }
+      if (use_alap)
+        for (unsigned k = 0; k < count; ++k)
+        {
+          if (folded[k] || !is_cherry(k)) continue;
+          if (consumer[k] >= 0 && level[consumer[k]] - 1 > level[k]) level[k] = level[consumer[k]] - 1;
           light[k] = 1;
         }
-        else if (tt) light[k] = 1;
-      }
     }
   }
 
   for (int l = 0; l <= max_level; ++l)
   {
-    OpBatch batch;
-    unsigned nb = 0;
+    OpBatch batch, cherries;
+    const uint8_t * tables[MAX_OPS_PER_LAUNCH];
+    unsigned nb = 0, nfolded = 0;
+    bool any_cherry = false;
     double batch_bytes = 0.0, batch_flops = 0.0;
+    const unsigned cap = folding ? S61_V4_OPS : MAX_OPS_PER_LAUNCH;
     // matrix-bound operations first, the light ones behind them (their workgroups fill the tail)
     for (unsigned pass = 0; pass < 2; ++pass)
     for (unsigned k = 0; k <= count; ++k)
     {
       if (k < count && (light[k] != (char)pass)) continue;
       if (k == count && pass == 0) continue;
-      if (k < count && level[k] == l) fill_desc(ops[k], batch.op[nb++], batch_bytes, batch_flops);
-      if (nb == MAX_OPS_PER_LAUNCH || (k == count && nb))
+      if (k < count && level[k] == l)
+      {
+        pll_operation_t o = ops[k];
+        memset(&cherries.op[nb], 0, sizeof(OpDesc));
+        tables[nb] = nullptr;
+        if (cherry_of[k] >= 0)
+        {
+          const pll_operation_t & c = ops[cherry_of[k]];
+          if (o.child2_clv_index == c.parent_clv_index)      // the folded cherry is child 1 (products commute)
+          {
+            std::swap(o.child1_clv_index, o.child2_clv_index);
+            std::swap(o.child1_matrix_index, o.child2_matrix_index);
+            std::swap(o.child1_scaler_index, o.child2_scaler_index);
+          }
+          fill_desc(c, cherries.op[nb], batch_bytes, batch_flops);
+          tables[nb] = cherry_table[cherry_of[k]];
+          any_cherry = true;
+          ++nfolded;
+        }
+        fill_desc(o, batch.op[nb++], batch_bytes, batch_flops);
+      }
+      if (nb == cap || (k == count && nb))
       {
         hipEvent_t ev1;
         if (!prof_begin(ev1)) return PLL_FAILURE;
-        if (!launch_partials(e, batch, nb)) return PLL_FAILURE;
-        if (!prof_end(ev1, batch_bytes, batch_flops, nb)) return PLL_FAILURE;
+        if (any_cherry ? !launch_partials_s61_cherries(e, batch, cherries, tables, nb) : !launch_partials(e, batch, nb))
+          return PLL_FAILURE;
+        if (!prof_end(ev1, batch_bytes, batch_flops, nb + nfolded)) return PLL_FAILURE;
         e->counters.partial_launches++;
-        nb = 0;
+        nb = nfolded = 0;
+        any_cherry = false;
         batch_bytes = 0.0;
         batch_flops = 0.0;
       }

@@ -218,13 +218,40 @@ with pc.build_instance(lib, states=61, rate_cats=4, ntips=130, nsites=97, coded=
     print("\n".join(out))
 """ % os.path.dirname(pc.__file__)
     runs = []
-    for mode in ("1", "0"):
-        env = dict(os.environ, PLLHIP_S61_RATEPAR=mode)
+    # rate-parallel with cherries folded into their consumers, rate-parallel without, rates in a workgroup
+    for mode, cherries in (("1", "1"), ("1", "0"), ("0", "1")):
+        env = dict(os.environ, PLLHIP_S61_RATEPAR=mode, PLLHIP_S61_CHERRIES=cherries)
         runs.append(subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True,
                                    text=True, timeout=300).stdout)
-    assert runs[0] == runs[1] and runs[0].count("\n") == 3
+    assert runs[0] == runs[1] == runs[2] and runs[0].count("\n") == 3
     first, second, third = runs[0].splitlines()
     assert first == second and third != first
+
+
+@pytest.mark.parametrize("rate_cats", [4, 2])
+def test_codon_cherries_that_scale(product, oracle, rate_cats):
+    """61 states: a tip x tip operation is computed inside the operation that consumes it, its own
+    scaling decided per pair of tip codes.  A cherry only ever scales when its entries are exact zeros
+    (P-matrix noise is 1e-17, far above 2^-256): pendant branches of length 0 -- identity matrices --
+    make every site with two different codons an all-zero, scaled site.  Scalers (exact) and vectors
+    must be what the oracle computes operation by operation; lnL is -inf on both sides."""
+    a, b = _pair(product, oracle, states=61, rate_cats=rate_cats, ntips=24, nsites=203, coded=True)
+    with a, b:
+        t = a.tree
+        cherries = [op for op in t.ops if op[2] < t.ntips and op[5] < t.ntips]
+        assert len(cherries) >= 3
+        for k, op in enumerate(cherries):        # the pair shares the tree: both engines see these lengths
+            if k % 3 != 2:                       # two of three cherries lose their pendant branches
+                t.brlens[op[3]] = 0.0
+                t.brlens[op[6]] = 0.0 if k % 3 == 0 else 0.05
+        for rep in range(2):                     # second pass: scaling predictions of the consumers in use
+            la, lb = pc.full_traversal(a), pc.full_traversal(b)
+            assert la == lb == -np.inf
+            for op in t.ops:
+                assert np.array_equal(a.get_scaler(op[1]), b.get_scaler(op[1])), f"scaler {op[1]}"
+                assert site_err(a.get_clv(op[0]), b.get_clv(op[0])) < CLV_SITE_61, f"CLV {op[0]}"
+        scaled = sum(int(b.get_scaler(op[1]).sum()) for op in cherries)
+        assert scaled > 0, "no cherry site reached the scaling regime"
 
 
 def test_scaling_on_equals_scaling_off(product):
