@@ -125,6 +125,7 @@ struct Engine
 {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool counted = false;               // in the per-device count of live partitions
   // engine-internal sharding (include/pllhip.h, pllhip_set_sharding): a ROUTER owns no device
   // memory; it forwards every call to its shards, ordinary partitions that each hold a
   // contiguous site range on their own device

@@ -583,7 +583,7 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_chain_s20(ChainBatc
 // workgroup's own barrier around the re-staging of the LDS tables.
 // grid = gx, block = 512, dynamic LDS = the largest chain area of the schedule.
 template <unsigned RT>
-__global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanView plan, unsigned nblk,
+__global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanView plan, unsigned nblk, unsigned slab,
                                                                            unsigned lut_codes, unsigned lut_used,
                                                                            unsigned flags)
 {
@@ -592,28 +592,35 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanVi
   const bool lut_lds = (flags & 8u) != 0;
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned wstride = gridDim.x * S20_CHAIN_WAVES;
-  for (unsigned c = 0; c < plan.nchains; ++c)
+  bool first_fill = true;
+  // slabs of `slab` site blocks go through the whole schedule one after the other
+  for (unsigned s0 = 0; s0 < nblk; s0 += slab)
   {
-    const PlanChain ch = plan_fetch(plan.chains + c);
-    if (c) __syncthreads();                           // every wave has left the previous chain's tables
-    for (unsigned i = 0; i < ch.len; ++i)
+    const unsigned s1 = min(nblk, s0 + slab);
+    for (unsigned c = 0; c < plan.nchains; ++c)
     {
-      const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
-      s20_fill_slot(lds + po.slot1, po.d.pmat1, po.d.pfrag1, po.d.codes1 ? po.d.lut1 : nullptr, RT, lut_codes, lut_used, lut_lds);
-      s20_fill_slot(lds + po.slot2, po.d.pmat2, po.d.pfrag2, po.d.codes2 ? po.d.lut2 : nullptr, RT, lut_codes, lut_used, lut_lds);
-    }
-    __syncthreads();
-
-    for (unsigned blk = blockIdx.x * S20_CHAIN_WAVES + wave; blk < nblk; blk += wstride)
-    {
-      double2 X[RT][5];
-      unsigned xe = 0, xo = 0;
-#pragma unroll 1
+      const PlanChain ch = plan_fetch(plan.chains + c);
+      if (!first_fill) __syncthreads();                 // every wave has left the previous chain's tables
+      first_fill = false;
       for (unsigned i = 0; i < ch.len; ++i)
       {
         const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
-        s20_chain_op<RT>(po.d, i ? po.carried : 0u, X, lds + po.slot1, lds + po.slot2,
-                         lut_codes, lut_used, lut_lds, blk, lane, nt_ld, nt_st, xe, xo);
+        s20_fill_slot(lds + po.slot1, po.d.pmat1, po.d.pfrag1, po.d.codes1 ? po.d.lut1 : nullptr, RT, lut_codes, lut_used, lut_lds);
+        s20_fill_slot(lds + po.slot2, po.d.pmat2, po.d.pfrag2, po.d.codes2 ? po.d.lut2 : nullptr, RT, lut_codes, lut_used, lut_lds);
+      }
+      __syncthreads();
+
+      for (unsigned blk = s0 + blockIdx.x * S20_CHAIN_WAVES + wave; blk < s1; blk += wstride)
+      {
+        double2 X[RT][5];
+        unsigned xe = 0, xo = 0;
+#pragma unroll 1
+        for (unsigned i = 0; i < ch.len; ++i)
+        {
+          const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
+          s20_chain_op<RT>(po.d, i ? po.carried : 0u, X, lds + po.slot1, lds + po.slot2,
+                           lut_codes, lut_used, lut_lds, blk, lane, nt_ld, nt_st, xe, xo);
+        }
       }
     }
   }
@@ -1064,13 +1071,18 @@ static int launch_traverse_s20(Engine * e, const PlanView & plan, unsigned lds_d
   }
   const unsigned need = (e->nblk + S20_CHAIN_WAVES - 1) / S20_CHAIN_WAVES;
   const unsigned gx = std::max(1u, std::min(need, e->cu_count));
+  // slab: site blocks that go through the whole schedule together (0 = all of them)
+  static const int env_slab = getenv("PLLHIP_S20_SLAB") ? atoi(getenv("PLLHIP_S20_SLAB")) : 0;
+  const unsigned per_pass = gx * S20_CHAIN_WAVES;
+  unsigned slab = env_slab > 0 ? (unsigned)env_slab : e->nblk;
+  slab = std::max(per_pass, (slab + per_pass - 1) / per_pass * per_pass);   // whole passes of the grid
   const dim3 grid(gx), block(64 * S20_CHAIN_WAVES);
   if (e->R == 4)
-    hipLaunchKernelGGL(k_traverse_s20<4>, grid, block, lds, e->stream, plan, e->nblk, e->lut_codes, lut_used, flags);
+    hipLaunchKernelGGL(k_traverse_s20<4>, grid, block, lds, e->stream, plan, e->nblk, slab, e->lut_codes, lut_used, flags);
   else if (e->R == 2)
-    hipLaunchKernelGGL(k_traverse_s20<2>, grid, block, lds, e->stream, plan, e->nblk, e->lut_codes, lut_used, flags);
+    hipLaunchKernelGGL(k_traverse_s20<2>, grid, block, lds, e->stream, plan, e->nblk, slab, e->lut_codes, lut_used, flags);
   else
-    hipLaunchKernelGGL(k_traverse_s20<1>, grid, block, lds, e->stream, plan, e->nblk, e->lut_codes, lut_used, flags);
+    hipLaunchKernelGGL(k_traverse_s20<1>, grid, block, lds, e->stream, plan, e->nblk, slab, e->lut_codes, lut_used, flags);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

@@ -236,29 +236,114 @@ constexpr unsigned S4_CHAIN_MAX = 8;
 // all rates of a code share their banks), two matrix sets [R][16]
 constexpr unsigned s4_chain_op_lds(unsigned R) { return 2 * R * S4_LUT_RS + 2 * R * 16; }
 
+// one operation of a chain for one 64-site chunk: X holds the handed-over operand on entry (when
+// carried != 0) and the result on exit, xcnt the scaler count that goes with it.
+// base: the operation's LDS tables
+template <unsigned U, unsigned R>
+__device__ inline void s4_chain_step(const OpDesc & op, unsigned carried, const double * base,
+                                     double2 (&X)[2 * R], unsigned & xcnt,
+                                     unsigned long long hc0, unsigned long long nsc, unsigned long long total,
+                                     unsigned N, unsigned lane, unsigned r, unsigned h)
+{
+  constexpr unsigned group = 2 * R, spi = 64 / group;
+  constexpr unsigned T2 = R * S4_LUT_RS, M1 = 2 * R * S4_LUT_RS, M2 = 2 * R * S4_LUT_RS + R * 16;
+  HalfP p1 = {}, p2 = {};
+  if (!op.codes1) p1 = s4_load_half_p(base + M1, r, h);
+  if (!op.codes2) p2 = s4_load_half_p(base + M2, r, h);
+  unsigned child_cnt = 0;
+  if (op.parent_scaler && nsc < N)
+  {
+    if (op.scaler1) child_cnt += (carried == 1) ? xcnt : op.scaler1[nsc];
+    if (op.scaler2) child_cnt += (carried == 2) ? xcnt : op.scaler2[nsc];
+  }
+  unsigned scaled_mask = 0;
+  // the tip codes of the chunk's 64 sites: one coalesced byte load per child (lane l holds
+  // site l of the chunk); an iteration picks its site's code with a lane shuffle, so no
+  // global load sits in front of the table lookup
+  const unsigned long long ncode = nsc < N ? nsc : 0ULL;
+  const int cb1 = op.codes1 ? (int)op.codes1[ncode] : 0;
+  const int cb2 = op.codes2 ? (int)op.codes2[ncode] : 0;
+#pragma unroll
+  for (unsigned k0 = 0; k0 < group; k0 += U)
+  {
+    double2 in1[U], in2[U];
+    bool live[U];
+#pragma unroll
+    for (unsigned u = 0; u < U; ++u)
+    {
+      const unsigned long long gu = hc0 + (unsigned long long)(k0 + u) * 64ULL;
+      const int src = (int)((k0 + u) * spi + lane / group);       // this lane's site within the chunk
+      live[u] = gu < total;
+      in1[u] = in2[u] = make_double2(0.0, 0.0);
+      const int code1 = op.codes1 ? __shfl(cb1, src, 64) : 0;
+      const int code2 = op.codes2 ? __shfl(cb2, src, 64) : 0;
+      if (live[u])
+      {
+        if (op.codes1)
+          in1[u] = *reinterpret_cast<const double2 *>(&base[r * S4_LUT_RS + code1 * 4 + 2 * h]);
+        else if (carried != 1) in1[u] = *reinterpret_cast<const double2 *>(op.clv1 + gu * 2);
+        if (op.codes2)
+          in2[u] = *reinterpret_cast<const double2 *>(&base[T2 + r * S4_LUT_RS + code2 * 4 + 2 * h]);
+        else if (carried != 2) in2[u] = *reinterpret_cast<const double2 *>(op.clv2 + gu * 2);
+      }
+    }
+#pragma unroll
+    for (unsigned u = 0; u < U; ++u)
+    {
+      const unsigned k = k0 + u;
+      const unsigned long long gu = hc0 + (unsigned long long)k * 64ULL;
+      const double2 a = op.codes1 ? in1[u] : s4_half_matvec(p1, carried == 1 ? X[k] : in1[u]);
+      const double2 b = op.codes2 ? in2[u] : s4_half_matvec(p2, carried == 2 ? X[k] : in2[u]);
+      double2 v = make_double2(a.x * b.x, a.y * b.y);
+      if (op.parent_scaler)
+      {
+        const int big = group_any(live[u] && !(v.x < SCALE_THRESHOLD && v.y < SCALE_THRESHOLD), lane, group);
+        if (!big)
+        {
+          v.x *= SCALE_FACTOR;
+          v.y *= SCALE_FACTOR;
+          scaled_mask |= 1u << k;
+        }
+      }
+      X[k] = v;
+      if (live[u]) *reinterpret_cast<double2 *>(op.parent + gu * 2) = v;
+    }
+  }
+  if (op.parent_scaler)
+  {
+    const unsigned src = (lane % spi) * group;
+    const unsigned m = (unsigned)__shfl((int)scaled_mask, (int)src, 64);
+    xcnt = child_cnt + ((m >> (lane / spi)) & 1u);
+    if (nsc < N) op.parent_scaler[nsc] = xcnt;
+  }
+  else xcnt = 0;
+}
+
+// stage an operation's tables: [R][16][4] lookup tables (rate stride padded) / [R][16] matrices
+template <unsigned R>
+__device__ inline void s4_chain_stage(const OpDesc & op, double * base)
+{
+  constexpr unsigned T2 = R * S4_LUT_RS, M1 = 2 * R * S4_LUT_RS, M2 = 2 * R * S4_LUT_RS + R * 16;
+  const unsigned trow = (threadIdx.x >> 6) * S4_LUT_RS + (threadIdx.x & 63);
+  if (op.codes1) { if (threadIdx.x < R * 64) base[trow] = op.lut1[threadIdx.x]; }
+  else if (threadIdx.x < R * 16) base[M1 + threadIdx.x] = op.pmat1[threadIdx.x];
+  if (op.codes2) { if (threadIdx.x < R * 64) base[T2 + trow] = op.lut2[threadIdx.x]; }
+  else if (threadIdx.x < R * 16) base[M2 + threadIdx.x] = op.pmat2[threadIdx.x];
+}
+
 // (152 VGPRs, three waves per SIMD; forcing four costs 24 spilled registers and 25 % of the rate)
 template <unsigned U, unsigned R>      // R in {1, 2, 4}; U <= 2R loads issued per batch
 __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
 {
-  constexpr unsigned group = 2 * R, spi = 64 / group;
-  constexpr unsigned S4_CHAIN_OP_LDS = s4_chain_op_lds(R), T2 = R * S4_LUT_RS, M1 = 2 * R * S4_LUT_RS,
-                     M2 = 2 * R * S4_LUT_RS + R * 16;
+  constexpr unsigned group = 2 * R;
+  constexpr unsigned S4_CHAIN_OP_LDS = s4_chain_op_lds(R);
   extern __shared__ double lds[];
   const unsigned first = batch.first[blockIdx.y], len = batch.len[blockIdx.y];
   const unsigned lane = threadIdx.x & 63;
   const unsigned h = lane & 1u, r = (lane >> 1) & (R - 1);
   const unsigned long long total = 2ULL * N * R;
 
-  for (unsigned i = 0; i < len; ++i)
-  {
-    const OpDesc & op = batch.op[first + i];
-    double * base = lds + i * S4_CHAIN_OP_LDS;
-    const unsigned trow = (threadIdx.x >> 6) * S4_LUT_RS + (threadIdx.x & 63);
-    if (op.codes1) { if (threadIdx.x < R * 64) base[trow] = op.lut1[threadIdx.x]; }
-    else if (threadIdx.x < R * 16) base[M1 + threadIdx.x] = op.pmat1[threadIdx.x];
-    if (op.codes2) { if (threadIdx.x < R * 64) base[T2 + trow] = op.lut2[threadIdx.x]; }
-    else if (threadIdx.x < R * 16) base[M2 + threadIdx.x] = op.pmat2[threadIdx.x];
-  }
+  for (unsigned i = 0; i < len; ++i) s4_chain_stage<R>(batch.op[first + i], lds + i * S4_CHAIN_OP_LDS);
   __syncthreads();
 
   const unsigned nchunks = (N + 63) / 64;
@@ -274,80 +359,50 @@ __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
     unsigned xcnt = 0;                                 // scaler count that goes with X
 #pragma unroll 1
     for (unsigned i = 0; i < len; ++i)
+      s4_chain_step<U, R>(batch.op[first + i], i ? batch.carried[first + i] : 0u, lds + i * S4_CHAIN_OP_LDS,
+                          X, xcnt, hc0, nsc, total, N, lane, r, h);
+  }
+}
+
+// A whole traversal in one launch (PlanView, engine.h; see k_traverse_s20): a workgroup walks its
+// range of chunks through every chain of the schedule, re-staging the tables between two chains.
+// More workgroups than fit the chip: each finishes its range and makes room for the next, so the
+// ranges in flight at any time are a slab of the alignment that moves through the whole tree.
+template <unsigned U, unsigned R>
+__global__ __launch_bounds__(256) void k_traverse_s4(PlanView plan, unsigned N)
+{
+  constexpr unsigned group = 2 * R;
+  constexpr unsigned S4_CHAIN_OP_LDS = s4_chain_op_lds(R);
+  extern __shared__ double lds[];
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned h = lane & 1u, r = (lane >> 1) & (R - 1);
+  const unsigned long long total = 2ULL * N * R;
+  const unsigned nchunks = (N + 63) / 64;
+  const unsigned cbeg = (unsigned)(((unsigned long long)nchunks * blockIdx.x) / gridDim.x);
+  const unsigned cend = (unsigned)(((unsigned long long)nchunks * (blockIdx.x + 1)) / gridDim.x);
+  for (unsigned c = 0; c < plan.nchains; ++c)
+  {
+    const PlanChain ch = plan_fetch(plan.chains + c);
+    if (c) __syncthreads();
+    for (unsigned i = 0; i < ch.len; ++i)
     {
-      const OpDesc & op = batch.op[first + i];
-      const unsigned carried = i ? batch.carried[first + i] : 0u;
-      const double * base = lds + i * S4_CHAIN_OP_LDS;
-      HalfP p1 = {}, p2 = {};
-      if (!op.codes1) p1 = s4_load_half_p(base + M1, r, h);
-      if (!op.codes2) p2 = s4_load_half_p(base + M2, r, h);
-      unsigned child_cnt = 0;
-      if (op.parent_scaler && nsc < N)
+      const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
+      s4_chain_stage<R>(po.d, lds + i * S4_CHAIN_OP_LDS);
+    }
+    __syncthreads();
+    for (unsigned chunk = cbeg + (threadIdx.x >> 6); chunk < cend; chunk += 4)
+    {
+      const unsigned long long hc0 = (unsigned long long)chunk * 64ULL * group + lane;
+      const unsigned long long nsc = (unsigned long long)chunk * 64ULL + lane;
+      double2 X[group];
+      unsigned xcnt = 0;
+#pragma unroll 1
+      for (unsigned i = 0; i < ch.len; ++i)
       {
-        if (op.scaler1) child_cnt += (carried == 1) ? xcnt : op.scaler1[nsc];
-        if (op.scaler2) child_cnt += (carried == 2) ? xcnt : op.scaler2[nsc];
+        const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
+        s4_chain_step<U, R>(po.d, i ? po.carried : 0u, lds + i * S4_CHAIN_OP_LDS,
+                            X, xcnt, hc0, nsc, total, N, lane, r, h);
       }
-      unsigned scaled_mask = 0;
-      // the tip codes of the chunk's 64 sites: one coalesced byte load per child (lane l holds
-      // site l of the chunk); an iteration picks its site's code with a lane shuffle, so no
-      // global load sits in front of the table lookup
-      const unsigned long long ncode = nsc < N ? nsc : 0ULL;
-      const int cb1 = op.codes1 ? (int)op.codes1[ncode] : 0;
-      const int cb2 = op.codes2 ? (int)op.codes2[ncode] : 0;
-#pragma unroll
-      for (unsigned k0 = 0; k0 < group; k0 += U)
-      {
-        double2 in1[U], in2[U];
-        bool live[U];
-#pragma unroll
-        for (unsigned u = 0; u < U; ++u)
-        {
-          const unsigned long long gu = hc0 + (unsigned long long)(k0 + u) * 64ULL;
-          const int src = (int)((k0 + u) * spi + lane / group);       // this lane's site within the chunk
-          live[u] = gu < total;
-          in1[u] = in2[u] = make_double2(0.0, 0.0);
-          const int code1 = op.codes1 ? __shfl(cb1, src, 64) : 0;
-          const int code2 = op.codes2 ? __shfl(cb2, src, 64) : 0;
-          if (live[u])
-          {
-            if (op.codes1)
-              in1[u] = *reinterpret_cast<const double2 *>(&base[r * S4_LUT_RS + code1 * 4 + 2 * h]);
-            else if (carried != 1) in1[u] = *reinterpret_cast<const double2 *>(op.clv1 + gu * 2);
-            if (op.codes2)
-              in2[u] = *reinterpret_cast<const double2 *>(&base[T2 + r * S4_LUT_RS + code2 * 4 + 2 * h]);
-            else if (carried != 2) in2[u] = *reinterpret_cast<const double2 *>(op.clv2 + gu * 2);
-          }
-        }
-#pragma unroll
-        for (unsigned u = 0; u < U; ++u)
-        {
-          const unsigned k = k0 + u;
-          const unsigned long long gu = hc0 + (unsigned long long)k * 64ULL;
-          const double2 a = op.codes1 ? in1[u] : s4_half_matvec(p1, carried == 1 ? X[k] : in1[u]);
-          const double2 b = op.codes2 ? in2[u] : s4_half_matvec(p2, carried == 2 ? X[k] : in2[u]);
-          double2 v = make_double2(a.x * b.x, a.y * b.y);
-          if (op.parent_scaler)
-          {
-            const int big = group_any(live[u] && !(v.x < SCALE_THRESHOLD && v.y < SCALE_THRESHOLD), lane, group);
-            if (!big)
-            {
-              v.x *= SCALE_FACTOR;
-              v.y *= SCALE_FACTOR;
-              scaled_mask |= 1u << k;
-            }
-          }
-          X[k] = v;
-          if (live[u]) *reinterpret_cast<double2 *>(op.parent + gu * 2) = v;
-        }
-      }
-      if (op.parent_scaler)
-      {
-        const unsigned src = (lane % spi) * group;
-        const unsigned m = (unsigned)__shfl((int)scaled_mask, (int)src, 64);
-        xcnt = child_cnt + ((m >> (lane / spi)) & 1u);
-        if (nsc < N) op.parent_scaler[nsc] = xcnt;
-      }
-      else xcnt = 0;
     }
   }
 }
@@ -599,6 +654,33 @@ static int launch_chains_s4(Engine * e, const ChainBatch & batch, unsigned nchai
     hipLaunchKernelGGL((k_chain_s4<4, 2>), grid, dim3(256), lds, e->stream, batch, e->N);
   else
     hipLaunchKernelGGL((k_chain_s4<2, 1>), grid, dim3(256), lds, e->stream, batch, e->N);
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+static int launch_traverse_s4(Engine * e, const PlanView & plan, unsigned longest)
+{
+  const unsigned nchunks = (e->N + 63) / 64;
+  const size_t lds = sizeof(double) * longest * s4_chain_op_lds(e->R);
+  // exactly the workgroups that are resident at once (measured on C2, workgroups per CU:
+  // 2: 4.06 ms, 3 = resident: 3.58, 4: 4.12, 6: 3.68, 8: 3.82; one launch per round of chains: 3.85)
+  static const int env_bpc = getenv("PLLHIP_S4_TRAVERSE_BPC") ? atoi(getenv("PLLHIP_S4_TRAVERSE_BPC")) : 0;
+  int per_cu = env_bpc;
+  if (per_cu <= 0)
+  {
+    const void * fn = e->R == 4 ? reinterpret_cast<const void *>(k_traverse_s4<4, 4>)
+                    : e->R == 2 ? reinterpret_cast<const void *>(k_traverse_s4<4, 2>)
+                                : reinterpret_cast<const void *>(k_traverse_s4<2, 1>);
+    PLLHIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
+    per_cu = std::max(1, per_cu);
+  }
+  const unsigned gx = std::max(1u, std::min((nchunks + 3) / 4, e->cu_count * (unsigned)per_cu));
+  if (e->R == 4)
+    hipLaunchKernelGGL((k_traverse_s4<4, 4>), dim3(gx), dim3(256), lds, e->stream, plan, e->N);
+  else if (e->R == 2)
+    hipLaunchKernelGGL((k_traverse_s4<4, 2>), dim3(gx), dim3(256), lds, e->stream, plan, e->N);
+  else
+    hipLaunchKernelGGL((k_traverse_s4<2, 1>), dim3(gx), dim3(256), lds, e->stream, plan, e->N);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

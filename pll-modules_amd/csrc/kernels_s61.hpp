@@ -520,20 +520,40 @@ struct CherryScaleBatch
   uint8_t * out[32];
 };
 
-// grid = (codes, cherries), block = 64
-__global__ __launch_bounds__(64) void k_s61_cherry_scale(CherryScaleBatch batch, unsigned lut_codes, unsigned R)
+// grid = cherries, block = 1024, dynamic LDS = 2 x codes x 61 doubles: the two tables of a rate are
+// staged with coalesced loads, a thread then owns code pairs
+__global__ __launch_bounds__(1024) void k_s61_cherry_scale(CherryScaleBatch batch, unsigned lut_codes, unsigned R)
 {
-  const double * l1 = batch.lut1[blockIdx.y], * l2 = batch.lut2[blockIdx.y];
-  const unsigned ca = blockIdx.x;
-  for (unsigned cb = threadIdx.x; cb < lut_codes; cb += blockDim.x)
+  extern __shared__ double tabs[];
+  const unsigned len = lut_codes * S61_S, pairs = lut_codes * lut_codes;
+  double * ta = tabs, * tb = tabs + len;
+  const double * l1 = batch.lut1[blockIdx.x], * l2 = batch.lut2[blockIdx.x];
+  unsigned small[5] = {1u, 1u, 1u, 1u, 1u};            // pairs threadIdx.x + 1024 j (codes <= 67: at most five)
+  for (unsigned r = 0; r < R; ++r)
   {
-    int small = 1;
-    for (unsigned r = 0; r < R; ++r)
+    __syncthreads();
+    for (unsigned e = threadIdx.x; e < len; e += blockDim.x)
     {
-      const double * ra = l1 + ((size_t)r * lut_codes + ca) * S61_S, * rb = l2 + ((size_t)r * lut_codes + cb) * S61_S;
-      for (unsigned i = 0; i < S61_S; ++i) small &= (ra[i] * rb[i] < SCALE_THRESHOLD);
+      ta[e] = l1[(size_t)r * len + e];
+      tb[e] = l2[(size_t)r * len + e];
     }
-    batch.out[blockIdx.y][(size_t)ca * lut_codes + cb] = (uint8_t)small;
+    __syncthreads();
+#pragma unroll
+    for (unsigned j = 0; j < 5; ++j)
+    {
+      const unsigned pr = threadIdx.x + 1024u * j;
+      if (pr >= pairs) break;
+      const double * ra = ta + (pr / lut_codes) * S61_S, * rb = tb + (pr % lut_codes) * S61_S;
+      unsigned sm = small[j];
+      for (unsigned i = 0; i < S61_S; ++i) sm &= (ra[i] * rb[i] < SCALE_THRESHOLD) ? 1u : 0u;
+      small[j] = sm;
+    }
+  }
+#pragma unroll
+  for (unsigned j = 0; j < 5; ++j)
+  {
+    const unsigned pr = threadIdx.x + 1024u * j;
+    if (pr < pairs) batch.out[blockIdx.x][pr] = (uint8_t)small[j];
   }
 }
 
@@ -1159,7 +1179,8 @@ static int launch_partials_s61_cherries(Engine * e, const OpBatch & batch, const
 // scaling tables of `count` cherries (CherryScaleBatch): out[i] = [codes][codes]
 static int launch_cherry_scale_s61(Engine * e, const CherryScaleBatch & batch, unsigned count)
 {
-  hipLaunchKernelGGL(k_s61_cherry_scale, dim3(e->lut_codes, count), dim3(64), 0, e->stream, batch, e->lut_codes, e->R);
+  const size_t lds = sizeof(double) * 2 * e->lut_codes * S61_S;      // <= 64 KiB (s61_cherries_supported)
+  hipLaunchKernelGGL(k_s61_cherry_scale, dim3(count), dim3(1024), lds, e->stream, batch, e->lut_codes, e->R);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

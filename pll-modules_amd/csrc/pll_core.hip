@@ -26,6 +26,7 @@
 #include "kernels_s16.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -112,6 +113,10 @@ static bool dev_alloc(T ** ptr, size_t count, const char * what)
   }
   return true;
 }
+
+// partitions alive per device (whole-traversal launches are the default for a partition that has
+// its device to itself)
+static std::atomic<int> engines_on_device[64];
 
 Engine * engine_create(pll_partition_t * p)
 {
@@ -211,6 +216,7 @@ Engine * engine_create(pll_partition_t * p)
   e->sc_len = (size_t)e->Nalloc * (e->rate_scalers ? e->R : 1);
 
   bool ok = hip_ok(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate");
+  if (ok) { e->counted = true; ++engines_on_device[e->device & 63]; }
   const size_t clv_len = e->blocked ? (size_t)e->nblk * e->R * e->rows * S20_BS : (size_t)e->N * e->R * e->Sp;
   e->clv_len = clv_len;
   e->d_clv.assign(e->nodes, nullptr);
@@ -299,6 +305,7 @@ void engine_destroy(Engine * e)
     return;
   }
   (void)hipSetDevice(e->device);
+  if (e->counted) --engines_on_device[e->device & 63];
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (double * ptr : e->d_clv) if (ptr) (void)hipFree(ptr);
   for (uint8_t * ptr : e->d_codes) if (ptr) (void)hipFree(ptr);
@@ -1096,9 +1103,14 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     ChainPlan plan;
     // tip tables are staged with the codes in use (at least one: an untouched partition)
     const unsigned lut_used = std::max(1u, std::min(p->maxstates, e->lut_codes));
-    // the whole traversal in one launch (PLLHIP_TRAVERSE=0: one launch per round of chains)
-    static const int use_traverse = getenv("PLLHIP_TRAVERSE") ? atoi(getenv("PLLHIP_TRAVERSE")) : 1;
-    if (use_traverse && chains20)
+    // The whole traversal in one launch -- when this partition has the device to itself.  With
+    // several partitions on one device (each on its own stream) the many short launches of the
+    // round schedule interleave better than long-lived workgroups with a fixed share of the sites
+    // (two DNA + two protein partitions, 250 k sites each: 7.4 against 8.1 ms per evaluation).
+    // PLLHIP_TRAVERSE=1 / 0: always / never.
+    static const int env_traverse = getenv("PLLHIP_TRAVERSE") ? atoi(getenv("PLLHIP_TRAVERSE")) : -1;
+    const bool use_traverse = env_traverse >= 0 ? env_traverse != 0 : engines_on_device[e->device & 63].load() <= 1;
+    if (use_traverse)
     {
       DevicePlan & dp = e->plan;
       std::vector<unsigned char> key(2 * sizeof(unsigned) + (size_t)count * sizeof(pll_operation_t));
@@ -1106,11 +1118,55 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
       memcpy(key.data() + sizeof(unsigned), &lut_used, sizeof(unsigned));
       memcpy(key.data() + 2 * sizeof(unsigned), ops, (size_t)count * sizeof(pll_operation_t));
       bool have = !dp.key.empty() && dp.key == key;
-      if (!have && plan_chains(e, ops, count, S20_CHAIN_MAX, S20_CHAIN_LDS, lut_used, plan))
+      if (!have && plan_chains(e, ops, count, chains20 ? S20_CHAIN_MAX : S4_CHAIN_MAX,
+                               chains20 ? S20_CHAIN_LDS : ~0u, lut_used, plan))
       {
-        std::vector<size_t> order(plan.chains.size());
-        for (size_t c = 0; c < order.size(); ++c) order[c] = c;
-        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return plan.launch[a] < plan.launch[b]; });
+        // Order of the chains: depth first, so that a vector is consumed soon after it was written
+        // (the kernel walks slabs of sites through ALL chains: what a slab wrote a few chains ago
+        // is still in L2 / the memory-side cache).  The chains form a tree -- chain c feeds the
+        // chain that reads c's last vector as a child from memory -- and the larger feeder goes
+        // first, which keeps the number of results waiting for their consumer small.
+        const size_t nch = plan.chains.size();
+        std::vector<int> chain_at(count, -1), producer_op(e->nodes, -1);
+        std::vector<unsigned> weight(nch, 0);
+        std::vector<std::vector<size_t>> feeders(nch);
+        std::vector<char> is_feeder(nch, 0);
+        for (size_t c = 0; c < nch; ++c)
+          for (unsigned k : plan.chains[c]) { chain_at[k] = (int)c; producer_op[ops[k].parent_clv_index] = (int)k; }
+        for (size_t c = 0; c < nch; ++c)                  // chains are numbered in creation order: feeders first
+        {
+          weight[c] += (unsigned)plan.chains[c].size();
+          for (unsigned k : plan.chains[c])
+          {
+            const unsigned child[2] = {ops[k].child1_clv_index, ops[k].child2_clv_index};
+            for (int x = 0; x < 2; ++x)
+            {
+              const int pk = producer_op[child[x]];
+              if (pk < 0 || pk >= (int)k || chain_at[pk] == (int)c) continue;
+              feeders[c].push_back((size_t)chain_at[pk]);
+              is_feeder[chain_at[pk]] = 1;
+              weight[c] += weight[chain_at[pk]];
+            }
+          }
+        }
+        std::vector<size_t> order;
+        order.reserve(nch);
+        {
+          std::vector<std::pair<size_t, size_t>> stack;   // (chain, next feeder)
+          for (size_t root = 0; root < nch; ++root)
+          {
+            if (is_feeder[root]) continue;
+            stack.emplace_back(root, 0);
+            while (!stack.empty())
+            {
+              const size_t c = stack.back().first;
+              if (stack.back().second == 0)
+                std::stable_sort(feeders[c].begin(), feeders[c].end(), [&](size_t a, size_t b) { return weight[a] > weight[b]; });
+              if (stack.back().second < feeders[c].size()) { const size_t f = feeders[c][stack.back().second++]; stack.emplace_back(f, 0); }
+              else { order.push_back(c); stack.pop_back(); }
+            }
+          }
+        }
         std::vector<PlanOp> pops(count);
         std::vector<PlanChain> pchains;
         unsigned nops = 0, lds_max = 0;
@@ -1132,12 +1188,15 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
             po.carried = i ? plan.carried[ch[i]] : 0;
             const bool t1 = e->coded_tips && o.child1_clv_index < e->tips;
             const bool t2 = e->coded_tips && o.child2_clv_index < e->tips;
-            po.slot1 = off;
-            off += s20_chain_slot(e, t1, lut_used);
-            po.slot2 = off;
-            off += s20_chain_slot(e, t2, lut_used);
+            if (chains20)
+            {
+              po.slot1 = off;
+              off += s20_chain_slot(e, t1, lut_used);
+              po.slot2 = off;
+              off += s20_chain_slot(e, t2, lut_used);
+            }
           }
-          lds_max = std::max(lds_max, off);
+          lds_max = std::max(lds_max, chains20 ? off : (unsigned)ch.size());   // 4 states: the longest chain
         }
         dp.bytes.resize(pops.size() * sizeof(PlanOp) + pchains.size() * sizeof(PlanChain));
         memcpy(dp.bytes.data(), pops.data(), pops.size() * sizeof(PlanOp));
@@ -1154,7 +1213,8 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
         if (!upload_plan(e, view)) return PLL_FAILURE;
         hipEvent_t ev1;
         if (!prof_begin(ev1)) return PLL_FAILURE;
-        if (!launch_traverse_s20(e, view, dp.lds_doubles, lut_used)) return PLL_FAILURE;
+        if (chains20 ? !launch_traverse_s20(e, view, dp.lds_doubles, lut_used) : !launch_traverse_s4(e, view, dp.lds_doubles))
+          return PLL_FAILURE;
         if (!prof_end(ev1, dp.algo_bytes, dp.algo_flops, count)) return PLL_FAILURE;
         e->counters.partial_launches++;
         e->counters.partial_ops += count;

@@ -228,6 +228,50 @@ with pc.build_instance(lib, states=61, rate_cats=4, ntips=130, nsites=97, coded=
     assert first == second and third != first
 
 
+@pytest.mark.parametrize("states,ntips", [(4, 300), (20, 120)])
+def test_traversal_schedules_agree_bitwise(product, states, ntips):
+    """4 / 20 states: a partition that has its device to itself runs a whole traversal as ONE launch
+    (waves keep their sites through every chain); otherwise one launch per round of chains.  Same
+    vectors, scalers and lnL either way -- full traversals, a second evaluation (cached schedule), a
+    partial traversal and a re-rooted one."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+import pllhip_ctypes as pc
+lib = pc.PllLib(pc.PRODUCT_LIB)
+with pc.build_instance(lib, states=%d, rate_cats=4, ntips=%d, nsites=1531, coded=True) as a:
+    out = []
+    t = a.tree
+    for rep in range(4):
+        if rep == 2:
+            t.set_root_edge(3)
+        if rep == 3:                          # partial traversal: the last third of the operations
+            ops = t.ops_with_scalers(True)
+            part = ops[2 * len(ops) // 3:]
+            a.update_partials(a.make_ops(part), len(part))
+            l = a.edge_lnl(t.root_a, t.scaler_of(t.root_a), t.root_b, t.scaler_of(t.root_b), t.root_matrix)
+        else:
+            l = pc.full_traversal(a)
+        h = hashlib.sha256()
+        for op in t.ops:
+            h.update(a.get_clv(op[0]).tobytes())
+            h.update(a.get_scaler(op[1]).tobytes())
+        out.append("%%.17g %%s" %% (l, h.hexdigest()))
+    print("\n".join(out))
+    print(a.counters().partial_launches)
+""" % (os.path.dirname(pc.__file__), states, ntips)
+    runs = []
+    for mode in ("1", "0"):
+        env = dict(os.environ, PLLHIP_TRAVERSE=mode)
+        runs.append(subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True,
+                                   text=True, timeout=300).stdout.splitlines())
+    assert runs[0][:4] == runs[1][:4] and len(runs[0]) == 5
+    assert int(runs[0][4]) == 4 and int(runs[1][4]) > 8        # one launch per traversal / several
+
+
 @pytest.mark.parametrize("rate_cats", [4, 2])
 def test_codon_cherries_that_scale(product, oracle, rate_cats):
     """61 states: a tip x tip operation is computed inside the operation that consumes it, its own
