@@ -520,15 +520,17 @@ struct CherryScaleBatch
   uint8_t * out[32];
 };
 
-// grid = cherries, block = 1024, dynamic LDS = 2 x codes x 61 doubles: the two tables of a rate are
-// staged with coalesced loads, a thread then owns code pairs
+// grid = (ceil(codes^2 / 1024), cherries), block = 1024, dynamic LDS = 2 x codes x 61 doubles: the two
+// tables of a rate are staged with coalesced loads, a thread then owns one pair of codes
 __global__ __launch_bounds__(1024) void k_s61_cherry_scale(CherryScaleBatch batch, unsigned lut_codes, unsigned R)
 {
   extern __shared__ double tabs[];
   const unsigned len = lut_codes * S61_S, pairs = lut_codes * lut_codes;
   double * ta = tabs, * tb = tabs + len;
-  const double * l1 = batch.lut1[blockIdx.x], * l2 = batch.lut2[blockIdx.x];
-  unsigned small[5] = {1u, 1u, 1u, 1u, 1u};            // pairs threadIdx.x + 1024 j (codes <= 67: at most five)
+  const double * l1 = batch.lut1[blockIdx.y], * l2 = batch.lut2[blockIdx.y];
+  const unsigned pr = blockIdx.x * 1024u + threadIdx.x;
+  const unsigned ca = pr < pairs ? pr / lut_codes : 0, cb = pr < pairs ? pr % lut_codes : 0;
+  unsigned small = 1u;
   for (unsigned r = 0; r < R; ++r)
   {
     __syncthreads();
@@ -538,23 +540,10 @@ __global__ __launch_bounds__(1024) void k_s61_cherry_scale(CherryScaleBatch batc
       tb[e] = l2[(size_t)r * len + e];
     }
     __syncthreads();
-#pragma unroll
-    for (unsigned j = 0; j < 5; ++j)
-    {
-      const unsigned pr = threadIdx.x + 1024u * j;
-      if (pr >= pairs) break;
-      const double * ra = ta + (pr / lut_codes) * S61_S, * rb = tb + (pr % lut_codes) * S61_S;
-      unsigned sm = small[j];
-      for (unsigned i = 0; i < S61_S; ++i) sm &= (ra[i] * rb[i] < SCALE_THRESHOLD) ? 1u : 0u;
-      small[j] = sm;
-    }
+    const double * ra = ta + ca * S61_S, * rb = tb + cb * S61_S;
+    for (unsigned i = 0; i < S61_S; ++i) small &= (ra[i] * rb[i] < SCALE_THRESHOLD) ? 1u : 0u;
   }
-#pragma unroll
-  for (unsigned j = 0; j < 5; ++j)
-  {
-    const unsigned pr = threadIdx.x + 1024u * j;
-    if (pr < pairs) batch.out[blockIdx.x][pr] = (uint8_t)small[j];
-  }
+  if (pr < pairs) batch.out[blockIdx.y][pr] = (uint8_t)small;
 }
 
 // k-steps 8 HALF .. 8 HALF + 7 of a cherry's unit: product of the two tips' rows with the cherry's
@@ -1180,7 +1169,8 @@ static int launch_partials_s61_cherries(Engine * e, const OpBatch & batch, const
 static int launch_cherry_scale_s61(Engine * e, const CherryScaleBatch & batch, unsigned count)
 {
   const size_t lds = sizeof(double) * 2 * e->lut_codes * S61_S;      // <= 64 KiB (s61_cherries_supported)
-  hipLaunchKernelGGL(k_s61_cherry_scale, dim3(count), dim3(1024), lds, e->stream, batch, e->lut_codes, e->R);
+  hipLaunchKernelGGL(k_s61_cherry_scale, dim3((e->lut_codes * e->lut_codes + 1023u) / 1024u, count), dim3(1024), lds, e->stream,
+                     batch, e->lut_codes, e->R);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

@@ -71,11 +71,12 @@ def main():
                          "hbm_bytes_per_dispatch": rd + wr}
     json.dump(summary, open(os.path.join(OUT, f"{rnd}_{cfg}_pmc.json"), "w"), indent=1)
     if kernel_key:
-        # all partials launches of the run -- chained (k_chain_*) and per-operation
-        # (k_partials_*, plus the 61-state fix-up that belongs to its launch) -- averaged per
-        # launch, the unit of bench.py's roofline.algorithmic_bytes_per_launch
-        dom = [v for k, v in summary.items() if "k_partials" in k or "k_chain" in k]
-        extra = [v for k, v in summary.items() if "k_s61_scale_fixup" in k]
+        # all partials launches of the run -- whole traversals (k_traverse_*), rounds of chains
+        # (k_chain_*) and per-operation launches (k_partials_*, plus the 61-state fix-up and
+        # cherry-table kernels that belong to them) -- averaged per launch, the unit of
+        # bench.py's roofline.algorithmic_bytes_per_launch
+        dom = [v for k, v in summary.items() if "k_partials" in k or "k_chain" in k or "k_traverse" in k]
+        extra = [v for k, v in summary.items() if "k_s61_scale_fixup" in k or "k_s61_cherry_scale" in k]
         if dom:
             total = sum(v["dispatches"] * v["hbm_bytes_per_dispatch"] for v in dom + extra)
             launches = sum(v["dispatches"] for v in dom)
