@@ -436,12 +436,15 @@ __device__ inline void s20_child_inner_c(const double * unit, const double * cfr
 
 // one operation for one site block; X holds the handed-over operand on entry (when
 // carried != 0) and the result on exit.  s1 / s2: the children's LDS tables.
-template <unsigned RT>
+// xe / xo: the scaler counts that go with X (per rate with RS = PLL_ATTRIB_RATE_SCALERS, where
+// the vote covers one (site, rate) unit and the counts live at scaler[site * R + rate];
+// otherwise one count per site, held in element 0).
+template <unsigned RT, bool RS>
 __device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2 X[RT][5],
                                     const double * s1, const double * s2,
                                     unsigned lut_codes, unsigned lut_used, bool lut_lds,
                                     unsigned blk, unsigned lane, bool nt_ld, bool nt_st,
-                                    unsigned & xe, unsigned & xo)
+                                    unsigned (&xe)[RS ? RT : 1], unsigned (&xo)[RS ? RT : 1])
 {
   const unsigned q = lane >> 4, n = lane & 15;
   const size_t site0 = (size_t)blk * S20_BS + 2 * n;
@@ -464,15 +467,57 @@ __device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2
     else if (lut_lds) s20_child_tip(s2 + r * lut_used * S20_LUT_RS, c2e, c2o, q, t2, S20_LUT_RS);
     else s20_child_tip(op.lut2 + (size_t)r * lut_codes * 20, c2e, c2o, q, t2);
     // X[r] has been consumed (if it was an operand at all): it now takes the result
+    int re = 1, ro = 1;
 #pragma unroll
     for (int k = 0; k < 5; ++k)
     {
       X[r][k].x = t1[k].x * t2[k].x;
       X[r][k].y = t1[k].y * t2[k].y;
-      small_e &= (X[r][k].x < SCALE_THRESHOLD);
-      small_o &= (X[r][k].y < SCALE_THRESHOLD);
+      re &= (X[r][k].x < SCALE_THRESHOLD);
+      ro &= (X[r][k].y < SCALE_THRESHOLD);
     }
+    if (!RS)
+    {
+      small_e &= re;
+      small_o &= ro;
+      continue;
+    }
+    // per-rate scalers: the vote covers this unit alone -- decide, scale, store, count
+    unsigned ce = 0, co = 0;
+    if (scaling)
+    {
+      const int se = s20_and_q(re), so = s20_and_q(ro);
+      const double fe = se ? SCALE_FACTOR : 1.0, fo = so ? SCALE_FACTOR : 1.0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+      {
+        X[r][k].x *= fe;
+        X[r][k].y *= fo;
+      }
+      if (q == 0)
+      {
+        const size_t ie = site0 * RT + r, io = (site0 + 1) * RT + r;
+        ce = se ? 1u : 0u;
+        co = so ? 1u : 0u;
+        if (op.scaler1)
+        {
+          if (carried == 1) { ce += xe[RS ? r : 0]; co += xo[RS ? r : 0]; }
+          else { ce += op.scaler1[ie]; co += op.scaler1[io]; }
+        }
+        if (op.scaler2)
+        {
+          if (carried == 2) { ce += xe[RS ? r : 0]; co += xo[RS ? r : 0]; }
+          else { ce += op.scaler2[ie]; co += op.scaler2[io]; }
+        }
+        op.parent_scaler[ie] = ce;
+        op.parent_scaler[io] = co;
+      }
+    }
+    s20_store_d(op.parent + ubase, lane, X[r], nt_st);
+    xe[RS ? r : 0] = ce;
+    xo[RS ? r : 0] = co;
   }
+  if (RS) return;
   double fe = 1.0, fo = 1.0;
   if (scaling)
   {
@@ -499,19 +544,19 @@ __device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2
     co = small_o ? 1u : 0u;
     if (op.scaler1)
     {
-      if (carried == 1) { ce += xe; co += xo; }
+      if (carried == 1) { ce += xe[0]; co += xo[0]; }
       else { ce += op.scaler1[site0]; co += op.scaler1[site0 + 1]; }
     }
     if (op.scaler2)
     {
-      if (carried == 2) { ce += xe; co += xo; }
+      if (carried == 2) { ce += xe[0]; co += xo[0]; }
       else { ce += op.scaler2[site0]; co += op.scaler2[site0 + 1]; }
     }
     op.parent_scaler[site0] = ce;
     op.parent_scaler[site0 + 1] = co;
   }
-  xe = ce;
-  xo = co;
+  xe[0] = ce;
+  xo[0] = co;
 }
 
 // row-major [R][20][20] matrix sets -> compact fragment order (after a host upload of the
@@ -546,7 +591,7 @@ __device__ inline void s20_fill_slot(double * slot, const double * pmat, const d
 // intermediate vector in registers.  One 512-thread workgroup per CU (eight waves share the
 // tables: same occupancy as two 256-thread workgroups, half the LDS).
 // grid = (gx, chains), block = 512, dynamic LDS = the largest chain area of the launch.
-template <unsigned RT>
+template <unsigned RT, bool RS>
 __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_chain_s20(ChainBatch batch, unsigned nblk,
                                                                         unsigned lut_codes, unsigned lut_used,
                                                                         unsigned flags)
@@ -568,10 +613,10 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_chain_s20(ChainBatc
   for (unsigned blk = blockIdx.x * S20_CHAIN_WAVES + wave; blk < nblk; blk += wstride)
   {
     double2 X[RT][5];
-    unsigned xe = 0, xo = 0;
+    unsigned xe[RS ? RT : 1] = {}, xo[RS ? RT : 1] = {};
 #pragma unroll 1
     for (unsigned i = 0; i < len; ++i)
-      s20_chain_op<RT>(batch.op[first + i], i ? batch.carried[first + i] : 0u, X,
+      s20_chain_op<RT, RS>(batch.op[first + i], i ? batch.carried[first + i] : 0u, X,
                        lds + batch.slot1[first + i], lds + batch.slot2[first + i],
                        lut_codes, lut_used, lut_lds, blk, lane, nt_ld, nt_st, xe, xo);
   }
@@ -582,7 +627,7 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_chain_s20(ChainBatc
 // reads from an earlier chain it has written itself -- there is nothing to wait for but the
 // workgroup's own barrier around the re-staging of the LDS tables.
 // grid = gx, block = 512, dynamic LDS = the largest chain area of the schedule.
-template <unsigned RT>
+template <unsigned RT, bool RS>
 __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanView plan, unsigned nblk, unsigned slab,
                                                                            unsigned lut_codes, unsigned lut_used,
                                                                            unsigned flags)
@@ -613,12 +658,12 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanVi
       for (unsigned blk = s0 + blockIdx.x * S20_CHAIN_WAVES + wave; blk < s1; blk += wstride)
       {
         double2 X[RT][5];
-        unsigned xe = 0, xo = 0;
+        unsigned xe[RS ? RT : 1] = {}, xo[RS ? RT : 1] = {};
 #pragma unroll 1
         for (unsigned i = 0; i < ch.len; ++i)
         {
           const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
-          s20_chain_op<RT>(po.d, i ? po.carried : 0u, X, lds + po.slot1, lds + po.slot2,
+          s20_chain_op<RT, RS>(po.d, i ? po.carried : 0u, X, lds + po.slot1, lds + po.slot2,
                            lut_codes, lut_used, lut_lds, blk, lane, nt_ld, nt_st, xe, xo);
         }
       }
@@ -998,8 +1043,7 @@ static int launch_partials_s20(Engine * e, const OpBatch & batch, unsigned nops)
   return PLL_SUCCESS;
 }
 
-// (per-rate scalers: the chain kernel votes per site; such partitions keep the level schedule)
-static bool chains_supported_s20(const Engine * e) { return !e->rate_scalers && (e->R == 4 || e->R == 2 || e->R == 1); }
+static bool chains_supported_s20(const Engine * e) { return e->R == 4 || e->R == 2 || e->R == 1; }
 
 // LDS doubles of the two children's tables of an operation in a chain (0: read from global)
 static bool s20_chain_lut_lds(const Engine * e, unsigned lut_used)
@@ -1017,6 +1061,32 @@ static unsigned s20_chain_slot(const Engine * e, bool tip, unsigned lut_used)
 // that one workgroup's fragment fill overlaps the other's streaming -- was measured at
 // 125 k / 250 k / 500 k sites and is 13 % / 15 % / 0 % slower than this one: the extra
 // re-reads cost more than the overlap gains.)
+// every instantiation of a chain kernel may use the whole LDS
+template <class K>
+static int s20_allow_full_lds(K kernel)
+{
+  PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(sizeof(double) * S20_CHAIN_LDS)));
+  return PLL_SUCCESS;
+}
+
+// R in {1, 2, 4} x per-site / per-rate scalers
+#define PLLHIP_S20_CHAIN_DISPATCH(KERNEL, CALL)                        \
+  do {                                                                 \
+    if (e->rate_scalers)                                               \
+    {                                                                  \
+      if (e->R == 4) { CALL((KERNEL<4, true>)); }                      \
+      else if (e->R == 2) { CALL((KERNEL<2, true>)); }                 \
+      else { CALL((KERNEL<1, true>)); }                                \
+    }                                                                  \
+    else                                                               \
+    {                                                                  \
+      if (e->R == 4) { CALL((KERNEL<4, false>)); }                     \
+      else if (e->R == 2) { CALL((KERNEL<2, false>)); }                \
+      else { CALL((KERNEL<1, false>)); }                               \
+    }                                                                  \
+  } while (0)
+
 static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned nchains, unsigned lds_doubles,
                              unsigned lut_used)
 {
@@ -1027,13 +1097,10 @@ static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned ncha
   bool & attr_set = attr_set_dev[e->device & 63];
   if (!attr_set)
   {
-    const int cap = (int)(sizeof(double) * S20_CHAIN_LDS);
-    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_s20<4>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_s20<2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_s20<1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    if (!s20_allow_full_lds(k_chain_s20<4, false>) || !s20_allow_full_lds(k_chain_s20<2, false>) ||
+        !s20_allow_full_lds(k_chain_s20<1, false>) || !s20_allow_full_lds(k_chain_s20<4, true>) ||
+        !s20_allow_full_lds(k_chain_s20<2, true>) || !s20_allow_full_lds(k_chain_s20<1, true>))
+      return PLL_FAILURE;
     attr_set = true;
   }
   // workgroups per CU and chain (measured at 1 M sites: 1 beats 2 and 4)
@@ -1041,12 +1108,9 @@ static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned ncha
   const unsigned need = (e->nblk + S20_CHAIN_WAVES - 1) / S20_CHAIN_WAVES;
   const unsigned gx = std::max(1u, std::min(need, e->cu_count * (unsigned)std::max(1, env_bpc)));
   const dim3 grid(gx, nchains), block(64 * S20_CHAIN_WAVES);
-  if (e->R == 4)
-    hipLaunchKernelGGL(k_chain_s20<4>, grid, block, lds, e->stream, batch, e->nblk, e->lut_codes, lut_used, flags);
-  else if (e->R == 2)
-    hipLaunchKernelGGL(k_chain_s20<2>, grid, block, lds, e->stream, batch, e->nblk, e->lut_codes, lut_used, flags);
-  else
-    hipLaunchKernelGGL(k_chain_s20<1>, grid, block, lds, e->stream, batch, e->nblk, e->lut_codes, lut_used, flags);
+#define PLLHIP_CALL(K) hipLaunchKernelGGL(K, grid, block, lds, e->stream, batch, e->nblk, e->lut_codes, lut_used, flags)
+  PLLHIP_S20_CHAIN_DISPATCH(k_chain_s20, PLLHIP_CALL);
+#undef PLLHIP_CALL
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }
@@ -1060,29 +1124,24 @@ static int launch_traverse_s20(Engine * e, const PlanView & plan, unsigned lds_d
   bool & attr_set = attr_set_dev[e->device & 63];
   if (!attr_set)
   {
-    const int cap = (int)(sizeof(double) * S20_CHAIN_LDS);
-    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_traverse_s20<4>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_traverse_s20<2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_traverse_s20<1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    if (!s20_allow_full_lds(k_traverse_s20<4, false>) || !s20_allow_full_lds(k_traverse_s20<2, false>) ||
+        !s20_allow_full_lds(k_traverse_s20<1, false>) || !s20_allow_full_lds(k_traverse_s20<4, true>) ||
+        !s20_allow_full_lds(k_traverse_s20<2, true>) || !s20_allow_full_lds(k_traverse_s20<1, true>))
+      return PLL_FAILURE;
     attr_set = true;
   }
   const unsigned need = (e->nblk + S20_CHAIN_WAVES - 1) / S20_CHAIN_WAVES;
   const unsigned gx = std::max(1u, std::min(need, e->cu_count));
-  // slab: site blocks that go through the whole schedule together (0 = all of them)
+  // slab: site blocks that go through the whole schedule together (default: all of them; smaller
+  // slabs were measured and lose to the per-chain re-staging)
   static const int env_slab = getenv("PLLHIP_S20_SLAB") ? atoi(getenv("PLLHIP_S20_SLAB")) : 0;
   const unsigned per_pass = gx * S20_CHAIN_WAVES;
   unsigned slab = env_slab > 0 ? (unsigned)env_slab : e->nblk;
   slab = std::max(per_pass, (slab + per_pass - 1) / per_pass * per_pass);   // whole passes of the grid
   const dim3 grid(gx), block(64 * S20_CHAIN_WAVES);
-  if (e->R == 4)
-    hipLaunchKernelGGL(k_traverse_s20<4>, grid, block, lds, e->stream, plan, e->nblk, slab, e->lut_codes, lut_used, flags);
-  else if (e->R == 2)
-    hipLaunchKernelGGL(k_traverse_s20<2>, grid, block, lds, e->stream, plan, e->nblk, slab, e->lut_codes, lut_used, flags);
-  else
-    hipLaunchKernelGGL(k_traverse_s20<1>, grid, block, lds, e->stream, plan, e->nblk, slab, e->lut_codes, lut_used, flags);
+#define PLLHIP_CALL(K) hipLaunchKernelGGL(K, grid, block, lds, e->stream, plan, e->nblk, slab, e->lut_codes, lut_used, flags)
+  PLLHIP_S20_CHAIN_DISPATCH(k_traverse_s20, PLLHIP_CALL);
+#undef PLLHIP_CALL
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }
