@@ -204,6 +204,183 @@ __global__ __launch_bounds__(256) void k_partials_s16(OpBatch batch, unsigned nb
 }
 
 // ---------------------------------------------------------------------------
+// Whole traversals in one launch (PlanView, engine.h; see k_traverse_s20): chains of operations
+// with the handed-over block in registers (the D layout of a result is the B layout of an
+// operand here as well), the tables of a whole chain in LDS, a workgroup walking all chains of
+// the schedule with the same site blocks.  Four rate categories (the register-resident block
+// needs the rate count at compile time); other rate counts keep the level schedule.
+// grid = gx <= CUs, block = 512, dynamic LDS = the largest chain area of the schedule.
+// ---------------------------------------------------------------------------
+constexpr unsigned S16_CHAIN_WAVES = 8;
+constexpr unsigned S16_CHAIN_MAX = 8;
+constexpr unsigned S16_CHAIN_LDS = 20480;             // doubles: the whole LDS of a CU
+
+template <unsigned KS>
+__device__ inline void s16_child_regs(const double2 b[KS], const double * frag_r, unsigned lane, double2 t[KS])
+{
+  v4d acc_e = {0, 0, 0, 0}, acc_o = {0, 0, 0, 0};
+#pragma unroll
+  for (unsigned ks = 0; ks < KS; ++ks)
+  {
+    const double f = frag_r[ks * 64 + lane];
+    acc_e = mfma_f64(f, b[ks].x, acc_e);
+    acc_o = mfma_f64(f, b[ks].y, acc_o);
+  }
+#pragma unroll
+  for (unsigned v = 0; v < KS; ++v) t[v] = make_double2(acc_e[v], acc_o[v]);
+}
+
+// one operation for one site block; X: the handed-over operand on entry (carried != 0), the result on
+// exit; xe / xo: the scaler counts that go with X (per rate with RS, else element 0)
+template <unsigned KS, unsigned RT, bool RS>
+__device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2 X[RT][KS],
+                                    const double * s1, const double * s2, unsigned S, unsigned lut_codes,
+                                    bool lut_lds, unsigned blk, unsigned lane,
+                                    unsigned (&xe)[RS ? RT : 1], unsigned (&xo)[RS ? RT : 1])
+{
+  constexpr unsigned UNIT = 4 * KS * S20_BS;
+  const unsigned q = lane >> 4, n = lane & 15;
+  const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+  unsigned c1e = 0, c1o = 0, c2e = 0, c2o = 0;
+  if (op.codes1) { c1e = op.codes1[site0]; c1o = op.codes1[site0 + 1]; }
+  if (op.codes2) { c2e = op.codes2[site0]; c2o = op.codes2[site0 + 1]; }
+  const bool scaling = op.parent_scaler != nullptr;
+  const double * l1 = lut_lds ? s1 : op.lut1, * l2 = lut_lds ? s2 : op.lut2;
+  int small_e = 1, small_o = 1;
+#pragma unroll
+  for (unsigned r = 0; r < RT; ++r)
+  {
+    const size_t ubase = ((size_t)blk * RT + r) * UNIT;
+    double2 t1[KS], t2[KS];
+    if (carried == 1) s16_child_regs<KS>(X[r], s1 + r * KS * 64, lane, t1);
+    else if (!op.codes1) s16_child_inner<KS>(op.clv1 + ubase, s1 + r * KS * 64, lane, t1);
+    else s16_child_tip<KS>(l1 + (size_t)r * lut_codes * S, c1e, c1o, q, S, t1);
+    if (carried == 2) s16_child_regs<KS>(X[r], s2 + r * KS * 64, lane, t2);
+    else if (!op.codes2) s16_child_inner<KS>(op.clv2 + ubase, s2 + r * KS * 64, lane, t2);
+    else s16_child_tip<KS>(l2 + (size_t)r * lut_codes * S, c2e, c2o, q, S, t2);
+    int re = 1, ro = 1;
+#pragma unroll
+    for (unsigned v = 0; v < KS; ++v)
+    {
+      X[r][v].x = t1[v].x * t2[v].x;
+      X[r][v].y = t1[v].y * t2[v].y;
+      re &= (X[r][v].x < SCALE_THRESHOLD);       // rows >= S are zero: they never veto
+      ro &= (X[r][v].y < SCALE_THRESHOLD);
+    }
+    if (!RS)
+    {
+      small_e &= re;
+      small_o &= ro;
+      continue;
+    }
+    unsigned ce = 0, co = 0;
+    if (scaling)
+    {
+      const int se = s20_and_q(re), so = s20_and_q(ro);
+      const double fe = se ? SCALE_FACTOR : 1.0, fo = so ? SCALE_FACTOR : 1.0;
+#pragma unroll
+      for (unsigned v = 0; v < KS; ++v) { X[r][v].x *= fe; X[r][v].y *= fo; }
+      if (q == 0)
+      {
+        const size_t ie = site0 * RT + r, io = (site0 + 1) * RT + r;
+        ce = se ? 1u : 0u;
+        co = so ? 1u : 0u;
+        if (op.scaler1)
+        {
+          if (carried == 1) { ce += xe[RS ? r : 0]; co += xo[RS ? r : 0]; }
+          else { ce += op.scaler1[ie]; co += op.scaler1[io]; }
+        }
+        if (op.scaler2)
+        {
+          if (carried == 2) { ce += xe[RS ? r : 0]; co += xo[RS ? r : 0]; }
+          else { ce += op.scaler2[ie]; co += op.scaler2[io]; }
+        }
+        op.parent_scaler[ie] = ce;
+        op.parent_scaler[io] = co;
+      }
+    }
+    s16_store_d<KS>(op.parent + ubase, lane, X[r]);
+    xe[RS ? r : 0] = ce;
+    xo[RS ? r : 0] = co;
+  }
+  if (RS) return;
+  double fe = 1.0, fo = 1.0;
+  if (scaling)
+  {
+    small_e = s20_and_q(small_e);
+    small_o = s20_and_q(small_o);
+    fe = small_e ? SCALE_FACTOR : 1.0;
+    fo = small_o ? SCALE_FACTOR : 1.0;
+  }
+#pragma unroll
+  for (unsigned r = 0; r < RT; ++r)
+  {
+#pragma unroll
+    for (unsigned v = 0; v < KS; ++v) { X[r][v].x *= fe; X[r][v].y *= fo; }
+    s16_store_d<KS>(op.parent + ((size_t)blk * RT + r) * UNIT, lane, X[r]);
+  }
+  unsigned ce = 0, co = 0;
+  if (scaling && q == 0)
+  {
+    ce = small_e ? 1u : 0u;
+    co = small_o ? 1u : 0u;
+    if (op.scaler1)
+    {
+      if (carried == 1) { ce += xe[0]; co += xo[0]; }
+      else { ce += op.scaler1[site0]; co += op.scaler1[site0 + 1]; }
+    }
+    if (op.scaler2)
+    {
+      if (carried == 2) { ce += xe[0]; co += xo[0]; }
+      else { ce += op.scaler2[site0]; co += op.scaler2[site0 + 1]; }
+    }
+    op.parent_scaler[site0] = ce;
+    op.parent_scaler[site0 + 1] = co;
+  }
+  xe[0] = ce;
+  xo[0] = co;
+}
+
+template <unsigned KS, unsigned RT, bool RS>
+__global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanView plan, unsigned nblk, unsigned S,
+                                                                           unsigned Sp, unsigned lut_codes,
+                                                                           unsigned lut_lds_flag)
+{
+  extern __shared__ double lds[];
+  const bool lut_lds = lut_lds_flag != 0;
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned wstride = gridDim.x * S16_CHAIN_WAVES;
+  for (unsigned c = 0; c < plan.nchains; ++c)
+  {
+    const PlanChain ch = plan_fetch(plan.chains + c);
+    if (c) __syncthreads();
+    for (unsigned i = 0; i < ch.len; ++i)
+    {
+      const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
+      if (!po.d.codes1) s16_fill_frags<KS>(lds + po.slot1, po.d.pmat1, RT, S, Sp);
+      else if (lut_lds)
+        for (unsigned e = threadIdx.x; e < RT * lut_codes * S; e += blockDim.x) lds[po.slot1 + e] = po.d.lut1[e];
+      if (!po.d.codes2) s16_fill_frags<KS>(lds + po.slot2, po.d.pmat2, RT, S, Sp);
+      else if (lut_lds)
+        for (unsigned e = threadIdx.x; e < RT * lut_codes * S; e += blockDim.x) lds[po.slot2 + e] = po.d.lut2[e];
+    }
+    __syncthreads();
+    for (unsigned blk = blockIdx.x * S16_CHAIN_WAVES + wave; blk < nblk; blk += wstride)
+    {
+      double2 X[RT][KS];
+      unsigned xe[RS ? RT : 1] = {}, xo[RS ? RT : 1] = {};
+#pragma unroll 1
+      for (unsigned i = 0; i < ch.len; ++i)
+      {
+        const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
+        s16_chain_op<KS, RT, RS>(po.d, i ? po.carried : 0u, X, lds + po.slot1, lds + po.slot2, S, lut_codes,
+                                 lut_lds, blk, lane, xe, xo);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // edge / root log-likelihood.  grid = nblocks, block = 256; dynamic LDS = R * KS * 64 doubles
 // ---------------------------------------------------------------------------
 template <unsigned KS>
@@ -376,6 +553,53 @@ static int launch_partials_s16(Engine * e, const OpBatch & batch, unsigned nops)
 #define PLLHIP_CALL(KK) \
   hipLaunchKernelGGL(k_partials_s16<KK>, dim3(s16_grid(e, 8), nops), dim3(256), sizeof(double) * 2 * table, e->stream, \
                      batch, e->nblk, e->R, e->S, e->Sp, e->lut_codes, table, e->rate_scalers ? 1u : 0u)
+  PLLHIP_DISPATCH_KS(s16_ks(e), PLLHIP_CALL);
+#undef PLLHIP_CALL
+  PLLHIP_TRY(hipGetLastError());
+  return PLL_SUCCESS;
+}
+
+// one-launch traversals: four rate categories
+static bool chains_supported_s16(const Engine * e) { return e->R == 4; }
+
+static bool s16_chain_lut_lds(const Engine * e) { return e->R * e->lut_codes * e->S <= S16_LUT_LDS; }
+
+// LDS doubles of one child's table in a chain (0: tip table gathered from global memory)
+static unsigned s16_chain_slot(const Engine * e, bool tip)
+{
+  if (!tip) return e->R * s16_ks(e) * 64;
+  return s16_chain_lut_lds(e) ? ((e->R * e->lut_codes * e->S + 7u) & ~7u) : 0u;
+}
+
+static int launch_traverse_s16(Engine * e, const PlanView & plan, unsigned lds_doubles)
+{
+  const size_t lds = sizeof(double) * lds_doubles;
+  const unsigned need = (e->nblk + S16_CHAIN_WAVES - 1) / S16_CHAIN_WAVES;
+  const unsigned gx = std::max(1u, std::min(need, e->cu_count));
+  const unsigned lut_lds = s16_chain_lut_lds(e) ? 1u : 0u;
+  static bool attr_set_dev[64] = {false};
+  bool & attr_set = attr_set_dev[e->device & 63];
+  const int cap = (int)(sizeof(double) * S16_CHAIN_LDS);
+#define PLLHIP_ATTR(KK) \
+  do { \
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_traverse_s16<KK, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_traverse_s16<KK, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
+  } while (0)
+  if (!attr_set)
+  {
+    PLLHIP_ATTR(1); PLLHIP_ATTR(2); PLLHIP_ATTR(3); PLLHIP_ATTR(4);
+    attr_set = true;
+  }
+#undef PLLHIP_ATTR
+#define PLLHIP_CALL(KK) \
+  do { \
+    if (e->rate_scalers) \
+      hipLaunchKernelGGL((k_traverse_s16<KK, 4, true>), dim3(gx), dim3(64 * S16_CHAIN_WAVES), lds, e->stream, \
+                         plan, e->nblk, e->S, e->Sp, e->lut_codes, lut_lds); \
+    else \
+      hipLaunchKernelGGL((k_traverse_s16<KK, 4, false>), dim3(gx), dim3(64 * S16_CHAIN_WAVES), lds, e->stream, \
+                         plan, e->nblk, e->S, e->Sp, e->lut_codes, lut_lds); \
+  } while (0)
   PLLHIP_DISPATCH_KS(s16_ks(e), PLLHIP_CALL);
 #undef PLLHIP_CALL
   PLLHIP_TRY(hipGetLastError());

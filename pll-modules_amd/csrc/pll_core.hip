@@ -861,9 +861,10 @@ struct ChainPlan
 // LDS doubles the tables of operation `op` take in a chain kernel (20 states; 0 otherwise)
 static unsigned chain_op_lds(const Engine * e, const pll_operation_t & op, unsigned lut_used)
 {
-  if (e->family != KernelFamily::S20) return 0u;
   const bool t1 = e->coded_tips && op.child1_clv_index < e->tips;
   const bool t2 = e->coded_tips && op.child2_clv_index < e->tips;
+  if (e->family == KernelFamily::S16) return s16_chain_slot(e, t1) + s16_chain_slot(e, t2);
+  if (e->family != KernelFamily::S20) return 0u;
   return s20_chain_slot(e, t1, lut_used) + s20_chain_slot(e, t2, lut_used);
 }
 
@@ -1098,7 +1099,9 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
   static const int use_chains = getenv("PLLHIP_CHAINS") ? atoi(getenv("PLLHIP_CHAINS")) : 1;
   const bool chains20 = e->family == KernelFamily::S20 && chains_supported_s20(e);
   const bool chains4 = e->family == KernelFamily::S4 && chains_supported_s4(e);
-  if (use_chains && count >= 2 && (chains20 || chains4))
+  // 2..16 states: chains exist in the one-launch form only
+  const bool chains16 = e->family == KernelFamily::S16 && chains_supported_s16(e);
+  if (use_chains && count >= 2 && (chains20 || chains4 || chains16))
   {
     ChainPlan plan;
     // tip tables are staged with the codes in use (at least one: an untouched partition)
@@ -1110,6 +1113,8 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     // PLLHIP_TRAVERSE=1 / 0: always / never.
     static const int env_traverse = getenv("PLLHIP_TRAVERSE") ? atoi(getenv("PLLHIP_TRAVERSE")) : -1;
     const bool use_traverse = env_traverse >= 0 ? env_traverse != 0 : engines_on_device[e->device & 63].load() <= 1;
+    const unsigned chain_max = chains20 ? S20_CHAIN_MAX : chains16 ? S16_CHAIN_MAX : S4_CHAIN_MAX;
+    const unsigned chain_lds = chains20 ? S20_CHAIN_LDS : chains16 ? S16_CHAIN_LDS : ~0u;
     if (use_traverse)
     {
       DevicePlan & dp = e->plan;
@@ -1118,8 +1123,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
       memcpy(key.data() + sizeof(unsigned), &lut_used, sizeof(unsigned));
       memcpy(key.data() + 2 * sizeof(unsigned), ops, (size_t)count * sizeof(pll_operation_t));
       bool have = !dp.key.empty() && dp.key == key;
-      if (!have && plan_chains(e, ops, count, chains20 ? S20_CHAIN_MAX : S4_CHAIN_MAX,
-                               chains20 ? S20_CHAIN_LDS : ~0u, lut_used, plan))
+      if (!have && plan_chains(e, ops, count, chain_max, chain_lds, lut_used, plan))
       {
         // Order of the chains: depth first, so that a vector is consumed soon after it was written
         // (the kernel walks slabs of sites through ALL chains: what a slab wrote a few chains ago
@@ -1188,15 +1192,15 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
             po.carried = i ? plan.carried[ch[i]] : 0;
             const bool t1 = e->coded_tips && o.child1_clv_index < e->tips;
             const bool t2 = e->coded_tips && o.child2_clv_index < e->tips;
-            if (chains20)
+            if (chains20 || chains16)
             {
               po.slot1 = off;
-              off += s20_chain_slot(e, t1, lut_used);
+              off += chains20 ? s20_chain_slot(e, t1, lut_used) : s16_chain_slot(e, t1);
               po.slot2 = off;
-              off += s20_chain_slot(e, t2, lut_used);
+              off += chains20 ? s20_chain_slot(e, t2, lut_used) : s16_chain_slot(e, t2);
             }
           }
-          lds_max = std::max(lds_max, chains20 ? off : (unsigned)ch.size());   // 4 states: the longest chain
+          lds_max = std::max(lds_max, chains4 ? (unsigned)ch.size() : off);   // 4 states: the longest chain
         }
         dp.bytes.resize(pops.size() * sizeof(PlanOp) + pchains.size() * sizeof(PlanChain));
         memcpy(dp.bytes.data(), pops.data(), pops.size() * sizeof(PlanOp));
@@ -1213,7 +1217,8 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
         if (!upload_plan(e, view)) return PLL_FAILURE;
         hipEvent_t ev1;
         if (!prof_begin(ev1)) return PLL_FAILURE;
-        if (chains20 ? !launch_traverse_s20(e, view, dp.lds_doubles, lut_used) : !launch_traverse_s4(e, view, dp.lds_doubles))
+        if (chains20 ? !launch_traverse_s20(e, view, dp.lds_doubles, lut_used)
+                     : chains16 ? !launch_traverse_s16(e, view, dp.lds_doubles) : !launch_traverse_s4(e, view, dp.lds_doubles))
           return PLL_FAILURE;
         if (!prof_end(ev1, dp.algo_bytes, dp.algo_flops, count)) return PLL_FAILURE;
         e->counters.partial_launches++;
@@ -1223,8 +1228,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
       }
       plan = ChainPlan();
     }
-    if (plan_chains(e, ops, count, chains20 ? S20_CHAIN_MAX : S4_CHAIN_MAX,
-                    chains20 ? S20_CHAIN_LDS : ~0u, lut_used, plan))
+    if (!chains16 && plan_chains(e, ops, count, chain_max, chain_lds, lut_used, plan))
     {
       for (int round = 0; round < plan.rounds; ++round)
       {

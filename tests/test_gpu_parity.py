@@ -228,10 +228,11 @@ with pc.build_instance(lib, states=61, rate_cats=4, ntips=130, nsites=97, coded=
     assert first == second and third != first
 
 
-@pytest.mark.parametrize("states,ntips", [(4, 300), (20, 120)])
+@pytest.mark.parametrize("states,ntips", [(4, 300), (20, 120), (10, 150), (2, 400)])
 def test_traversal_schedules_agree_bitwise(product, states, ntips):
-    """4 / 20 states: a partition that has its device to itself runs a whole traversal as ONE launch
-    (waves keep their sites through every chain); otherwise one launch per round of chains.  Same
+    """4 / 20 / 2..16 states: a partition that has its device to itself runs a whole traversal as ONE
+    launch (waves keep their sites through every chain); otherwise one launch per round of chains (per
+    dependency level at 2..16 states).  Same
     vectors, scalers and lnL either way -- full traversals, a second evaluation (cached schedule), a
     partial traversal and a re-rooted one."""
     import subprocess
