@@ -50,15 +50,45 @@ __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, 
   else if (staged)
   {
     const double rt = mv.rates()[r] * t / (1.0 - mv.pinv()[pi_]);
-    double * A = lds, * B = lds + S * Sp;
-    for (unsigned e = threadIdx.x; e < S * Sp; e += blockDim.x)
+    const unsigned arows = (Sp == 64) ? 64u : S;          // 64 columns: whole 64 x 64 operands, zero beyond S
+    double * A = lds, * B = lds + arows * Sp;
+    for (unsigned e = threadIdx.x; e < arows * Sp; e += blockDim.x)
     {
       const unsigned k = e % Sp;
-      A[e] = (k < S) ? V[e] * exp(L[k] * rt) : 0.0;
-      B[e] = Vi[e];
+      A[e] = (e < S * Sp && k < S) ? V[e] * exp(L[k] * rt) : 0.0;
+      B[e] = (e < S * Sp) ? Vi[e] : 0.0;
     }
     __syncthreads();
     double res[16];
+    if (Sp == 64)
+    {
+      // 64 x 64 operands (61 codon states, any alphabet padded to 64): the product on the matrix
+      // cores, wave w = rows 16 w .. 16 w + 15, four 16-column tiles, 16 k-steps.  The scalar loop
+      // below takes 36 us of a 55 us launch at 61 states (LDS-bound: two reads per multiply-add).
+      // D layout: register v of lane 16 q + n = row 4 v + q, column n of the tile.
+      typedef double pm_v4d __attribute__((ext_vector_type(4)));
+      const unsigned lane = threadIdx.x & 63u, mt = threadIdx.x >> 6, q = lane >> 4, n = lane & 15u;
+      pm_v4d acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+      for (unsigned ks = 0; ks < 16; ++ks)
+      {
+        const double a = A[(16 * mt + n) * Sp + 4 * ks + q];
+#pragma unroll
+        for (unsigned nt = 0; nt < 4; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, B[(4 * ks + q) * Sp + 16 * nt + n], acc[nt], 0, 0, 0);
+      }
+      __syncthreads();
+      // straight to the result area (rows >= S are not kept)
+#pragma unroll
+      for (unsigned nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (unsigned v = 0; v < 4; ++v)
+        {
+          const unsigned i = 16 * mt + 4 * v + q, j = 16 * nt + n;
+          if (i < S) Pl[i * Sp + j] = (j < S && acc[nt][v] > 0.0) ? acc[nt][v] : 0.0;
+        }
+    }
+    else
+    {
 #pragma unroll
     for (unsigned u = 0; u < 16; ++u)
     {
@@ -81,6 +111,7 @@ __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, 
     {
       const unsigned e = threadIdx.x + u * 256;
       if (e < S * Sp) Pl[e] = res[u];
+    }
     }
   }
   else

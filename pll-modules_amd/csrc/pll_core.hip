@@ -534,7 +534,7 @@ int flush_pmatrices(pll_partition_t * p)
   const ModelView mv = model_view(e);
   // operands staged in LDS when two S x Sp matrices fit the kernel's register tiling (S <= 64)
   const int staged = (size_t)e->S * e->Sp <= 4096;
-  const size_t lds = staged ? sizeof(double) * 2 * (size_t)e->S * e->Sp
+  const size_t lds = staged ? sizeof(double) * 2 * (size_t)(e->Sp == 64 ? 64 : e->S) * e->Sp   // 64 columns: whole 64 x 64 operands (matrix cores)
                             : sizeof(double) * ((size_t)e->Sp + (size_t)e->S * e->Sp);
   const unsigned count = (unsigned)e->pend_midx.size();
   for (unsigned base = 0; base < count; base += MAX_PMAT_PER_LAUNCH)
