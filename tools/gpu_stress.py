@@ -16,11 +16,12 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10, (int(sys.argv[1
     err = max(abs(x - y) / abs(y) for x, y in zip(g, c))
     if err > 1e-9: bad += 1; print("walk seed", seed, err)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
-for trial in range(24):
-    S = [4, 20, 61][trial % 3]; R = [1, 2, 4][(trial // 3) % 3]
+for trial in range(42):
+    S = [4, 20, 61, 7, 16, 2, 10][trial % 7]; R = [1, 2, 4, 4][(trial // 7) % 4]
     n = int(rng.integers(5, 60)) if S < 61 else int(rng.integers(5, 14)); N = int(rng.integers(1, 700))
     tr = pc.Tree(n, 100 + trial, 200 + trial, ladder=bool(trial % 2))
-    kw = dict(states=S, rate_cats=R, ntips=n, nsites=N, coded=bool(trial % 4 != 3), tree=tr)
+    kw = dict(states=S, rate_cats=R, ntips=n, nsites=N, coded=bool(trial % 4 != 3), tree=tr,
+              attributes=pc.PLL_ATTRIB_RATE_SCALERS if trial % 5 == 4 else 0)
     with pc.build_instance(product, **kw) as a, pc.build_instance(oracle, **kw) as b:
         la, lb = pc.full_traversal(a), pc.full_traversal(b)
         tol = (2e-6 if S > 20 else 1e-11) * abs(lb) + 2e-9 * N
