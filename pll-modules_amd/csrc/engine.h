@@ -186,6 +186,8 @@ struct Engine
   //              evecs[nrm][S*Sp] ievecs[nrm][S*Sp]
   double * d_model = nullptr;
   std::vector<double> model_shadow;
+  bool pmatrix_burst = false;         // the last model check was made by a P-matrix request (sync_model, light)
+  bool eigen_touched = true;          // an eigen-system was recomputed or loaded since the last check
   size_t off_rates = 0, off_weights = 0, off_pinv = 0, off_freqs = 0,
          off_evals = 0, off_evecs = 0, off_ievecs = 0, model_len = 0;
 
@@ -250,7 +252,7 @@ int derivatives_impl(pll_partition_t * p, int parent_scaler_index, int child_sca
 int wait_sequence(hipStream_t stream, const volatile unsigned long long * flag, unsigned long long seq);
 Engine * engine_create(pll_partition_t * p);
 void engine_destroy(Engine * e);
-int sync_model(pll_partition_t * p);              // host model arrays -> HBM if changed
+int sync_model(pll_partition_t * p, bool light = false);              // host model arrays -> HBM if changed
 int upload_tip_codes(pll_partition_t * p, unsigned tip);
 int upload_tip_clv(pll_partition_t * p, unsigned tip, const double * host_clv);
 int upload_weights(pll_partition_t * p);

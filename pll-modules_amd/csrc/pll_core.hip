@@ -482,10 +482,33 @@ void invalidate_luts(pll_partition_t * p)
   if (e) for (pll_partition_t * c : e->shards) invalidate_luts(c);
 }
 
-// host model arrays -> device if anything changed since the last call
-int sync_model(pll_partition_t * p)
+// host model arrays -> device if anything changed since the last call.  The arrays are compared
+// in place against the shadow of what the device holds (no copy, no allocation: the reference
+// issues one pll_update_prob_matrices call per branch, 397 per C3 evaluation).
+// light: only the arrays a caller pokes between two consecutive P-matrix requests (rates, weights,
+// p-inv, frequencies); the eigen-systems -- 2 S Sp doubles per rate matrix, 63 KiB at 61 states --
+// were compared by the first request of the burst and change only through ensure_eigen, which
+// runs before this.
+int sync_model(pll_partition_t * p, bool light)
 {
   Engine * e = engine_of(p);
+  const double * sh = e->model_shadow.data();
+  bool same = e->model_shadow.size() == e->model_len &&
+              memcmp(sh + e->off_rates, p->rates, sizeof(double) * e->R) == 0 &&
+              memcmp(sh + e->off_weights, p->rate_weights, sizeof(double) * e->R) == 0 &&
+              memcmp(sh + e->off_pinv, p->prop_invar, sizeof(double) * e->nrm) == 0;
+  for (unsigned m = 0; same && m < e->nrm; ++m)
+  {
+    same = memcmp(sh + e->off_freqs + (size_t)m * e->Sp, p->frequencies[m], sizeof(double) * e->Sp) == 0;
+    if (same && !(light && !e->eigen_touched))
+      same = memcmp(sh + e->off_evals + (size_t)m * e->Sp, p->eigenvals[m], sizeof(double) * e->Sp) == 0 &&
+             memcmp(sh + e->off_evecs + (size_t)m * e->S * e->Sp, p->inv_eigenvecs[m], sizeof(double) * e->S * e->Sp) == 0 &&
+             memcmp(sh + e->off_ievecs + (size_t)m * e->S * e->Sp, p->eigenvecs[m], sizeof(double) * e->S * e->Sp) == 0;
+  }
+  if (!light) e->pmatrix_burst = false;
+  e->eigen_touched = false;
+  if (same) return PLL_SUCCESS;
+
   std::vector<double> cur(e->model_len, 0.0);
   memcpy(&cur[e->off_rates], p->rates, sizeof(double) * e->R);
   memcpy(&cur[e->off_weights], p->rate_weights, sizeof(double) * e->R);
@@ -499,18 +522,15 @@ int sync_model(pll_partition_t * p)
     memcpy(&cur[e->off_evecs + (size_t)m * e->S * e->Sp], p->inv_eigenvecs[m], sizeof(double) * e->S * e->Sp);
     memcpy(&cur[e->off_ievecs + (size_t)m * e->S * e->Sp], p->eigenvecs[m], sizeof(double) * e->S * e->Sp);
   }
-  if (memcmp(cur.data(), e->model_shadow.data(), sizeof(double) * e->model_len) != 0)
-  {
-    // queued P-matrix requests belong to the model state they were issued under,
-    // which is the one still on the device
-    if (!flush_pmatrices(p)) return PLL_FAILURE;
-    // pageable source: the runtime stages it before returning, so `cur` may die
-    PLLHIP_TRY(hipMemcpyAsync(e->d_model, cur.data(), sizeof(double) * e->model_len,
-                              hipMemcpyHostToDevice, e->stream));
-    PLLHIP_TRY(hipStreamSynchronize(e->stream));
-    e->model_shadow.swap(cur);
-    e->counters.model_uploads++;
-  }
+  // queued P-matrix requests belong to the model state they were issued under,
+  // which is the one still on the device
+  if (!flush_pmatrices(p)) return PLL_FAILURE;
+  // pageable source: the runtime stages it before returning, so `cur` may die
+  PLLHIP_TRY(hipMemcpyAsync(e->d_model, cur.data(), sizeof(double) * e->model_len,
+                            hipMemcpyHostToDevice, e->stream));
+  PLLHIP_TRY(hipStreamSynchronize(e->stream));
+  e->model_shadow.swap(cur);
+  e->counters.model_uploads++;
   // pattern weights (4*N bytes) are NOT re-compared here: pll-modules changes them
   // only through pll_set_pattern_weights (SURVEY.md section 0.3 lists the fields it
   // pokes directly; weights are not among them), which uploads them itself.
@@ -570,7 +590,10 @@ static int ensure_eigen(pll_partition_t * p, const unsigned * params_indices)
       return PLL_FAILURE;
     }
     if (!p->eigen_decomp_valid[idx])
+    {
       if (!update_eigen_host(p, idx)) return PLL_FAILURE;
+      engine_of(p)->eigen_touched = true;           // the next model check looks at the eigen-systems as well
+    }
   }
   return PLL_SUCCESS;
 }
@@ -1553,7 +1576,8 @@ int pll_update_prob_matrices(pll_partition_t * p,
   }
   PLLHIP_TRY(hipSetDevice(e->device));
   if (!ensure_eigen(p, params_indices)) return PLL_FAILURE;
-  if (!sync_model(p)) return PLL_FAILURE;
+  if (!sync_model(p, e->pmatrix_burst)) return PLL_FAILURE;
+  e->pmatrix_burst = true;                    // until another entry point looks at the model
   for (unsigned m = 0; m < count; ++m)
     if (matrix_indices[m] >= e->nmat || !(branch_lengths[m] >= 0.0))
     {
@@ -2244,6 +2268,8 @@ int pllhip_sync_to_device(pll_partition_t * p, unsigned int what)
   if (!e->shards.empty())
     for (pll_partition_t * c : e->shards) push_model(p, c);     // a loader filled the parent's model arrays
   if (e->shards.empty()) PLLHIP_TRY(hipSetDevice(e->device));
+  e->eigen_touched = true;                                  // a loader may have filled the model arrays
+  e->pmatrix_burst = false;
   if (what & PLLHIP_SYNC_TIPS)
   {
     if (e->coded_tips)
