@@ -1040,14 +1040,15 @@ __global__ __launch_bounds__(256) void k_sumtable_prep_s61(ModelView mv, ParamId
 
 // --- launchers -------------------------------------------------------------
 
-// rate-parallel launches are used when a GPU has few blocks per wave: one workgroup per (range,
-// rate) balances the matrix pipes better and quarters the critical path of small slices; the
-// scaling votes then meet in a second kernel
+// Rate-parallel launches: one workgroup per (range of site blocks, rate), the scaling votes of the R
+// workgroups of a site meet in a second kernel.  Introduced for slices with few blocks per wave
+// (it balances the matrix pipes and quarters the critical path), it is the faster form at every
+// size: 1 M sites, 50 taxa: 40.0 ms against 43.4 ms with the rates walked inside a workgroup
+// (35.7 ms with the cherries folded, which needs this form).  PLLHIP_S61_RATEPAR=0 / 1 forces either.
 static bool s61_rate_parallel(const Engine * e)
 {
   static const int env_rp = getenv("PLLHIP_S61_RATEPAR") ? atoi(getenv("PLLHIP_S61_RATEPAR")) : -1;
-  const unsigned slots = e->cu_count * 2u;
-  return e->R > 1 && (env_rp >= 0 ? env_rp != 0 : e->nblk < slots * 4u * 8u);
+  return e->R > 1 && (env_rp >= 0 ? env_rp != 0 : true);
 }
 
 // cherries can be folded into their consumers (k_partials_s61v4)
