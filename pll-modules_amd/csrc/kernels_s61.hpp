@@ -1152,7 +1152,8 @@ static int launch_partials_s61_cherries(Engine * e, const OpBatch & batch, const
     sb.ttscale[i] = ttscale[i];
     sb.pred_in[i] = preds.in[i];
   }
-  const unsigned per = std::max(1u, e->cu_count / e->R);
+  static const int env_per = getenv("PLLHIP_S61_V4_PER") ? atoi(getenv("PLLHIP_S61_V4_PER")) : 0;
+  const unsigned per = env_per > 0 ? (unsigned)env_per : std::max(1u, e->cu_count / e->R);
   const unsigned gx = std::max(1u, std::min((e->nblk + S61_V4_WAVES - 1) / S61_V4_WAVES, per));
   hipLaunchKernelGGL(k_partials_s61v4, dim3(gx, nops, e->R), dim3(64 * S61_V4_WAVES), lds, e->stream,
                      sb, e->nblk, e->R, e->lut_codes, e->d_s61_votes);
