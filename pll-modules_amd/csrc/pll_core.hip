@@ -1135,7 +1135,11 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     // (two DNA + two protein partitions, 250 k sites each: 7.4 against 8.1 ms per evaluation).
     // PLLHIP_TRAVERSE=1 / 0: always / never.
     static const int env_traverse = getenv("PLLHIP_TRAVERSE") ? atoi(getenv("PLLHIP_TRAVERSE")) : -1;
-    const bool use_traverse = env_traverse >= 0 ? env_traverse != 0 : engines_on_device[e->device & 63].load() <= 1;
+    // Short lists (the 1 - 3 operations of an SPR insertion) keep the round schedule as well: their
+    // descriptors travel in the kernel arguments, while a schedule has to be copied to the device
+    // first (W3 at C2 size: 165 against 178 us per iteration).
+    const bool use_traverse = env_traverse >= 0 ? env_traverse != 0
+                            : (engines_on_device[e->device & 63].load() <= 1 && (count >= 6 || chains16));
     const unsigned chain_max = chains20 ? S20_CHAIN_MAX : chains16 ? S16_CHAIN_MAX : S4_CHAIN_MAX;
     const unsigned chain_lds = chains20 ? S20_CHAIN_LDS : chains16 ? S16_CHAIN_LDS : ~0u;
     if (use_traverse)
