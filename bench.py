@@ -63,6 +63,10 @@ def parse_args():
                          "them (src/tree/treeinfo.c:845-865); batched = one call with count = 2n-3")
     ap.add_argument("--rate-scalers", action="store_true",
                     help="PLL_ATTRIB_RATE_SCALERS: one scaling count per (site, rate) instead of per site")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
+                    help="N > 1: rccl = the library's own RCCL communicator, lnL reduced on the device (default); "
+                         "torch = the reduce callback through torch.distributed (a rehearsal path: with "
+                         "PLLHIP_BENCH_DIST_BACKEND=gloo and PLLHIP_ALLOW_DEVICE_WRAP=1 all ranks can share one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sites", type=int, default=0, help="sites of the CPU baseline sample")
     return ap.parse_args()
@@ -182,7 +186,7 @@ def launch_ranks(args):
     if not probe:
         import torch
         have = torch.cuda.device_count()          # counting devices does not initialise the GPU
-        if have < args.gpus:
+        if have < args.gpus and os.environ.get("PLLHIP_ALLOW_DEVICE_WRAP") != "1":
             raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -243,6 +247,11 @@ def main():
     if os.environ.get("PLLHIP_BENCH_LAUNCH_PROBE") == "1":
         return launch_probe(args, rank, world)
 
+    if world > 1:
+        # torch brings its own HIP and RCCL runtimes (same SONAMEs as /opt/rocm's): whichever is
+        # loaded first serves the whole process, and torch does not find the GPU on the system's.
+        # Load torch first, so that the engine binds to the runtime torch.cuda uses.
+        import torch  # noqa: F401
     import pllhip_ctypes as pc
     global ATTRIBUTES
     if args.rate_scalers:
@@ -256,8 +265,14 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        backend = os.environ.get("PLLHIP_BENCH_DIST_BACKEND", "nccl")
+        if os.environ.get("PLLHIP_ALLOW_DEVICE_WRAP") == "1":
+            local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if not product.lib.pllhip_set_device(local_rank):
         raise SystemExit(product.errmsg)
     if internal and not product.lib.pllhip_set_sharding(args.gpus, None):
@@ -286,7 +301,8 @@ def main():
     ev, insts = make_evaluation(pc, product, tree, plan, rate_cats, 44, per_branch, first_sites)
     inst = max(insts, key=lambda i: i.N * i.S)        # the partition that dominates the traffic
 
-    if world > 1:
+    reduce_cb = None
+    if world > 1 and args.comm == "rccl":
         # one RCCL communicator per rank (C, behind the reference's parallel_reduce_cb
         # semantics); its unique id travels through torch's store.  The driver leaves every
         # partition's lnL in a device-resident slot and all-reduces the slots in place
@@ -301,6 +317,22 @@ def main():
             raise SystemExit(product.errmsg)
         if not product.lib.pllhip_eval_attach_comm(ev.ev, comm):
             raise SystemExit(product.errmsg)
+    elif world > 1:
+        # rehearsal path: the reference's reduce hook served by torch.distributed (any backend)
+        import torch
+        ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}    # include/pllhip.h PLLHIP_REDUCE_*
+        on_gpu = dist.get_backend() == "nccl"
+
+        def _reduce(ctx, data, n, op):
+            arr = np.ctypeslib.as_array(data, shape=(n,))
+            t = torch.from_numpy(arr.copy())
+            if on_gpu:
+                t = t.cuda()
+            dist.all_reduce(t, op=ops[op])
+            arr[:] = t.cpu().numpy()
+
+        reduce_cb = pc.REDUCE_CB(_reduce)
+        ev.set_parallel_context(reduce_cb)
 
     nops = ntips - 2
 
@@ -335,7 +367,7 @@ def main():
 
     if dist is not None:
         import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

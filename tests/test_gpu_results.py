@@ -284,3 +284,22 @@ def test_driver_on_a_partition_spread_over_devices(product):
             assert L.pllhip_set_sharding(0, None)
     assert abs(out[0][0] - out[1][0]) < 1e-11 * abs(out[0][0])
     assert abs(out[0][1] - out[1][1]) < 1e-8 * abs(out[0][1]) and out[0][2] == out[1][2]
+
+
+def test_bench_two_ranks_sharing_one_gpu():
+    """`bench.py --gpus 2` end to end where only one GPU exists: the launcher starts two ranks
+    (torch.distributed.run), both use GPU 0 (PLLHIP_ALLOW_DEVICE_WRAP), each owns half of the sites of ONE
+    alignment, and the lnL is reduced through the reference's reduce hook over gloo (`--comm torch`; the
+    default `--comm rccl` needs one GPU per rank).  Same lnL as the one-rank run of the same configuration."""
+    root = ROOT
+    args = ["--config", "c2", "--sites", "30000", "--taxa", "24", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    env = dict(os.environ, PLLHIP_ALLOW_DEVICE_WRAP="1", PLLHIP_BENCH_DIST_BACKEND="gloo")
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--comm", "torch"] + args,
+                         env=env, check=True, capture_output=True, text=True, timeout=600).stdout
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args,
+                         check=True, capture_output=True, text=True, timeout=600).stdout
+    a = json.loads([ln for ln in two.splitlines() if ln.startswith("{")][-1])
+    b = json.loads([ln for ln in one.splitlines() if ln.startswith("{")][-1])
+    assert a["n_gpus"] == 2 and b["n_gpus"] == 1 and a["scaling"] == "strong"
+    assert a["config"]["sites_total"] == b["config"]["sites_total"] == 30000 and a["config"]["sites_per_gpu"] == 15000
+    assert abs(a["lnl"] - b["lnl"]) <= 1e-9 * abs(b["lnl"])
