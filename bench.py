@@ -247,6 +247,12 @@ def main():
     if os.environ.get("PLLHIP_BENCH_LAUNCH_PROBE") == "1":
         return launch_probe(args, rank, world)
 
+    # ONE line on stdout: libraries that talk on file descriptor 1 (RCCL prints a banner when a
+    # communicator is created) are pointed at stderr; the JSON line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     if world > 1:
         # torch brings its own HIP and RCCL runtimes (same SONAMEs as /opt/rocm's): whichever is
         # loaded first serves the whole process, and torch does not find the GPU on the system's.
@@ -478,7 +484,8 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -303,3 +303,37 @@ def test_bench_two_ranks_sharing_one_gpu():
     assert a["n_gpus"] == 2 and b["n_gpus"] == 1 and a["scaling"] == "strong"
     assert a["config"]["sites_total"] == b["config"]["sites_total"] == 30000 and a["config"]["sites_per_gpu"] == 15000
     assert abs(a["lnl"] - b["lnl"]) <= 1e-9 * abs(b["lnl"])
+
+
+def test_engine_on_the_runtime_torch_loaded():
+    """a rank of `bench.py --gpus N` imports torch first, so the engine and its communicator run on the
+    HIP / RCCL libraries of the torch wheel (same SONAMEs as the system's): torch.cuda
+    works next to the engine, a world-of-one communicator reduces a driver's lnL on the device, and the
+    numbers are those of a process that never saw torch"""
+    code = r"""
+import sys, ctypes as C
+import torch
+torch.cuda.set_device(0)
+t = torch.ones(8, device="cuda").sum().item()
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import pllhip_ctypes as pc
+from test_eval_driver import build
+lib = pc.PllLib(pc.PRODUCT_LIB)
+L = lib.lib
+idbuf = C.create_string_buffer(128)
+assert L.pllhip_comm_get_unique_id(idbuf), lib.errmsg
+comm = L.pllhip_comm_create(idbuf.raw, 0, 1, 0)
+assert comm, lib.errmsg
+with build(lib, ntips=12) as ev:
+    ev.attach_comm(comm)
+    res = "%%.17g %%.17g %%g" %% (ev.loglh(), ev.optimize_branches(1e-4, 10.0, 0.01, 2, -1), t)
+L.pllhip_comm_destroy(comm)
+maps = open("/proc/self/maps").read()
+print("RESULT", res, "torch_hip" if any("torch/lib/libamdhip64" in ln for ln in maps.splitlines()) else "system_hip")
+""" % (os.path.dirname(pc.__file__), os.path.join(ROOT, "tests"))
+    text = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True, timeout=600).stdout
+    out = [ln for ln in text.splitlines() if ln.startswith("RESULT")][-1].split()[1:]   # (RCCL prints a banner)
+    with build(pc.PllLib(pc.PRODUCT_LIB), ntips=12) as ev:
+        want = (ev.loglh(), ev.optimize_branches(1e-4, 10.0, 0.01, 2, -1))
+    assert (float(out[0]), float(out[1])) == want and float(out[2]) == 8.0
+    assert out[3] == "torch_hip"
