@@ -509,7 +509,7 @@ struct S61Batch
 {
   OpDesc op[S61_V4_OPS];                 // child 1 is the folded cherry's vector when tt[i].parent != nullptr
   OpDesc tt[S61_V4_OPS];                 // the folded cherry: codes1/2, lut1/2, parent, scalers
-  const uint8_t * ttscale[S61_V4_OPS];   // [codes][codes] "every entry of every rate is small" per code pair (null: unscaled)
+  const uint8_t * ttscale[S61_V4_OPS];   // [codes][codes] per code pair: bit r = "every entry of rate r is small" (null: unscaled)
   const uint8_t * pred_in[S61_V4_OPS];   // predicted scaling of op[i] (see k_partials_s61v3)
 };
 
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(1024) void k_s61_cherry_scale(CherryScaleBatch batc
   const double * l1 = batch.lut1[blockIdx.y], * l2 = batch.lut2[blockIdx.y];
   const unsigned pr = blockIdx.x * 1024u + threadIdx.x;
   const unsigned ca = pr < pairs ? pr / lut_codes : 0, cb = pr < pairs ? pr % lut_codes : 0;
-  unsigned small = 1u;
+  unsigned mask = 0u;                                   // bit r: every entry of rate r is small
   for (unsigned r = 0; r < R; ++r)
   {
     __syncthreads();
@@ -541,9 +541,11 @@ __global__ __launch_bounds__(1024) void k_s61_cherry_scale(CherryScaleBatch batc
     }
     __syncthreads();
     const double * ra = ta + ca * S61_S, * rb = tb + cb * S61_S;
+    unsigned small = 1u;
     for (unsigned i = 0; i < S61_S; ++i) small &= (ra[i] * rb[i] < SCALE_THRESHOLD) ? 1u : 0u;
+    mask |= small << r;
   }
-  if (pr < pairs) batch.out[blockIdx.y][pr] = (uint8_t)small;
+  if (pr < pairs) batch.out[blockIdx.y][pr] = (uint8_t)mask;
 }
 
 // k-steps 8 HALF .. 8 HALF + 7 of a cherry's unit: product of the two tips' rows with the cherry's
@@ -575,8 +577,9 @@ __device__ inline void s61_rate_cherry(const OpDesc & op, const OpDesc & tt, con
                                        const double * frag1, const double * frag2, const double * lut2_r,
                                        const double * luta_r, const double * lutb_r, bool tip2,
                                        unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
-                                       unsigned & small_e, unsigned & small_o, const uint8_t * pred, unsigned W)
+                                       unsigned & small_e, unsigned & small_o, const uint8_t * pred, unsigned W, bool rs)
 {
+  const unsigned all_rates = (1u << R) - 1u;
   const double2 * f1 = reinterpret_cast<const double2 *>(frag1);
   const double2 * f2 = reinterpret_cast<const double2 *>(frag2);
   const unsigned q = lane >> 4, n = lane & 15;
@@ -600,16 +603,19 @@ __device__ inline void s61_rate_cherry(const OpDesc & op, const OpDesc & tt, con
     unsigned de = 0, dd = 0;
     if (ttscale)
     {
-      de = ttscale[(size_t)cae * lut_codes + cbe];
-      dd = ttscale[(size_t)cao * lut_codes + cbo];
+      // per-site scaling: all rates small; per-rate scalers: this rate small
+      const unsigned me = ttscale[(size_t)cae * lut_codes + cbe], mo = ttscale[(size_t)cao * lut_codes + cbo];
+      de = rs ? (me >> r) & 1u : (me == all_rates ? 1u : 0u);
+      dd = rs ? (mo >> r) & 1u : (mo == all_rates ? 1u : 0u);
     }
-    if (tt.parent_scaler && r == 0 && q == 0)
+    if (tt.parent_scaler && q == 0 && (rs || r == 0))
     {
+      const size_t ie = rs ? site0 * R + r : site0, io = rs ? (site0 + 1) * R + r : site0 + 1;
       unsigned ce = de, co = dd;
-      if (tt.scaler1) { ce += tt.scaler1[site0]; co += tt.scaler1[site0 + 1]; }
-      if (tt.scaler2) { ce += tt.scaler2[site0]; co += tt.scaler2[site0 + 1]; }
-      tt.parent_scaler[site0] = ce;
-      tt.parent_scaler[site0 + 1] = co;
+      if (tt.scaler1) { ce += tt.scaler1[ie]; co += tt.scaler1[io]; }
+      if (tt.scaler2) { ce += tt.scaler2[ie]; co += tt.scaler2[io]; }
+      tt.parent_scaler[ie] = ce;
+      tt.parent_scaler[io] = co;
     }
     const double tfe = de ? SCALE_FACTOR : 1.0, tfo = dd ? SCALE_FACTOR : 1.0;
     const double * ae = luta_r + cae * S61_S, * ao = luta_r + cao * S61_S;
@@ -640,17 +646,23 @@ __device__ inline void s61_rate_cherry(const OpDesc & op, const OpDesc & tt, con
       s61_acc_to_t(acc, t2);
     }
     else s61_child_tip(lut2_r, c2e, c2o, q, t2);
-    double fe, fo;
-    s61_pred_factors(pred, blk, lane, fe, fo);
-    s61_finish_unit(op.parent + ub, lane, q, t1, t2, 1u << i, small_e, small_o, fe, fo);
+    if (rs) s61_finish_unit_rs(op, blk, r, R, op.parent + ub, lane, t1, t2);
+    else
+    {
+      double fe, fo;
+      s61_pred_factors(pred, blk, lane, fe, fo);
+      s61_finish_unit(op.parent + ub, lane, q, t1, t2, 1u << i, small_e, small_o, fe, fo);
+    }
     cae = nae; cao = nao; cbe = nbe; cbo = nbo;
   }
 }
 
 // grid = (<= CUs / R, ops, R), block = 512, dynamic LDS = 4 x 32 KiB
 __global__ __launch_bounds__(64 * S61_V4_WAVES, 1) void k_partials_s61v4(S61Batch batch, unsigned nblk, unsigned R,
-                                                                         unsigned lut_codes, uint8_t * votes)
+                                                                         unsigned lut_codes, uint8_t * votes,
+                                                                         unsigned rate_scalers)
 {
+  const bool rs = rate_scalers != 0;
   extern __shared__ double frag[];
   double * const frag2 = frag + S61_FRAGS, * const luta = frag + 2 * S61_FRAGS, * const lutb = frag + 3 * S61_FRAGS;
   const OpDesc & op = batch.op[blockIdx.y];
@@ -658,7 +670,7 @@ __global__ __launch_bounds__(64 * S61_V4_WAVES, 1) void k_partials_s61v4(S61Batc
   const bool cherry = tt.parent != nullptr;
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned q = lane >> 4, n = lane & 15;
-  const bool scaling = op.parent_scaler != nullptr;
+  const bool scaling = op.parent_scaler != nullptr && !rs;      // per-rate scalers are settled unit by unit
   const bool tip1 = op.codes1 != nullptr, tip2 = op.codes2 != nullptr;
   const unsigned beg = (unsigned)(((unsigned long long)nblk * blockIdx.x) / gridDim.x);
   const unsigned end = (unsigned)(((unsigned long long)nblk * (blockIdx.x + 1)) / gridDim.x);
@@ -687,11 +699,11 @@ __global__ __launch_bounds__(64 * S61_V4_WAVES, 1) void k_partials_s61v4(S61Batc
     unsigned small_e = ~0u, small_o = ~0u;
     if (nb == 0) continue;
     if (cherry) s61_rate_cherry(op, tt, batch.ttscale[blockIdx.y], lut_codes, frag, frag2, frag2, luta, lutb, tip2,
-                                r, R, first, nb, lane, small_e, small_o, pred, W);
-    else if (tip1 && tip2) s61_rate_tt(op, frag, frag2, r, R, first, nb, lane, small_e, small_o, pred, false, W);
-    else if (!tip1 && !tip2) s61_rate_ii(op, frag, frag2, r, R, first, nb, lane, small_e, small_o, pred, false, W);
-    else if (tip1) s61_rate_ti(op, op.clv2, frag2, op.codes1, frag, r, R, first, nb, lane, small_e, small_o, pred, false, W);
-    else s61_rate_ti(op, op.clv1, frag, op.codes2, frag2, r, R, first, nb, lane, small_e, small_o, pred, false, W);
+                                r, R, first, nb, lane, small_e, small_o, pred, W, rs);
+    else if (tip1 && tip2) s61_rate_tt(op, frag, frag2, r, R, first, nb, lane, small_e, small_o, pred, rs, W);
+    else if (!tip1 && !tip2) s61_rate_ii(op, frag, frag2, r, R, first, nb, lane, small_e, small_o, pred, rs, W);
+    else if (tip1) s61_rate_ti(op, op.clv2, frag2, op.codes1, frag, r, R, first, nb, lane, small_e, small_o, pred, rs, W);
+    else s61_rate_ti(op, op.clv1, frag, op.codes2, frag2, r, R, first, nb, lane, small_e, small_o, pred, rs, W);
 
     if (scaling)
     {
@@ -1055,7 +1067,10 @@ static bool s61_rate_parallel(const Engine * e)
 static bool s61_cherries_supported(const Engine * e)
 {
   static const int env = getenv("PLLHIP_S61_CHERRIES") ? atoi(getenv("PLLHIP_S61_CHERRIES")) : 1;
-  return env && e->coded_tips && !e->rate_scalers && s61_rate_parallel(e) && e->lut_codes * S61_S <= S61_FRAGS;
+  // (per-rate scalers: the kernel carries them -- env = 2 forces the folding -- but C5 --rate-scalers
+  // runs 9.09 ms folded against 8.94 ms unfolded, so such partitions keep their cherries as launches)
+  if (e->rate_scalers && env != 2) return false;
+  return env && e->coded_tips && s61_rate_parallel(e) && e->lut_codes * S61_S <= S61_FRAGS && e->R <= 8;
 }
 
 // last scaling decisions per parent vector, double-buffered (the fix-up kernel reads the
@@ -1140,6 +1155,7 @@ static int launch_partials_s61_cherries(Engine * e, const OpBatch & batch, const
   }
   bool scaling = false;
   for (unsigned i = 0; i < nops; ++i) scaling |= batch.op[i].parent_scaler != nullptr;
+  if (e->rate_scalers) scaling = false;      // per-rate scalers: no votes, no predictions, no fix-up kernel
   PredBatch preds;
   memset(&preds, 0, sizeof(preds));
   if (scaling && !s61_prepare_preds(e, batch, nops, preds)) return PLL_FAILURE;
@@ -1156,7 +1172,7 @@ static int launch_partials_s61_cherries(Engine * e, const OpBatch & batch, const
   const unsigned per = env_per > 0 ? (unsigned)env_per : std::max(1u, e->cu_count / e->R);
   const unsigned gx = std::max(1u, std::min((e->nblk + S61_V4_WAVES - 1) / S61_V4_WAVES, per));
   hipLaunchKernelGGL(k_partials_s61v4, dim3(gx, nops, e->R), dim3(64 * S61_V4_WAVES), lds, e->stream,
-                     sb, e->nblk, e->R, e->lut_codes, e->d_s61_votes);
+                     sb, e->nblk, e->R, e->lut_codes, e->d_s61_votes, e->rate_scalers ? 1u : 0u);
   PLLHIP_TRY(hipGetLastError());
   if (scaling)
   {

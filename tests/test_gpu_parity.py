@@ -273,14 +273,15 @@ with pc.build_instance(lib, states=%d, rate_cats=4, ntips=%d, nsites=1531, coded
     assert int(runs[0][4]) == 4 and int(runs[1][4]) > 8        # one launch per traversal / several
 
 
-@pytest.mark.parametrize("rate_cats", [4, 2])
-def test_codon_cherries_that_scale(product, oracle, rate_cats):
+@pytest.mark.parametrize("rate_cats,attributes", [(4, 0), (2, 0), (4, pc.PLL_ATTRIB_RATE_SCALERS)])
+def test_codon_cherries_that_scale(product, oracle, rate_cats, attributes):
     """61 states: a tip x tip operation is computed inside the operation that consumes it, its own
     scaling decided per pair of tip codes.  A cherry only ever scales when its entries are exact zeros
     (P-matrix noise is 1e-17, far above 2^-256): pendant branches of length 0 -- identity matrices --
     make every site with two different codons an all-zero, scaled site.  Scalers (exact) and vectors
     must be what the oracle computes operation by operation; lnL is -inf on both sides."""
-    a, b = _pair(product, oracle, states=61, rate_cats=rate_cats, ntips=24, nsites=203, coded=True)
+    a, b = _pair(product, oracle, states=61, rate_cats=rate_cats, ntips=24, nsites=203, coded=True,
+                 attributes=attributes)
     with a, b:
         t = a.tree
         cherries = [op for op in t.ops if op[2] < t.ntips and op[5] < t.ntips]
@@ -294,7 +295,12 @@ def test_codon_cherries_that_scale(product, oracle, rate_cats):
             assert la == lb == -np.inf
             for op in t.ops:
                 assert np.array_equal(a.get_scaler(op[1]), b.get_scaler(op[1])), f"scaler {op[1]}"
-                assert site_err(a.get_clv(op[0]), b.get_clv(op[0])) < CLV_SITE_61, f"CLV {op[0]}"
+                # (with per-rate scalers a rate that carries only P-matrix noise -- 1e-18 through a zero-length
+                # branch -- is scaled up until it is the largest entry of its site: the vectors above the
+                # cherries then differ by the two engines' noise, with or without the folding; the counts
+                # are exact)
+                if not attributes or op in cherries:
+                    assert site_err(a.get_clv(op[0]), b.get_clv(op[0])) < CLV_SITE_61, f"CLV {op[0]}"
         scaled = sum(int(b.get_scaler(op[1]).sum()) for op in cherries)
         assert scaled > 0, "no cherry site reached the scaling regime"
 
