@@ -573,11 +573,12 @@ __device__ inline void s61_cherry_half(const double * ae, const double * ao, con
 
 // one rate of a wave's blocks: child 1 is a folded cherry, child 2 an inner vector (tip2 == false)
 // or a coded tip (its table at lut2_r)
+template <bool rs>
 __device__ inline void s61_rate_cherry(const OpDesc & op, const OpDesc & tt, const uint8_t * ttscale, unsigned lut_codes,
                                        const double * frag1, const double * frag2, const double * lut2_r,
                                        const double * luta_r, const double * lutb_r, bool tip2,
                                        unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
-                                       unsigned & small_e, unsigned & small_o, const uint8_t * pred, unsigned W, bool rs)
+                                       unsigned & small_e, unsigned & small_o, const uint8_t * pred, unsigned W)
 {
   const unsigned all_rates = (1u << R) - 1u;
   const double2 * f1 = reinterpret_cast<const double2 *>(frag1);
@@ -658,11 +659,10 @@ __device__ inline void s61_rate_cherry(const OpDesc & op, const OpDesc & tt, con
 }
 
 // grid = (<= CUs / R, ops, R), block = 512, dynamic LDS = 4 x 32 KiB
+template <bool rs>          // PLL_ATTRIB_RATE_SCALERS (a template parameter: as a run-time flag it cost the per-site form 54 spilled VGPRs)
 __global__ __launch_bounds__(64 * S61_V4_WAVES, 1) void k_partials_s61v4(S61Batch batch, unsigned nblk, unsigned R,
-                                                                         unsigned lut_codes, uint8_t * votes,
-                                                                         unsigned rate_scalers)
+                                                                         unsigned lut_codes, uint8_t * votes)
 {
-  const bool rs = rate_scalers != 0;
   extern __shared__ double frag[];
   double * const frag2 = frag + S61_FRAGS, * const luta = frag + 2 * S61_FRAGS, * const lutb = frag + 3 * S61_FRAGS;
   const OpDesc & op = batch.op[blockIdx.y];
@@ -698,8 +698,8 @@ __global__ __launch_bounds__(64 * S61_V4_WAVES, 1) void k_partials_s61v4(S61Batc
     const unsigned nb = first < c1 ? (c1 - first + W - 1) / W : 0;
     unsigned small_e = ~0u, small_o = ~0u;
     if (nb == 0) continue;
-    if (cherry) s61_rate_cherry(op, tt, batch.ttscale[blockIdx.y], lut_codes, frag, frag2, frag2, luta, lutb, tip2,
-                                r, R, first, nb, lane, small_e, small_o, pred, W, rs);
+    if (cherry) s61_rate_cherry<rs>(op, tt, batch.ttscale[blockIdx.y], lut_codes, frag, frag2, frag2, luta, lutb, tip2,
+                                    r, R, first, nb, lane, small_e, small_o, pred, W);
     else if (tip1 && tip2) s61_rate_tt(op, frag, frag2, r, R, first, nb, lane, small_e, small_o, pred, rs, W);
     else if (!tip1 && !tip2) s61_rate_ii(op, frag, frag2, r, R, first, nb, lane, small_e, small_o, pred, rs, W);
     else if (tip1) s61_rate_ti(op, op.clv2, frag2, op.codes1, frag, r, R, first, nb, lane, small_e, small_o, pred, rs, W);
@@ -1067,9 +1067,7 @@ static bool s61_rate_parallel(const Engine * e)
 static bool s61_cherries_supported(const Engine * e)
 {
   static const int env = getenv("PLLHIP_S61_CHERRIES") ? atoi(getenv("PLLHIP_S61_CHERRIES")) : 1;
-  // (per-rate scalers: the kernel carries them -- env = 2 forces the folding -- but C5 --rate-scalers
-  // runs 9.09 ms folded against 8.94 ms unfolded, so such partitions keep their cherries as launches)
-  if (e->rate_scalers && env != 2) return false;
+  // (per-rate scalers are carried as well: C5 --rate-scalers 8.93 -> 7.86 ms)
   return env && e->coded_tips && s61_rate_parallel(e) && e->lut_codes * S61_S <= S61_FRAGS && e->R <= 8;
 }
 
@@ -1149,7 +1147,9 @@ static int launch_partials_s61_cherries(Engine * e, const OpBatch & batch, const
   bool & attr_set = attr_set_dev[e->device & 63];
   if (!attr_set)
   {
-    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_partials_s61v4),
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_partials_s61v4<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_partials_s61v4<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -1171,8 +1171,12 @@ static int launch_partials_s61_cherries(Engine * e, const OpBatch & batch, const
   static const int env_per = getenv("PLLHIP_S61_V4_PER") ? atoi(getenv("PLLHIP_S61_V4_PER")) : 0;
   const unsigned per = env_per > 0 ? (unsigned)env_per : std::max(1u, e->cu_count / e->R);
   const unsigned gx = std::max(1u, std::min((e->nblk + S61_V4_WAVES - 1) / S61_V4_WAVES, per));
-  hipLaunchKernelGGL(k_partials_s61v4, dim3(gx, nops, e->R), dim3(64 * S61_V4_WAVES), lds, e->stream,
-                     sb, e->nblk, e->R, e->lut_codes, e->d_s61_votes, e->rate_scalers ? 1u : 0u);
+  if (e->rate_scalers)
+    hipLaunchKernelGGL(k_partials_s61v4<true>, dim3(gx, nops, e->R), dim3(64 * S61_V4_WAVES), lds, e->stream,
+                       sb, e->nblk, e->R, e->lut_codes, e->d_s61_votes);
+  else
+    hipLaunchKernelGGL(k_partials_s61v4<false>, dim3(gx, nops, e->R), dim3(64 * S61_V4_WAVES), lds, e->stream,
+                       sb, e->nblk, e->R, e->lut_codes, e->d_s61_votes);
   PLLHIP_TRY(hipGetLastError());
   if (scaling)
   {
