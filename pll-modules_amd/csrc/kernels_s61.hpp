@@ -1169,7 +1169,12 @@ static int launch_partials_s61_cherries(Engine * e, const OpBatch & batch, const
     sb.pred_in[i] = preds.in[i];
   }
   static const int env_per = getenv("PLLHIP_S61_V4_PER") ? atoi(getenv("PLLHIP_S61_V4_PER")) : 0;
-  const unsigned per = env_per > 0 ? (unsigned)env_per : std::max(1u, e->cu_count / e->R);
+  // workgroups per (operation, rate): at most a quarter of the CUs each, and about three workgroups per CU
+  // over the whole launch -- fewer, longer ranges per table fill when a launch has many operations
+  // (25 k / 50 k / 100 k / 200 k sites: 1.75 -> 1.68, 2.58 -> 2.52, 4.27 -> 4.23, 7.55 -> 7.57 ms per step)
+  static const int env_fill = getenv("PLLHIP_S61_V4_FILL") ? atoi(getenv("PLLHIP_S61_V4_FILL")) : 3;
+  unsigned per = env_per > 0 ? (unsigned)env_per : std::max(1u, e->cu_count / e->R);
+  if (env_fill > 0) per = std::min(per, std::max(1u, (unsigned)env_fill * e->cu_count / (nops * e->R)));
   const unsigned gx = std::max(1u, std::min((e->nblk + S61_V4_WAVES - 1) / S61_V4_WAVES, per));
   if (e->rate_scalers)
     hipLaunchKernelGGL(k_partials_s61v4<true>, dim3(gx, nops, e->R), dim3(64 * S61_V4_WAVES), lds, e->stream,
