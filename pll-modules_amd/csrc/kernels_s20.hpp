@@ -578,11 +578,17 @@ __device__ inline void s20_fill_slot(double * slot, const double * pmat, const d
     else s20_fill_cfrags(slot, pmat, R);
   }
   else if (lut_lds)
-    for (unsigned e = threadIdx.x; e < R * lut_used * 20; e += blockDim.x)
+  {
+    // (index arithmetic with constant divisors only: a division by the run-time row count per element
+    // made this loop a third of a chain's staging time)
+    const unsigned per_rate = lut_used * 20;
+    for (unsigned x = threadIdx.x; x < per_rate; x += blockDim.x)
     {
-      const unsigned r = e / (lut_used * 20), x = e % (lut_used * 20), c = x / 20, i = x % 20;
-      slot[(r * lut_used + c) * S20_LUT_RS + i] = lut[((size_t)r * lut_codes + c) * 20 + i];
+      const unsigned c = x / 20, i = x - c * 20;
+      for (unsigned r = 0; r < R; ++r)
+        slot[(r * lut_used + c) * S20_LUT_RS + i] = lut[(size_t)r * lut_codes * 20 + x];
     }
+  }
 }
 
 // Operation chains: the tables of ALL operations of a chain stay in LDS, so -- exactly like
