@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pll-modules_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-# PLLHIP_ORACLE_LIB: another build of the oracle (tools/host_sanitizers.sh: ASan + UBSan)
+# PLLHIP_ORACLE_LIB: another build of the oracle (tests/host_sanitizers.sh: ASan + UBSan)
 ORACLE_LIB = os.environ.get("PLLHIP_ORACLE_LIB") or os.path.join(ROOT, "oracle", "_build", "libpll_oracle.so")
 PRODUCT_LIB = os.path.join(ROOT, "pll-modules_amd", "libpll_hip.so")
 

@@ -2,7 +2,7 @@
 # Host sanitizers, CPU build only: the oracle and every host-side C file of
 # the product (tree utilities, evaluation driver, SPR search) built with
 # -fsanitize=address,undefined, then the CPU test-suite on that build.
-#   tools/host_sanitizers.sh [pytest args]
+#   tests/host_sanitizers.sh [pytest args]
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/oracle/_build_asan
