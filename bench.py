@@ -319,11 +319,20 @@ def main():
         obj = [idbuf.raw]
         dist.broadcast_object_list(obj, src=0)
         comm = product.lib.pllhip_comm_create(obj[0], rank, world, local_rank)
-        if not comm:
-            raise SystemExit(product.errmsg)
-        if not product.lib.pllhip_eval_attach_comm(ev.ev, comm):
-            raise SystemExit(product.errmsg)
-    elif world > 1:
+        ok = bool(comm) and bool(product.lib.pllhip_eval_attach_comm(ev.ev, comm))
+        # every rank must take the same path: agree on the outcome before going on
+        import torch
+        flag = torch.tensor([1.0 if ok else 0.0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() < 1.0:
+            print(f"bench.py: rank {rank}: the library's communicator is not available ({product.errmsg}); "
+                  "falling back to the reduce hook over torch.distributed", file=sys.stderr)
+            product.lib.pllhip_eval_set_fused(ev.ev, None)      # back to blocking calls + the reduce hook
+            if comm:
+                product.lib.pllhip_comm_destroy(comm)
+            comm = None
+            args.comm = "torch"
+    if world > 1 and args.comm == "torch":
         # rehearsal path: the reference's reduce hook served by torch.distributed (any backend)
         import torch
         ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}    # include/pllhip.h PLLHIP_REDUCE_*
@@ -463,7 +472,7 @@ def main():
                 "workload": f"{names[args.config]}: {states} states, {rate_cats} rate cats, {ntips} taxa, "
                             f"{total_sites} sites total ({local_sites} on rank 0), full traversal "
                             f"({nops} ops + {tree.nedges} P-matrices + edge lnL"
-                            f"{' + RCCL all-reduce of the lnL' if world > 1 else ''}) per step",
+                            f"{(' + RCCL all-reduce of the lnL on the device' if args.comm == 'rccl' else ' + lnL summed through the reduce hook (torch.distributed)') if world > 1 else ''}) per step",
                 "config": args.config, "states": states, "rate_cats": rate_cats, "taxa": ntips,
                 "sites_total": total_sites, "sites_per_gpu": local_sites, "ops_per_step": nops,
                 "partitions": [{"states": s, "sites_per_gpu": n} for s, n in plan],

@@ -276,6 +276,8 @@ class PllLib:
             L.pllhip_comm_rank.argtypes = [C.c_void_p]
             L.pllhip_comm_size.argtypes = [C.c_void_p]
             L.pllhip_eval_attach_comm.argtypes = [C.c_void_p, C.c_void_p]
+            L.pllhip_eval_set_fused.argtypes = [C.c_void_p, C.c_void_p]
+            L.pllhip_eval_set_fused.restype = None
             L.pllhip_results_create.restype = C.c_void_p
             L.pllhip_results_create.argtypes = [C.c_void_p, C.c_uint]
             L.pllhip_results_destroy.argtypes = [C.c_void_p]
