@@ -1138,8 +1138,15 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     // Short lists (the 1 - 3 operations of an SPR insertion) keep the round schedule as well: their
     // descriptors travel in the kernel arguments, while a schedule has to be copied to the device
     // first (W3 at C2 size: 165 against 178 us per iteration).
+    // Small partitions too: a workgroup walks ALL chains one after the other (12 - 15 us each), while the
+    // rounds run the chains of a round side by side -- that wins until the site blocks alone fill the chip
+    // (20 states, 200 taxa: 32 k sites 1.76 against 2.14 ms, 64 k sites 2.88 against 2.55 ms; 4 states,
+    // 100 taxa: 64 k sites 0.42 against 0.54 ms, 100 k sites equal, 125 k sites 0.66 against 0.61 ms;
+    // 2..16 states, whose alternative is one launch per dependency level: from 25 k sites).
+    const bool fills_chip = chains4 ? (e->N + 63) / 64 >= 6u * e->cu_count
+                                    : e->nblk >= (chains16 ? 3u : 6u) * e->cu_count;
     const bool use_traverse = env_traverse >= 0 ? env_traverse != 0
-                            : (engines_on_device[e->device & 63].load() <= 1 && (count >= 6 || chains16));
+                            : (engines_on_device[e->device & 63].load() <= 1 && fills_chip && (count >= 6 || chains16));
     const unsigned chain_max = chains20 ? S20_CHAIN_MAX : chains16 ? S16_CHAIN_MAX : S4_CHAIN_MAX;
     const unsigned chain_lds = chains20 ? S20_CHAIN_LDS : chains16 ? S16_CHAIN_LDS : ~0u;
     if (use_traverse)
