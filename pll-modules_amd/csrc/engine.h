@@ -117,6 +117,10 @@ struct DevicePlan                                 // the schedule resident on th
   std::vector<unsigned char> bytes;               // serialised [PlanOp ...][PlanChain ...]
   unsigned nops = 0, nchains = 0, lds_doubles = 0;
   double algo_bytes = 0.0, algo_flops = 0.0;      // algorithmic traffic / work of the traversal
+  // launches of the schedule: one for a whole traversal, or one per round of chains (chains
+  // [begin, end) side by side) for a partition that does not fill the chip on its own
+  struct Launch { unsigned begin, end, ops; double bytes, flops; };
+  std::vector<Launch> launches;
 };
 
 enum class KernelFamily { Generic, S4, S16, S20, S61 };

@@ -342,7 +342,8 @@ __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2
 }
 
 template <unsigned KS, unsigned RT, bool RS>
-__global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanView plan, unsigned nblk, unsigned S,
+__global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanView plan, unsigned chain_begin,
+                                                                           unsigned chain_end, unsigned nblk, unsigned S,
                                                                            unsigned Sp, unsigned lut_codes,
                                                                            unsigned lut_lds_flag)
 {
@@ -350,10 +351,12 @@ __global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanVi
   const bool lut_lds = lut_lds_flag != 0;
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned wstride = gridDim.x * S16_CHAIN_WAVES;
-  for (unsigned c = 0; c < plan.nchains; ++c)
+  bool first_fill = true;
+  for (unsigned c = chain_begin + blockIdx.y; c < chain_end; c += gridDim.y)
   {
     const PlanChain ch = plan_fetch(plan.chains + c);
-    if (c) __syncthreads();
+    if (!first_fill) __syncthreads();
+    first_fill = false;
     for (unsigned i = 0; i < ch.len; ++i)
     {
       const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
@@ -571,7 +574,8 @@ static unsigned s16_chain_slot(const Engine * e, bool tip)
   return s16_chain_lut_lds(e) ? ((e->R * e->lut_codes * e->S + 7u) & ~7u) : 0u;
 }
 
-static int launch_traverse_s16(Engine * e, const PlanView & plan, unsigned lds_doubles)
+static int launch_traverse_s16(Engine * e, const PlanView & plan, unsigned lds_doubles, unsigned chain_begin,
+                               unsigned chain_end, unsigned rows)
 {
   const size_t lds = sizeof(double) * lds_doubles;
   const unsigned need = (e->nblk + S16_CHAIN_WAVES - 1) / S16_CHAIN_WAVES;
@@ -594,11 +598,11 @@ static int launch_traverse_s16(Engine * e, const PlanView & plan, unsigned lds_d
 #define PLLHIP_CALL(KK) \
   do { \
     if (e->rate_scalers) \
-      hipLaunchKernelGGL((k_traverse_s16<KK, 4, true>), dim3(gx), dim3(64 * S16_CHAIN_WAVES), lds, e->stream, \
-                         plan, e->nblk, e->S, e->Sp, e->lut_codes, lut_lds); \
+      hipLaunchKernelGGL((k_traverse_s16<KK, 4, true>), dim3(gx, std::max(1u, rows)), dim3(64 * S16_CHAIN_WAVES), lds, e->stream, \
+                         plan, chain_begin, chain_end, e->nblk, e->S, e->Sp, e->lut_codes, lut_lds); \
     else \
-      hipLaunchKernelGGL((k_traverse_s16<KK, 4, false>), dim3(gx), dim3(64 * S16_CHAIN_WAVES), lds, e->stream, \
-                         plan, e->nblk, e->S, e->Sp, e->lut_codes, lut_lds); \
+      hipLaunchKernelGGL((k_traverse_s16<KK, 4, false>), dim3(gx, std::max(1u, rows)), dim3(64 * S16_CHAIN_WAVES), lds, e->stream, \
+                         plan, chain_begin, chain_end, e->nblk, e->S, e->Sp, e->lut_codes, lut_lds); \
   } while (0)
   PLLHIP_DISPATCH_KS(s16_ks(e), PLLHIP_CALL);
 #undef PLLHIP_CALL

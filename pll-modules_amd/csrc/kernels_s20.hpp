@@ -634,9 +634,10 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_chain_s20(ChainBatc
 // workgroup's own barrier around the re-staging of the LDS tables.
 // grid = gx, block = 512, dynamic LDS = the largest chain area of the schedule.
 template <unsigned RT, bool RS>
-__global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanView plan, unsigned nblk, unsigned slab,
-                                                                           unsigned lut_codes, unsigned lut_used,
-                                                                           unsigned flags)
+__global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanView plan, unsigned chain_begin,
+                                                                           unsigned chain_end, unsigned nblk,
+                                                                           unsigned slab, unsigned lut_codes,
+                                                                           unsigned lut_used, unsigned flags)
 {
   extern __shared__ double lds[];
   const bool nt_ld = flags & 1u, nt_st = flags & 2u;
@@ -648,7 +649,9 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanVi
   for (unsigned s0 = 0; s0 < nblk; s0 += slab)
   {
     const unsigned s1 = min(nblk, s0 + slab);
-    for (unsigned c = 0; c < plan.nchains; ++c)
+    // chains [chain_begin, chain_end) of the schedule, shared out over gridDim.y: the whole schedule with
+    // gridDim.y = 1 (a traversal in one launch), one chain per workgroup row for a round of chains
+    for (unsigned c = chain_begin + blockIdx.y; c < chain_end; c += gridDim.y)
     {
       const PlanChain ch = plan_fetch(plan.chains + c);
       if (!first_fill) __syncthreads();                 // every wave has left the previous chain's tables
@@ -1121,7 +1124,8 @@ static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned ncha
   return PLL_SUCCESS;
 }
 
-static int launch_traverse_s20(Engine * e, const PlanView & plan, unsigned lds_doubles, unsigned lut_used)
+static int launch_traverse_s20(Engine * e, const PlanView & plan, unsigned lds_doubles, unsigned lut_used,
+                               unsigned chain_begin, unsigned chain_end, unsigned rows)
 {
   const size_t lds = sizeof(double) * lds_doubles;
   const unsigned env_flags = []() { const char * v = getenv("PLLHIP_S20_NT"); return v ? (unsigned)atoi(v) & 3u : 0u; }();
@@ -1144,8 +1148,8 @@ static int launch_traverse_s20(Engine * e, const PlanView & plan, unsigned lds_d
   const unsigned per_pass = gx * S20_CHAIN_WAVES;
   unsigned slab = env_slab > 0 ? (unsigned)env_slab : e->nblk;
   slab = std::max(per_pass, (slab + per_pass - 1) / per_pass * per_pass);   // whole passes of the grid
-  const dim3 grid(gx), block(64 * S20_CHAIN_WAVES);
-#define PLLHIP_CALL(K) hipLaunchKernelGGL(K, grid, block, lds, e->stream, plan, e->nblk, slab, e->lut_codes, lut_used, flags)
+  const dim3 grid(gx, std::max(1u, rows)), block(64 * S20_CHAIN_WAVES);
+#define PLLHIP_CALL(K) hipLaunchKernelGGL(K, grid, block, lds, e->stream, plan, chain_begin, chain_end, e->nblk, slab, e->lut_codes, lut_used, flags)
   PLLHIP_S20_CHAIN_DISPATCH(k_traverse_s20, PLLHIP_CALL);
 #undef PLLHIP_CALL
   PLLHIP_TRY(hipGetLastError());

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
 // More workgroups than fit the chip: each finishes its range and makes room for the next, so the
 // ranges in flight at any time are a slab of the alignment that moves through the whole tree.
 template <unsigned U, unsigned R>
-__global__ __launch_bounds__(256) void k_traverse_s4(PlanView plan, unsigned N)
+__global__ __launch_bounds__(256) void k_traverse_s4(PlanView plan, unsigned chain_begin, unsigned chain_end, unsigned N)
 {
   constexpr unsigned group = 2 * R;
   constexpr unsigned S4_CHAIN_OP_LDS = s4_chain_op_lds(R);
@@ -380,10 +380,12 @@ __global__ __launch_bounds__(256) void k_traverse_s4(PlanView plan, unsigned N)
   const unsigned nchunks = (N + 63) / 64;
   const unsigned cbeg = (unsigned)(((unsigned long long)nchunks * blockIdx.x) / gridDim.x);
   const unsigned cend = (unsigned)(((unsigned long long)nchunks * (blockIdx.x + 1)) / gridDim.x);
-  for (unsigned c = 0; c < plan.nchains; ++c)
+  bool first_fill = true;
+  for (unsigned c = chain_begin + blockIdx.y; c < chain_end; c += gridDim.y)
   {
     const PlanChain ch = plan_fetch(plan.chains + c);
-    if (c) __syncthreads();
+    if (!first_fill) __syncthreads();
+    first_fill = false;
     for (unsigned i = 0; i < ch.len; ++i)
     {
       const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
@@ -658,7 +660,8 @@ static int launch_chains_s4(Engine * e, const ChainBatch & batch, unsigned nchai
   return PLL_SUCCESS;
 }
 
-static int launch_traverse_s4(Engine * e, const PlanView & plan, unsigned longest)
+static int launch_traverse_s4(Engine * e, const PlanView & plan, unsigned longest, unsigned chain_begin, unsigned chain_end,
+                              unsigned rows)
 {
   const unsigned nchunks = (e->N + 63) / 64;
   const size_t lds = sizeof(double) * longest * s4_chain_op_lds(e->R);
@@ -674,13 +677,15 @@ static int launch_traverse_s4(Engine * e, const PlanView & plan, unsigned longes
     PLLHIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
     per_cu = std::max(1, per_cu);
   }
-  const unsigned gx = std::max(1u, std::min((nchunks + 3) / 4, e->cu_count * (unsigned)per_cu));
+  // a round of chains (rows > 1): the chains share the chip, eight workgroups per CU and chain as in k_chain_s4
+  const unsigned gx = std::max(1u, std::min((nchunks + 3) / 4, e->cu_count * (rows > 1 ? 8u : (unsigned)per_cu)));
+  const dim3 grid(gx, std::max(1u, rows));
   if (e->R == 4)
-    hipLaunchKernelGGL((k_traverse_s4<4, 4>), dim3(gx), dim3(256), lds, e->stream, plan, e->N);
+    hipLaunchKernelGGL((k_traverse_s4<4, 4>), grid, dim3(256), lds, e->stream, plan, chain_begin, chain_end, e->N);
   else if (e->R == 2)
-    hipLaunchKernelGGL((k_traverse_s4<4, 2>), dim3(gx), dim3(256), lds, e->stream, plan, e->N);
+    hipLaunchKernelGGL((k_traverse_s4<4, 2>), grid, dim3(256), lds, e->stream, plan, chain_begin, chain_end, e->N);
   else
-    hipLaunchKernelGGL((k_traverse_s4<2, 1>), dim3(gx), dim3(256), lds, e->stream, plan, e->N);
+    hipLaunchKernelGGL((k_traverse_s4<2, 1>), grid, dim3(256), lds, e->stream, plan, chain_begin, chain_end, e->N);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

@@ -1149,13 +1149,20 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
                             : (engines_on_device[e->device & 63].load() <= 1 && fills_chip && (count >= 6 || chains16));
     const unsigned chain_max = chains20 ? S20_CHAIN_MAX : chains16 ? S16_CHAIN_MAX : S4_CHAIN_MAX;
     const unsigned chain_lds = chains20 ? S20_CHAIN_LDS : chains16 ? S16_CHAIN_LDS : ~0u;
-    if (use_traverse)
+    // Device-resident schedules serve both forms: the whole traversal in one launch, or (lists of six
+    // operations and more) one launch per round with the chains of the round as grid rows.  Launching
+    // from a resident schedule costs 4 - 5 us of host time; with the descriptors by value in the
+    // kernel arguments (3.6 KB per launch) it is 9 - 14 us, which is what binds small partitions.
+    const bool by_rounds = !use_traverse && !chains16 && count >= 6;
+    if (use_traverse || by_rounds)
     {
       DevicePlan & dp = e->plan;
-      std::vector<unsigned char> key(2 * sizeof(unsigned) + (size_t)count * sizeof(pll_operation_t));
+      const unsigned mode = use_traverse ? 1u : 0u;
+      std::vector<unsigned char> key(3 * sizeof(unsigned) + (size_t)count * sizeof(pll_operation_t));
       memcpy(key.data(), &count, sizeof(unsigned));
       memcpy(key.data() + sizeof(unsigned), &lut_used, sizeof(unsigned));
-      memcpy(key.data() + 2 * sizeof(unsigned), ops, (size_t)count * sizeof(pll_operation_t));
+      memcpy(key.data() + 2 * sizeof(unsigned), &mode, sizeof(unsigned));
+      memcpy(key.data() + 3 * sizeof(unsigned), ops, (size_t)count * sizeof(pll_operation_t));
       bool have = !dp.key.empty() && dp.key == key;
       if (!have && plan_chains(e, ops, count, chain_max, chain_lds, lut_used, plan))
       {
@@ -1189,6 +1196,17 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
         }
         std::vector<size_t> order;
         order.reserve(nch);
+        if (by_rounds)
+        {
+          // round by round, longest chains first within a round (their workgroups are dispatched first)
+          for (size_t c = 0; c < nch; ++c) order.push_back(c);
+          std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b)
+          {
+            if (plan.launch[a] != plan.launch[b]) return plan.launch[a] < plan.launch[b];
+            return plan.chains[a].size() > plan.chains[b].size();
+          });
+        }
+        else
         {
           std::vector<std::pair<size_t, size_t>> stack;   // (chain, next feeder)
           for (size_t root = 0; root < nch; ++root)
@@ -1209,9 +1227,30 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
         std::vector<PlanChain> pchains;
         unsigned nops = 0, lds_max = 0;
         dp.algo_bytes = dp.algo_flops = 0.0;
+        dp.launches.clear();
+        int cur_round = -1;
         for (size_t c : order)
         {
           const std::vector<unsigned> & ch = plan.chains[c];
+          if (dp.launches.empty() || (by_rounds && plan.launch[c] != cur_round))
+          {
+            if (!dp.launches.empty())
+            {
+              DevicePlan::Launch & done = dp.launches.back();
+              done.end = (unsigned)pchains.size();
+              done.ops = nops - done.ops;
+              done.bytes = dp.algo_bytes - done.bytes;
+              done.flops = dp.algo_flops - done.flops;
+            }
+            DevicePlan::Launch l;
+            l.begin = (unsigned)pchains.size();
+            l.end = l.begin;
+            l.ops = nops;                     // running totals until the launch is closed
+            l.bytes = dp.algo_bytes;
+            l.flops = dp.algo_flops;
+            dp.launches.push_back(l);
+            cur_round = plan.launch[c];
+          }
           PlanChain pc;
           pc.first = nops;
           pc.len = (unsigned)ch.size();
@@ -1239,6 +1278,14 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
         dp.bytes.resize(pops.size() * sizeof(PlanOp) + pchains.size() * sizeof(PlanChain));
         memcpy(dp.bytes.data(), pops.data(), pops.size() * sizeof(PlanOp));
         memcpy(dp.bytes.data() + pops.size() * sizeof(PlanOp), pchains.data(), pchains.size() * sizeof(PlanChain));
+        if (!dp.launches.empty())
+        {
+          DevicePlan::Launch & done = dp.launches.back();
+          done.end = (unsigned)pchains.size();
+          done.ops = nops - done.ops;
+          done.bytes = dp.algo_bytes - done.bytes;
+          done.flops = dp.algo_flops - done.flops;
+        }
         dp.nops = nops;
         dp.nchains = (unsigned)pchains.size();
         dp.lds_doubles = lds_max;
@@ -1249,13 +1296,18 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
       {
         PlanView view;
         if (!upload_plan(e, view)) return PLL_FAILURE;
-        hipEvent_t ev1;
-        if (!prof_begin(ev1)) return PLL_FAILURE;
-        if (chains20 ? !launch_traverse_s20(e, view, dp.lds_doubles, lut_used)
-                     : chains16 ? !launch_traverse_s16(e, view, dp.lds_doubles) : !launch_traverse_s4(e, view, dp.lds_doubles))
-          return PLL_FAILURE;
-        if (!prof_end(ev1, dp.algo_bytes, dp.algo_flops, count)) return PLL_FAILURE;
-        e->counters.partial_launches++;
+        for (const DevicePlan::Launch & l : dp.launches)
+        {
+          const unsigned rows = use_traverse ? 1u : l.end - l.begin;
+          hipEvent_t ev1;
+          if (!prof_begin(ev1)) return PLL_FAILURE;
+          if (chains20 ? !launch_traverse_s20(e, view, dp.lds_doubles, lut_used, l.begin, l.end, rows)
+                       : chains16 ? !launch_traverse_s16(e, view, dp.lds_doubles, l.begin, l.end, rows)
+                                  : !launch_traverse_s4(e, view, dp.lds_doubles, l.begin, l.end, rows))
+            return PLL_FAILURE;
+          if (!prof_end(ev1, l.bytes, l.flops, l.ops)) return PLL_FAILURE;
+          e->counters.partial_launches++;
+        }
         e->counters.partial_ops += count;
         e->counters.site_updates += (unsigned long long)count * e->N * e->R;
         return PLL_SUCCESS;
