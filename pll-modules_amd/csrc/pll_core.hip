@@ -1135,16 +1135,20 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     // (two DNA + two protein partitions, 250 k sites each: 7.4 against 8.1 ms per evaluation).
     // PLLHIP_TRAVERSE=1 / 0: always / never.
     static const int env_traverse = getenv("PLLHIP_TRAVERSE") ? atoi(getenv("PLLHIP_TRAVERSE")) : -1;
-    // Short lists (the 1 - 3 operations of an SPR insertion) keep the round schedule as well: their
-    // descriptors travel in the kernel arguments, while a schedule has to be copied to the device
-    // first (W3 at C2 size: 165 against 178 us per iteration).
-    // Small partitions too: a workgroup walks ALL chains one after the other (12 - 15 us each), while the
-    // rounds run the chains of a round side by side -- that wins until the site blocks alone fill the chip
-    // (20 states, 200 taxa: 32 k sites 1.76 against 2.14 ms, 64 k sites 2.88 against 2.55 ms; 4 states,
-    // 100 taxa: 64 k sites 0.42 against 0.54 ms, 100 k sites equal, 125 k sites 0.66 against 0.61 ms;
-    // 2..16 states, whose alternative is one launch per dependency level: from 25 k sites).
-    const bool fills_chip = chains4 ? (e->N + 63) / 64 >= 6u * e->cu_count
-                                    : e->nblk >= (chains16 ? 3u : 6u) * e->cu_count;
+    // One launch for the whole traversal, or one launch per round with the chains of the round as grid
+    // rows (both from the device-resident schedule)?  In one launch a workgroup walks ALL chains one
+    // after the other and no launch boundary is paid; by rounds the chains run side by side (which is
+    // what a partition needs that does not fill the chip with its site blocks) and the workgroups of
+    // a round are shared out dynamically (which wins again on very large partitions).  Measured per
+    // traversal, rounds / one launch:
+    //   20 states, 200 taxa:  32 k sites 1.55 / 2.14 ms, 64 k 2.64 / 2.59, 125 k 4.83 / 4.66,
+    //                         250 k 8.66 / 8.93, 500 k 16.4 / 17.2, 1 M 32.4 / 33.0
+    //    4 states, 100 taxa:  100 k 0.52 / 0.58, 250 k 1.08 / 1.18, 500 k 1.94 / 1.99, 1 M 3.64 / 3.52
+    //   16 states,  50 taxa:  8 k 0.23 / 0.38, 32 k 0.36 / 0.44, 128 k 1.03 / 0.94, 500 k 3.22 / 3.17
+    //    2 states,  50 taxa:  1 M 2.20 / 2.74
+    const bool fills_chip = chains4 ? (e->N + 63) / 64 >= 48u * e->cu_count
+                          : chains16 ? (e->nblk >= 12u * e->cu_count && e->nblk < 48u * e->cu_count && e->S > 8)
+                                     : (e->nblk >= 6u * e->cu_count && e->nblk < 24u * e->cu_count);
     const bool use_traverse = env_traverse >= 0 ? env_traverse != 0
                             : (engines_on_device[e->device & 63].load() <= 1 && fills_chip && (count >= 6 || chains16));
     const unsigned chain_max = chains20 ? S20_CHAIN_MAX : chains16 ? S16_CHAIN_MAX : S4_CHAIN_MAX;
@@ -1153,7 +1157,10 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     // operations and more) one launch per round with the chains of the round as grid rows.  Launching
     // from a resident schedule costs 4 - 5 us of host time; with the descriptors by value in the
     // kernel arguments (3.6 KB per launch) it is 9 - 14 us, which is what binds small partitions.
-    const bool by_rounds = !use_traverse && !chains16 && count >= 6;
+    // Short lists (the 1 - 3 operations of an SPR insertion) keep their descriptors in the kernel
+    // arguments: a schedule would have to be copied to the device first (W3 at C2 size: 165 against
+    // 178 us per iteration).
+    const bool by_rounds = !use_traverse && count >= 6;
     if (use_traverse || by_rounds)
     {
       DevicePlan & dp = e->plan;
