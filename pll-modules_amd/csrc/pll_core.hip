@@ -114,6 +114,17 @@ static bool dev_alloc(T ** ptr, size_t count, const char * what)
   return true;
 }
 
+// Kernel arguments in device memory (the ROCm runtime's HIP_FORCE_DEV_KERNARG): by default they sit in
+// host memory, and the first wave of every workgroup pays a trip over the fabric for its operation
+// descriptors -- 3 to 5 us on a kernel that runs for 10 (an SPR insertion's partial traversal, a
+// 25 k-site codon slice: W3 -3 ... -6 %, C5 at 25 k sites 1.73 -> 1.65 ms per step).  Set when the
+// library is loaded, i.e. before its first HIP call, unless the user has decided otherwise; a runtime
+// that another component initialised earlier keeps its setting.
+__attribute__((constructor)) static void pllhip_runtime_defaults()
+{
+  setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
+}
+
 // partitions alive per device (whole-traversal launches are the default for a partition that has
 // its device to itself)
 static std::atomic<int> engines_on_device[64];
