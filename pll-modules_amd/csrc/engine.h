@@ -119,7 +119,7 @@ struct DevicePlan                                 // the schedule resident on th
   double algo_bytes = 0.0, algo_flops = 0.0;      // algorithmic traffic / work of the traversal
   // launches of the schedule: one for a whole traversal, or one per round of chains (chains
   // [begin, end) side by side) for a partition that does not fill the chip on its own
-  struct Launch { unsigned begin, end, ops; double bytes, flops; };
+  struct Launch { unsigned begin, end, rows, ops; double bytes, flops; };   // chains [begin, end) over `rows` grid rows
   std::vector<Launch> launches;
 };
 

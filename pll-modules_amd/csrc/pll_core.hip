@@ -1261,6 +1261,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
               done.flops = dp.algo_flops - done.flops;
             }
             DevicePlan::Launch l;
+            l.rows = 1;
             l.begin = (unsigned)pchains.size();
             l.end = l.begin;
             l.ops = nops;                     // running totals until the launch is closed
@@ -1304,6 +1305,31 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
           done.bytes = dp.algo_bytes - done.bytes;
           done.flops = dp.algo_flops - done.flops;
         }
+        // rounds of ONE chain each that follow one another (the spine towards the root) need no launch
+        // boundary between them: one workgroup row walks them in turn, exactly as in a one-launch traversal
+        if (by_rounds)
+        {
+          std::vector<DevicePlan::Launch> merged;
+          for (const DevicePlan::Launch & l : dp.launches)
+          {
+            if (!merged.empty() && l.end - l.begin == 1 && merged.back().rows == 1)
+            {
+              DevicePlan::Launch & m = merged.back();
+              m.end = l.end;
+              m.ops += l.ops;
+              m.bytes += l.bytes;
+              m.flops += l.flops;
+            }
+            else
+            {
+              merged.push_back(l);
+              merged.back().rows = l.end - l.begin;
+            }
+          }
+          dp.launches.swap(merged);
+        }
+        else
+          for (DevicePlan::Launch & l : dp.launches) l.rows = 1;
         dp.nops = nops;
         dp.nchains = (unsigned)pchains.size();
         dp.lds_doubles = lds_max;
@@ -1316,7 +1342,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
         if (!upload_plan(e, view)) return PLL_FAILURE;
         for (const DevicePlan::Launch & l : dp.launches)
         {
-          const unsigned rows = use_traverse ? 1u : l.end - l.begin;
+          const unsigned rows = l.rows;
           hipEvent_t ev1;
           if (!prof_begin(ev1)) return PLL_FAILURE;
           if (chains20 ? !launch_traverse_s20(e, view, dp.lds_doubles, lut_used, l.begin, l.end, rows)
