@@ -403,7 +403,12 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and world == 1 and not args.sites and not args.taxa and not args.rate_scalers:
         try:
-            traffic = json.load(open(tpath)).get(f"{args.config}:{kernel}")
+            tj = json.load(open(tpath))
+            per_step = tj.get(f"{args.config}:{kernel}:per_step")
+            if per_step and prof.launches:
+                traffic = round(per_step * args.steps / prof.launches)      # per launch, like `achieved`
+            else:
+                traffic = tj.get(f"{args.config}:{kernel}")
             traffic_source = ("profiles/traffic.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                               "this command (tools/gpu_profile.sh), NOT measured in this run")
         except Exception:

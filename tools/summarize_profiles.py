@@ -80,9 +80,14 @@ def main():
         if dom:
             total = sum(v["dispatches"] * v["hbm_bytes_per_dispatch"] for v in dom + extra)
             launches = sum(v["dispatches"] for v in dom)
+            # one edge-lnL kernel per evaluation = the number of steps of the PMC run
+            steps = sum(v["dispatches"] for k, v in summary.items() if "k_edge_lnl" in k) or 1
             tpath = os.path.join(OUT, "traffic.json")
             t = json.load(open(tpath)) if os.path.exists(tpath) else {}
             t[f"{cfg}:{kernel_key}"] = round(total / launches)
+            # per step (traversal): what bench.py divides by its own launch count, so that a change of the
+            # schedule (launches per traversal) does not invalidate the committed figure
+            t[f"{cfg}:{kernel_key}:per_step"] = round(total / steps)
             json.dump(t, open(tpath, "w"), indent=1)
     for k, v in summary.items():
         print(f"{k:40s} n={v['dispatches']:4d} read={v['hbm_read_bytes_per_dispatch']/1e6:10.1f} MB "
