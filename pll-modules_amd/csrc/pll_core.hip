@@ -1140,11 +1140,9 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     ChainPlan plan;
     // tip tables are staged with the codes in use (at least one: an untouched partition)
     const unsigned lut_used = std::max(1u, std::min(p->maxstates, e->lut_codes));
-    // The whole traversal in one launch -- when this partition has the device to itself.  With
-    // several partitions on one device (each on its own stream) the many short launches of the
-    // round schedule interleave better than long-lived workgroups with a fixed share of the sites
-    // (two DNA + two protein partitions, 250 k sites each: 7.4 against 8.1 ms per evaluation).
-    // PLLHIP_TRAVERSE=1 / 0: always / never.
+    // PLLHIP_TRAVERSE=1 / 0: whole traversals always / never in one launch (default: by size, below; never
+    // when several partitions share the device, each on its own stream: long-lived workgroups with a fixed
+    // share of the sites interleave worse than rounds -- two DNA + two protein partitions: 7.7 against 7.1 ms).
     static const int env_traverse = getenv("PLLHIP_TRAVERSE") ? atoi(getenv("PLLHIP_TRAVERSE")) : -1;
     // One launch for the whole traversal, or one launch per round with the chains of the round as grid
     // rows (both from the device-resident schedule)?  In one launch a workgroup walks ALL chains one
@@ -1165,9 +1163,11 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     const unsigned chain_max = chains20 ? S20_CHAIN_MAX : chains16 ? S16_CHAIN_MAX : S4_CHAIN_MAX;
     const unsigned chain_lds = chains20 ? S20_CHAIN_LDS : chains16 ? S16_CHAIN_LDS : ~0u;
     // Device-resident schedules serve both forms: the whole traversal in one launch, or (lists of six
-    // operations and more) one launch per round with the chains of the round as grid rows.  Launching
-    // from a resident schedule costs 4 - 5 us of host time; with the descriptors by value in the
-    // kernel arguments (3.6 KB per launch) it is 9 - 14 us, which is what binds small partitions.
+    // operations and more) one launch per round with the chains of the round as grid rows.  A repeated
+    // list is neither planned nor copied again: replaying it costs 2.5 us of host time per launch, where
+    // the by-value form below plans at every call (30 - 130 us for 100 - 200 operations; 72 -> 21 us and
+    // 212 -> 23 us per full-traversal call at 4 / 20 states), splits a round at 24 operations and falls
+    // back to the per-operation kernel for rounds of single operations.
     // Short lists (the 1 - 3 operations of an SPR insertion) keep their descriptors in the kernel
     // arguments: a schedule would have to be copied to the device first (W3 at C2 size: 165 against
     // 178 us per iteration).
