@@ -1164,10 +1164,10 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     const unsigned chain_lds = chains20 ? S20_CHAIN_LDS : chains16 ? S16_CHAIN_LDS : ~0u;
     // Device-resident schedules serve both forms: the whole traversal in one launch, or (lists of six
     // operations and more) one launch per round with the chains of the round as grid rows.  A repeated
-    // list is neither planned nor copied again: replaying it costs 2.5 us of host time per launch, where
-    // the by-value form below plans at every call (30 - 130 us for 100 - 200 operations; 72 -> 21 us and
-    // 212 -> 23 us per full-traversal call at 4 / 20 states), splits a round at 24 operations and falls
-    // back to the per-operation kernel for rounds of single operations.
+    // list is neither planned nor copied again (2.5 us of host time per launch), its kernels read their
+    // descriptors from device memory, a round is never split at 24 operations and rounds of single
+    // operations stay on the chain kernel: 72 -> 21 us and 212 -> 23 us per full-traversal call of a
+    // 2 000-site partition at 4 / 20 states against the by-value form below.
     // Short lists (the 1 - 3 operations of an SPR insertion) keep their descriptors in the kernel
     // arguments: a schedule would have to be copied to the device first (W3 at C2 size: 165 against
     // 178 us per iteration).
