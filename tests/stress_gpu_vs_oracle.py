@@ -27,4 +27,14 @@ for trial in range(42):
         tol = (2e-6 if S > 20 else 1e-11) * abs(lb) + 2e-9 * N
         ok = abs(la - lb) <= tol and all(np.array_equal(a.get_scaler(op[1]), b.get_scaler(op[1])) for op in tr.ops)
         if not ok: bad += 1; print("trav", S, R, n, N, la, lb)
+# sizes at which the schedule changes form (rounds of chains as grid rows / the whole traversal in one launch)
+for S, N, n in ((4, 70_000, 14), (4, 900_000, 8), (20, 40_000, 12), (20, 120_000, 10), (16, 110_000, 9), (2, 150_000, 16), (10, 30_000, 11)):
+    tr = pc.Tree(n, int(rng.integers(1, 1000)), int(rng.integers(1, 1000)))
+    kw = dict(states=S, rate_cats=4, ntips=n, nsites=N, coded=True, tree=tr)
+    with pc.build_instance(product, **kw) as a, pc.build_instance(oracle, **kw) as b:
+        for rep in range(2):                                  # second pass: cached schedule
+            la, lb = pc.full_traversal(a), pc.full_traversal(b)
+            ok = abs(la - lb) <= 1e-11 * abs(lb) + 2e-9 * N and \
+                all(np.array_equal(a.get_scaler(op[1]), b.get_scaler(op[1])) for op in tr.ops)
+            if not ok: bad += 1; print("big", S, N, n, la, lb)
 print("stress done, failures:", bad)
