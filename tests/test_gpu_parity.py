@@ -273,6 +273,27 @@ with pc.build_instance(lib, states=%d, rate_cats=4, ntips=%d, nsites=1531, coded
     assert int(runs[0][4]) == 4 and int(runs[1][4]) > 8        # one launch per traversal / several
 
 
+@pytest.mark.parametrize("states,nsites,ntips,launches", [(4, 900_000, 8, 1), (4, 70_000, 14, None), (20, 120_000, 10, 1),
+                                                          (20, 40_000, 12, None), (16, 110_000, 9, 1), (2, 150_000, 16, None)])
+def test_schedules_at_the_sizes_that_select_them(product, oracle, states, nsites, ntips, launches):
+    """the form of a traversal follows the size of the partition (rounds of chains as grid rows / everything
+    in one launch): both forms at sizes that select them by default, against the oracle (lnL, exact scaler
+    counts), twice (the second pass replays the resident schedule)"""
+    a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=ntips, nsites=nsites, coded=True)
+    with a, b:
+        for rep in range(2):
+            before = a.counters().partial_launches
+            la, lb = pc.full_traversal(a), pc.full_traversal(b)
+            used = a.counters().partial_launches - before
+            assert abs(la - lb) <= 1e-11 * abs(lb) + 2e-9 * nsites, (la, lb)
+            for op in a.tree.ops:
+                assert np.array_equal(a.get_scaler(op[1]), b.get_scaler(op[1]))
+            if launches is not None:
+                assert used == launches
+            else:
+                assert 1 < used < len(a.tree.ops)
+
+
 @pytest.mark.parametrize("rate_cats,attributes", [(4, 0), (2, 0), (4, pc.PLL_ATTRIB_RATE_SCALERS)])
 def test_codon_cherries_that_scale(product, oracle, rate_cats, attributes):
     """61 states: a tip x tip operation is computed inside the operation that consumes it, its own
