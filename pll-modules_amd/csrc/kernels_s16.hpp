@@ -91,6 +91,19 @@ __device__ inline void s16_load_d(const double * unit, unsigned lane, double2 t[
   for (unsigned v = 0; v < KS; ++v) t[v] = *reinterpret_cast<const double2 *>(unit + v * 128 + lane * 2);
 }
 
+// (stores that do not allocate in the caches: a vector is written once and read, if at all, by a later chain)
+template <unsigned KS>
+__device__ inline void s16_store_d_nt(double * unit, unsigned lane, const double2 t[KS])
+{
+  typedef double nt_v2d __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (unsigned v = 0; v < KS; ++v)
+  {
+    nt_v2d w; w.x = t[v].x; w.y = t[v].y;
+    __builtin_nontemporal_store(w, reinterpret_cast<nt_v2d *>(unit + v * 128 + lane * 2));
+  }
+}
+
 template <unsigned KS>
 __device__ inline void s16_store_d(double * unit, unsigned lane, const double2 t[KS])
 {
@@ -236,7 +249,7 @@ template <unsigned KS, unsigned RT, bool RS>
 __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2 X[RT][KS],
                                     const double * s1, const double * s2, unsigned S, unsigned lut_codes,
                                     bool lut_lds, unsigned blk, unsigned lane,
-                                    unsigned (&xe)[RS ? RT : 1], unsigned (&xo)[RS ? RT : 1])
+                                    unsigned (&xe)[RS ? RT : 1], unsigned (&xo)[RS ? RT : 1], bool nt)
 {
   constexpr unsigned UNIT = 4 * KS * S20_BS;
   const unsigned q = lane >> 4, n = lane & 15;
@@ -299,7 +312,7 @@ __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2
         op.parent_scaler[io] = co;
       }
     }
-    s16_store_d<KS>(op.parent + ubase, lane, X[r]);
+    if (nt) s16_store_d_nt<KS>(op.parent + ubase, lane, X[r]); else s16_store_d<KS>(op.parent + ubase, lane, X[r]);
     xe[RS ? r : 0] = ce;
     xo[RS ? r : 0] = co;
   }
@@ -317,7 +330,8 @@ __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2
   {
 #pragma unroll
     for (unsigned v = 0; v < KS; ++v) { X[r][v].x *= fe; X[r][v].y *= fo; }
-    s16_store_d<KS>(op.parent + ((size_t)blk * RT + r) * UNIT, lane, X[r]);
+    if (nt) s16_store_d_nt<KS>(op.parent + ((size_t)blk * RT + r) * UNIT, lane, X[r]);
+    else s16_store_d<KS>(op.parent + ((size_t)blk * RT + r) * UNIT, lane, X[r]);
   }
   unsigned ce = 0, co = 0;
   if (scaling && q == 0)
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanVi
                                                                            unsigned lut_lds_flag)
 {
   extern __shared__ double lds[];
-  const bool lut_lds = lut_lds_flag != 0;
+  const bool lut_lds = (lut_lds_flag & 1u) != 0, nt = (lut_lds_flag & 2u) != 0;
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned wstride = gridDim.x * S16_CHAIN_WAVES;
   bool first_fill = true;
@@ -377,7 +391,7 @@ __global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanVi
       {
         const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
         s16_chain_op<KS, RT, RS>(po.d, i ? po.carried : 0u, X, lds + po.slot1, lds + po.slot2, S, lut_codes,
-                                 lut_lds, blk, lane, xe, xo);
+                                 lut_lds, blk, lane, xe, xo, nt);
       }
     }
   }
@@ -580,7 +594,8 @@ static int launch_traverse_s16(Engine * e, const PlanView & plan, unsigned lds_d
   const size_t lds = sizeof(double) * lds_doubles;
   const unsigned need = (e->nblk + S16_CHAIN_WAVES - 1) / S16_CHAIN_WAVES;
   const unsigned gx = std::max(1u, std::min(need, e->cu_count));
-  const unsigned lut_lds = s16_chain_lut_lds(e) ? 1u : 0u;
+  static const int env_nt = getenv("PLLHIP_S16_NT") ? atoi(getenv("PLLHIP_S16_NT")) : 1;   // 1 - 7 % faster
+  const unsigned lut_lds = (s16_chain_lut_lds(e) ? 1u : 0u) | (env_nt ? 2u : 0u);
   static bool attr_set_dev[64] = {false};
   bool & attr_set = attr_set_dev[e->device & 63];
   const int cap = (int)(sizeof(double) * S16_CHAIN_LDS);
