@@ -239,7 +239,19 @@ constexpr unsigned s4_chain_op_lds(unsigned R) { return 2 * R * S4_LUT_RS + 2 * 
 // one operation of a chain for one 64-site chunk: X holds the handed-over operand on entry (when
 // carried != 0) and the result on exit, xcnt the scaler count that goes with it.
 // base: the operation's LDS tables
-template <unsigned U, unsigned R, bool NT = false>
+template <bool NTL>
+__device__ inline double2 s4_ld2(const double * p)
+{
+  if (NTL)
+  {
+    typedef double nt_v2d __attribute__((ext_vector_type(2)));
+    const nt_v2d w = __builtin_nontemporal_load(reinterpret_cast<const nt_v2d *>(p));
+    return make_double2(w.x, w.y);
+  }
+  return *reinterpret_cast<const double2 *>(p);
+}
+
+template <unsigned U, unsigned R, int NT = 0>
 __device__ inline void s4_chain_step(const OpDesc & op, unsigned carried, const double * base,
                                      double2 (&X)[2 * R], unsigned & xcnt,
                                      unsigned long long hc0, unsigned long long nsc, unsigned long long total,
@@ -281,10 +293,10 @@ __device__ inline void s4_chain_step(const OpDesc & op, unsigned carried, const 
       {
         if (op.codes1)
           in1[u] = *reinterpret_cast<const double2 *>(&base[r * S4_LUT_RS + code1 * 4 + 2 * h]);
-        else if (carried != 1) in1[u] = *reinterpret_cast<const double2 *>(op.clv1 + gu * 2);
+        else if (carried != 1) in1[u] = s4_ld2<NT == 2>(op.clv1 + gu * 2);
         if (op.codes2)
           in2[u] = *reinterpret_cast<const double2 *>(&base[T2 + r * S4_LUT_RS + code2 * 4 + 2 * h]);
-        else if (carried != 2) in2[u] = *reinterpret_cast<const double2 *>(op.clv2 + gu * 2);
+        else if (carried != 2) in2[u] = s4_ld2<NT == 2>(op.clv2 + gu * 2);
       }
     }
 #pragma unroll
@@ -308,7 +320,7 @@ __device__ inline void s4_chain_step(const OpDesc & op, unsigned carried, const 
       X[k] = v;
       if (live[u])
       {
-        if (NT)
+        if (NT != 0)
         {
           typedef double nt_v2d __attribute__((ext_vector_type(2)));
           nt_v2d w; w.x = v.x; w.y = v.y;
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
 // range of chunks through every chain of the schedule, re-staging the tables between two chains.
 // More workgroups than fit the chip: each finishes its range and makes room for the next, so the
 // ranges in flight at any time are a slab of the alignment that moves through the whole tree.
-template <unsigned U, unsigned R, bool NT = false>
+template <unsigned U, unsigned R, int NT = 0>
 __global__ __launch_bounds__(256) void k_traverse_s4(PlanView plan, unsigned chain_begin, unsigned chain_end, unsigned N)
 {
   constexpr unsigned group = 2 * R;
@@ -689,21 +701,21 @@ static int launch_traverse_s4(Engine * e, const PlanView & plan, unsigned longes
   // a round of chains (rows > 1): the chains share the chip, eight workgroups per CU and chain as in k_chain_s4
   const unsigned gx = std::max(1u, std::min((nchunks + 3) / 4, e->cu_count * (rows > 1 ? 8u : (unsigned)per_cu)));
   const dim3 grid(gx, std::max(1u, rows));
-  // vectors are written once and read (if at all) by a later chain: stores that do not allocate in the
-  // caches are 2 % (1 M sites) to 9 % (100 k sites) faster.  PLLHIP_S4_NT=0: plain stores.
+  // vectors are written once and read (if at all) once, by a later chain: stores and loads that do not
+  // allocate in the caches are 5 % (1 M sites) to 17 % (100 k - 250 k sites) faster.  PLLHIP_S4_NT=0: plain.
   static const int env_nt = getenv("PLLHIP_S4_NT") ? atoi(getenv("PLLHIP_S4_NT")) : 1;
 #define PLLHIP_CALL(K) hipLaunchKernelGGL(K, grid, dim3(256), lds, e->stream, plan, chain_begin, chain_end, e->N)
   if (env_nt)
   {
-    if (e->R == 4) PLLHIP_CALL((k_traverse_s4<4, 4, true>));
-    else if (e->R == 2) PLLHIP_CALL((k_traverse_s4<4, 2, true>));
-    else PLLHIP_CALL((k_traverse_s4<2, 1, true>));
+    if (e->R == 4) PLLHIP_CALL((k_traverse_s4<4, 4, 2>));
+    else if (e->R == 2) PLLHIP_CALL((k_traverse_s4<4, 2, 2>));
+    else PLLHIP_CALL((k_traverse_s4<2, 1, 2>));
   }
   else
   {
-    if (e->R == 4) PLLHIP_CALL((k_traverse_s4<4, 4, false>));
-    else if (e->R == 2) PLLHIP_CALL((k_traverse_s4<4, 2, false>));
-    else PLLHIP_CALL((k_traverse_s4<2, 1, false>));
+    if (e->R == 4) PLLHIP_CALL((k_traverse_s4<4, 4, 0>));
+    else if (e->R == 2) PLLHIP_CALL((k_traverse_s4<4, 2, 0>));
+    else PLLHIP_CALL((k_traverse_s4<2, 1, 0>));
   }
 #undef PLLHIP_CALL
   PLLHIP_TRY(hipGetLastError());
