@@ -40,11 +40,21 @@ __device__ inline void s16_fill_frags(double * frag, const double * mats, unsign
 
 // child term in D layout: t[v] = {even site, odd site} of row 4 v + q
 template <unsigned KS>
-__device__ inline void s16_child_inner(const double * unit, const double * frag_r, unsigned lane, double2 t[KS])
+__device__ inline void s16_child_inner(const double * unit, const double * frag_r, unsigned lane, double2 t[KS],
+                                       bool nt = false)
 {
   double2 b[KS];
+  typedef double nt_v2d __attribute__((ext_vector_type(2)));
 #pragma unroll
-  for (unsigned ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const double2 *>(unit + ks * 128 + lane * 2);
+  for (unsigned ks = 0; ks < KS; ++ks)
+  {
+    if (nt)
+    {
+      const nt_v2d w = __builtin_nontemporal_load(reinterpret_cast<const nt_v2d *>(unit + ks * 128 + lane * 2));
+      b[ks] = make_double2(w.x, w.y);
+    }
+    else b[ks] = *reinterpret_cast<const double2 *>(unit + ks * 128 + lane * 2);
+  }
   v4d acc_e = {0, 0, 0, 0}, acc_o = {0, 0, 0, 0};
 #pragma unroll
   for (unsigned ks = 0; ks < KS; ++ks)
@@ -249,7 +259,7 @@ template <unsigned KS, unsigned RT, bool RS>
 __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2 X[RT][KS],
                                     const double * s1, const double * s2, unsigned S, unsigned lut_codes,
                                     bool lut_lds, unsigned blk, unsigned lane,
-                                    unsigned (&xe)[RS ? RT : 1], unsigned (&xo)[RS ? RT : 1], bool nt)
+                                    unsigned (&xe)[RS ? RT : 1], unsigned (&xo)[RS ? RT : 1], bool nt, bool ntl = false)
 {
   constexpr unsigned UNIT = 4 * KS * S20_BS;
   const unsigned q = lane >> 4, n = lane & 15;
@@ -266,10 +276,10 @@ __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2
     const size_t ubase = ((size_t)blk * RT + r) * UNIT;
     double2 t1[KS], t2[KS];
     if (carried == 1) s16_child_regs<KS>(X[r], s1 + r * KS * 64, lane, t1);
-    else if (!op.codes1) s16_child_inner<KS>(op.clv1 + ubase, s1 + r * KS * 64, lane, t1);
+    else if (!op.codes1) s16_child_inner<KS>(op.clv1 + ubase, s1 + r * KS * 64, lane, t1, ntl);
     else s16_child_tip<KS>(l1 + (size_t)r * lut_codes * S, c1e, c1o, q, S, t1);
     if (carried == 2) s16_child_regs<KS>(X[r], s2 + r * KS * 64, lane, t2);
-    else if (!op.codes2) s16_child_inner<KS>(op.clv2 + ubase, s2 + r * KS * 64, lane, t2);
+    else if (!op.codes2) s16_child_inner<KS>(op.clv2 + ubase, s2 + r * KS * 64, lane, t2, ntl);
     else s16_child_tip<KS>(l2 + (size_t)r * lut_codes * S, c2e, c2o, q, S, t2);
     int re = 1, ro = 1;
 #pragma unroll
@@ -362,7 +372,7 @@ __global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanVi
                                                                            unsigned lut_lds_flag)
 {
   extern __shared__ double lds[];
-  const bool lut_lds = (lut_lds_flag & 1u) != 0, nt = (lut_lds_flag & 2u) != 0;
+  const bool lut_lds = (lut_lds_flag & 1u) != 0, nt = (lut_lds_flag & 2u) != 0, ntl = (lut_lds_flag & 4u) != 0;
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned wstride = gridDim.x * S16_CHAIN_WAVES;
   bool first_fill = true;
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanVi
       {
         const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
         s16_chain_op<KS, RT, RS>(po.d, i ? po.carried : 0u, X, lds + po.slot1, lds + po.slot2, S, lut_codes,
-                                 lut_lds, blk, lane, xe, xo, nt);
+                                 lut_lds, blk, lane, xe, xo, nt, ntl);
       }
     }
   }
@@ -594,8 +604,8 @@ static int launch_traverse_s16(Engine * e, const PlanView & plan, unsigned lds_d
   const size_t lds = sizeof(double) * lds_doubles;
   const unsigned need = (e->nblk + S16_CHAIN_WAVES - 1) / S16_CHAIN_WAVES;
   const unsigned gx = std::max(1u, std::min(need, e->cu_count));
-  static const int env_nt = getenv("PLLHIP_S16_NT") ? atoi(getenv("PLLHIP_S16_NT")) : 1;   // 1 - 7 % faster
-  const unsigned lut_lds = (s16_chain_lut_lds(e) ? 1u : 0u) | (env_nt ? 2u : 0u);
+  static const int env_nt = getenv("PLLHIP_S16_NT") ? atoi(getenv("PLLHIP_S16_NT")) : 2;   // stores and loads past the caches: 3 - 15 % faster
+  const unsigned lut_lds = (s16_chain_lut_lds(e) ? 1u : 0u) | (env_nt ? 2u : 0u) | (env_nt == 2 ? 4u : 0u);
   static bool attr_set_dev[64] = {false};
   bool & attr_set = attr_set_dev[e->device & 63];
   const int cap = (int)(sizeof(double) * S16_CHAIN_LDS);
