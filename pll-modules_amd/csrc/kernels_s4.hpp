@@ -115,6 +115,28 @@ __device__ inline int group_any(int vote, unsigned lane, unsigned group)
   return ((b >> (lane & ~(group - 1u))) & m) != 0ULL;
 }
 
+// vectors are written once and read (if at all) once: accesses that do not allocate in the caches
+template <bool NTL>
+__device__ inline double2 s4_ld2(const double * p)
+{
+  if (NTL)
+  {
+    typedef double nt_v2d __attribute__((ext_vector_type(2)));
+    const nt_v2d w = __builtin_nontemporal_load(reinterpret_cast<const nt_v2d *>(p));
+    return make_double2(w.x, w.y);
+  }
+  return *reinterpret_cast<const double2 *>(p);
+}
+
+__device__ inline void s4_st2_nt(double * p, const double2 & v)
+{
+  typedef double nt_v2d __attribute__((ext_vector_type(2)));
+  nt_v2d w;
+  w.x = v.x;
+  w.y = v.y;
+  __builtin_nontemporal_store(w, reinterpret_cast<nt_v2d *>(p));
+}
+
 template <unsigned U>    // iterations issued per batch (loads first, arithmetic after)
 __global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, unsigned R,
                                                      unsigned lut_codes)
@@ -179,12 +201,12 @@ __global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, 
         const int code2 = op.codes2 ? __shfl(cb2, src, 64) : 0;
         if (live[u])
         {
-          if (!op.codes1) in1[u] = *reinterpret_cast<const double2 *>(op.clv1 + gu * 2);
+          if (!op.codes1) in1[u] = s4_ld2<true>(op.clv1 + gu * 2);
           else if (lut_lds)
             in1[u] = *reinterpret_cast<const double2 *>(&lut_s[0][r * S4_LUT_RS + code1 * 4 + 2 * h]);
           else
             in1[u] = *reinterpret_cast<const double2 *>(op.lut1 + ((size_t)r * lut_codes + code1) * 4 + 2 * h);
-          if (!op.codes2) in2[u] = *reinterpret_cast<const double2 *>(op.clv2 + gu * 2);
+          if (!op.codes2) in2[u] = s4_ld2<true>(op.clv2 + gu * 2);
           else if (lut_lds)
             in2[u] = *reinterpret_cast<const double2 *>(&lut_s[1][r * S4_LUT_RS + code2 * 4 + 2 * h]);
           else
@@ -209,7 +231,7 @@ __global__ __launch_bounds__(256) void k_partials_s4(OpBatch batch, unsigned N, 
             scaled_mask |= 1u << (k0 + u);
           }
         }
-        if (live[u]) *reinterpret_cast<double2 *>(op.parent + gu * 2) = v;
+        if (live[u]) s4_st2_nt(op.parent + gu * 2, v);
       }
     }
     if (op.parent_scaler)
@@ -239,18 +261,6 @@ constexpr unsigned s4_chain_op_lds(unsigned R) { return 2 * R * S4_LUT_RS + 2 * 
 // one operation of a chain for one 64-site chunk: X holds the handed-over operand on entry (when
 // carried != 0) and the result on exit, xcnt the scaler count that goes with it.
 // base: the operation's LDS tables
-template <bool NTL>
-__device__ inline double2 s4_ld2(const double * p)
-{
-  if (NTL)
-  {
-    typedef double nt_v2d __attribute__((ext_vector_type(2)));
-    const nt_v2d w = __builtin_nontemporal_load(reinterpret_cast<const nt_v2d *>(p));
-    return make_double2(w.x, w.y);
-  }
-  return *reinterpret_cast<const double2 *>(p);
-}
-
 template <unsigned U, unsigned R, int NT = 0>
 __device__ inline void s4_chain_step(const OpDesc & op, unsigned carried, const double * base,
                                      double2 (&X)[2 * R], unsigned & xcnt,
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
     unsigned xcnt = 0;                                 // scaler count that goes with X
 #pragma unroll 1
     for (unsigned i = 0; i < len; ++i)
-      s4_chain_step<U, R>(batch.op[first + i], i ? batch.carried[first + i] : 0u, lds + i * S4_CHAIN_OP_LDS,
+      s4_chain_step<U, R, 2>(batch.op[first + i], i ? batch.carried[first + i] : 0u, lds + i * S4_CHAIN_OP_LDS,
                           X, xcnt, hc0, nsc, total, N, lane, r, h);
   }
 }
