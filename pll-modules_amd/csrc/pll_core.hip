@@ -359,9 +359,17 @@ static void push_model(const pll_partition_t * p, pll_partition_t * c)
   {
     memcpy(c->frequencies[m], p->frequencies[m], sizeof(double) * Sp);
     memcpy(c->subst_params[m], p->subst_params[m], sizeof(double) * S * (S - 1) / 2);
-    memcpy(c->eigenvals[m], p->eigenvals[m], sizeof(double) * Sp);
-    memcpy(c->eigenvecs[m], p->eigenvecs[m], sizeof(double) * S * Sp);
-    memcpy(c->inv_eigenvecs[m], p->inv_eigenvecs[m], sizeof(double) * S * Sp);
+    // an eigen-system that differs from the shard's copy (the parent decomposed again, or a caller wrote
+    // the arrays): the shard's next model check has to look at it, also inside a burst of P-matrix requests
+    if (memcmp(c->eigenvals[m], p->eigenvals[m], sizeof(double) * Sp) != 0 ||
+        memcmp(c->eigenvecs[m], p->eigenvecs[m], sizeof(double) * S * Sp) != 0 ||
+        memcmp(c->inv_eigenvecs[m], p->inv_eigenvecs[m], sizeof(double) * S * Sp) != 0)
+    {
+      memcpy(c->eigenvals[m], p->eigenvals[m], sizeof(double) * Sp);
+      memcpy(c->eigenvecs[m], p->eigenvecs[m], sizeof(double) * S * Sp);
+      memcpy(c->inv_eigenvecs[m], p->inv_eigenvecs[m], sizeof(double) * S * Sp);
+      engine_of(c)->eigen_touched = true;
+    }
   }
 }
 

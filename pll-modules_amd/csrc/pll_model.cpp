@@ -223,6 +223,9 @@ int update_eigen_host(pll_partition_t * p, unsigned idx)
                        p->inv_eigenvecs[idx], p->eigenvecs[idx], p->eigenvals[idx]))
     return PLL_FAILURE;
   p->eigen_decomp_valid[idx] = 1;
+  // every path that decomposes -- the engine's own ensure_eigen and the public pll_update_eigen --
+  // tells the next model check to compare the eigen-systems, also inside a burst of P-matrix requests
+  if (p->engine) engine_of(p)->eigen_touched = true;
   return PLL_SUCCESS;
 }
 

@@ -346,6 +346,13 @@ class Instance:
     def params_p(self):
         return self.params.ctypes.data_as(c_uint_p)
 
+    def set_params_indices(self, indices):
+        """per-rate-category parameter-set indices (params_indices / freqs_indices of every kernel
+        call; src/tree/treeinfo.c:288-306): category r uses rate matrix indices[r]"""
+        idx = _u32(indices)
+        assert len(idx) == self.R
+        self.params = idx
+
     # --- model ------------------------------------------------------------
     def set_model(self, subst, freqs, rates, weights=None, idx=0):
         s, f, r = _f64(subst), _f64(freqs), _f64(rates)
@@ -892,12 +899,30 @@ CONFIGS = {
 }
 
 
+def mixture_component(subst, freqs, m):
+    """model of mixture component m > 0: the base model's exchangeabilities and frequencies under
+    seeded log-normal / Gamma noise (component 0 is the base model itself)"""
+    subst, freqs = np.asarray(subst, dtype=float), np.asarray(freqs, dtype=float)
+    if m == 0:
+        return subst, freqs
+    u = uniform01(9000 + 17 * m, 2 * len(subst))
+    z = np.sqrt(-2.0 * np.log(np.maximum(u[0::2], 1e-300))) * np.cos(2 * np.pi * u[1::2])
+    sub = subst * np.exp(0.4 * z)
+    g = freqs * (0.5 + uniform01(9500 + 17 * m, len(freqs)))
+    return sub, g / g.sum()
+
+
 def build_instance(lib, states, rate_cats, ntips, nsites, coded=True, scalers=True, alpha=None,
-                   seed_shift=0, tree=None, pinv=0.0, attributes=0):
-    """partition + tree + model + tips for one synthetic configuration"""
+                   seed_shift=0, tree=None, pinv=0.0, attributes=0, mixture=None, mixture_pinv=None):
+    """partition + tree + model + tips for one synthetic configuration.
+    mixture: per-rate-category rate-matrix indices (e.g. [0, 1, 0, 1]): the partition gets
+    max(mixture) + 1 rate matrices, each with a model of its own (mixture_component) and, with
+    mixture_pinv, its own proportion of invariant sites."""
     tree = tree or Tree(ntips, 42 + seed_shift, 43 + seed_shift)
+    nrm = 1 if mixture is None else int(max(mixture)) + 1
     inst = Instance(lib, ntips, states, nsites, rate_cats,
-                    attributes=(PLL_ATTRIB_PATTERN_TIP if coded else 0) | attributes, scalers=scalers)
+                    attributes=(PLL_ATTRIB_PATTERN_TIP if coded else 0) | attributes, scalers=scalers,
+                    rate_matrices=nrm)
     if states == 4:
         subst, freqs, a = DNA_GTR_RATES, DNA_FREQS, 0.841
     elif states == 20:
@@ -912,12 +937,22 @@ def build_instance(lib, states, rate_cats, ntips, nsites, coded=True, scalers=Tr
     alpha = a if alpha is None else alpha
     rates = lib.gamma_cats(alpha, rate_cats) if rate_cats > 1 else np.ones(1)
     inst.set_model(subst, freqs, rates)
+    if mixture is not None:
+        assert len(mixture) == rate_cats
+        for m in range(1, nrm):
+            inst.set_model(*mixture_component(subst, freqs, m), rates, idx=m)
+        inst.set_params_indices(mixture)
     cmap = state_charmap(states)
     codes = random_codes(ntips, nsites, states, 44 + seed_shift)
     for t in range(ntips):
         inst.set_tip_states(t, cmap, (codes[t] + 48).tobytes())
     if pinv > 0:
         inst.set_pinv(pinv)
+    if mixture_pinv is not None:
+        if not inst.L.pll_update_invariant_sites(inst.p):
+            raise RuntimeError(lib.errmsg)
+        for m, v in enumerate(mixture_pinv):
+            inst.set_pinv(v, idx=m)
     inst.tree = tree
     inst.codes = codes
     return inst
