@@ -408,6 +408,8 @@ PLL_EXPORT extern __thread char pll_errmsg[200];
 PLL_EXPORT extern const pll_state_t pll_map_bin[256];
 PLL_EXPORT extern const pll_state_t pll_map_nt[256];
 PLL_EXPORT extern const pll_state_t pll_map_aa[256];
+/* validity classes of the FASTA reader (test/src/tree/treemove-spr.c:178, test/src/binary/binary-random.c:82) */
+PLL_EXPORT extern const unsigned int pll_map_fasta[256];
 
 /* ------------------------------------------------------------------ */
 /* B1: lifecycle and setters                                          */

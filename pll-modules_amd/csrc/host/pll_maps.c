@@ -36,3 +36,20 @@ const pll_state_t pll_map_aa[256] = {
   ['j'] = (1ULL << 9) | (1ULL << 10), ['J'] = (1ULL << 9) | (1ULL << 10),
   ['x'] = AA_ALL, ['X'] = AA_ALL, ['*'] = AA_ALL, ['-'] = AA_ALL, ['?'] = AA_ALL
 };
+
+/* Validity classes of the FASTA reader (test/src/tree/treemove-spr.c:178 and the other tree / binary test
+ * programs pass it to pll_fasta_open; [libpll-2 knowledge]: 0 = illegal, reported with its line number;
+ * 1 = legal sequence symbol; 2 = fatal; 3 = silently stripped white space).  The reader itself is
+ * tier B3 (PLL_ERROR_NOT_IMPLEMENTED); the table exists so that those programs compile and link. */
+#define FA_RANGE_26(first) [first] = 1, [first + 1] = 1, [first + 2] = 1, [first + 3] = 1, [first + 4] = 1, \
+  [first + 5] = 1, [first + 6] = 1, [first + 7] = 1, [first + 8] = 1, [first + 9] = 1, [first + 10] = 1,   \
+  [first + 11] = 1, [first + 12] = 1, [first + 13] = 1, [first + 14] = 1, [first + 15] = 1, [first + 16] = 1, \
+  [first + 17] = 1, [first + 18] = 1, [first + 19] = 1, [first + 20] = 1, [first + 21] = 1, [first + 22] = 1, \
+  [first + 23] = 1, [first + 24] = 1, [first + 25] = 1
+
+const unsigned int pll_map_fasta[256] = {
+  FA_RANGE_26('A'), FA_RANGE_26('a'),
+  ['*'] = 1, ['-'] = 1, ['.'] = 1, ['?'] = 1, ['!'] = 1, ['0'] = 1, ['1'] = 1,
+  ['\t'] = 3, ['\n'] = 3, ['\v'] = 3, ['\f'] = 3, ['\r'] = 3, [' '] = 3,
+  [0] = 2
+};

@@ -161,6 +161,66 @@ def test_driver_counters_reach_the_engine(product):
         assert c.partial_ops == 12 and c.partial_launches < 12       # level-scheduled
 
 
+# C4 (BASELINE.json configs[3]): two DNA + two protein partitions under one 100-taxon tree with linked
+# branch lengths, evaluated through the driver as pllmod_treeinfo does (src/tree/treeinfo.c:1020-1056)
+C4_SHAPE = [(4, 250_000), (4, 250_000), (20, 125_000), (20, 125_000)]
+
+
+def _c4_evaluation(lib, tree, sizes, tile_codes=None, tile=0):
+    ev = pc.Evaluation(lib, tree.newick(), flags=1, nparts=len(C4_SHAPE))
+    codes_out = []
+    for k, ((states, _), n) in enumerate(zip(C4_SHAPE, sizes)):
+        subst, freqs, alpha = (pc.DNA_GTR_RATES, pc.DNA_FREQS, 0.841) if states == 4 else (*pc.protein_model(), 0.5)
+        codes = pc.random_codes(tree.ntips, n, states, 44 + 101 * k) if tile_codes is None else \
+            np.tile(tile_codes[k], (1, n // tile))
+        codes_out.append(codes)
+        ev.add_partition(k, states, n, 4, codes, subst, freqs, alpha, coded=True)
+    return ev, codes_out
+
+
+@pytest.mark.gpu
+def test_c4_shape_at_full_size_through_tiling(product, oracle):
+    """C4 at its own shape -- 4 partitions, 100 taxa, 2 x 250 k DNA + 2 x 125 k protein sites -- is out of the
+    oracle's reach in seconds; an alignment made of K copies of a 500-site tile per partition is not:
+    lnL(full) = sum_p K_p lnL_p(tile), per-site lnL periodic in the tile, incremental re-evaluation after a
+    branch-length change agrees with the tile as well"""
+    tile = 500
+    t = pc.Tree(100, 42, 43)
+    ev_o, codes = _c4_evaluation(oracle, t, [tile] * 4)
+    with ev_o:
+        l_tile = ev_o.loglh()
+        per_o = [ev_o.persite_lnl(k)[1] for k in range(4)]
+    ev_t, _ = _c4_evaluation(product, t, [tile] * 4, tile_codes=codes, tile=tile)
+    with ev_t:
+        l_ref = ev_t.loglh()
+        per_g = [ev_t.persite_lnl(k)[1] for k in range(4)]
+    assert abs(l_ref - l_tile) <= 2e-9 * 4 * tile
+    for a, b in zip(per_g, per_o):
+        assert np.abs(a - b).max() < 1e-9
+    sizes = [n for _, n in C4_SHAPE]
+    want = sum((n // tile) * per_o[k].sum() for k, n in enumerate(sizes))
+    ev, _ = _c4_evaluation(product, t, sizes, tile_codes=codes, tile=tile)
+    with ev:
+        l_full = ev.loglh()
+        assert abs(l_full - want) <= 1e-10 * abs(want)
+        for k, n in enumerate(sizes):
+            ps = ev.persite_lnl(k)[1]
+            assert np.array_equal(ps.reshape(n // tile, tile), np.broadcast_to(ps[:tile], (n // tile, tile)))
+        # incremental: one branch changes, the driver recomputes the path to the root only
+        rec = next(r for r in ev.records() if r.contents.next)
+        ev.L.pllhip_eval_set_branch_length(ev.ev, rec, 0.31)
+        l_inc = ev.loglh(incremental=True)
+    ev_o2, _ = _c4_evaluation(oracle, t, [tile] * 4)
+    with ev_o2:
+        ev_o2.loglh()
+        rec = next(r for r in ev_o2.records() if r.contents.next)
+        ev_o2.L.pllhip_eval_set_branch_length(ev_o2.ev, rec, 0.31)
+        ev_o2.loglh(incremental=True)
+        per2 = [ev_o2.persite_lnl(k)[1] for k in range(4)]
+    want2 = sum((n // tile) * per2[k].sum() for k, n in enumerate(sizes))
+    assert abs(l_inc - want2) <= 1e-9 * abs(want2) and abs(l_inc - l_full) > 1.0
+
+
 # ---------------------------------------------------------------------------
 # SPR round (pllhip_eval_spr_round; tests/test_dropin_modules.py pins it against
 # the reference's pllmod_algo_spr_round where the reference is present)
