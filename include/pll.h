@@ -140,6 +140,8 @@ extern "C" {
 #define PLL_ERROR_HIP_RUNTIME      900 /* a HIP / RCCL call failed        */
 #define PLL_ERROR_HIP_NODEVICE     901 /* no gfx950 device visible        */
 #define PLL_ERROR_NOT_IMPLEMENTED  902 /* declared for link compatibility */
+#define PLL_ERROR_HIP_TIMEOUT      903 /* a result that depends on another rank did not arrive (peer lost) */
+#define PLL_ERROR_HIP_COMM_ABORTED 904 /* the communicator was aborted after a failure; no further collectives */
 
 /* tree traversal orders */
 #define PLL_TREE_TRAVERSE_POSTORDER 1

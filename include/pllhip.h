@@ -143,6 +143,8 @@ typedef struct pllhip_profile
   double kernel_ms;
   double algorithmic_bytes;
   double algorithmic_flops;   /* 2*S*S per non-tip child matvec + S products, per site-update */
+  double minimum_bytes;       /* what the schedule has to move: as algorithmic_bytes, but a child vector (and its
+                                 scaler counts) that an operation chain hands over in registers is not read */
 } pllhip_profile_t;
 
 PLL_EXPORT int pllhip_profile_partials(pll_partition_t * partition, int enable);
@@ -197,6 +199,19 @@ PLL_EXPORT int pllhip_compute_likelihood_derivatives_multi(pll_partition_t * par
    lengths (include/pllhip_eval.h) use it to decide whether speculation is free. */
 PLL_EXPORT unsigned int pllhip_free_trial_lengths(const pll_partition_t * partition);
 
+/* pll_update_partials for several partitions that are evaluated on ONE tree: the result is what
+   pll_update_partials(partitions[i], operations, count) stores for every non-NULL partitions[i], bit for
+   bit.  pll-modules walks the partitions of an analysis one after the other
+   (src/tree/treeinfo.c:1020-1056, src/optimize/pll_optimize.c:748-775); partitions of one kernel family on
+   one device share their launches here (the chains of a round of every partition are grid rows of one
+   launch), which is what keeps data sets with one small partition per gene -- and the per-GPU share of a
+   partitioned analysis on eight GPUs -- off the launch-latency floor.  NULL entries (partitions another
+   worker owns, src/tree/treeinfo.c:1024-1031) are skipped.  PLLHIP_BATCH=0: per-partition calls. */
+PLL_EXPORT int pllhip_update_partials_batch(pll_partition_t * const * partitions,
+                                            unsigned int partition_count,
+                                            const pll_operation_t * operations,
+                                            unsigned int count);
+
 /* ---- deferred scalar results -----------------------------------------------
  * pll_compute_edge_loglikelihood and pll_compute_likelihood_derivatives hand a double back
  * to the host: one wait per call and partition, and with several workers a host-side
@@ -230,10 +245,21 @@ PLL_EXPORT int pllhip_results_derivatives(pllhip_results_t * results, unsigned i
                                           const unsigned int * params_indices,
                                           const double * sumtable);
 
-/* out[i] = reduce over all workers of slot first + i; NaN in every out[i] and
-   PLL_FAILURE on a HIP / RCCL error */
+/* out[i] = reduce over all workers of slot first + i; NaN in every out[i] and PLL_FAILURE on error.
+   Failure handling (no worker is left inside a collective; the process is expected to exit or to start a
+   fresh child -- the library never re-executes anything):
+     * a deposit that failed on this worker (or pllhip_results_poison) makes the fetch contribute NaN to
+       every slot and still take part in the all-reduce: every worker gets NaN and PLL_FAILURE in this call;
+     * an RCCL / HIP error in the collective path, or no result within PLLHIP_COLLECTIVE_TIMEOUT_S seconds
+       (default 120: a peer that died never joins), aborts the communicator (ncclCommAbort), sets pll_errno
+       (PLL_ERROR_HIP_RUNTIME / PLL_ERROR_HIP_TIMEOUT) and returns NaN; every later collective on that
+       communicator fails at once with PLL_ERROR_HIP_COMM_ABORTED.  pllhip_reduce_cb behaves the same way.
+   The group itself is reset on every path and can take new deposits. */
 PLL_EXPORT int pllhip_results_fetch(pllhip_results_t * results, unsigned int first,
                                     unsigned int count, int op, double * out);
+
+/* this worker cannot contribute to the pending fetch (a local failure outside the deposits) */
+PLL_EXPORT void pllhip_results_poison(pllhip_results_t * results);
 
 /* give a pllhip_eval driver (include/pllhip_eval.h) a result group over `comm` (NULL: this
    process only) sized for its partitions; the driver then reduces its lnL and

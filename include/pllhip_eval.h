@@ -105,6 +105,10 @@ typedef struct pllhip_eval_fused
                      const unsigned int * params_indices, const double * sumtable);
   int (*fetch)(void * results, unsigned int first, unsigned int count, int op, double * out);
   void (*destroy)(void * results);
+  /* a local failure before the fetch (this worker could not compute or enqueue its part): the next fetch
+     contributes NaN and reports failure, so that all workers fail in the same call instead of one of them
+     leaving the others inside the collective.  May be NULL. */
+  void (*poison)(void * results);
 } pllhip_eval_fused_t;
 
 PLL_EXPORT void pllhip_eval_set_fused(pllhip_eval_t * ev, const pllhip_eval_fused_t * fused);

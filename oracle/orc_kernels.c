@@ -669,6 +669,17 @@ int pll_compute_likelihood_derivatives(pll_partition_t * p,
 
 unsigned int pllhip_free_trial_lengths(const pll_partition_t * p) { (void)p; return 1; }
 
+/* several partitions on one tree (include/pllhip.h): the oracle simply walks them, as the reference does
+   (src/tree/treeinfo.c:1020-1056) */
+int pllhip_update_partials_batch(pll_partition_t * const * partitions, unsigned int partition_count,
+                                 const pll_operation_t * ops, unsigned int count)
+{
+  unsigned int i;
+  for (i = 0; i < partition_count; ++i)
+    if (partitions[i]) pll_update_partials(partitions[i], ops, count);
+  return PLL_SUCCESS;
+}
+
 /* several trial branch lengths: the oracle simply repeats the single-length computation
    (include/pllhip.h; the product evaluates them in one pass over the sumtable) */
 int pllhip_compute_likelihood_derivatives_multi(pll_partition_t * p, int psc, int csc,

@@ -101,7 +101,11 @@ struct PlanOp
   unsigned slot1, slot2; // 20 states: LDS offsets (doubles) of the two children's tables
   unsigned pad;
 };
-struct PlanChain { unsigned first, len; };       // operations [first, first + len) of PlanOp[]
+// operations [first, first + len) of PlanOp[], and what the kernels need to know about the partition
+// the chain belongs to (a batched schedule -- pllhip_update_partials_batch -- holds chains of several
+// partitions): extent = site blocks (blocked families) or sites (4-state family), the row count of its
+// tip lookup tables in memory, the rows staged in LDS, flags (bit 0: tip tables are staged in LDS)
+struct PlanChain { unsigned first, len, extent, lut_codes, lut_used, flags; };
 struct PlanView { const PlanOp * ops; const PlanChain * chains; unsigned nchains; };
 
 struct DevicePlan                                 // the schedule resident on the device
@@ -117,10 +121,24 @@ struct DevicePlan                                 // the schedule resident on th
   std::vector<unsigned char> bytes;               // serialised [PlanOp ...][PlanChain ...]
   unsigned nops = 0, nchains = 0, lds_doubles = 0;
   double algo_bytes = 0.0, algo_flops = 0.0;      // algorithmic traffic / work of the traversal
+  double min_bytes = 0.0;                         // traffic without the child vectors handed over in registers
   // launches of the schedule: one for a whole traversal, or one per round of chains (chains
   // [begin, end) side by side) for a partition that does not fill the chip on its own
-  struct Launch { unsigned begin, end, rows, ops; double bytes, flops; };   // chains [begin, end) over `rows` grid rows
+  struct Launch { unsigned begin, end, rows, ops; double bytes, flops, min_bytes; };   // chains [begin, end) over `rows` grid rows
   std::vector<Launch> launches;
+  unsigned long long generation = 0;              // changes whenever `bytes` / `launches` are rebuilt (unique across engines)
+  unsigned max_extent = 0;                        // largest PlanChain::extent of the schedule
+};
+
+// a schedule over several partitions of one kernel family (pllhip_update_partials_batch): the members'
+// round schedules side by side, resident in the leader's memory
+struct BatchPlan
+{
+  std::vector<const void *> members;              // engines, in call order
+  std::vector<unsigned long long> generations;    // of the members' schedules it was merged from
+  DevicePlan plan;
+  std::vector<hipEvent_t> ready;                  // per member: its stream has reached the batch call
+  hipEvent_t done = nullptr;                      // the leader's stream has run the batch
 };
 
 enum class KernelFamily { Generic, S4, S16, S20, S61 };
@@ -221,12 +239,14 @@ struct Engine
   pllhip_counters_t counters = {};
 
   DevicePlan plan;                    // schedule of the last whole-traversal launch
+  BatchPlan * batch = nullptr;        // leader of a batch: the merged schedule of the last batched call
 
   // optional timing of the partials launches with HIP events on `stream`
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;  // pool, reused
   size_t prof_used = 0;
   double prof_bytes = 0.0;        // algorithmic bytes of the recorded launches
+  double prof_min_bytes = 0.0;    // bytes those launches have to move (carried children not read)
   double prof_flops = 0.0;        // algorithmic flops of the recorded launches
   unsigned long long prof_ops = 0;
 };
@@ -253,7 +273,9 @@ int derivatives_impl(pll_partition_t * p, int parent_scaler_index, int child_sca
                      const double * brlens, unsigned count, const unsigned * params_indices,
                      const double * sumtable, const Engine::Sink * deferred,
                      double * out_df, double * out_ddf);
-int wait_sequence(hipStream_t stream, const volatile unsigned long long * flag, unsigned long long seq);
+// timeout_s > 0: give up after that many seconds (PLL_ERROR_HIP_TIMEOUT; results that depend on another rank)
+int wait_sequence(hipStream_t stream, const volatile unsigned long long * flag, unsigned long long seq,
+                  double timeout_s = 0.0);
 Engine * engine_create(pll_partition_t * p);
 void engine_destroy(Engine * e);
 int sync_model(pll_partition_t * p, bool light = false);              // host model arrays -> HBM if changed

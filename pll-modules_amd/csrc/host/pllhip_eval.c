@@ -6,6 +6,7 @@
  */
 #include "pllhip_eval_internal.h"
 #include "pllhip.h"
+#pragma weak pllhip_eval_attach_comm   /* HIP engine only (pllhip_comm.hip) */
 #include <stdarg.h>
 
 static __thread pllhip_eval_t * cb_self;   /* pll_utree_traverse callbacks carry no user pointer */
@@ -76,6 +77,20 @@ pllhip_eval_t * pllhip_eval_create(pll_utree_t * tree, unsigned int partition_co
     } while (s && s != n);
   }
   ev->root = tree->vroot->next ? tree->vroot : tree->vroot->back;
+  /* Several partitions: leave every partition's lnL / derivative totals on the device and wait ONCE per
+     evaluation / Newton round (include/pllhip.h, pllhip_results_*) instead of once per partition -- the
+     reference's per-partition loop (src/tree/treeinfo.c:1020-1056) with the waits taken out.  Only where the
+     library has such result groups (the HIP engine; the CPU oracle does not export the symbol).
+     A reduce callback set later replaces it (pllhip_eval_set_parallel_context).  PLLHIP_EVAL_DEFERRED=0: off. */
+  if (partition_count > 1 && pllhip_eval_attach_comm)
+  {
+    const char * env = getenv("PLLHIP_EVAL_DEFERRED");
+    if (!env || atoi(env))
+    {
+      if (pllhip_eval_attach_comm(ev, NULL)) ev->fused_auto = 1;
+      else pll_errno = 0;
+    }
+  }
   return ev;
 nomem:
   pllhip_eval_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate evaluator");
@@ -139,6 +154,8 @@ int pllhip_eval_set_partition(pllhip_eval_t * ev, unsigned int index, pll_partit
 
 void pllhip_eval_set_parallel_context(pllhip_eval_t * ev, void * ctx, pllhip_reduce_fn reduce_cb)
 {
+  /* sums go through the caller's hook from now on, not through the local result group of pllhip_eval_create */
+  if (reduce_cb && ev->fused_auto) pllhip_eval_set_fused(ev, NULL);
   ev->ctx = ctx;
   ev->reduce_cb = reduce_cb;
   ev->spec_trials = 0;
@@ -148,6 +165,7 @@ void pllhip_eval_set_fused(pllhip_eval_t * ev, const pllhip_eval_fused_t * fused
 {
   if (ev->fused.destroy && ev->fused.results) ev->fused.destroy(ev->fused.results);
   memset(&ev->fused, 0, sizeof(ev->fused));
+  ev->fused_auto = 0;
   if (fused) ev->fused = *fused;
 }
 
@@ -325,10 +343,38 @@ static int update_pmatrices(pllhip_eval_t * ev)
   return PLL_SUCCESS;
 }
 
-static double edge_loglh(pllhip_eval_t * ev, const pll_unode_t * e)
+/* A worker that fails locally must not leave its peers inside the reduction: it still takes part, with NaN,
+   so that every worker fails in the same call (include/pllhip.h, pllhip_results_fetch).  `failed`: this
+   worker could not bring its vectors up to date. */
+static void poison_and_reduce(pllhip_eval_t * ev, double * buf, unsigned int n)
+{
+  unsigned int i;
+  const int code = pll_errno;
+  char msg[200];
+  memcpy(msg, pll_errmsg, sizeof(msg));
+  if (ev->fused.fetch)
+  {
+    if (ev->fused.poison) ev->fused.poison(ev->fused.results);
+    (void)ev->fused.fetch(ev->fused.results, 0, n, 0 /* SUM */, buf);
+  }
+  else if (ev->reduce_cb)
+  {
+    for (i = 0; i < n; ++i) buf[i] = NAN;
+    ev->reduce_cb(ev->ctx, buf, n, 0 /* SUM */);
+  }
+  for (i = 0; i < n; ++i) buf[i] = NAN;
+  if (code) { pll_errno = code; memcpy(pll_errmsg, msg, sizeof(msg)); }    /* the cause, not the consequence */
+}
+
+static double edge_loglh(pllhip_eval_t * ev, const pll_unode_t * e, int failed)
 {
   unsigned int p;
   double total = 0.0;
+  if (failed)
+  {
+    poison_and_reduce(ev, ev->part_lnl, ev->nparts);
+    return NAN;
+  }
   if (ev->fused.fetch)
   {
     /* every partition's kernel is enqueued, then ONE fetch: all-reduce on the device, one wait */
@@ -337,7 +383,10 @@ static double edge_loglh(pllhip_eval_t * ev, const pll_unode_t * e)
           !ev->fused.edge_loglikelihood(ev->fused.results, p, ev->parts[p], e->clv_index, e->scaler_index,
                                         e->back->clv_index, e->back->scaler_index, e->pmatrix_index,
                                         ev->params[p]))
+      {
+        poison_and_reduce(ev, ev->part_lnl, ev->nparts);
         return NAN;
+      }
     if (!ev->fused.fetch(ev->fused.results, 0, ev->nparts, 0 /* SUM */, ev->part_lnl)) return NAN;
   }
   else
@@ -356,27 +405,45 @@ static double edge_loglh(pllhip_eval_t * ev, const pll_unode_t * e)
   return total;
 }
 
+/* PLLHIP_EVAL_FAULT=N (+ PLLHIP_EVAL_FAULT_RANK is up to the caller: set the variable on one worker only):
+   the N-th evaluation of this process fails before its reduction -- for the tests of the path above */
+static int injected_fault(void)
+{
+  static long at = -1, n = 0;
+  if (at < 0) { const char * e = getenv("PLLHIP_EVAL_FAULT"); at = e ? atol(e) : 0; }
+  if (at > 0 && ++n == at)
+  {
+    pllhip_eval_error(PLL_ERROR_PARAM_INVALID, "injected evaluation failure");
+    return 1;
+  }
+  return 0;
+}
+
 double pllhip_eval_loglh(pllhip_eval_t * ev, int incremental)
 {
-  unsigned int n = 0, nops = 0, i, p;
+  unsigned int n = 0, nops = 0, i;
+  int failed = 0;
   if (!incremental) pllhip_eval_invalidate_all(ev);
   pll_errno = 0;
-  if (!update_pmatrices(ev)) return NAN;
+  failed = injected_fault() || !update_pmatrices(ev);
 
   cb_self = ev;
-  if (!pll_utree_traverse(ev->root, PLL_TREE_TRAVERSE_POSTORDER, cb_invalid_only, ev->trav, &n))
-    return NAN;
-  pll_utree_create_operations(ev->trav, n, NULL, NULL, ev->ops, NULL, &nops);
-  if (nops)
+  if (!failed && !pll_utree_traverse(ev->root, PLL_TREE_TRAVERSE_POSTORDER, cb_invalid_only, ev->trav, &n))
+    failed = 1;
+  if (!failed) pll_utree_create_operations(ev->trav, n, NULL, NULL, ev->ops, NULL, &nops);
+  if (!failed && nops)
   {
-    for (p = 0; p < ev->nparts; ++p)
-      if (ev->parts[p]) pll_update_partials(ev->parts[p], ev->ops, nops);
-    if (pll_errno) return NAN;
-    for (i = 0; i < n; ++i)
-      if (ev->trav[i]->next) mark_clv_valid(ev, ev->trav[i]);
-    ev->n_ops += nops;
+    /* every partition walks the same list (src/tree/treeinfo.c:1020-1056): one call, so that partitions
+       of one kernel family can share their launches */
+    if (!pllhip_update_partials_batch(ev->parts, ev->nparts, ev->ops, nops) || pll_errno) failed = 1;
+    else
+    {
+      for (i = 0; i < n; ++i)
+        if (ev->trav[i]->next) mark_clv_valid(ev, ev->trav[i]);
+      ev->n_ops += nops;
+    }
   }
-  return edge_loglh(ev, ev->root);
+  return edge_loglh(ev, ev->root, failed);
 }
 
 /* ---------------------------------------------------------------------- */
@@ -428,7 +495,10 @@ static int derivatives(pllhip_eval_t * ev, const pll_unode_t * e, const double *
       for (k = 0; k < count; ++k) tp[k] = ev->brlen_scalers[p] * t[k];
       if (!ev->fused.derivatives(ev->fused.results, p * 2 * count, ev->parts[p], e->scaler_index,
                                  e->back->scaler_index, tp, count, ev->params[p], ev->sumtables[p]))
+      {
+        poison_and_reduce(ev, buf, ev->nparts * 2 * count);
         return PLL_FAILURE;
+      }
     }
     if (!ev->fused.fetch(ev->fused.results, 0, ev->nparts * 2 * count, 0 /* SUM */, buf)) return PLL_FAILURE;
     for (p = 0; p < ev->nparts; ++p)
@@ -447,18 +517,21 @@ static int derivatives(pllhip_eval_t * ev, const pll_unode_t * e, const double *
     for (p = 0; p < ev->nparts; ++p)
     {
       const double sc = ev->brlen_scalers[p];
+      int ok;
       if (!ev->parts[p]) continue;
       for (k = 0; k < count; ++k) tp[k] = sc * t[k];
       if (count == 1)
+        ok = pll_compute_likelihood_derivatives(ev->parts[p], e->scaler_index, e->back->scaler_index, tp[0],
+                                                ev->params[p], ev->sumtables[p], &a[0], &b[0]);
+      else
+        ok = pllhip_compute_likelihood_derivatives_multi(ev->parts[p], e->scaler_index,
+                                                         e->back->scaler_index, tp, count, ev->params[p],
+                                                         ev->sumtables[p], a, b);
+      if (!ok)
       {
-        if (!pll_compute_likelihood_derivatives(ev->parts[p], e->scaler_index, e->back->scaler_index, tp[0],
-                                                ev->params[p], ev->sumtables[p], &a[0], &b[0]))
-          return PLL_FAILURE;
-      }
-      else if (!pllhip_compute_likelihood_derivatives_multi(ev->parts[p], e->scaler_index,
-                                                            e->back->scaler_index, tp, count, ev->params[p],
-                                                            ev->sumtables[p], a, b))
+        poison_and_reduce(ev, buf, 2 * count);
         return PLL_FAILURE;
+      }
       for (k = 0; k < count; ++k) { f[k] += sc * a[k]; df[k] += sc * sc * b[k]; }
     }
     if (ev->reduce_cb)
@@ -486,7 +559,10 @@ static int derivatives_unlinked(pllhip_eval_t * ev, const pll_unode_t * e, const
       if (ev->parts[p] &&
           !ev->fused.derivatives(ev->fused.results, 2 * p, ev->parts[p], e->scaler_index,
                                  e->back->scaler_index, &x[p], 1, ev->params[p], ev->sumtables[p]))
+      {
+        poison_and_reduce(ev, buf, 2 * ev->nparts);
         return PLL_FAILURE;
+      }
     if (!ev->fused.fetch(ev->fused.results, 0, 2 * ev->nparts, 0 /* SUM */, buf)) return PLL_FAILURE;
   }
   else
@@ -497,7 +573,10 @@ static int derivatives_unlinked(pllhip_eval_t * ev, const pll_unode_t * e, const
       if (ev->parts[p] &&
           !pll_compute_likelihood_derivatives(ev->parts[p], e->scaler_index, e->back->scaler_index, x[p],
                                               ev->params[p], ev->sumtables[p], &buf[2 * p], &buf[2 * p + 1]))
+      {
+        poison_and_reduce(ev, buf, 2 * ev->nparts);
         return PLL_FAILURE;
+      }
     }
     if (ev->reduce_cb) ev->reduce_cb(ev->ctx, buf, 2 * ev->nparts, 0 /* SUM */);
   }
@@ -687,8 +766,8 @@ static int reorient(pllhip_eval_t * ev, const pll_unode_t * parent, const pll_un
   op.child2_clv_index = c2->back->clv_index;
   op.child2_matrix_index = c2->back->pmatrix_index;
   op.child2_scaler_index = c2->back->scaler_index;
-  for (p = 0; p < ev->nparts; ++p)
-    if (ev->parts[p]) pll_update_partials(ev->parts[p], &op, 1);
+  (void)p;
+  if (!pllhip_update_partials_batch(ev->parts, ev->nparts, &op, 1)) return PLL_FAILURE;
   ev->n_ops++;
   return pll_errno ? PLL_FAILURE : PLL_SUCCESS;
 }
@@ -806,7 +885,7 @@ double pllhip_eval_optimize_impl(pllhip_eval_t * ev, double min_brlen, double ma
   {
     if (!optimise_around(&b, root, radius)) return 0.0;
     if (radius && !optimise_around(&b, root->back, radius - 1)) return 0.0;
-    new_lnl = edge_loglh(ev, root->back);
+    new_lnl = edge_loglh(ev, root->back, 0);
     if (new_lnl - lnl > new_lnl * 1e-13)
     {
       iters--;

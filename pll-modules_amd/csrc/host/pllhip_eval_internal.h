@@ -27,6 +27,7 @@ struct pllhip_eval
   pllhip_reduce_fn reduce_cb;
   unsigned long n_ops, n_pmat, n_deriv, n_newton;
   pllhip_eval_fused_t fused;      /* fused.fetch != NULL: deferred results */
+  int fused_auto;                 /* the result group was attached by pllhip_eval_create itself */
   double * slot_buf;              /* [nparts * 2 * PLLHIP_EVAL_MAX_TRIALS] */
   unsigned int spec_trials;       /* trial lengths per scan; 0 = not decided yet */
   int linkage;                    /* PLLHIP_EVAL_BRLEN_* */

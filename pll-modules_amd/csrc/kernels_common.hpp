@@ -358,4 +358,19 @@ __device__ inline PlanOp plan_fetch_op(const PlanOp * p)
   return po;
 }
 
+// Workgroups per grid row of a launch whose rows are the chains of a round.  Every workgroup of a row stages
+// the tables of its chain before its waves stream site blocks, so a row should have no more workgroups than
+// it takes to fill the chip TOGETHER with the other rows: with many rows (a round of a bushy tree, or the
+// rounds of many partitions in one launch, pllhip_update_partials_batch) a row gets few workgroups and each
+// of them many blocks, and the staging is paid once per row instead of once per eight blocks.
+// PLLHIP_ROUND_WGS: workgroups per CU the launch aims for (0: a row takes what its partition could use alone).
+static unsigned round_grid(const Engine * e, unsigned gx, unsigned rows, unsigned per_cu_default = 4u)
+{
+  static const int env = getenv("PLLHIP_ROUND_WGS") ? atoi(getenv("PLLHIP_ROUND_WGS")) : -1;
+  const unsigned per_cu = (env >= 0 && per_cu_default >= 4u) ? (unsigned)env : per_cu_default;
+  if (rows <= 1 || per_cu == 0) return gx;
+  const unsigned share = (e->cu_count * per_cu + rows - 1) / rows;
+  return std::max(1u, std::min(gx, share));
+}
+
 } // namespace pllhip

@@ -367,18 +367,20 @@ __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2
 
 template <unsigned KS, unsigned RT, bool RS>
 __global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanView plan, unsigned chain_begin,
-                                                                           unsigned chain_end, unsigned nblk, unsigned S,
-                                                                           unsigned Sp, unsigned lut_codes,
-                                                                           unsigned lut_lds_flag)
+                                                                           unsigned chain_end, unsigned S,
+                                                                           unsigned Sp, unsigned nt_flags)
 {
   extern __shared__ double lds[];
-  const bool lut_lds = (lut_lds_flag & 1u) != 0, nt = (lut_lds_flag & 2u) != 0, ntl = (lut_lds_flag & 4u) != 0;
+  const bool nt = (nt_flags & 2u) != 0, ntl = (nt_flags & 4u) != 0;
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned wstride = gridDim.x * S16_CHAIN_WAVES;
   bool first_fill = true;
   for (unsigned c = chain_begin + blockIdx.y; c < chain_end; c += gridDim.y)
   {
     const PlanChain ch = plan_fetch(plan.chains + c);
+    // site blocks and tip tables of the partition this chain belongs to
+    const unsigned nblk = ch.extent, lut_codes = ch.lut_codes;
+    const bool lut_lds = (ch.flags & 1u) != 0;
     if (!first_fill) __syncthreads();
     first_fill = false;
     for (unsigned i = 0; i < ch.len; ++i)
@@ -598,14 +600,14 @@ static unsigned s16_chain_slot(const Engine * e, bool tip)
   return s16_chain_lut_lds(e) ? ((e->R * e->lut_codes * e->S + 7u) & ~7u) : 0u;
 }
 
-static int launch_traverse_s16(Engine * e, const PlanView & plan, unsigned lds_doubles, unsigned chain_begin,
-                               unsigned chain_end, unsigned rows)
+static int launch_traverse_s16(Engine * e, const PlanView & plan, unsigned lds_doubles, unsigned extent, unsigned chain_begin,
+                               unsigned chain_end, unsigned rows, unsigned row_wgs_per_cu = 0)
 {
   const size_t lds = sizeof(double) * lds_doubles;
-  const unsigned need = (e->nblk + S16_CHAIN_WAVES - 1) / S16_CHAIN_WAVES;
-  const unsigned gx = std::max(1u, std::min(need, e->cu_count));
+  const unsigned need = (extent + S16_CHAIN_WAVES - 1) / S16_CHAIN_WAVES;
+  const unsigned gx = round_grid(e, std::max(1u, std::min(need, e->cu_count)), rows, row_wgs_per_cu ? row_wgs_per_cu : 4u);
   static const int env_nt = getenv("PLLHIP_S16_NT") ? atoi(getenv("PLLHIP_S16_NT")) : 2;   // stores and loads past the caches: 3 - 15 % faster
-  const unsigned lut_lds = (s16_chain_lut_lds(e) ? 1u : 0u) | (env_nt ? 2u : 0u) | (env_nt == 2 ? 4u : 0u);
+  const unsigned nt_flags = (env_nt ? 2u : 0u) | (env_nt == 2 ? 4u : 0u);
   static bool attr_set_dev[64] = {false};
   bool & attr_set = attr_set_dev[e->device & 63];
   const int cap = (int)(sizeof(double) * S16_CHAIN_LDS);
@@ -624,10 +626,10 @@ static int launch_traverse_s16(Engine * e, const PlanView & plan, unsigned lds_d
   do { \
     if (e->rate_scalers) \
       hipLaunchKernelGGL((k_traverse_s16<KK, 4, true>), dim3(gx, std::max(1u, rows)), dim3(64 * S16_CHAIN_WAVES), lds, e->stream, \
-                         plan, chain_begin, chain_end, e->nblk, e->S, e->Sp, e->lut_codes, lut_lds); \
+                         plan, chain_begin, chain_end, e->S, e->Sp, nt_flags); \
     else \
       hipLaunchKernelGGL((k_traverse_s16<KK, 4, false>), dim3(gx, std::max(1u, rows)), dim3(64 * S16_CHAIN_WAVES), lds, e->stream, \
-                         plan, chain_begin, chain_end, e->nblk, e->S, e->Sp, e->lut_codes, lut_lds); \
+                         plan, chain_begin, chain_end, e->S, e->Sp, nt_flags); \
   } while (0)
   PLLHIP_DISPATCH_KS(s16_ks(e), PLLHIP_CALL);
 #undef PLLHIP_CALL

@@ -636,24 +636,25 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_chain_s20(ChainBatc
 template <unsigned RT, bool RS>
 __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanView plan, unsigned chain_begin,
                                                                            unsigned chain_end, unsigned nblk,
-                                                                           unsigned slab, unsigned lut_codes,
-                                                                           unsigned lut_used, unsigned flags)
+                                                                           unsigned slab, unsigned flags)
 {
   extern __shared__ double lds[];
   const bool nt_ld = flags & 1u, nt_st = flags & 2u;
-  const bool lut_lds = (flags & 8u) != 0;
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned wstride = gridDim.x * S20_CHAIN_WAVES;
   bool first_fill = true;
   // slabs of `slab` site blocks go through the whole schedule one after the other
+  // (nblk: the largest partition of the schedule; a chain knows its own partition's extent and tables)
   for (unsigned s0 = 0; s0 < nblk; s0 += slab)
   {
-    const unsigned s1 = min(nblk, s0 + slab);
     // chains [chain_begin, chain_end) of the schedule, shared out over gridDim.y: the whole schedule with
     // gridDim.y = 1 (a traversal in one launch), one chain per workgroup row for a round of chains
     for (unsigned c = chain_begin + blockIdx.y; c < chain_end; c += gridDim.y)
     {
       const PlanChain ch = plan_fetch(plan.chains + c);
+      const unsigned s1 = min(ch.extent, s0 + slab);
+      const unsigned lut_codes = ch.lut_codes, lut_used = ch.lut_used;
+      const bool lut_lds = (ch.flags & 1u) != 0;
       if (!first_fill) __syncthreads();                 // every wave has left the previous chain's tables
       first_fill = false;
       for (unsigned i = 0; i < ch.len; ++i)
@@ -1124,12 +1125,12 @@ static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned ncha
   return PLL_SUCCESS;
 }
 
-static int launch_traverse_s20(Engine * e, const PlanView & plan, unsigned lds_doubles, unsigned lut_used,
-                               unsigned chain_begin, unsigned chain_end, unsigned rows)
+// `extent`: site blocks of the largest partition the chains [chain_begin, chain_end) belong to
+static int launch_traverse_s20(Engine * e, const PlanView & plan, unsigned lds_doubles, unsigned extent,
+                               unsigned chain_begin, unsigned chain_end, unsigned rows, unsigned row_wgs_per_cu = 0)
 {
   const size_t lds = sizeof(double) * lds_doubles;
-  const unsigned env_flags = []() { const char * v = getenv("PLLHIP_S20_NT"); return v ? (unsigned)atoi(v) & 3u : 0u; }();
-  const unsigned flags = env_flags | (s20_chain_lut_lds(e, lut_used) ? 8u : 0u);
+  const unsigned flags = []() { const char * v = getenv("PLLHIP_S20_NT"); return v ? (unsigned)atoi(v) & 3u : 0u; }();
   static bool attr_set_dev[64] = {false};
   bool & attr_set = attr_set_dev[e->device & 63];
   if (!attr_set)
@@ -1140,16 +1141,16 @@ static int launch_traverse_s20(Engine * e, const PlanView & plan, unsigned lds_d
       return PLL_FAILURE;
     attr_set = true;
   }
-  const unsigned need = (e->nblk + S20_CHAIN_WAVES - 1) / S20_CHAIN_WAVES;
-  const unsigned gx = std::max(1u, std::min(need, e->cu_count));
+  const unsigned need = (extent + S20_CHAIN_WAVES - 1) / S20_CHAIN_WAVES;
+  const unsigned gx = round_grid(e, std::max(1u, std::min(need, e->cu_count)), rows, row_wgs_per_cu ? row_wgs_per_cu : 4u);
   // slab: site blocks that go through the whole schedule together (default: all of them; smaller
   // slabs were measured and lose to the per-chain re-staging)
   static const int env_slab = getenv("PLLHIP_S20_SLAB") ? atoi(getenv("PLLHIP_S20_SLAB")) : 0;
   const unsigned per_pass = gx * S20_CHAIN_WAVES;
-  unsigned slab = env_slab > 0 ? (unsigned)env_slab : e->nblk;
+  unsigned slab = env_slab > 0 ? (unsigned)env_slab : extent;
   slab = std::max(per_pass, (slab + per_pass - 1) / per_pass * per_pass);   // whole passes of the grid
   const dim3 grid(gx, std::max(1u, rows)), block(64 * S20_CHAIN_WAVES);
-#define PLLHIP_CALL(K) hipLaunchKernelGGL(K, grid, block, lds, e->stream, plan, chain_begin, chain_end, e->nblk, slab, e->lut_codes, lut_used, flags)
+#define PLLHIP_CALL(K) hipLaunchKernelGGL(K, grid, block, lds, e->stream, plan, chain_begin, chain_end, extent, slab, flags)
   PLLHIP_S20_CHAIN_DISPATCH(k_traverse_s20, PLLHIP_CALL);
 #undef PLLHIP_CALL
   PLLHIP_TRY(hipGetLastError());

@@ -400,21 +400,23 @@ __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
 // More workgroups than fit the chip: each finishes its range and makes room for the next, so the
 // ranges in flight at any time are a slab of the alignment that moves through the whole tree.
 template <unsigned U, unsigned R, int NT = 0>
-__global__ __launch_bounds__(256) void k_traverse_s4(PlanView plan, unsigned chain_begin, unsigned chain_end, unsigned N)
+__global__ __launch_bounds__(256) void k_traverse_s4(PlanView plan, unsigned chain_begin, unsigned chain_end)
 {
   constexpr unsigned group = 2 * R;
   constexpr unsigned S4_CHAIN_OP_LDS = s4_chain_op_lds(R);
   extern __shared__ double lds[];
   const unsigned lane = threadIdx.x & 63;
   const unsigned h = lane & 1u, r = (lane >> 1) & (R - 1);
-  const unsigned long long total = 2ULL * N * R;
-  const unsigned nchunks = (N + 63) / 64;
-  const unsigned cbeg = (unsigned)(((unsigned long long)nchunks * blockIdx.x) / gridDim.x);
-  const unsigned cend = (unsigned)(((unsigned long long)nchunks * (blockIdx.x + 1)) / gridDim.x);
   bool first_fill = true;
   for (unsigned c = chain_begin + blockIdx.y; c < chain_end; c += gridDim.y)
   {
     const PlanChain ch = plan_fetch(plan.chains + c);
+    // the sites of the partition this chain belongs to (a batched schedule holds several partitions)
+    const unsigned N = ch.extent;
+    const unsigned long long total = 2ULL * N * R;
+    const unsigned nchunks = (N + 63) / 64;
+    const unsigned cbeg = (unsigned)(((unsigned long long)nchunks * blockIdx.x) / gridDim.x);
+    const unsigned cend = (unsigned)(((unsigned long long)nchunks * (blockIdx.x + 1)) / gridDim.x);
     if (!first_fill) __syncthreads();
     first_fill = false;
     for (unsigned i = 0; i < ch.len; ++i)
@@ -691,10 +693,11 @@ static int launch_chains_s4(Engine * e, const ChainBatch & batch, unsigned nchai
   return PLL_SUCCESS;
 }
 
-static int launch_traverse_s4(Engine * e, const PlanView & plan, unsigned longest, unsigned chain_begin, unsigned chain_end,
-                              unsigned rows)
+// `extent`: sites of the largest partition the chains [chain_begin, chain_end) belong to
+static int launch_traverse_s4(Engine * e, const PlanView & plan, unsigned longest, unsigned extent, unsigned chain_begin,
+                              unsigned chain_end, unsigned rows, unsigned row_wgs_per_cu = 0)
 {
-  const unsigned nchunks = (e->N + 63) / 64;
+  const unsigned nchunks = (extent + 63) / 64;
   const size_t lds = sizeof(double) * longest * s4_chain_op_lds(e->R);
   // exactly the workgroups that are resident at once (measured on C2, workgroups per CU:
   // 2: 4.06 ms, 3 = resident: 3.58, 4: 4.12, 6: 3.68, 8: 3.82; one launch per round of chains: 3.85)
@@ -709,12 +712,12 @@ static int launch_traverse_s4(Engine * e, const PlanView & plan, unsigned longes
     per_cu = std::max(1, per_cu);
   }
   // a round of chains (rows > 1): the chains share the chip, eight workgroups per CU and chain as in k_chain_s4
-  const unsigned gx = std::max(1u, std::min((nchunks + 3) / 4, e->cu_count * (rows > 1 ? 8u : (unsigned)per_cu)));
+  const unsigned gx = round_grid(e, std::max(1u, std::min((nchunks + 3) / 4, e->cu_count * (rows > 1 ? 8u : (unsigned)per_cu))), rows, row_wgs_per_cu ? row_wgs_per_cu : 8u);
   const dim3 grid(gx, std::max(1u, rows));
   // vectors are written once and read (if at all) once, by a later chain: stores and loads that do not
   // allocate in the caches are 5 % (1 M sites) to 17 % (100 k - 250 k sites) faster.  PLLHIP_S4_NT=0: plain.
   static const int env_nt = getenv("PLLHIP_S4_NT") ? atoi(getenv("PLLHIP_S4_NT")) : 1;
-#define PLLHIP_CALL(K) hipLaunchKernelGGL(K, grid, dim3(256), lds, e->stream, plan, chain_begin, chain_end, e->N)
+#define PLLHIP_CALL(K) hipLaunchKernelGGL(K, grid, dim3(256), lds, e->stream, plan, chain_begin, chain_end)
   if (env_nt)
   {
     if (e->R == 4) PLLHIP_CALL((k_traverse_s4<4, 4, 2>));

@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <time.h>
 
 namespace pllhip {
 
@@ -56,6 +57,8 @@ static int current_device()
 
 int flush_pmatrices(pll_partition_t * p);
 static int ensure_luts(pll_partition_t * p);
+static void batch_free(BatchPlan * b);
+static void batch_free_hook(BatchPlan * b) { batch_free(b); }
 
 // ---------------------------------------------------------------------------
 // engine-internal sharding: which devices the partitions created next are spread over
@@ -338,6 +341,7 @@ void engine_destroy(Engine * e)
   if (e->h_result) (void)hipHostFree(e->h_result);
   if (e->h_asc) (void)hipHostFree(e->h_asc);
   (void)hipFree(e->d_counter);
+  batch_free_hook(e->batch);
   (void)hipFree(e->plan.d_buf);
   if (e->plan.h_stage) (void)hipHostFree(e->plan.h_stage);
   if (e->plan.copied) (void)hipEventDestroy(e->plan.copied);
@@ -787,13 +791,13 @@ static int finish_launch(Engine * e, unsigned nblocks, unsigned n_quant)
 // while -- scalar-returning calls are latency-bound for small slices (Newton-Raphson: a
 // 14 us kernel per call) -- then fall back to a blocking stream synchronisation.
 // PLLHIP_SPIN_US=0 disables the polling.
-int wait_sequence(hipStream_t stream, const volatile unsigned long long * flag, unsigned long long seq)
+int wait_sequence(hipStream_t stream, const volatile unsigned long long * flag, unsigned long long seq, double timeout_s)
 {
   static const long spin_us = getenv("PLLHIP_SPIN_US") ? atol(getenv("PLLHIP_SPIN_US")) : 400;
   bool done = false;
+  const auto t0 = std::chrono::steady_clock::now();
   if (spin_us > 0)
   {
-    const auto t0 = std::chrono::steady_clock::now();
     for (unsigned it = 0; !done; ++it)
     {
       if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) done = true;
@@ -802,14 +806,30 @@ int wait_sequence(hipStream_t stream, const volatile unsigned long long * flag, 
         break;
     }
   }
-  if (!done)
+  if (!done && timeout_s > 0.0)
   {
-    PLLHIP_TRY(hipStreamSynchronize(stream));
-    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq)
+    // a result another rank contributes to (a collective sits in front of it): never block without a bound --
+    // a peer that died leaves the collective's kernel spinning for ever.  Poll the stream and the flag.
+    for (;;)
     {
-      set_error(PLL_ERROR_HIP_RUNTIME, "a reduction finished without publishing its result");
-      return PLL_FAILURE;
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return PLL_SUCCESS;
+      const hipError_t q = hipStreamQuery(stream);
+      if (q == hipSuccess) break;                      // the stream has drained: the flag decides below
+      if (q != hipErrorNotReady) { (void)hip_ok(q, "hipStreamQuery"); return PLL_FAILURE; }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+      {
+        set_error(PLL_ERROR_HIP_TIMEOUT, "no result after %.1f s: a collective did not complete (peer lost?)", timeout_s);
+        return PLL_FAILURE;
+      }
+      struct timespec ts = {0, 50000};
+      nanosleep(&ts, nullptr);
     }
+  }
+  else if (!done) PLLHIP_TRY(hipStreamSynchronize(stream));
+  if (!done && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq)
+  {
+    set_error(PLL_ERROR_HIP_RUNTIME, "a reduction finished without publishing its result");
+    return PLL_FAILURE;
   }
   return PLL_SUCCESS;
 }
@@ -983,15 +1003,14 @@ static bool plan_chains(const Engine * e, const pll_operation_t * ops, unsigned 
 
 // make DevicePlan::bytes resident on the device (stream-ordered; nothing is copied when the
 // device already holds exactly these bytes) and point `view` at it
-static int upload_plan(Engine * e, PlanView & view)
+static int upload_plan(DevicePlan & dp, hipStream_t stream, PlanView & view)
 {
-  DevicePlan & dp = e->plan;
   const size_t len = dp.bytes.size();
   if (dp.resident != dp.bytes)
   {
     if (len > dp.cap)
     {
-      PLLHIP_TRY(hipStreamSynchronize(e->stream));    // a running traversal may still read the old buffer
+      PLLHIP_TRY(hipStreamSynchronize(stream));    // a running traversal may still read the old buffer
       (void)hipFree(dp.d_buf);
       dp.d_buf = nullptr;
       dp.cap = 0;
@@ -1011,8 +1030,8 @@ static int upload_plan(Engine * e, PlanView & view)
       dp.h_cap = cap;
     }
     memcpy(dp.h_stage, dp.bytes.data(), len);
-    PLLHIP_TRY(hipMemcpyAsync(dp.d_buf, dp.h_stage, len, hipMemcpyHostToDevice, e->stream));
-    PLLHIP_TRY(hipEventRecord(dp.copied, e->stream));
+    PLLHIP_TRY(hipMemcpyAsync(dp.d_buf, dp.h_stage, len, hipMemcpyHostToDevice, stream));
+    PLLHIP_TRY(hipEventRecord(dp.copied, stream));
     dp.resident = dp.bytes;
   }
   view.ops = reinterpret_cast<const PlanOp *>(dp.d_buf);
@@ -1021,16 +1040,243 @@ static int upload_plan(Engine * e, PlanView & view)
   return PLL_SUCCESS;
 }
 
-static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops, unsigned count)
+// resolve one operation to device pointers and add its algorithmic bytes
+// (child vectors in -- 8*S per (site, rate), a coded tip is 1 byte
+// per site --, parent vector out, scalers, the two P-matrices or lookup tables
+// once per op) and flops (a 2*S*S matvec per non-tip child + S products)
+static void fill_desc(const Engine * e, const pll_operation_t & op, OpDesc & d, double & bytes, double & flops)
 {
-  Engine * e = engine_of(p);
-  PLLHIP_TRY(hipSetDevice(e->device));
-  if (!flush_pmatrices(p) || !ensure_luts(p)) return PLL_FAILURE;
+  const size_t pm_stride = (size_t)e->R * e->S * e->Sp;
+  const size_t lut_stride = (size_t)e->R * e->lut_codes * e->S;
+    const bool t1 = e->coded_tips && op.child1_clv_index < e->tips;
+  const bool t2 = e->coded_tips && op.child2_clv_index < e->tips;
+  d.clv1 = t1 ? nullptr : e->d_clv[op.child1_clv_index];
+  d.codes1 = t1 ? e->d_codes[op.child1_clv_index] : nullptr;
+  d.pmat1 = e->d_pmat + pm_stride * op.child1_matrix_index;
+  d.pfrag1 = e->d_pfrag ? e->d_pfrag + (size_t)op.child1_matrix_index * e->R * 400 : nullptr;
+  d.pfrag2 = e->d_pfrag ? e->d_pfrag + (size_t)op.child2_matrix_index * e->R * 400 : nullptr;
+  d.lut1 = t1 ? e->d_lut + lut_stride * op.child1_matrix_index : nullptr;
+  d.clv2 = t2 ? nullptr : e->d_clv[op.child2_clv_index];
+  d.codes2 = t2 ? e->d_codes[op.child2_clv_index] : nullptr;
+  d.pmat2 = e->d_pmat + pm_stride * op.child2_matrix_index;
+  d.lut2 = t2 ? e->d_lut + lut_stride * op.child2_matrix_index : nullptr;
+  d.scaler1 = scaler_ptr(e, op.child1_scaler_index);
+  d.scaler2 = scaler_ptr(e, op.child2_scaler_index);
+  d.parent = e->d_clv[op.parent_clv_index];
+  d.parent_index = op.parent_clv_index;
+  d.child1_index = op.child1_clv_index;
+  d.child2_index = op.child2_clv_index;
+  d.parent_scaler = const_cast<unsigned *>(scaler_ptr(e, op.parent_scaler_index));
+  const double nr = (double)e->N * e->R;
+  bytes += nr * 8.0 * e->S * (1.0 + (t1 ? 0.0 : 1.0) + (t2 ? 0.0 : 1.0));
+  bytes += (double)e->N * ((t1 ? 1.0 : 0.0) + (t2 ? 1.0 : 0.0));
+  bytes += (double)e->N * 4.0 * ((d.scaler1 ? 1 : 0) + (d.scaler2 ? 1 : 0) + (d.parent_scaler ? 1 : 0));
+  bytes += 8.0 * e->R * e->S * ((t1 ? (double)e->lut_codes : (double)e->Sp) +
+                                (t2 ? (double)e->lut_codes : (double)e->Sp));
+  flops += nr * (2.0 * e->S * e->S * ((t1 ? 0.0 : 1.0) + (t2 ? 0.0 : 1.0)) + e->S);
+}
 
-  // dependency levels: an op runs after the producers of its children and
-  // after every earlier op that touched its output buffers
-  std::vector<int> clv_level(e->nodes, -1), sc_level(e->nscalers, -1), level(count, 0);
-  int max_level = 0;
+// The device-resident schedule of an operation list (chains in dependency order, DevicePlan) in e->plan:
+// built unless the cached one was made from the same list and settings.  mode 1: the whole traversal in
+// one launch (chains depth first); mode 0: one launch per round of chains.  false: the list does not have
+// the shape of a tree traversal (plan_chains).
+static std::atomic<unsigned long long> plan_generation{0};
+
+static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_operation_t * ops, unsigned count,
+                             unsigned mode)
+{
+  const bool chains20 = e->family == KernelFamily::S20, chains16 = e->family == KernelFamily::S16;
+  const bool chains4 = e->family == KernelFamily::S4;
+  const unsigned lut_used = std::max(1u, std::min(p->maxstates, e->lut_codes));
+  const unsigned chain_max = chains20 ? S20_CHAIN_MAX : chains16 ? S16_CHAIN_MAX : S4_CHAIN_MAX;
+  const unsigned chain_lds = chains20 ? S20_CHAIN_LDS : chains16 ? S16_CHAIN_LDS : ~0u;
+  DevicePlan & dp = e->plan;
+  const bool by_rounds = mode == 0;
+  ChainPlan plan;
+  std::vector<unsigned char> key(3 * sizeof(unsigned) + (size_t)count * sizeof(pll_operation_t));
+  memcpy(key.data(), &count, sizeof(unsigned));
+  memcpy(key.data() + sizeof(unsigned), &lut_used, sizeof(unsigned));
+  memcpy(key.data() + 2 * sizeof(unsigned), &mode, sizeof(unsigned));
+  memcpy(key.data() + 3 * sizeof(unsigned), ops, (size_t)count * sizeof(pll_operation_t));
+  bool have = !dp.key.empty() && dp.key == key;
+  if (!have && plan_chains(e, ops, count, chain_max, chain_lds, lut_used, plan))
+  {
+    // Order of the chains: depth first, so that a vector is consumed soon after it was written
+    // (the kernel walks slabs of sites through ALL chains: what a slab wrote a few chains ago
+    // is still in L2 / the memory-side cache).  The chains form a tree -- chain c feeds the
+    // chain that reads c's last vector as a child from memory -- and the larger feeder goes
+    // first, which keeps the number of results waiting for their consumer small.
+    const size_t nch = plan.chains.size();
+    std::vector<int> chain_at(count, -1), producer_op(e->nodes, -1);
+    std::vector<unsigned> weight(nch, 0);
+    std::vector<std::vector<size_t>> feeders(nch);
+    std::vector<char> is_feeder(nch, 0);
+    for (size_t c = 0; c < nch; ++c)
+      for (unsigned k : plan.chains[c]) { chain_at[k] = (int)c; producer_op[ops[k].parent_clv_index] = (int)k; }
+    for (size_t c = 0; c < nch; ++c)                  // chains are numbered in creation order: feeders first
+    {
+      weight[c] += (unsigned)plan.chains[c].size();
+      for (unsigned k : plan.chains[c])
+      {
+        const unsigned child[2] = {ops[k].child1_clv_index, ops[k].child2_clv_index};
+        for (int x = 0; x < 2; ++x)
+        {
+          const int pk = producer_op[child[x]];
+          if (pk < 0 || pk >= (int)k || chain_at[pk] == (int)c) continue;
+          feeders[c].push_back((size_t)chain_at[pk]);
+          is_feeder[chain_at[pk]] = 1;
+          weight[c] += weight[chain_at[pk]];
+        }
+      }
+    }
+    std::vector<size_t> order;
+    order.reserve(nch);
+    if (by_rounds)
+    {
+      // round by round, longest chains first within a round (their workgroups are dispatched first)
+      for (size_t c = 0; c < nch; ++c) order.push_back(c);
+      std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b)
+      {
+        if (plan.launch[a] != plan.launch[b]) return plan.launch[a] < plan.launch[b];
+        return plan.chains[a].size() > plan.chains[b].size();
+      });
+    }
+    else
+    {
+      std::vector<std::pair<size_t, size_t>> stack;   // (chain, next feeder)
+      for (size_t root = 0; root < nch; ++root)
+      {
+        if (is_feeder[root]) continue;
+        stack.emplace_back(root, 0);
+        while (!stack.empty())
+        {
+          const size_t c = stack.back().first;
+          if (stack.back().second == 0)
+            std::stable_sort(feeders[c].begin(), feeders[c].end(), [&](size_t a, size_t b) { return weight[a] > weight[b]; });
+          if (stack.back().second < feeders[c].size()) { const size_t f = feeders[c][stack.back().second++]; stack.emplace_back(f, 0); }
+          else { order.push_back(c); stack.pop_back(); }
+        }
+      }
+    }
+    std::vector<PlanOp> pops(count);
+    std::vector<PlanChain> pchains;
+    unsigned nops = 0, lds_max = 0;
+    dp.algo_bytes = dp.algo_flops = dp.min_bytes = 0.0;
+    dp.launches.clear();
+    int cur_round = -1;
+    const unsigned extent = chains4 ? e->N : e->nblk;
+    const unsigned chain_flags = (chains20 ? s20_chain_lut_lds(e, lut_used) : chains16 ? s16_chain_lut_lds(e) : false) ? 1u : 0u;
+    for (size_t c : order)
+    {
+      const std::vector<unsigned> & ch = plan.chains[c];
+      if (dp.launches.empty() || (by_rounds && plan.launch[c] != cur_round))
+      {
+        if (!dp.launches.empty())
+        {
+          DevicePlan::Launch & done = dp.launches.back();
+          done.end = (unsigned)pchains.size();
+          done.ops = nops - done.ops;
+          done.bytes = dp.algo_bytes - done.bytes;
+          done.flops = dp.algo_flops - done.flops;
+          done.min_bytes = dp.min_bytes - done.min_bytes;
+        }
+        DevicePlan::Launch l;
+        l.rows = 1;
+        l.begin = (unsigned)pchains.size();
+        l.end = l.begin;
+        l.ops = nops;                     // running totals until the launch is closed
+        l.bytes = dp.algo_bytes;
+        l.flops = dp.algo_flops;
+        l.min_bytes = dp.min_bytes;
+        dp.launches.push_back(l);
+        cur_round = plan.launch[c];
+      }
+      PlanChain pc;
+      pc.first = nops;
+      pc.len = (unsigned)ch.size();
+      pc.extent = extent;
+      pc.lut_codes = e->lut_codes;
+      pc.lut_used = lut_used;
+      pc.flags = chain_flags;
+      pchains.push_back(pc);
+      unsigned off = 0;
+      for (size_t i = 0; i < ch.size(); ++i)
+      {
+        const pll_operation_t & o = ops[ch[i]];
+        PlanOp & po = pops[nops++];
+        memset(&po, 0, sizeof(po));
+        const double before = dp.algo_bytes;
+        fill_desc(e, o, po.d, dp.algo_bytes, dp.algo_flops);
+        po.carried = i ? plan.carried[ch[i]] : 0;
+        // the handed-over child stays in registers: neither its vector nor its scaler counts are read
+        dp.min_bytes += dp.algo_bytes - before;
+        if (po.carried)
+          dp.min_bytes -= (double)e->N * e->R * 8.0 * e->S +
+                          ((po.carried == 1 ? po.d.scaler1 : po.d.scaler2) ? 4.0 * (double)e->N * (e->rate_scalers ? e->R : 1) : 0.0);
+        const bool t1 = e->coded_tips && o.child1_clv_index < e->tips;
+        const bool t2 = e->coded_tips && o.child2_clv_index < e->tips;
+        if (chains20 || chains16)
+        {
+          po.slot1 = off;
+          off += chains20 ? s20_chain_slot(e, t1, lut_used) : s16_chain_slot(e, t1);
+          po.slot2 = off;
+          off += chains20 ? s20_chain_slot(e, t2, lut_used) : s16_chain_slot(e, t2);
+        }
+      }
+      lds_max = std::max(lds_max, chains4 ? (unsigned)ch.size() : off);   // 4 states: the longest chain
+    }
+    dp.bytes.resize(pops.size() * sizeof(PlanOp) + pchains.size() * sizeof(PlanChain));
+    memcpy(dp.bytes.data(), pops.data(), pops.size() * sizeof(PlanOp));
+    memcpy(dp.bytes.data() + pops.size() * sizeof(PlanOp), pchains.data(), pchains.size() * sizeof(PlanChain));
+    if (!dp.launches.empty())
+    {
+      DevicePlan::Launch & done = dp.launches.back();
+      done.end = (unsigned)pchains.size();
+      done.ops = nops - done.ops;
+      done.bytes = dp.algo_bytes - done.bytes;
+      done.flops = dp.algo_flops - done.flops;
+      done.min_bytes = dp.min_bytes - done.min_bytes;
+    }
+    // rounds of ONE chain each that follow one another (the spine towards the root) need no launch
+    // boundary between them: one workgroup row walks them in turn, exactly as in a one-launch traversal
+    if (by_rounds)
+    {
+      std::vector<DevicePlan::Launch> merged;
+      for (const DevicePlan::Launch & l : dp.launches)
+      {
+        if (!merged.empty() && l.end - l.begin == 1 && merged.back().rows == 1)
+        {
+          DevicePlan::Launch & m = merged.back();
+          m.end = l.end;
+          m.ops += l.ops;
+          m.bytes += l.bytes;
+          m.flops += l.flops;
+          m.min_bytes += l.min_bytes;
+        }
+        else
+        {
+          merged.push_back(l);
+          merged.back().rows = l.end - l.begin;
+        }
+      }
+      dp.launches.swap(merged);
+    }
+    else
+      for (DevicePlan::Launch & l : dp.launches) l.rows = 1;
+    dp.nops = nops;
+    dp.nchains = (unsigned)pchains.size();
+    dp.lds_doubles = lds_max;
+    dp.max_extent = extent;
+    dp.generation = ++plan_generation;
+    dp.key.swap(key);
+    have = true;
+  }
+  return have;
+}
+
+// index checks of an operation list (the reference interface returns nothing: errors go to pll_errno)
+static int validate_ops(const Engine * e, const pll_operation_t * ops, unsigned count)
+{
   for (unsigned k = 0; k < count; ++k)
   {
     const pll_operation_t & op = ops[k];
@@ -1051,6 +1297,24 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
       set_error(PLL_ERROR_PARAM_INVALID, "operation %u writes a coded tip", k);
       return PLL_FAILURE;
     }
+  }
+  return PLL_SUCCESS;
+}
+
+static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops, unsigned count)
+{
+  Engine * e = engine_of(p);
+  PLLHIP_TRY(hipSetDevice(e->device));
+  if (!flush_pmatrices(p) || !ensure_luts(p)) return PLL_FAILURE;
+
+  // dependency levels: an op runs after the producers of its children and
+  // after every earlier op that touched its output buffers
+  std::vector<int> clv_level(e->nodes, -1), sc_level(e->nscalers, -1), level(count, 0);
+  int max_level = 0;
+  if (!validate_ops(e, ops, count)) return PLL_FAILURE;
+  for (unsigned k = 0; k < count; ++k)
+  {
+    const pll_operation_t & op = ops[k];
     int l = 0;
     l = std::max(l, clv_level[op.child1_clv_index] + 1);
     l = std::max(l, clv_level[op.child2_clv_index] + 1);
@@ -1074,41 +1338,6 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     max_level = std::max(max_level, l);
   }
 
-  const size_t pm_stride = (size_t)e->R * e->S * e->Sp;
-  const size_t lut_stride = (size_t)e->R * e->lut_codes * e->S;
-  // resolve one operation to device pointers and add its algorithmic bytes
-  // (child vectors in -- 8*S per (site, rate), a coded tip is 1 byte
-  // per site --, parent vector out, scalers, the two P-matrices or lookup tables
-  // once per op) and flops (a 2*S*S matvec per non-tip child + S products)
-  auto fill_desc = [&](const pll_operation_t & op, OpDesc & d, double & bytes, double & flops)
-  {
-    const bool t1 = e->coded_tips && op.child1_clv_index < e->tips;
-    const bool t2 = e->coded_tips && op.child2_clv_index < e->tips;
-    d.clv1 = t1 ? nullptr : e->d_clv[op.child1_clv_index];
-    d.codes1 = t1 ? e->d_codes[op.child1_clv_index] : nullptr;
-    d.pmat1 = e->d_pmat + pm_stride * op.child1_matrix_index;
-    d.pfrag1 = e->d_pfrag ? e->d_pfrag + (size_t)op.child1_matrix_index * e->R * 400 : nullptr;
-    d.pfrag2 = e->d_pfrag ? e->d_pfrag + (size_t)op.child2_matrix_index * e->R * 400 : nullptr;
-    d.lut1 = t1 ? e->d_lut + lut_stride * op.child1_matrix_index : nullptr;
-    d.clv2 = t2 ? nullptr : e->d_clv[op.child2_clv_index];
-    d.codes2 = t2 ? e->d_codes[op.child2_clv_index] : nullptr;
-    d.pmat2 = e->d_pmat + pm_stride * op.child2_matrix_index;
-    d.lut2 = t2 ? e->d_lut + lut_stride * op.child2_matrix_index : nullptr;
-    d.scaler1 = scaler_ptr(e, op.child1_scaler_index);
-    d.scaler2 = scaler_ptr(e, op.child2_scaler_index);
-    d.parent = e->d_clv[op.parent_clv_index];
-    d.parent_index = op.parent_clv_index;
-    d.child1_index = op.child1_clv_index;
-    d.child2_index = op.child2_clv_index;
-    d.parent_scaler = const_cast<unsigned *>(scaler_ptr(e, op.parent_scaler_index));
-    const double nr = (double)e->N * e->R;
-    bytes += nr * 8.0 * e->S * (1.0 + (t1 ? 0.0 : 1.0) + (t2 ? 0.0 : 1.0));
-    bytes += (double)e->N * ((t1 ? 1.0 : 0.0) + (t2 ? 1.0 : 0.0));
-    bytes += (double)e->N * 4.0 * ((d.scaler1 ? 1 : 0) + (d.scaler2 ? 1 : 0) + (d.parent_scaler ? 1 : 0));
-    bytes += 8.0 * e->R * e->S * ((t1 ? (double)e->lut_codes : (double)e->Sp) +
-                                  (t2 ? (double)e->lut_codes : (double)e->Sp));
-    flops += nr * (2.0 * e->S * e->S * ((t1 ? 0.0 : 1.0) + (t2 ? 0.0 : 1.0)) + e->S);
-  };
   auto prof_begin = [&](hipEvent_t & ev1) -> int
   {
     ev1 = nullptr;
@@ -1126,11 +1355,12 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     PLLHIP_TRY(hipEventRecord(ev0, e->stream));
     return PLL_SUCCESS;
   };
-  auto prof_end = [&](hipEvent_t ev1, double bytes, double flops, unsigned nops) -> int
+  auto prof_end = [&](hipEvent_t ev1, double bytes, double flops, unsigned nops, double min_bytes = -1.0) -> int
   {
     if (!e->profiling) return PLL_SUCCESS;
     PLLHIP_TRY(hipEventRecord(ev1, e->stream));
     e->prof_bytes += bytes;
+    e->prof_min_bytes += (min_bytes >= 0.0) ? min_bytes : bytes;
     e->prof_flops += flops;
     e->prof_ops += nops;
     return PLL_SUCCESS;
@@ -1182,182 +1412,23 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     const bool by_rounds = !use_traverse && count >= 6;
     if (use_traverse || by_rounds)
     {
-      DevicePlan & dp = e->plan;
       const unsigned mode = use_traverse ? 1u : 0u;
-      std::vector<unsigned char> key(3 * sizeof(unsigned) + (size_t)count * sizeof(pll_operation_t));
-      memcpy(key.data(), &count, sizeof(unsigned));
-      memcpy(key.data() + sizeof(unsigned), &lut_used, sizeof(unsigned));
-      memcpy(key.data() + 2 * sizeof(unsigned), &mode, sizeof(unsigned));
-      memcpy(key.data() + 3 * sizeof(unsigned), ops, (size_t)count * sizeof(pll_operation_t));
-      bool have = !dp.key.empty() && dp.key == key;
-      if (!have && plan_chains(e, ops, count, chain_max, chain_lds, lut_used, plan))
-      {
-        // Order of the chains: depth first, so that a vector is consumed soon after it was written
-        // (the kernel walks slabs of sites through ALL chains: what a slab wrote a few chains ago
-        // is still in L2 / the memory-side cache).  The chains form a tree -- chain c feeds the
-        // chain that reads c's last vector as a child from memory -- and the larger feeder goes
-        // first, which keeps the number of results waiting for their consumer small.
-        const size_t nch = plan.chains.size();
-        std::vector<int> chain_at(count, -1), producer_op(e->nodes, -1);
-        std::vector<unsigned> weight(nch, 0);
-        std::vector<std::vector<size_t>> feeders(nch);
-        std::vector<char> is_feeder(nch, 0);
-        for (size_t c = 0; c < nch; ++c)
-          for (unsigned k : plan.chains[c]) { chain_at[k] = (int)c; producer_op[ops[k].parent_clv_index] = (int)k; }
-        for (size_t c = 0; c < nch; ++c)                  // chains are numbered in creation order: feeders first
-        {
-          weight[c] += (unsigned)plan.chains[c].size();
-          for (unsigned k : plan.chains[c])
-          {
-            const unsigned child[2] = {ops[k].child1_clv_index, ops[k].child2_clv_index};
-            for (int x = 0; x < 2; ++x)
-            {
-              const int pk = producer_op[child[x]];
-              if (pk < 0 || pk >= (int)k || chain_at[pk] == (int)c) continue;
-              feeders[c].push_back((size_t)chain_at[pk]);
-              is_feeder[chain_at[pk]] = 1;
-              weight[c] += weight[chain_at[pk]];
-            }
-          }
-        }
-        std::vector<size_t> order;
-        order.reserve(nch);
-        if (by_rounds)
-        {
-          // round by round, longest chains first within a round (their workgroups are dispatched first)
-          for (size_t c = 0; c < nch; ++c) order.push_back(c);
-          std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b)
-          {
-            if (plan.launch[a] != plan.launch[b]) return plan.launch[a] < plan.launch[b];
-            return plan.chains[a].size() > plan.chains[b].size();
-          });
-        }
-        else
-        {
-          std::vector<std::pair<size_t, size_t>> stack;   // (chain, next feeder)
-          for (size_t root = 0; root < nch; ++root)
-          {
-            if (is_feeder[root]) continue;
-            stack.emplace_back(root, 0);
-            while (!stack.empty())
-            {
-              const size_t c = stack.back().first;
-              if (stack.back().second == 0)
-                std::stable_sort(feeders[c].begin(), feeders[c].end(), [&](size_t a, size_t b) { return weight[a] > weight[b]; });
-              if (stack.back().second < feeders[c].size()) { const size_t f = feeders[c][stack.back().second++]; stack.emplace_back(f, 0); }
-              else { order.push_back(c); stack.pop_back(); }
-            }
-          }
-        }
-        std::vector<PlanOp> pops(count);
-        std::vector<PlanChain> pchains;
-        unsigned nops = 0, lds_max = 0;
-        dp.algo_bytes = dp.algo_flops = 0.0;
-        dp.launches.clear();
-        int cur_round = -1;
-        for (size_t c : order)
-        {
-          const std::vector<unsigned> & ch = plan.chains[c];
-          if (dp.launches.empty() || (by_rounds && plan.launch[c] != cur_round))
-          {
-            if (!dp.launches.empty())
-            {
-              DevicePlan::Launch & done = dp.launches.back();
-              done.end = (unsigned)pchains.size();
-              done.ops = nops - done.ops;
-              done.bytes = dp.algo_bytes - done.bytes;
-              done.flops = dp.algo_flops - done.flops;
-            }
-            DevicePlan::Launch l;
-            l.rows = 1;
-            l.begin = (unsigned)pchains.size();
-            l.end = l.begin;
-            l.ops = nops;                     // running totals until the launch is closed
-            l.bytes = dp.algo_bytes;
-            l.flops = dp.algo_flops;
-            dp.launches.push_back(l);
-            cur_round = plan.launch[c];
-          }
-          PlanChain pc;
-          pc.first = nops;
-          pc.len = (unsigned)ch.size();
-          pchains.push_back(pc);
-          unsigned off = 0;
-          for (size_t i = 0; i < ch.size(); ++i)
-          {
-            const pll_operation_t & o = ops[ch[i]];
-            PlanOp & po = pops[nops++];
-            memset(&po, 0, sizeof(po));
-            fill_desc(o, po.d, dp.algo_bytes, dp.algo_flops);
-            po.carried = i ? plan.carried[ch[i]] : 0;
-            const bool t1 = e->coded_tips && o.child1_clv_index < e->tips;
-            const bool t2 = e->coded_tips && o.child2_clv_index < e->tips;
-            if (chains20 || chains16)
-            {
-              po.slot1 = off;
-              off += chains20 ? s20_chain_slot(e, t1, lut_used) : s16_chain_slot(e, t1);
-              po.slot2 = off;
-              off += chains20 ? s20_chain_slot(e, t2, lut_used) : s16_chain_slot(e, t2);
-            }
-          }
-          lds_max = std::max(lds_max, chains4 ? (unsigned)ch.size() : off);   // 4 states: the longest chain
-        }
-        dp.bytes.resize(pops.size() * sizeof(PlanOp) + pchains.size() * sizeof(PlanChain));
-        memcpy(dp.bytes.data(), pops.data(), pops.size() * sizeof(PlanOp));
-        memcpy(dp.bytes.data() + pops.size() * sizeof(PlanOp), pchains.data(), pchains.size() * sizeof(PlanChain));
-        if (!dp.launches.empty())
-        {
-          DevicePlan::Launch & done = dp.launches.back();
-          done.end = (unsigned)pchains.size();
-          done.ops = nops - done.ops;
-          done.bytes = dp.algo_bytes - done.bytes;
-          done.flops = dp.algo_flops - done.flops;
-        }
-        // rounds of ONE chain each that follow one another (the spine towards the root) need no launch
-        // boundary between them: one workgroup row walks them in turn, exactly as in a one-launch traversal
-        if (by_rounds)
-        {
-          std::vector<DevicePlan::Launch> merged;
-          for (const DevicePlan::Launch & l : dp.launches)
-          {
-            if (!merged.empty() && l.end - l.begin == 1 && merged.back().rows == 1)
-            {
-              DevicePlan::Launch & m = merged.back();
-              m.end = l.end;
-              m.ops += l.ops;
-              m.bytes += l.bytes;
-              m.flops += l.flops;
-            }
-            else
-            {
-              merged.push_back(l);
-              merged.back().rows = l.end - l.begin;
-            }
-          }
-          dp.launches.swap(merged);
-        }
-        else
-          for (DevicePlan::Launch & l : dp.launches) l.rows = 1;
-        dp.nops = nops;
-        dp.nchains = (unsigned)pchains.size();
-        dp.lds_doubles = lds_max;
-        dp.key.swap(key);
-        have = true;
-      }
+      DevicePlan & dp = e->plan;
+      const bool have = prepare_schedule(e, p, ops, count, mode);
       if (have)
       {
         PlanView view;
-        if (!upload_plan(e, view)) return PLL_FAILURE;
+        if (!upload_plan(e->plan, e->stream, view)) return PLL_FAILURE;
         for (const DevicePlan::Launch & l : dp.launches)
         {
           const unsigned rows = l.rows;
           hipEvent_t ev1;
           if (!prof_begin(ev1)) return PLL_FAILURE;
-          if (chains20 ? !launch_traverse_s20(e, view, dp.lds_doubles, lut_used, l.begin, l.end, rows)
-                       : chains16 ? !launch_traverse_s16(e, view, dp.lds_doubles, l.begin, l.end, rows)
-                                  : !launch_traverse_s4(e, view, dp.lds_doubles, l.begin, l.end, rows))
+          if (chains20 ? !launch_traverse_s20(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows)
+                       : chains16 ? !launch_traverse_s16(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows)
+                                  : !launch_traverse_s4(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows))
             return PLL_FAILURE;
-          if (!prof_end(ev1, l.bytes, l.flops, l.ops)) return PLL_FAILURE;
+          if (!prof_end(ev1, l.bytes, l.flops, l.ops, l.min_bytes)) return PLL_FAILURE;
           e->counters.partial_launches++;
         }
         e->counters.partial_ops += count;
@@ -1372,7 +1443,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
       {
         ChainBatch cb;
         unsigned nops = 0, nchains = 0, longest = 0, lds_max = 0;
-        double bytes = 0.0, flops = 0.0;
+        double bytes = 0.0, flops = 0.0, minb = 0.0;
         auto flush = [&]() -> int
         {
           if (!nchains) return PLL_SUCCESS;
@@ -1387,10 +1458,10 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
           else if (chains20 ? !launch_chains_s20(e, cb, nchains, lds_max, lut_used)
                             : !launch_chains_s4(e, cb, nchains, longest))
             return PLL_FAILURE;
-          if (!prof_end(ev1, bytes, flops, nops)) return PLL_FAILURE;
+          if (!prof_end(ev1, bytes, flops, nops, bytes - minb)) return PLL_FAILURE;
           e->counters.partial_launches++;
           nops = nchains = longest = lds_max = 0;
-          bytes = flops = 0.0;
+          bytes = flops = minb = 0.0;
           return PLL_SUCCESS;
         };
         // longest chains first: their workgroups are dispatched first, which keeps the tail
@@ -1410,8 +1481,11 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
           for (size_t i = 0; i < ch.size(); ++i)
           {
             const pll_operation_t & o = ops[ch[i]];
-            fill_desc(o, cb.op[nops], bytes, flops);
+            fill_desc(e, o, cb.op[nops], bytes, flops);
             cb.carried[nops] = i ? plan.carried[ch[i]] : 0;
+            if (cb.carried[nops])       // handed over in registers: not read
+              minb += (double)e->N * e->R * 8.0 * e->S +
+                      ((cb.carried[nops] == 1 ? cb.op[nops].scaler1 : cb.op[nops].scaler2) ? 4.0 * (double)e->N * (e->rate_scalers ? e->R : 1) : 0.0);
             if (chains20)
             {
               const bool t1 = e->coded_tips && o.child1_clv_index < e->tips;
@@ -1492,6 +1566,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
         for (unsigned k = 0; k < count; ++k)
           if (folded[k] && ops[k].parent_scaler_index != PLL_SCALE_BUFFER_NONE) need.push_back(k);
         const size_t tab = (size_t)e->lut_codes * e->lut_codes;
+        const size_t lut_stride = (size_t)e->R * e->lut_codes * e->S;
         if (need.size() * tab > e->s61_ttscale_cap)
         {
           PLLHIP_TRY(hipStreamSynchronize(e->stream));
@@ -1555,12 +1630,12 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
             std::swap(o.child1_matrix_index, o.child2_matrix_index);
             std::swap(o.child1_scaler_index, o.child2_scaler_index);
           }
-          fill_desc(c, cherries.op[nb], batch_bytes, batch_flops);
+          fill_desc(e, c, cherries.op[nb], batch_bytes, batch_flops);
           tables[nb] = cherry_table[cherry_of[k]];
           any_cherry = true;
           ++nfolded;
         }
-        fill_desc(o, batch.op[nb++], batch_bytes, batch_flops);
+        fill_desc(e, o, batch.op[nb++], batch_bytes, batch_flops);
       }
       if (nb == cap || (k == count && nb))
       {
@@ -1586,6 +1661,263 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
 }
 
 } // namespace pllhip
+
+
+namespace pllhip {
+
+// ---------------------------------------------------------------------------
+// One operation list over several partitions (pllhip_update_partials_batch).
+// pll-modules evaluates every partition of an analysis on the same tree, one after the other
+// (src/tree/treeinfo.c:1020-1056); with one partition per gene a partition holds a few thousand sites
+// and every launch of its own costs more than it computes.  Partitions of one kernel family on one
+// device share their launches instead: the round schedules of the members (prepare_schedule) are laid
+// side by side in ONE resident schedule -- the chains of a round of every member become grid rows of the
+// same launch, a chain knows its partition's extent and tables (PlanChain) -- on the first member's stream,
+// with one event per member on either side.  What is stored is what the per-partition calls store,
+// bit for bit: the same kernels run the same chains.
+// ---------------------------------------------------------------------------
+static bool batch_family(const Engine * e)
+{
+  static const int use_chains = getenv("PLLHIP_CHAINS") ? atoi(getenv("PLLHIP_CHAINS")) : 1;
+  static const int use_batch = getenv("PLLHIP_BATCH") ? atoi(getenv("PLLHIP_BATCH")) : 1;
+  if (!use_chains || !use_batch || !e->shards.empty()) return false;
+  return (e->family == KernelFamily::S20 && chains_supported_s20(e)) ||
+         (e->family == KernelFamily::S4 && chains_supported_s4(e)) ||
+         (e->family == KernelFamily::S16 && chains_supported_s16(e));
+}
+
+static bool batch_compatible(const Engine * a, const Engine * b)
+{
+  return a->device == b->device && a->family == b->family && a->S == b->S && a->R == b->R &&
+         a->rate_scalers == b->rate_scalers;
+}
+
+static void batch_free(BatchPlan * b)
+{
+  if (!b) return;
+  (void)hipFree(b->plan.d_buf);
+  if (b->plan.h_stage) (void)hipHostFree(b->plan.h_stage);
+  if (b->plan.copied) (void)hipEventDestroy(b->plan.copied);
+  for (hipEvent_t ev : b->ready) if (ev) (void)hipEventDestroy(ev);
+  if (b->done) (void)hipEventDestroy(b->done);
+  delete b;
+}
+
+// 1 = done as one batch, 0 = the members' schedules cannot share launches (the caller falls back to
+// per-partition calls), -1 = error
+static int update_partials_group(const std::vector<pll_partition_t *> & g, const pll_operation_t * ops, unsigned count)
+{
+  Engine * lead = engine_of(g[0]);
+  const size_t M = g.size();
+  if (hipSetDevice(lead->device) != hipSuccess) { set_error(PLL_ERROR_HIP_RUNTIME, "hipSetDevice"); return -1; }
+  // One launch for the whole list (every member gets grid rows of its own, whose workgroups walk ALL chains
+  // of the member for their share of its site blocks: no launch boundary, no tail between rounds), or one
+  // launch per round of chains (the chains of a round of every member side by side)?  The first needs enough
+  // site blocks in the group to fill the chip without the parallelism of the chains.  PLLHIP_BATCH_MODE=1 / 0.
+  static const int env_mode = getenv("PLLHIP_BATCH_MODE") ? atoi(getenv("PLLHIP_BATCH_MODE")) : -1;
+  unsigned long long units = 0;       // workgroups the members could use side by side
+  for (pll_partition_t * p : g)
+  {
+    const Engine * e = engine_of(p);
+    units += e->family == KernelFamily::S4 ? (e->N + 255u) / 256u : (e->nblk + 7u) / 8u;
+  }
+  const unsigned mode = env_mode >= 0 ? (env_mode ? 1u : 0u) : (units >= 2ull * lead->cu_count && count >= 2) ? 1u : 0u;
+  for (pll_partition_t * p : g)
+  {
+    Engine * e = engine_of(p);
+    if (!validate_ops(e, ops, count)) return -1;
+    if (!prepare_schedule(e, p, ops, count, mode)) return 0;
+  }
+  // launches can be shared when every member's schedule has the same shape (same list, same family: always,
+  // unless the tables of one member fill the LDS earlier and cut its chains elsewhere)
+  const DevicePlan & first = lead->plan;
+  for (size_t m = 1; m < M; ++m)
+  {
+    const DevicePlan & dp = engine_of(g[m])->plan;
+    if (dp.launches.size() != first.launches.size() || dp.nchains != first.nchains) return 0;
+    for (size_t j = 0; j < dp.launches.size(); ++j)
+      if (dp.launches[j].rows != first.launches[j].rows ||
+          dp.launches[j].end - dp.launches[j].begin != first.launches[j].end - first.launches[j].begin)
+        return 0;
+  }
+
+  if (!lead->batch) lead->batch = new BatchPlan();
+  BatchPlan & b = *lead->batch;
+  bool same = b.members.size() == M;
+  for (size_t m = 0; same && m < M; ++m)
+    same = b.members[m] == (const void *)engine_of(g[m]) && b.generations[m] == engine_of(g[m])->plan.generation;
+  if (!same)
+  {
+    b.members.resize(M);
+    b.generations.resize(M);
+    DevicePlan & mp = b.plan;
+    std::vector<PlanOp> pops;
+    std::vector<PlanChain> pchains;
+    std::vector<unsigned> base(M);
+    mp.lds_doubles = 0;
+    mp.max_extent = 0;
+    for (size_t m = 0; m < M; ++m)
+    {
+      const DevicePlan & dp = engine_of(g[m])->plan;
+      b.members[m] = engine_of(g[m]);
+      b.generations[m] = dp.generation;
+      base[m] = (unsigned)pops.size();
+      const PlanOp * src = reinterpret_cast<const PlanOp *>(dp.bytes.data());
+      pops.insert(pops.end(), src, src + dp.nops);
+      mp.lds_doubles = std::max(mp.lds_doubles, dp.lds_doubles);
+      mp.max_extent = std::max(mp.max_extent, dp.max_extent);
+    }
+    mp.launches.clear();
+    for (size_t j = 0; j < first.launches.size(); ++j)
+    {
+      DevicePlan::Launch l = first.launches[j];
+      const unsigned nch = l.end - l.begin;
+      l.begin = (unsigned)pchains.size();
+      l.ops = 0;
+      l.bytes = l.flops = l.min_bytes = 0.0;
+      // a round: the chains of every member side by side (a row each).  A run of single chains (rows == 1:
+      // one row walks them in turn): step-major, so that with one row per member row m walks member m's chains
+      const bool run = first.launches[j].rows == 1;
+      const size_t row0 = pchains.size();
+      for (unsigned x = 0; x < (run ? nch : (unsigned)M); ++x)
+        for (unsigned y = 0; y < (run ? (unsigned)M : nch); ++y)
+        {
+          const size_t m = run ? y : x;
+          const unsigned c = run ? x : y;
+          const DevicePlan & dp = engine_of(g[m])->plan;
+          const PlanChain * chains = reinterpret_cast<const PlanChain *>(dp.bytes.data() + (size_t)dp.nops * sizeof(PlanOp));
+          PlanChain pc = chains[dp.launches[j].begin + c];
+          pc.first += base[m];
+          pchains.push_back(pc);
+        }
+      // the rows of a round are independent: the most expensive ones (operations x site blocks) are dispatched first,
+      // whatever partition they belong to, which keeps the tail of the launch short
+      if (!run)
+        std::stable_sort(pchains.begin() + row0, pchains.end(), [](const PlanChain & a, const PlanChain & b)
+        { return (unsigned long long)a.len * a.extent > (unsigned long long)b.len * b.extent; });
+      for (size_t m = 0; m < M; ++m)
+      {
+        const DevicePlan::Launch & lm = engine_of(g[m])->plan.launches[j];
+        l.ops += lm.ops; l.bytes += lm.bytes; l.flops += lm.flops; l.min_bytes += lm.min_bytes;
+      }
+      l.end = (unsigned)pchains.size();
+      l.rows = first.launches[j].rows * (unsigned)M;
+      mp.launches.push_back(l);
+    }
+    mp.nops = (unsigned)pops.size();
+    mp.nchains = (unsigned)pchains.size();
+    mp.bytes.resize(pops.size() * sizeof(PlanOp) + pchains.size() * sizeof(PlanChain));
+    memcpy(mp.bytes.data(), pops.data(), pops.size() * sizeof(PlanOp));
+    memcpy(mp.bytes.data() + pops.size() * sizeof(PlanOp), pchains.data(), pchains.size() * sizeof(PlanChain));
+  }
+  while (b.ready.size() < M)
+  {
+    hipEvent_t ev;
+    if (!hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate")) return -1;
+    b.ready.push_back(ev);
+  }
+  if (!b.done && !hip_ok(hipEventCreateWithFlags(&b.done, hipEventDisableTiming), "hipEventCreate")) return -1;
+
+  // the members' streams have issued what the traversal reads (P-matrices, tables, tip data)
+  for (size_t m = 1; m < M; ++m)
+    if (!hip_ok(hipEventRecord(b.ready[m], engine_of(g[m])->stream), "hipEventRecord") ||
+        !hip_ok(hipStreamWaitEvent(lead->stream, b.ready[m], 0), "hipStreamWaitEvent"))
+      return -1;
+  PlanView view;
+  if (!upload_plan(b.plan, lead->stream, view)) return -1;
+  for (const DevicePlan::Launch & l : b.plan.launches)
+  {
+    hipEvent_t ev1 = nullptr;
+    if (lead->profiling)
+    {
+      if (lead->prof_used == lead->prof_events.size())
+      {
+        hipEvent_t x, y;
+        if (!hip_ok(hipEventCreate(&x), "hipEventCreate") || !hip_ok(hipEventCreate(&y), "hipEventCreate")) return -1;
+        lead->prof_events.emplace_back(x, y);
+      }
+      ev1 = lead->prof_events[lead->prof_used].second;
+      if (!hip_ok(hipEventRecord(lead->prof_events[lead->prof_used].first, lead->stream), "hipEventRecord")) return -1;
+      lead->prof_used++;
+    }
+    // one launch for the whole list: the rows are the members, every workgroup has the same long walk in front
+    // of it, so exactly the workgroups that are resident at once (one per CU; three at 4 states)
+    static const int env_walk = getenv("PLLHIP_BATCH_WGS") ? atoi(getenv("PLLHIP_BATCH_WGS")) : 0;
+    const unsigned wgs = mode ? (env_walk > 0 ? (unsigned)env_walk : lead->family == KernelFamily::S4 ? 3u : 1u) : 0u;
+    const int ok = lead->family == KernelFamily::S20 ? launch_traverse_s20(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs)
+                 : lead->family == KernelFamily::S16 ? launch_traverse_s16(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs)
+                                                     : launch_traverse_s4(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs);
+    if (!ok) return -1;
+    if (lead->profiling)
+    {
+      if (!hip_ok(hipEventRecord(ev1, lead->stream), "hipEventRecord")) return -1;
+      lead->prof_bytes += l.bytes;
+      lead->prof_min_bytes += l.min_bytes;
+      lead->prof_flops += l.flops;
+      lead->prof_ops += l.ops;
+    }
+    lead->counters.partial_launches++;
+  }
+  // whatever a member's stream does next comes after the traversal
+  if (!hip_ok(hipEventRecord(b.done, lead->stream), "hipEventRecord")) return -1;
+  for (size_t m = 1; m < M; ++m)
+    if (!hip_ok(hipStreamWaitEvent(engine_of(g[m])->stream, b.done, 0), "hipStreamWaitEvent")) return -1;
+  for (pll_partition_t * p : g)
+  {
+    Engine * e = engine_of(p);
+    e->counters.partial_ops += count;
+    e->counters.site_updates += (unsigned long long)count * e->N * e->R;
+  }
+  return 1;
+}
+
+} // namespace pllhip
+
+extern "C" int pllhip_update_partials_batch(pll_partition_t * const * partitions, unsigned int partition_count,
+                                            const pll_operation_t * ops, unsigned int count)
+{
+  using namespace pllhip;
+  if (!count) return PLL_SUCCESS;
+  int rc = PLL_SUCCESS;
+  std::vector<char> taken(partition_count, 0);
+  // pending P-matrices and the tip tables first: whether a partition's traversals can run from a shared
+  // schedule depends on its tables (and every member needs them anyway)
+  for (unsigned i = 0; i < partition_count; ++i)
+    if (partitions[i] && !is_router(partitions[i]))
+    {
+      PLLHIP_TRY(hipSetDevice(engine_of(partitions[i])->device));
+      if (!flush_pmatrices(partitions[i]) || !ensure_luts(partitions[i])) return PLL_FAILURE;
+    }
+  for (unsigned i = 0; i < partition_count; ++i)
+  {
+    if (!partitions[i] || taken[i]) continue;
+    taken[i] = 1;
+    std::vector<pll_partition_t *> group(1, partitions[i]);
+    const Engine * e = engine_of(partitions[i]);
+    if (batch_family(e))
+      for (unsigned j = i + 1; j < partition_count; ++j)
+        if (partitions[j] && !taken[j] && partitions[j] != partitions[i] && batch_family(engine_of(partitions[j])) &&
+            batch_compatible(e, engine_of(partitions[j])))
+        {
+          taken[j] = 1;
+          group.push_back(partitions[j]);
+        }
+    int done = 0;
+    if (group.size() > 1)
+    {
+      done = update_partials_group(group, ops, count);
+      if (done < 0) { rc = PLL_FAILURE; continue; }
+    }
+    if (!done)
+      for (pll_partition_t * p : group)
+      {
+        pll_errno = 0;
+        pll_update_partials(p, ops, count);
+        if (pll_errno) rc = PLL_FAILURE;
+      }
+  }
+  return rc;
+}
 
 namespace pllhip {
 
@@ -1723,7 +2055,10 @@ int pll_update_prob_matrices(pll_partition_t * p,
   }
   e->pmat_host_dirty = true;
   e->counters.pmatrix_updates += count;
-  if (e->pend_midx.size() >= 4 * MAX_PMAT_PER_LAUNCH) return flush_pmatrices(p);
+  // every matrix of the partition is queued: no later request can join this launch (a repeated one replaces its
+  // entry), so it goes now -- with several partitions the kernel of this one runs while the host issues the
+  // per-branch calls of the next (src/tree/treeinfo.c:845-865 loops the partitions inside every branch)
+  if (e->pend_midx.size() >= 4 * MAX_PMAT_PER_LAUNCH || e->pend_midx.size() == e->nmat) return flush_pmatrices(p);
   return PLL_SUCCESS;
 }
 
@@ -2452,6 +2787,7 @@ int pllhip_profile_partials(pll_partition_t * p, int enable)
   e->profiling = enable != 0;
   e->prof_used = 0;
   e->prof_bytes = 0.0;
+  e->prof_min_bytes = 0.0;
   e->prof_flops = 0.0;
   e->prof_ops = 0;
   return PLL_SUCCESS;
@@ -2473,6 +2809,7 @@ int pllhip_profile_read(pll_partition_t * p, pllhip_profile_t * out)
       out->kernel_ms = std::max(out->kernel_ms, one.kernel_ms);
       out->algorithmic_bytes += one.algorithmic_bytes;
       out->algorithmic_flops += one.algorithmic_flops;
+      out->minimum_bytes += one.minimum_bytes;
     }
     return PLL_SUCCESS;
   }
@@ -2490,8 +2827,10 @@ int pllhip_profile_read(pll_partition_t * p, pllhip_profile_t * out)
   out->kernel_ms = ms;
   out->algorithmic_bytes = e->prof_bytes;
   out->algorithmic_flops = e->prof_flops;
+  out->minimum_bytes = e->prof_min_bytes;
   e->prof_used = 0;
   e->prof_bytes = 0.0;
+  e->prof_min_bytes = 0.0;
   e->prof_flops = 0.0;
   e->prof_ops = 0;
   return PLL_SUCCESS;

@@ -97,7 +97,7 @@ class Counters(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("launches", C.c_ulonglong), ("ops", C.c_ulonglong),
                 ("kernel_ms", C.c_double), ("algorithmic_bytes", C.c_double),
-                ("algorithmic_flops", C.c_double)]
+                ("algorithmic_flops", C.c_double), ("minimum_bytes", C.c_double)]
 
 
 TRAVERSE_CB = C.CFUNCTYPE(C.c_int, C.POINTER(UNode))
@@ -138,7 +138,7 @@ pllhip_profile_partials pllhip_profile_read pllhip_comm_rank pllhip_comm_size
 pllhip_compute_likelihood_derivatives_multi pllhip_free_trial_lengths pllhip_set_sharding
 pllhip_shard_count pllhip_results_create pllhip_results_destroy
 pllhip_results_edge_loglikelihood pllhip_results_derivatives pllhip_results_fetch
-pllhip_eval_attach_comm""".split()
+pllhip_eval_attach_comm pllhip_update_partials_batch pllhip_results_poison""".split()
 
 
 def _u32(a):
@@ -286,6 +286,10 @@ class PllLib:
             L.pllhip_results_derivatives.argtypes = [C.c_void_p, C.c_uint, pp, C.c_int, C.c_int, c_double_p,
                                                      C.c_uint, c_uint_p, c_double_p]
             L.pllhip_results_fetch.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_int, c_double_p]
+            L.pllhip_results_poison.argtypes = [C.c_void_p]
+            L.pllhip_results_poison.restype = None
+        if hasattr(L, "pllhip_update_partials_batch"):
+            L.pllhip_update_partials_batch.argtypes = [C.POINTER(pp), C.c_uint, C.POINTER(Operation), C.c_uint]
         if hasattr(L, "pllhip_compute_likelihood_derivatives_multi"):
             L.pllhip_compute_likelihood_derivatives_multi.argtypes = [pp, C.c_int, C.c_int, c_double_p, C.c_uint,
                                                                       c_uint_p, c_double_p, c_double_p, c_double_p]
@@ -956,6 +960,17 @@ def build_instance(lib, states, rate_cats, ntips, nsites, coded=True, scalers=Tr
     inst.tree = tree
     inst.codes = codes
     return inst
+
+
+def update_partials_batch(lib, insts, ops, count=None):
+    """pllhip_update_partials_batch over `insts` (None = a partition another worker owns)"""
+    if not isinstance(ops, C.Array):
+        count = len(ops)
+        ops = Instance.make_ops(ops)
+    arr = (C.POINTER(Partition) * len(insts))(*[i.p if i is not None else None for i in insts])
+    lib.errno = 0
+    if not lib.lib.pllhip_update_partials_batch(arr, len(insts), ops, len(ops) if count is None else count):
+        raise RuntimeError(lib.errmsg)
 
 
 def full_traversal(inst, one_by_one_pmatrices=False):

@@ -209,6 +209,41 @@ def test_c_driver_across_two_processes_on_one_gpu(tmp_path):
         check_driver_ranks(_run_driver_workers("product", mode, d))
 
 
+def test_a_failing_rank_takes_its_peers_down_with_it_on_the_gpu(tmp_path):
+    """the same with both workers on GPU 0 of the HIP engine (reduce callback over gloo)"""
+    from test_multirank import run_fault_workers
+    run_fault_workers("product", tmp_path)
+
+
+@pytest.mark.parametrize("mode", ["deposit", "collective", "publish"])
+def test_communicator_failure_paths(tmp_path, mode):
+    """the library's own RCCL communicator (a world of one: all this box can hold) with injected failures
+    (include/pllhip.h, pllhip_results_fetch):
+      deposit     a deferred result cannot be enqueued: that evaluation returns NaN with the cause in pll_errmsg,
+                  the collective still runs (with NaN), the group is clean afterwards and the next evaluations work
+      collective  the all-reduce fails: ncclCommAbort, NaN, and every later evaluation fails at once (aborted)
+      publish     the result never arrives (what a lost peer looks like): the bounded wait gives up after
+                  PLLHIP_COLLECTIVE_TIMEOUT_S, the communicator is aborted, later evaluations fail at once"""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_fault_worker.py"), "product", mode,
+                          str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 3, out.stderr[-2000:]
+    r = json.load(open(tmp_path / "rank0.json"))
+    assert r["lnl"][0] is not None
+    assert r["lnl"][1] is None and r["errno"][1] != 0
+    if mode == "deposit":
+        assert "injected deposit" in r["errmsg"][1]
+        assert r["lnl"][2] == r["lnl"][0] and r["lnl"][3] == r["lnl"][0]
+    else:
+        assert "aborted" in r["errmsg"][1]
+        if mode == "publish":
+            assert r["errno"][1] == 903                                     # PLL_ERROR_HIP_TIMEOUT
+        assert r["lnl"][2] is None and r["lnl"][3] is None
+        assert r["errno"][2] == 904 and r["errno"][3] == 904                # PLL_ERROR_HIP_COMM_ABORTED
+
+
 @pytest.mark.parametrize("states,nshards", [(20, 3), (4, 2), (61, 2), (10, 4)])
 def test_partition_spread_over_devices(product, states, nshards):
     """engine-internal sharding (include/pllhip.h: pllhip_set_sharding; SURVEY.md 8e topology i): ONE

@@ -78,6 +78,28 @@ def test_c_driver_across_two_processes(oracle, tmp_path, mode):
     check_driver_ranks(_run_driver_workers("oracle", mode, tmp_path))
 
 
+def run_fault_workers(lib, tmp_path):
+    """two gloo ranks, rank 1's second evaluation fails locally: both ranks see NaN in that call (the failing
+    rank takes part in the reduction with NaN), nobody hangs, both exit non-zero; the third evaluation works"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "_fault_worker.py"), lib, "eval", str(tmp_path)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, env=env, timeout=300, capture_output=True, text=True)
+    assert out.returncode != 0
+    ranks = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    for r in ranks:
+        assert r["lnl"][0] is not None and r["lnl"][1] is None and r["lnl"][2] is not None, r
+        assert r["lnl"][0] == r["lnl"][2]
+    assert ranks[0]["lnl"][0] == ranks[1]["lnl"][0]
+    assert "injected" in ranks[1]["errmsg"][1]            # the cause stays visible on the rank that failed
+    return ranks
+
+
+def test_a_failing_rank_takes_its_peers_down_with_it(oracle, tmp_path):
+    run_fault_workers("oracle", tmp_path)
+
+
 def test_bench_launcher_starts_the_ranks(tmp_path):
     """`python bench.py --gpus N` without a rank environment starts N ranks itself (child
     process, before any GPU call) and forwards their line; PLLHIP_BENCH_LAUNCH_PROBE=1 makes
