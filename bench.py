@@ -24,6 +24,11 @@ torch.distributed.run child, created before anything in this process touches
 the GPU) and forwards the child's JSON line and exit code; under a launcher
 (RANK / WORLD_SIZE set) it is one of the ranks.
 
+The default run (one GPU, no overrides) times C3 -- the configuration the north star quotes -- and then, in
+the same process, a few steps of C2, C4 and C5, one Newton-Raphson smoothing pass on the 125 k-site slice of
+C3 and one SPR round on the 25 k-site slice of C5 (the per-GPU shares of an 8-way split): their figures go
+into `also` of the same line (`--no-also` skips them).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -68,6 +73,9 @@ def parse_args():
                          "torch = the reduce callback through torch.distributed (a rehearsal path: with "
                          "PLLHIP_BENCH_DIST_BACKEND=gloo and PLLHIP_ALLOW_DEVICE_WRAP=1 all ranks can share one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="default run only: skip the C2 / C4 / C5 / branch-length / SPR legs behind the C3 line")
+    ap.add_argument("--also-steps", type=int, default=5)
     ap.add_argument("--cpu-sites", type=int, default=0, help="sites of the CPU baseline sample")
     return ap.parse_args()
 
@@ -117,41 +125,61 @@ def evaluate_with_persite(ev, plan):
     return lnl, persite
 
 
-def cpu_baseline(pc, product, tree, config, states, rate_cats, nsites_gpu, cpu_sites, per_branch):
-    """the oracle (a from-scratch CPU port, NOT libpll) timed on the host cores
-    on a bounded sample of the same workload: same tree, model, C driver and the
-    FIRST cpu_sites sites of the same alignment, sized for ~10-30 s of CPU work.
-    The same sample is then evaluated on the GPU: |dlnL| per site on identical
-    inputs (BASELINE.json's metric, second half)."""
-    host_cores = os.cpu_count() or 1
-    threads = min(host_cores, 16)      # the 1-GPU box share of host cores
-    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("ORC_FAST", "1")      # the oracle's AVX2-vectorised partials (4 / 20 / 61 states)
-    oracle = pc.PllLib(os.path.join(ROOT, "oracle", "_build", "libpll_oracle.so"))
-    ntips = tree.ntips
-    if not cpu_sites:
-        per_update = (4.0 * states * states + states) / 1.5e9      # ~scalar flop rate of one core
-        cpu_sites = int(15.0 * threads / (per_update * rate_cats * (ntips - 2)))
-        cpu_sites = max(1000, min(nsites_gpu, cpu_sites // 1000 * 1000))
-    plan = partition_plan(config, states, cpu_sites)
-    cpu_sites = sum(n for _, n in plan)
+def _omp_set_threads(n):
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+        return True
+    except OSError:
+        return False
+
+
+def _time_oracle(pc, oracle, tree, plan, rate_cats, per_branch, budget_s, max_reps=5):
+    """full evaluations of `plan` on the oracle until budget_s has passed: (updates/s, reps, lnl, persite)"""
     ev, _ = make_evaluation(pc, oracle, tree, plan, rate_cats, 44, per_branch)
     with ev:
         ev.loglh()                                  # warm-up
         t0 = time.perf_counter()
         reps = 0
         while True:
-            lnl = ev.loglh()
+            ev.loglh()
             reps += 1
-            if time.perf_counter() - t0 > 10.0 or reps >= 5:
+            if time.perf_counter() - t0 > budget_s or reps >= max_reps:
                 break
         dt = time.perf_counter() - t0
-        lnl_cpu, persite_cpu = evaluate_with_persite(ev, plan)
+        lnl, persite = evaluate_with_persite(ev, plan)
+    sites = sum(n for _, n in plan)
+    return reps * (tree.ntips - 2) * sites * rate_cats / dt, reps, lnl, persite
+
+
+def cpu_baseline(pc, product, tree, config, states, rate_cats, nsites_gpu, cpu_sites, per_branch, quick=False):
+    """the oracle (a from-scratch CPU port, NOT libpll) timed on the host cores
+    on a bounded sample of the same workload: same tree, model, C driver and the
+    FIRST cpu_sites sites of the same alignment, sized for ~10 s of CPU work at 16 threads;
+    also with ONE thread and with ALL cores of the host, each on a sample
+    sized for a few seconds.  The 16-thread sample is then evaluated on the GPU: |dlnL| per site on
+    identical inputs (BASELINE.json's metric, second half).  quick: parity sample only (no timing legs)."""
+    host_cores = os.cpu_count() or 1
+    threads = min(host_cores, 16)      # the 1-GPU box share of host cores
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("ORC_FAST", "1")      # the oracle's AVX2-vectorised partials (4 / 20 / 61 states)
+    oracle = pc.PllLib(os.path.join(ROOT, "oracle", "_build", "libpll_oracle.so"))
+    can_set = _omp_set_threads(threads)
+    ntips = tree.ntips
+    per_update = (4.0 * states * states + states) / 1.5e9      # ~scalar flop rate of one core
+
+    def sample(seconds, nthreads):
+        n = int(seconds * nthreads / (per_update * rate_cats * (ntips - 2)))
+        return max(1000, min(nsites_gpu, n // 1000 * 1000))
+    if not cpu_sites:
+        cpu_sites = sample(1.0 if quick else 15.0, threads)
+    plan = partition_plan(config, states, cpu_sites)
+    cpu_sites = sum(n for _, n in plan)
+    rate, reps, lnl_cpu, persite_cpu = _time_oracle(pc, oracle, tree, plan, rate_cats, per_branch,
+                                                    0.5 if quick else 10.0, 1 if quick else 5)
     gev, _ = make_evaluation(pc, product, tree, plan, rate_cats, 44, per_branch)
     with gev:
         lnl_gpu, persite_gpu = evaluate_with_persite(gev, plan)
-    updates = reps * (ntips - 2) * cpu_sites * rate_cats
     parity = {
         "dlnl_per_site": abs(lnl_gpu - lnl_cpu) / cpu_sites,
         "max_persite_dlnl": float(np.max(np.abs(persite_gpu - persite_cpu))),
@@ -160,12 +188,27 @@ def cpu_baseline(pc, product, tree, config, states, rate_cats, nsites_gpu, cpu_s
                    "not available offline) on the first sample_sites sites of the benchmark alignment",
         "tolerance_per_site": 1e-6,
     }
-    base = {"value": updates / dt, "unit": "CLV site-updates/s", "cores": threads, "kind": "port",
+    if quick:
+        return None, parity
+    base = {"value": rate, "unit": "CLV site-updates/s", "cores": threads, "kind": "port",
             "host_cores": host_cores, "threads": threads, "sample_sites": cpu_sites, "sample_evaluations": reps,
-            "lnl_per_site": lnl / cpu_sites,
+            "lnl_per_site": lnl_cpu / cpu_sites,
             "sample": f"{reps} full evaluations of the same tree/model on the first {cpu_sites} sites of the "
                       f"benchmark alignment (oracle/, plain C + OpenMP over sites, AVX2-vectorised partials, "
                       f"{threads} threads on a host with {host_cores} cores)"}
+    # one thread, and every core of the host: a few seconds each, own sample sizes
+    if can_set:
+        for label, nthreads in (("one_thread", 1), ("all_cores", host_cores)):
+            if label == "all_cores" and host_cores == threads:
+                base[label] = {"value": rate, "threads": threads, "sample_sites": cpu_sites, "same_as": "value"}
+                continue
+            _omp_set_threads(nthreads)
+            n = sample(4.0, nthreads)
+            sub = partition_plan(config, states, n)
+            r, k, _, _ = _time_oracle(pc, oracle, tree, sub, rate_cats, per_branch, 4.0, 3)
+            base[label] = {"value": r, "threads": nthreads, "sample_sites": sum(x for _, x in sub),
+                           "sample_evaluations": k}
+        _omp_set_threads(threads)
     return base, parity
 
 
@@ -177,6 +220,24 @@ def free_port():
     return port
 
 
+def kfd_gpu_count():
+    """GPU nodes of /sys/class/kfd/kfd/topology (no HIP call, no torch import); None if unreadable"""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        if vis:
+            n = min(n, len([v for v in vis.split(",") if v.strip() != ""]))
+        return n
+    except (OSError, ValueError):
+        return None
+
+
 def launch_ranks(args):
     """`bench.py --gpus N` without a rank environment: start the N ranks as ONE child
     process (torch.distributed.run -> one process per GPU).  Nothing in this process has
@@ -184,9 +245,11 @@ def launch_ranks(args):
     the child's JSON line and exit code."""
     probe = os.environ.get("PLLHIP_BENCH_LAUNCH_PROBE") == "1"
     if not probe:
-        import torch
-        have = torch.cuda.device_count()          # counting devices does not initialise the GPU
-        if have < args.gpus and os.environ.get("PLLHIP_ALLOW_DEVICE_WRAP") != "1":
+        # the parent stays free of torch and HIP (a device count through either may initialise the runtime
+        # in the process the ranks are forked from): GPUs are counted from the KFD topology, and a rank that
+        # finds no device for its LOCAL_RANK fails on pllhip_set_device anyway
+        have = kfd_gpu_count()
+        if have is not None and have < args.gpus and os.environ.get("PLLHIP_ALLOW_DEVICE_WRAP") != "1":
             raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -224,6 +287,316 @@ def launch_probe(args, rank, world):
                           "distinct_processes": len({p for _, _, p in seen})}))
 
 
+def partition_cost(states, rate_cats):
+    """relative cost of one site of a partition: bytes per site across one operation for the HBM-bound
+    families (24 S per rate), flops over the ridge (~10 flop/B) where the matrix pipe bounds it"""
+    return rate_cats * max(24.0 * states, 2.0 * states * states / 10.2)
+
+
+def assign_partitions(job_plan, rate_cats, rank, world):
+    """Cost-balanced assignment of the partitions of a job to the ranks: all partitions are
+    laid end to end, every site weighted with its partition's cost, and cut into `world` pieces of equal
+    cost -- a rank gets the (few, large) partition slices inside its piece and NULL slots for the rest
+    (src/tree/treeinfo.c:1024-1031), instead of a 1/world slice of EVERY partition.  Slice borders sit on whole
+    32-site blocks.  Returns [(first_site, sites) or None per partition]."""
+    costs = [partition_cost(s_, rate_cats) * n_ for s_, n_ in job_plan]
+    total = sum(costs)
+    lo_c, hi_c = total * rank / world, total * (rank + 1) / world
+    out, start = [], 0.0
+    for (s_, n_), c in zip(job_plan, costs):
+        end = start + c
+        a, b = max(lo_c, start), min(hi_c, end)
+        if b <= a or c <= 0:
+            out.append(None)
+        else:
+            def cut(x, last):
+                if last:
+                    return n_
+                v = int(round((x - start) / c * n_ / 32.0)) * 32
+                return max(0, min(n_, v))
+            first = cut(a, False) if a > start else 0
+            stop = cut(b, b >= end)
+            out.append((first, stop - first) if stop > first else None)
+        start = end
+    return out
+
+
+class Ctx:
+    """what every leg of a run shares"""
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
+    """one timed workload (W1 on `config`); returns the JSON object of its line.
+    cpu: "full" = CPU baseline + parity sample, "parity" = parity sample only, None = neither"""
+    pc, product, args = ctx.pc, ctx.product, ctx.args
+    rank, world, dist, comm = ctx.rank, ctx.world, ctx.dist, ctx.comm
+    states, rate_cats, ntips, nsites = pc.CONFIGS[config]
+    if sites:
+        nsites = sites
+    if taxa:
+        ntips = taxa
+    per_branch = args.pmatrix_calls == "per-branch"
+    tree = pc.Tree(ntips, 42, 43)
+
+    # ONE alignment for the whole job (strong: the configured site count is split; weak: it is the per-GPU share).
+    # One partition: rank r owns a contiguous site range.  Several partitions on several ranks: whole partitions /
+    # large slices go to few ranks each, balanced by cost (assign_partitions); the others are NULL slots there.
+    job_plan = partition_plan(config, states, nsites * (world if args.scaling == "weak" else 1))
+    balanced = world > 1 and len(job_plan) > 1 and os.environ.get("PLLHIP_BENCH_BALANCE", "1") != "0"
+    if balanced:
+        mine = assign_partitions(job_plan, rate_cats, rank, world)
+    else:
+        mine = [(n_ * rank // world, n_ * (rank + 1) // world - n_ * rank // world) for _, n_ in job_plan]
+    plan = [(s_, m[1]) if m else None for (s_, _), m in zip(job_plan, mine)]
+    first_sites = [m[0] if m else 0 for m in mine]
+    local_sites = sum(p_[1] for p_ in plan if p_)
+    total_sites = sum(n for _, n in job_plan)
+    if not balanced and min(p_[1] for p_ in plan) < 1:
+        raise SystemExit("bench.py: fewer sites than ranks")
+    ev = pc.Evaluation(product, tree.newick(), flags=1 if per_branch else 0, nparts=len(plan))
+    insts = []
+    for k, p_ in enumerate(plan):
+        if p_ is None:
+            ev.add_remote_partition(k)
+            continue
+        subst, freqs, alpha = model_of(pc, p_[0])
+        codes = pc.random_codes(tree.ntips, p_[1], p_[0], 44 + 101 * k, first_site=first_sites[k])
+        insts.append(ev.add_partition(k, p_[0], p_[1], rate_cats, codes, subst, freqs, alpha, coded=True,
+                                      attributes=ATTRIBUTES))
+        del codes
+    if not insts:
+        raise SystemExit("bench.py: a rank without work")
+    inst = max(insts, key=lambda i: i.N * i.S)        # the partition that dominates the traffic
+
+    comm_mode = ctx.comm_mode
+    reduce_cb = None
+    if world > 1 and comm_mode == "rccl":
+        if not product.lib.pllhip_eval_attach_comm(ev.ev, comm):
+            raise SystemExit(product.errmsg)
+    if world > 1 and comm_mode == "torch":
+        # rehearsal path: the reference's reduce hook served by torch.distributed (any backend)
+        import torch
+        ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}    # include/pllhip.h PLLHIP_REDUCE_*
+        on_gpu = dist.get_backend() == "nccl"
+
+        def _reduce(c_, data, n, op):
+            arr = np.ctypeslib.as_array(data, shape=(n,))
+            t = torch.from_numpy(arr.copy())
+            if on_gpu:
+                t = t.cuda()
+            dist.all_reduce(t, op=ops[op])
+            arr[:] = t.cpu().numpy()
+
+        reduce_cb = pc.REDUCE_CB(_reduce)
+        ev.set_parallel_context(reduce_cb)
+
+    nops = ntips - 2
+
+    def barrier():
+        for i in insts:
+            product.lib.pllhip_synchronize(i.p)
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        ev.loglh()
+    for i in insts:
+        product.lib.pllhip_profile_partials(i.p, 1)
+    barrier()
+    t0 = time.perf_counter()
+    lnl = 0.0
+    for _ in range(steps):
+        lnl = ev.loglh()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = pc.Profile()           # summed over the partitions of the evaluation
+    for i in insts:
+        one = pc.Profile()
+        product.lib.pllhip_profile_read(i.p, C.byref(one))
+        product.lib.pllhip_profile_partials(i.p, 0)
+        for f, _ in pc.Profile._fields_:
+            setattr(prof, f, getattr(prof, f) + getattr(one, f))
+    counters = [i.counters() for i in insts]
+    partial_launches = sum(c.partial_launches for c in counters)
+    pmatrix_launches = sum(c.pmatrix_launches for c in counters)
+
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    kernel = product.lib.pllhip_partials_kernel_name(inst.p).decode()
+    updates_per_step = nops * total_sites * rate_cats
+    value = updates_per_step * steps / elapsed
+
+    # roofline of the dominant kernel (pll_update_partials), from the HIP events
+    # recorded around its launches during the timed region on rank 0
+    several = len(insts) > 1
+    kernel_s = prof.kernel_ms * 1e-3
+    achieved = prof.algorithmic_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    minimum = prof.minimum_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    if several:
+        # partitions of different families run on their own streams and overlap on the device: the summed
+        # event times exceed the wall time, so the kernels are priced against the
+        # whole step instead (a lower bound of what they achieve)
+        achieved = prof.algorithmic_bytes / elapsed / 1e9
+        minimum = prof.minimum_bytes / elapsed / 1e9
+    traffic = None
+    traffic_source = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and world == 1 and not sites and not taxa and not args.rate_scalers:
+        try:
+            tj = json.load(open(tpath))
+            per_step = tj.get(f"{config}:{kernel}:per_step")
+            if per_step and prof.launches:
+                traffic = round(per_step * steps / prof.launches)      # per launch, like `achieved`
+            else:
+                traffic = tj.get(f"{config}:{kernel}")
+            traffic_source = ("profiles/traffic.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                              "this command (tools/gpu_profile.sh), NOT measured in this run")
+        except Exception:
+            traffic = None
+    tflops = prof.algorithmic_flops / kernel_s / 1e12 if kernel_s > 0 else 0.0
+    # the kernel is priced against the roof that bounds it: HBM for 4 and 20 states
+    # (0.7 and 3.4 flop/B), the FP64 matrix pipe for 61 states (10.2 flop/B ~ the ridge)
+    mfma_bound = states > 32
+    launches = max(1, prof.launches)
+    traffic_gbps = (traffic / (prof.kernel_ms / launches * 1e-3) / 1e9
+                    if traffic and prof.kernel_ms > 0 and not several else None)
+    roofline = {
+        "bound": "mfma" if mfma_bound else "hbm", "kernel": kernel,
+        "achieved": round(tflops, 2) if mfma_bound else round(achieved, 1),
+        "peak": FP64_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
+        "unit": "TFLOP/s" if mfma_bound else "GB/s",
+        "frac": round(tflops / FP64_MFMA_PEAK_TFLOPS, 4) if mfma_bound else round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": traffic, "traffic_source": traffic_source,
+        "algorithmic_GBps": round(achieved, 1), "algorithmic_TFLOPs": round(tflops, 2),
+        # `frac` prices SURVEY.md 8d's algorithmic bytes (every child vector one read).  Operation chains hand
+        # the carried child over in registers, so the schedule has to move less than that:
+        #   frac_minimum   the bytes the schedule as planned must move (carried children and their scaler
+        #                  counts not read; every vector still written) / time / peak: the rate an HBM-bound
+        #                  kernel can be held to -- this is the figure that still discriminates
+        #   frac_physical  the PMC traffic of the committed profile of this command / time / peak
+        "minimum_GBps": round(minimum, 1),
+        "frac_minimum": round(minimum / HBM_PEAK_GBS, 4),
+        "minimum_over_algorithmic": (round(prof.minimum_bytes / prof.algorithmic_bytes, 4)
+                                     if prof.algorithmic_bytes > 0 else None),
+        "frac_physical": round(traffic_gbps / HBM_PEAK_GBS, 4) if traffic_gbps else None,
+        "hbm_copy_rate_measured_GBps": 6290.0,      # MI355X_MICROARCH.md: what a plain copy reaches of the 8 TB/s
+        "launches": int(prof.launches), "ops": int(prof.ops),
+        "avg_launch_ms": round(prof.kernel_ms / launches, 4),
+        "algorithmic_bytes_per_launch": round(prof.algorithmic_bytes / launches),
+        "minimum_bytes_per_launch": round(prof.minimum_bytes / launches),
+        "kernel_share_of_step": round(kernel_s / elapsed, 4),
+        # tools/micro/mfma_f64.hip: v_mfma_f64_16x16x4_f64 back to back on every SIMD sustains
+        # 47.5 TFLOP/s on this chip (29.9 ns per MFMA per SIMD with <= 128 CUs busy, 44.1 ns with
+        # all 256: clocks drop under a full-chip FP64 matrix load), not the 78.6 TFLOP/s data-sheet peak
+        "mfma_sustained_measured_TFLOPs": FP64_MFMA_SUSTAINED_TFLOPS if mfma_bound else None,
+        "frac_of_sustained": round(tflops / FP64_MFMA_SUSTAINED_TFLOPS, 4) if mfma_bound else None,
+        "traffic_GBps": round(traffic_gbps, 1) if traffic_gbps else None,
+        "traffic_over_algorithmic": (round(traffic / (prof.algorithmic_bytes / launches), 3)
+                                     if traffic and prof.algorithmic_bytes > 0 and not several else None),
+        "method": ("algorithmic bytes of all partials launches / step wall time (partitions overlap on "
+                   "concurrent streams)") if several else
+                  "algorithmic bytes of the partials launches / their HIP-event time (rank 0)",
+    }
+
+    ev.close()                   # frees the CLVs: the parity sample below gets its own partitions
+    cpu_base = parity = None
+    if rank == 0 and world == 1 and not ctx.internal and cpu:
+        cpu_base, parity = cpu_baseline(pc, product, tree, config, states, rate_cats, local_sites,
+                                        args.cpu_sites, per_branch, quick=(cpu == "parity"))
+    names = {"c2": "C2 DNA GTR+G4", "c4": "C4 mixed: 2 DNA GTR+G4 + 2 protein GTR20+G4 partitions, linked branch lengths",
+             "c3": "C3 protein 'LG-shaped' GTR20+G4 (real LG table unavailable offline)",
+             "c5": "C5 codon GY94-shaped+G4"}
+    evals = max(1, steps + warmup)
+    comm_note = ""
+    if world > 1:
+        comm_note = (" + RCCL all-reduce of the lnL on the device" if comm_mode == "rccl"
+                     else " + lnL summed through the reduce hook (torch.distributed)")
+    return {
+        "metric": "CLV site-updates/sec (sites x rates x edges); |dlnL| vs ref",
+        "value": value, "unit": "CLV site-updates/s",
+        "n_gpus": args.gpus if ctx.internal else world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": f"{names[config]}: {states} states, {rate_cats} rate cats, {ntips} taxa, "
+                        f"{total_sites} sites total ({local_sites} on rank 0), full traversal "
+                        f"({nops} ops + {tree.nedges} P-matrices + edge lnL{comm_note}) per step",
+            "config": config, "states": states, "rate_cats": rate_cats, "taxa": ntips,
+            "sites_total": total_sites, "sites_per_gpu": local_sites, "ops_per_step": nops,
+            "partitions": [({"states": p_[0], "first_site": f_, "sites_on_rank0": p_[1]} if p_ else
+                            {"states": job_plan[k][0], "sites_on_rank0": 0, "remote": True})
+                           for k, (p_, f_) in enumerate(zip(plan, first_sites))],
+            "partition_assignment": ("cost-balanced: whole partitions / large slices per rank, NULL slots elsewhere"
+                                     if balanced else "every rank holds a contiguous 1/N site range of every partition"),
+            "tips": "1-byte codes",
+            "scalers": ("per (site, rate)" if args.rate_scalers else "per-site") + ", one buffer per inner node",
+            "pmatrix_calls": args.pmatrix_calls,
+            "pmatrix_launches_per_step": pmatrix_launches // evals,
+            "partial_launches_per_step": partial_launches // evals,
+            "parallelism": (f"one process, every partition spread over {args.gpus} devices inside the engine, "
+                            f"lnL summed on the host" if ctx.internal else
+                            f"sites sharded over {world} GPU(s), lnL all-reduced" if world > 1 else "1 GPU"),
+        },
+        # the same alignment at every N: the summed lnL must not depend on n_gpus
+        "lnl": lnl, "lnl_per_site": lnl / total_sites,
+        "dlnl_per_site": parity["dlnl_per_site"] if parity else None,
+        "max_persite_dlnl": parity["max_persite_dlnl"] if parity else None,
+        "parity": parity,
+        "roofline": roofline,
+        "cpu_baseline": cpu_base,
+    }
+
+
+def also_legs(ctx):
+    """behind the default C3 line, in the same process: the other BASELINE configurations (a few steps each, with a
+    small parity sample) and the two secondary workloads VERDICT r2 asks for at the per-GPU slice of an 8-way split"""
+    also = {}
+    steps = ctx.args.also_steps
+    for cfg in ("c2", "c4", "c5"):
+        t0 = time.perf_counter()
+        d = run_leg(ctx, cfg, steps=steps, warmup=2, cpu="parity")
+        r = d["roofline"]
+        also[cfg] = {
+            "workload": d["config"]["workload"], "value": d["value"], "ms_per_step": d["ms_per_step"], "steps": steps,
+            "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_minimum",
+                                           "frac_physical", "frac_of_sustained", "traffic_over_algorithmic",
+                                           "avg_launch_ms", "launches", "kernel_share_of_step")},
+            "traffic_over_algorithmic": r["traffic_over_algorithmic"],
+            "dlnl_per_site": d["dlnl_per_site"], "max_persite_dlnl": d["max_persite_dlnl"],
+            "parity_sample_sites": d["parity"]["sample_sites"] if d["parity"] else None,
+            "partial_launches_per_step": d["config"]["partial_launches_per_step"],
+            "leg_wall_s": round(time.perf_counter() - t0, 2),
+        }
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gpu_workloads as gw
+    out = {}
+    t0 = time.perf_counter()
+    gw.blo(ctx.product, "c3", out, nsites=125_000)
+    b = out["BLO_c3_125000"]
+    also["blo_c3_125k_us_per_iterate"] = b["us_per_derivative_call_incl_everything"]
+    also["blo_c3_125k"] = {k: b[k] for k in ("s_per_smoothing_pass", "newton_iterations", "sumtable_scans",
+                                             "single_op_updates", "pmatrix_updates", "branches", "lnl_before", "lnl_after")}
+    also["blo_c3_125k"]["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+    t0 = time.perf_counter()
+    gw.spr(ctx.product, out, nsites=25_000)
+    sp = out["SPR_c5_50x25000_fast"]
+    also["spr_c5_25k_s"] = sp["s_per_round"]
+    also["spr_c5_25k"] = {k: sp[k] for k in ("prunings", "insertions", "moves_applied", "rescored", "clv_ops",
+                                             "pmatrix_updates", "derivative_calls", "lnl_before", "lnl_after")}
+    also["spr_c5_25k"]["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+    return also
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
@@ -231,9 +604,9 @@ def main():
     in_rank_env = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     internal = args.topology == "internal" and args.gpus > 1
     if internal:
-        import torch
-        if torch.cuda.device_count() < args.gpus and os.environ.get("PLLHIP_ALLOW_DEVICE_WRAP") != "1":
-            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible")
+        have = kfd_gpu_count()
+        if have is not None and have < args.gpus and os.environ.get("PLLHIP_ALLOW_DEVICE_WRAP") != "1":
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible")
     elif args.gpus > 1 and not in_rank_env:
         launch_ranks(args)                      # never returns
     rank = int(os.environ.get("RANK", "0"))
@@ -253,6 +626,9 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    # kernel arguments in device memory (3 - 5 us per short launch, pll_core.hip): decided HERE, before any
+    # library that initialises the HIP runtime is loaded, so that N = 1 and N > 1 run under the same setting
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     if world > 1:
         # torch brings its own HIP and RCCL runtimes (same SONAMEs as /opt/rocm's): whichever is
         # loaded first serves the whole process, and torch does not find the GPU on the system's.
@@ -284,31 +660,8 @@ def main():
     if internal and not product.lib.pllhip_set_sharding(args.gpus, None):
         raise SystemExit(product.errmsg)
 
-    states, rate_cats, ntips, nsites = pc.CONFIGS[args.config]
-    if args.sites:
-        nsites = args.sites
-    if args.taxa:
-        ntips = args.taxa
-    per_branch = args.pmatrix_calls == "per-branch"
-    tree = pc.Tree(ntips, 42, 43)
-
-    # ONE alignment for the whole job; rank r owns a contiguous site range of every partition
-    # (strong: the configured site count is split; weak: it is the per-GPU share)
-    job_plan = partition_plan(args.config, states, nsites * (world if args.scaling == "weak" else 1))
-    plan, first_sites = [], []
-    for s_, n_ in job_plan:
-        lo, hi = n_ * rank // world, n_ * (rank + 1) // world
-        plan.append((s_, hi - lo))
-        first_sites.append(lo)
-    local_sites = sum(n for _, n in plan)
-    total_sites = sum(n for _, n in job_plan)
-    if min(n for _, n in plan) < 1:
-        raise SystemExit("bench.py: fewer sites than ranks")
-    ev, insts = make_evaluation(pc, product, tree, plan, rate_cats, 44, per_branch, first_sites)
-    inst = max(insts, key=lambda i: i.N * i.S)        # the partition that dominates the traffic
-
-    reduce_cb = None
-    if world > 1 and args.comm == "rccl":
+    comm_mode = args.comm
+    if world > 1 and comm_mode == "rccl":
         # one RCCL communicator per rank (C, behind the reference's parallel_reduce_cb
         # semantics); its unique id travels through torch's store.  The driver leaves every
         # partition's lnL in a device-resident slot and all-reduces the slots in place
@@ -319,185 +672,39 @@ def main():
         obj = [idbuf.raw]
         dist.broadcast_object_list(obj, src=0)
         comm = product.lib.pllhip_comm_create(obj[0], rank, world, local_rank)
-        ok = bool(comm) and bool(product.lib.pllhip_eval_attach_comm(ev.ev, comm))
         # every rank must take the same path: agree on the outcome before going on
         import torch
-        flag = torch.tensor([1.0 if ok else 0.0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        flag = torch.tensor([1.0 if comm else 0.0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if flag.item() < 1.0:
             print(f"bench.py: rank {rank}: the library's communicator is not available ({product.errmsg}); "
                   "falling back to the reduce hook over torch.distributed", file=sys.stderr)
-            product.lib.pllhip_eval_set_fused(ev.ev, None)      # back to blocking calls + the reduce hook
             if comm:
                 product.lib.pllhip_comm_destroy(comm)
             comm = None
-            args.comm = "torch"
-    if world > 1 and args.comm == "torch":
-        # rehearsal path: the reference's reduce hook served by torch.distributed (any backend)
-        import torch
-        ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}    # include/pllhip.h PLLHIP_REDUCE_*
-        on_gpu = dist.get_backend() == "nccl"
+            comm_mode = "torch"
 
-        def _reduce(ctx, data, n, op):
-            arr = np.ctypeslib.as_array(data, shape=(n,))
-            t = torch.from_numpy(arr.copy())
-            if on_gpu:
-                t = t.cuda()
-            dist.all_reduce(t, op=ops[op])
-            arr[:] = t.cpu().numpy()
+    ctx = Ctx(pc=pc, product=product, args=args, rank=rank, world=world, dist=dist, comm=comm,
+              comm_mode=comm_mode, internal=internal)
+    out = run_leg(ctx, args.config, sites=args.sites, taxa=args.taxa, steps=args.steps, warmup=args.warmup,
+                  cpu=None if args.no_cpu_baseline else "full")
+    out["runtime"] = {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG"),
+                      "torch_loaded_before_engine": world > 1}
+    default_run = (world == 1 and not internal and args.config == "c3" and not args.sites and not args.taxa and
+                   not args.rate_scalers and not args.no_also and not args.no_cpu_baseline)
+    if default_run:
+        t0 = time.perf_counter()
+        out["also"] = also_legs(ctx)
+        out["also"]["wall_s"] = round(time.perf_counter() - t0, 1)
 
-        reduce_cb = pc.REDUCE_CB(_reduce)
-        ev.set_parallel_context(reduce_cb)
-
-    nops = ntips - 2
-
-    def barrier():
-        for i in insts:
-            product.lib.pllhip_synchronize(i.p)
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        ev.loglh()
-    for i in insts:
-        product.lib.pllhip_profile_partials(i.p, 1)
-    barrier()
-    t0 = time.perf_counter()
-    lnl = 0.0
-    for _ in range(args.steps):
-        lnl = ev.loglh()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = pc.Profile()           # summed over the partitions of the evaluation
-    for i in insts:
-        one = pc.Profile()
-        product.lib.pllhip_profile_read(i.p, C.byref(one))
-        product.lib.pllhip_profile_partials(i.p, 0)
-        for f, _ in pc.Profile._fields_:
-            setattr(prof, f, getattr(prof, f) + getattr(one, f))
-    counters = inst.counters()
-
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    kernel = product.lib.pllhip_partials_kernel_name(inst.p).decode()
-    updates_per_step = nops * total_sites * rate_cats
-    value = updates_per_step * args.steps / elapsed
-
-    # roofline of the dominant kernel (pll_update_partials), from the HIP events
-    # recorded around its launches during the timed region on rank 0
-    achieved = prof.algorithmic_bytes / (prof.kernel_ms * 1e-3) / 1e9 if prof.kernel_ms > 0 else 0.0
-    if len(insts) > 1:
-        # partitions run on their own streams and overlap on the device: the summed
-        # event times exceed the wall time, so the kernels are priced against the
-        # whole step instead (a lower bound of what they achieve)
-        achieved = prof.algorithmic_bytes / elapsed / 1e9
-    traffic = None
-    traffic_source = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and world == 1 and not args.sites and not args.taxa and not args.rate_scalers:
-        try:
-            tj = json.load(open(tpath))
-            per_step = tj.get(f"{args.config}:{kernel}:per_step")
-            if per_step and prof.launches:
-                traffic = round(per_step * args.steps / prof.launches)      # per launch, like `achieved`
-            else:
-                traffic = tj.get(f"{args.config}:{kernel}")
-            traffic_source = ("profiles/traffic.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                              "this command (tools/gpu_profile.sh), NOT measured in this run")
-        except Exception:
-            traffic = None
-    tflops = prof.algorithmic_flops / (prof.kernel_ms * 1e-3) / 1e12 if prof.kernel_ms > 0 else 0.0
-    # the kernel is priced against the roof that bounds it: HBM for 4 and 20 states
-    # (0.7 and 3.4 flop/B), the FP64 matrix pipe for 61 states (10.2 flop/B ~ the ridge)
-    mfma_bound = states > 32
-    roofline = {
-        "bound": "mfma" if mfma_bound else "hbm", "kernel": kernel,
-        "achieved": round(tflops, 2) if mfma_bound else round(achieved, 1),
-        "peak": FP64_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
-        "unit": "TFLOP/s" if mfma_bound else "GB/s",
-        "frac": round(tflops / FP64_MFMA_PEAK_TFLOPS, 4) if mfma_bound else round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": traffic, "traffic_source": traffic_source,
-        "algorithmic_GBps": round(achieved, 1), "algorithmic_TFLOPs": round(tflops, 2),
-        "launches": int(prof.launches), "ops": int(prof.ops),
-        "avg_launch_ms": round(prof.kernel_ms / max(1, prof.launches), 4),
-        "algorithmic_bytes_per_launch": round(prof.algorithmic_bytes / max(1, prof.launches)),
-        "kernel_share_of_step": round(prof.kernel_ms * 1e-3 / elapsed, 4),
-        # tools/micro/mfma_f64.hip: v_mfma_f64_16x16x4_f64 back to back on every SIMD sustains
-        # 47.5 TFLOP/s on this chip (29.9 ns per MFMA per SIMD with <= 128 CUs busy, 44.1 ns with
-        # all 256: clocks drop under a full-chip FP64 matrix load), not the 78.6 TFLOP/s data-sheet peak
-        "mfma_sustained_measured_TFLOPs": FP64_MFMA_SUSTAINED_TFLOPS if mfma_bound else None,
-        "frac_of_sustained": round(tflops / FP64_MFMA_SUSTAINED_TFLOPS, 4) if mfma_bound else None,
-        # HBM rate implied by the PMC traffic of the committed profile (same command): with
-        # operation chains the carried child of a link is not re-read, so the real traffic
-        # is BELOW the algorithmic bytes (SURVEY.md 8d counts every child as one read)
-        "traffic_GBps": (round(traffic / (prof.kernel_ms / max(1, prof.launches) * 1e-3) / 1e9, 1)
-                         if traffic and prof.kernel_ms > 0 and len(insts) == 1 else None),
-        "traffic_over_algorithmic": (round(traffic / (prof.algorithmic_bytes / max(1, prof.launches)), 3)
-                                     if traffic and prof.algorithmic_bytes > 0 and len(insts) == 1 else None),
-        "method": ("algorithmic bytes of all partials launches / step wall time (partitions overlap on "
-                   "concurrent streams)") if len(insts) > 1 else
-                  "algorithmic bytes of the partials launches / their HIP-event time (rank 0)",
-    }
-
-    ev.close()                   # frees the CLVs: the parity sample below gets its own partitions
     if comm:
         product.lib.pllhip_comm_destroy(comm)
-
-    cpu = parity = None
     if internal:
         product.lib.pllhip_set_sharding(0, None)
-    if rank == 0 and world == 1 and not internal and not args.no_cpu_baseline:
-        cpu, parity = cpu_baseline(pc, product, tree, args.config, states, rate_cats, local_sites,
-                                   args.cpu_sites, per_branch)
-
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-
     if rank == 0:
-        names = {"c2": "C2 DNA GTR+G4", "c4": "C4 mixed: 2 DNA GTR+G4 + 2 protein GTR20+G4 partitions, linked branch lengths",
-                 "c3": "C3 protein 'LG-shaped' GTR20+G4 (real LG table unavailable offline)",
-                 "c5": "C5 codon GY94-shaped+G4"}
-        evals = max(1, args.steps + args.warmup)
-        out = {
-            "metric": "CLV site-updates/sec (sites x rates x edges); |dlnL| vs ref",
-            "value": value, "unit": "CLV site-updates/s",
-            "n_gpus": args.gpus if internal else world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {
-                "workload": f"{names[args.config]}: {states} states, {rate_cats} rate cats, {ntips} taxa, "
-                            f"{total_sites} sites total ({local_sites} on rank 0), full traversal "
-                            f"({nops} ops + {tree.nedges} P-matrices + edge lnL"
-                            f"{(' + RCCL all-reduce of the lnL on the device' if args.comm == 'rccl' else ' + lnL summed through the reduce hook (torch.distributed)') if world > 1 else ''}) per step",
-                "config": args.config, "states": states, "rate_cats": rate_cats, "taxa": ntips,
-                "sites_total": total_sites, "sites_per_gpu": local_sites, "ops_per_step": nops,
-                "partitions": [{"states": s, "sites_per_gpu": n} for s, n in plan],
-                "tips": "1-byte codes",
-                "scalers": ("per (site, rate)" if args.rate_scalers else "per-site") + ", one buffer per inner node",
-                "pmatrix_calls": args.pmatrix_calls,
-                "pmatrix_launches_per_step": counters.pmatrix_launches // evals,
-                "partial_launches_per_step": counters.partial_launches // evals,
-                "parallelism": (f"one process, every partition spread over {args.gpus} devices inside the engine, "
-                                f"lnL summed on the host" if internal else
-                                f"sites sharded over {world} GPU(s), lnL all-reduced" if world > 1 else "1 GPU"),
-            },
-            # the same alignment at every N: the summed lnL must not depend on n_gpus
-            "lnl": lnl, "lnl_per_site": lnl / total_sites,
-            "dlnl_per_site": parity["dlnl_per_site"] if parity else None,
-            "max_persite_dlnl": parity["max_persite_dlnl"] if parity else None,
-            "parity": parity,
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-        }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 

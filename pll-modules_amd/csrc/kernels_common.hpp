@@ -123,7 +123,24 @@ __device__ inline void publish_result(const ReduceOut & ro)
 }
 
 // what every block does after its totals are stored (write-through) and waited for:
-// draw the ticket(s); the last block adds all block totals and publishes
+// draw the ticket(s); the last block adds all block totals and publishes.
+//
+// Memory-model note.  The hand-off is: producer -- relaxed agent-scope atomic STORES of its totals,
+// `s_waitcnt vmcnt(0)` (the stores have been acknowledged), relaxed agent-scope fetch-add on the ticket;
+// consumer (the block that draws the last ticket) -- acquire fence at agent scope, relaxed agent-scope atomic
+// LOADS of all totals.  In the language's model a relaxed store followed by a relaxed RMW gives no
+// happens-before edge; the code relies on what the AMDGPU backend documents for gfx942 / gfx950 in the LLVM
+// "User Guide for AMDGPU Backend", section "Memory Model" (tables "AMDHSA Memory Model Code Sequences
+// GFX942"): an agent-scope atomic store is emitted with sc1 = 1, i.e. written through to the memory every XCD's
+// L2 is coherent with; `s_waitcnt vmcnt(0)` is exactly what a release at agent scope inserts in front of
+// the following atomic to order earlier stores; the acquire fence invalidates the consumer's L1 / non-coherent
+// L2 lines (buffer_inv sc1), and agent-scope atomic loads bypass them anyway.  So the instruction sequence IS
+// the release-acquire sequence of that guide, minus the `buffer_wbl2 sc1` write-back of the whole L2 that a
+// __threadfence() / release fence adds -- which is what made the straightforward form 3x slower (thousands of
+// short streaming blocks each flushing their XCD's L2).  It is outside the C++ model, therefore guarded:
+// tests/test_gpu_results.py::test_single_launch_reduction_equals_two_launch_form compares it bit for bit with
+// the two-launch form (PLLHIP_FUSED_FINISH=0), which needs no such argument, and a port to another target
+// must re-derive it (or set fused_finish = false).
 template <int Q>
 __device__ inline void grid_reduce_tail(const ReduceOut & ro, double * scratch)
 {

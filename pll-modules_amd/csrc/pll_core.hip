@@ -123,10 +123,18 @@ static bool dev_alloc(T ** ptr, size_t count, const char * what)
 // 25 k-site codon slice: W3 -3 ... -6 %, C5 at 25 k sites 1.73 -> 1.65 ms per step).  Set when the
 // library is loaded, i.e. before its first HIP call, unless the user has decided otherwise; a runtime
 // that another component initialised earlier keeps its setting.
+// The setting is process-global and setenv() is not safe against a concurrent getenv() in another thread of a
+// host application that dlopen()s this library late: such an application sets HIP_FORCE_DEV_KERNARG itself
+// before it starts threads (what bench.py and the tools do) and switches this off -- at run time with
+// PLLHIP_SET_RUNTIME_DEFAULTS=0, or at build time with -DPLLHIP_NO_RUNTIME_DEFAULTS.
+#ifndef PLLHIP_NO_RUNTIME_DEFAULTS
 __attribute__((constructor)) static void pllhip_runtime_defaults()
 {
-  setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
+  const char * opt = getenv("PLLHIP_SET_RUNTIME_DEFAULTS");
+  if (opt && !atoi(opt)) return;
+  if (!getenv("HIP_FORCE_DEV_KERNARG")) setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
 }
+#endif
 
 // partitions alive per device (whole-traversal launches are the default for a partition that has
 // its device to itself)

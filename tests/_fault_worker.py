@@ -27,7 +27,7 @@ def main():
         if rank == 1:
             os.environ["PLLHIP_EVAL_FAULT"] = "2"
     else:
-        os.environ["PLLHIP_FAULT"] = {"deposit": "deposit@3", "collective": "collective@2", "publish": "publish@2"}[mode]
+        os.environ["PLLHIP_FAULT"] = {"deposit": "deposit@5", "collective": "collective@2", "publish": "publish@2"}[mode]
         os.environ["PLLHIP_COLLECTIVE_TIMEOUT_S"] = "1"
     import pllhip_ctypes as pc
     import _evaldriver_worker as W

@@ -347,6 +347,24 @@ def test_bench_two_ranks_sharing_one_gpu():
             assert "falling back" in two.stderr
 
 
+def test_bench_c4_partitions_balanced_over_two_ranks():
+    """`bench.py --config c4 --gpus 2`: the four partitions are shared out by cost -- whole partitions / large
+    slices per rank, NULL slots for the rest -- and the summed lnL is that of the one-rank run"""
+    args = ["--config", "c4", "--sites", "40000", "--taxa", "24", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    env = dict(os.environ, PLLHIP_ALLOW_DEVICE_WRAP="1", PLLHIP_BENCH_DIST_BACKEND="gloo")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args,
+                         check=True, capture_output=True, text=True, timeout=600).stdout
+    b = json.loads([ln for ln in one.splitlines() if ln.startswith("{")][-1])
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "torch"] + args,
+                         env=env, check=True, capture_output=True, text=True, timeout=600)
+    a = json.loads(two.stdout)
+    assert a["n_gpus"] == 2 and a["config"]["sites_total"] == b["config"]["sites_total"] == 30000
+    assert "cost-balanced" in a["config"]["partition_assignment"]
+    parts = a["config"]["partitions"]
+    assert any(p.get("remote") for p in parts) and sum(p["sites_on_rank0"] for p in parts) < 30000
+    assert abs(a["lnl"] - b["lnl"]) <= 1e-9 * abs(b["lnl"])
+
+
 def test_engine_on_the_runtime_torch_loaded():
     """a rank of `bench.py --gpus N` imports torch first, so the engine and its communicator run on the
     HIP / RCCL libraries of the torch wheel (same SONAMEs as the system's): torch.cuda
