@@ -1,7 +1,7 @@
-// kernels_s16.hpp -- 2 .. 16 states on the fp64 matrix cores: binary, genotype (10 / 16
-// states, src/util/models_gt.c), multistate alphabets (src/util/models_mult.c), and 4 states
-// with a rate count the 4-state family does not take.  Also the family that carries
-// PLL_ATTRIB_RATE_SCALERS for these alphabets.
+// kernels_s16.hpp -- 2 .. 32 states on the fp64 matrix cores: binary, genotype (10 / 16
+// states, src/util/models_gt.c), multistate alphabets (up to 64 states, src/util/models_mult.c:92-97; this
+// family takes them up to 32, the 61-state family from 33), and 4 / 20 states with a rate count their own
+// families do not take.  Also the family that carries PLL_ATTRIB_RATE_SCALERS for these alphabets.
 //
 // Same blocked device layout and lane mapping as the 20- and 61-state families
 // (kernels_s20.hpp): clv[site_block][rate][state row][32 sites]; a (block, rate) unit is a
@@ -9,7 +9,8 @@
 // l = 16 q + n holds sites 2n, 2n + 1 and slot k of a lane is row 4 k + q -- for the MFMA B
 // operand (k-step k) and the MFMA D result (register k) alike, so every CLV access is a fully
 // coalesced 1 KiB wave instruction and what one operation stores is what the next one loads.
-// One 16-row M tile covers all states: KS MFMAs per child, unit and site parity.  The kernels
+// MT = ceil(KS / 4) 16-row M tiles cover all states (one up to 16 states, two up to 32): MT x KS MFMAs per
+// child, unit and site parity; slot k of a lane is D register k % 4 of M tile k / 4.  The kernels
 // are HBM-bound at every S (S = 16: 512 MACs per 128 B loaded).
 //
 // Scaling: per site (all R x S entries below 2^-256: store unscaled, rare fix-up of the units
@@ -25,20 +26,46 @@ namespace pllhip {
 
 constexpr unsigned S16_LUT_LDS = 3072;       // doubles of LDS a tip lookup table may take per child
 
+constexpr unsigned s16_mt(unsigned KS) { return (KS + 3) / 4; }            // 16-row M tiles
+constexpr unsigned s16_fr(unsigned KS) { return s16_mt(KS) * KS * 64; }     // fragment doubles per (child, rate)
+
 // A fragments of a matrix set [R][S][Sp] (row-major) into LDS:
-//   frag[(r * KS + ks) * 64 + lane] = M[r][lane & 15][4 ks + (lane >> 4)]   (0 beyond S)
+//   frag[((r * MT + mt) * KS + ks) * 64 + lane] = M[r][16 mt + (lane & 15)][4 ks + (lane >> 4)]   (0 beyond S)
 template <unsigned KS>
 __device__ inline void s16_fill_frags(double * frag, const double * mats, unsigned R, unsigned S, unsigned Sp)
 {
-  for (unsigned e = threadIdx.x; e < R * KS * 64; e += blockDim.x)
+  constexpr unsigned MT = s16_mt(KS);
+  for (unsigned e = threadIdx.x; e < R * MT * KS * 64; e += blockDim.x)
   {
-    const unsigned lane = e & 63, f = e >> 6, ks = f % KS, r = f / KS;
-    const unsigned i = lane & 15, j = 4 * ks + (lane >> 4);
+    const unsigned lane = e & 63, f = e >> 6, ks = f % KS, mt = (f / KS) % MT, r = f / (KS * MT);
+    const unsigned i = 16 * mt + (lane & 15), j = 4 * ks + (lane >> 4);
     frag[e] = (i < S && j < S) ? mats[((size_t)r * S + i) * Sp + j] : 0.0;
   }
 }
 
-// child term in D layout: t[v] = {even site, odd site} of row 4 v + q
+// child term from a B operand in registers (b[ks] = rows 4 ks + q of the child vector), D layout out:
+// t[v] = {even site, odd site} of row 4 v + q
+template <unsigned KS>
+__device__ inline void s16_child_regs(const double2 b[KS], const double * frag_r, unsigned lane, double2 t[KS])
+{
+  constexpr unsigned MT = s16_mt(KS);
+  v4d acc_e[MT], acc_o[MT];
+#pragma unroll
+  for (unsigned mt = 0; mt < MT; ++mt) { acc_e[mt] = v4d{0, 0, 0, 0}; acc_o[mt] = v4d{0, 0, 0, 0}; }
+#pragma unroll
+  for (unsigned ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (unsigned mt = 0; mt < MT; ++mt)
+    {
+      const double f = frag_r[(mt * KS + ks) * 64 + lane];
+      acc_e[mt] = mfma_f64(f, b[ks].x, acc_e[mt]);
+      acc_o[mt] = mfma_f64(f, b[ks].y, acc_o[mt]);
+    }
+#pragma unroll
+  for (unsigned v = 0; v < KS; ++v) t[v] = make_double2(acc_e[v / 4][v % 4], acc_o[v / 4][v % 4]);
+}
+
+// child term in D layout from a unit in memory
 template <unsigned KS>
 __device__ inline void s16_child_inner(const double * unit, const double * frag_r, unsigned lane, double2 t[KS],
                                        bool nt = false)
@@ -55,16 +82,7 @@ __device__ inline void s16_child_inner(const double * unit, const double * frag_
     }
     else b[ks] = *reinterpret_cast<const double2 *>(unit + ks * 128 + lane * 2);
   }
-  v4d acc_e = {0, 0, 0, 0}, acc_o = {0, 0, 0, 0};
-#pragma unroll
-  for (unsigned ks = 0; ks < KS; ++ks)
-  {
-    const double f = frag_r[ks * 64 + lane];
-    acc_e = mfma_f64(f, b[ks].x, acc_e);
-    acc_o = mfma_f64(f, b[ks].y, acc_o);
-  }
-#pragma unroll
-  for (unsigned v = 0; v < KS; ++v) t[v] = make_double2(acc_e[v], acc_o[v]);
+  s16_child_regs<KS>(b, frag_r, lane, t);
 }
 
 // lookup table rows [code][S]
@@ -161,9 +179,9 @@ __global__ __launch_bounds__(256) void k_partials_s16(OpBatch batch, unsigned nb
     {
       const size_t ubase = ((size_t)blk * R + r) * UNIT;
       double2 t1[KS], t2[KS];
-      if (!op.codes1) s16_child_inner<KS>(op.clv1 + ubase, tab1 + r * KS * 64, lane, t1);
+      if (!op.codes1) s16_child_inner<KS>(op.clv1 + ubase, tab1 + r * s16_fr(KS), lane, t1);
       else s16_child_tip<KS>(l1 + (size_t)r * lut_codes * S, c1e, c1o, q, S, t1);
-      if (!op.codes2) s16_child_inner<KS>(op.clv2 + ubase, tab2 + r * KS * 64, lane, t2);
+      if (!op.codes2) s16_child_inner<KS>(op.clv2 + ubase, tab2 + r * s16_fr(KS), lane, t2);
       else s16_child_tip<KS>(l2 + (size_t)r * lut_codes * S, c2e, c2o, q, S, t2);
       int re = 1, ro = 1;
 #pragma unroll
@@ -238,21 +256,6 @@ constexpr unsigned S16_CHAIN_WAVES = 8;
 constexpr unsigned S16_CHAIN_MAX = 8;
 constexpr unsigned S16_CHAIN_LDS = 20480;             // doubles: the whole LDS of a CU
 
-template <unsigned KS>
-__device__ inline void s16_child_regs(const double2 b[KS], const double * frag_r, unsigned lane, double2 t[KS])
-{
-  v4d acc_e = {0, 0, 0, 0}, acc_o = {0, 0, 0, 0};
-#pragma unroll
-  for (unsigned ks = 0; ks < KS; ++ks)
-  {
-    const double f = frag_r[ks * 64 + lane];
-    acc_e = mfma_f64(f, b[ks].x, acc_e);
-    acc_o = mfma_f64(f, b[ks].y, acc_o);
-  }
-#pragma unroll
-  for (unsigned v = 0; v < KS; ++v) t[v] = make_double2(acc_e[v], acc_o[v]);
-}
-
 // one operation for one site block; X: the handed-over operand on entry (carried != 0), the result on
 // exit; xe / xo: the scaler counts that go with X (per rate with RS, else element 0)
 template <unsigned KS, unsigned RT, bool RS>
@@ -275,11 +278,11 @@ __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2
   {
     const size_t ubase = ((size_t)blk * RT + r) * UNIT;
     double2 t1[KS], t2[KS];
-    if (carried == 1) s16_child_regs<KS>(X[r], s1 + r * KS * 64, lane, t1);
-    else if (!op.codes1) s16_child_inner<KS>(op.clv1 + ubase, s1 + r * KS * 64, lane, t1, ntl);
+    if (carried == 1) s16_child_regs<KS>(X[r], s1 + r * s16_fr(KS), lane, t1);
+    else if (!op.codes1) s16_child_inner<KS>(op.clv1 + ubase, s1 + r * s16_fr(KS), lane, t1, ntl);
     else s16_child_tip<KS>(l1 + (size_t)r * lut_codes * S, c1e, c1o, q, S, t1);
-    if (carried == 2) s16_child_regs<KS>(X[r], s2 + r * KS * 64, lane, t2);
-    else if (!op.codes2) s16_child_inner<KS>(op.clv2 + ubase, s2 + r * KS * 64, lane, t2, ntl);
+    if (carried == 2) s16_child_regs<KS>(X[r], s2 + r * s16_fr(KS), lane, t2);
+    else if (!op.codes2) s16_child_inner<KS>(op.clv2 + ubase, s2 + r * s16_fr(KS), lane, t2, ntl);
     else s16_child_tip<KS>(l2 + (size_t)r * lut_codes * S, c2e, c2o, q, S, t2);
     int re = 1, ro = 1;
 #pragma unroll
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(256) void k_edge_lnl_s16(ModelView mv, ParamIdx fid
         for (unsigned v = 0; v < KS; ++v) t[v] = make_double2(1.0, 1.0);
       }
       else if (child.codes) s16_child_tip<KS>(lut + (size_t)r * lut_codes * S, cce, cco, q, S, t);
-      else s16_child_inner<KS>(child.clv + ubase, frag + r * KS * 64, lane, t);
+      else s16_child_inner<KS>(child.clv + ubase, frag + r * s16_fr(KS), lane, t);
       if (parent.codes) s16_tip_d<KS>(pme, pmo, q, S, pv);
       else s16_load_d<KS>(parent.clv + ubase, lane, pv);
       double le = 0.0, lo = 0.0;
@@ -559,9 +562,18 @@ __global__ __launch_bounds__(256) void k_sumtable_prep_s16(ModelView mv, ParamId
 // --- launchers -------------------------------------------------------------
 
 #define PLLHIP_DISPATCH_KS(ks, CALL) \
-  do { switch (ks) { case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; default: CALL(4); } } while (0)
+  do { switch (ks) { case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; \
+                     case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; default: CALL(8); } } while (0)
 
 static unsigned s16_ks(const Engine * e) { return (e->S + 3) / 4; }
+// A-fragment doubles per (child, rate): MT x KS x 64
+static unsigned s16_frags(const Engine * e) { const unsigned ks = s16_ks(e); return ((ks + 3) / 4) * ks * 64; }
+// can the family carry this alphabet and rate count?  (both children's fragments of all rates in LDS)
+static bool s16_supported(unsigned S, unsigned R)
+{
+  const unsigned ks = (S + 3) / 4;
+  return S >= 2 && S <= 32 && (size_t)2 * R * ((ks + 3) / 4) * ks * 64 * sizeof(double) <= 160 * 1024;
+}
 
 static unsigned s16_grid(const Engine * e, unsigned blocks_per_cu)
 {
@@ -572,13 +584,31 @@ static unsigned s16_grid(const Engine * e, unsigned blocks_per_cu)
 // LDS doubles per child table: its A fragments, or its tip lookup table when that is small enough
 static unsigned s16_table(const Engine * e)
 {
-  const unsigned frags = e->R * s16_ks(e) * 64, lut = e->R * e->lut_codes * e->S;
+  const unsigned frags = e->R * s16_frags(e), lut = e->R * e->lut_codes * e->S;
   return (e->coded_tips && lut <= S16_LUT_LDS) ? std::max(frags, lut) : frags;
+}
+
+// beyond 16 states with many rates the tables pass the 64 KiB a kernel gets without asking
+static int s16_allow_lds(Engine * e)
+{
+  static bool attr_set_dev[64] = {false};
+  bool & attr_set = attr_set_dev[e->device & 63];
+  if (attr_set) return PLL_SUCCESS;
+#define PLLHIP_ATTR(KK) \
+  do { \
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_partials_s16<KK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_lnl_s16<KK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+  } while (0)
+  PLLHIP_ATTR(5); PLLHIP_ATTR(6); PLLHIP_ATTR(7); PLLHIP_ATTR(8);
+#undef PLLHIP_ATTR
+  attr_set = true;
+  return PLL_SUCCESS;
 }
 
 static int launch_partials_s16(Engine * e, const OpBatch & batch, unsigned nops)
 {
   const unsigned table = s16_table(e);
+  if (sizeof(double) * 2 * table > 64 * 1024 && !s16_allow_lds(e)) return PLL_FAILURE;
 #define PLLHIP_CALL(KK) \
   hipLaunchKernelGGL(k_partials_s16<KK>, dim3(s16_grid(e, 8), nops), dim3(256), sizeof(double) * 2 * table, e->stream, \
                      batch, e->nblk, e->R, e->S, e->Sp, e->lut_codes, table, e->rate_scalers ? 1u : 0u)
@@ -596,7 +626,7 @@ static bool s16_chain_lut_lds(const Engine * e) { return e->R * e->lut_codes * e
 // LDS doubles of one child's table in a chain (0: tip table gathered from global memory)
 static unsigned s16_chain_slot(const Engine * e, bool tip)
 {
-  if (!tip) return e->R * s16_ks(e) * 64;
+  if (!tip) return e->R * s16_frags(e);
   return s16_chain_lut_lds(e) ? ((e->R * e->lut_codes * e->S + 7u) & ~7u) : 0u;
 }
 
@@ -619,6 +649,7 @@ static int launch_traverse_s16(Engine * e, const PlanView & plan, unsigned lds_d
   if (!attr_set)
   {
     PLLHIP_ATTR(1); PLLHIP_ATTR(2); PLLHIP_ATTR(3); PLLHIP_ATTR(4);
+    PLLHIP_ATTR(5); PLLHIP_ATTR(6); PLLHIP_ATTR(7); PLLHIP_ATTR(8);
     attr_set = true;
   }
 #undef PLLHIP_ATTR
@@ -643,8 +674,9 @@ static int launch_edge_lnl_s16(Engine * e, const ModelView & mv, const ParamIdx 
                                const unsigned * ps, const unsigned * cs,
                                double * persite, unsigned nblocks)
 {
+  if (sizeof(double) * e->R * s16_frags(e) > 64 * 1024 && !s16_allow_lds(e)) return PLL_FAILURE;
 #define PLLHIP_CALL(KK) \
-  hipLaunchKernelGGL(k_edge_lnl_s16<KK>, dim3(nblocks), dim3(256), sizeof(double) * e->R * KK * 64, e->stream, \
+  hipLaunchKernelGGL(k_edge_lnl_s16<KK>, dim3(nblocks), dim3(256), sizeof(double) * e->R * s16_fr(KK), e->stream, \
                      mv, fidx, parent, child, pm, lut, e->lut_codes, ps, cs, e->d_weights, e->d_invariant, \
                      e->d_tipmap, e->N, e->nblk, e->R, persite, reduce_out(e), e->rate_scalers ? 1u : 0u)
   PLLHIP_DISPATCH_KS(s16_ks(e), PLLHIP_CALL);

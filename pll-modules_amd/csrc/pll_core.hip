@@ -229,7 +229,8 @@ Engine * engine_create(pll_partition_t * p)
   else if (e->S == 4 && (e->R & (e->R - 1)) == 0) e->family = KernelFamily::S4;
   else if (e->S == 20 && e->R <= 8) e->family = KernelFamily::S20;
   else if (e->S == 61) e->family = KernelFamily::S61;
-  else if (e->S <= 16 && !no_s16) e->family = KernelFamily::S16;
+  // 2 .. 32 states (17 .. 32: two M tiles): every alphabet the 4- and 20-state families do not take
+  else if (s16_supported(e->S, e->R) && !no_s16) e->family = KernelFamily::S16;
   else e->family = KernelFamily::Generic;
   e->blocked = (e->family == KernelFamily::S20 || e->family == KernelFamily::S61 || e->family == KernelFamily::S16);
   e->rows = !e->blocked ? 0u : (e->family == KernelFamily::S16) ? 4u * ((e->S + 3u) / 4u) : e->Sp;

@@ -535,6 +535,62 @@ def test_run_to_run_determinism(product):
         assert len(vals) == 1
 
 
+MATRIX_CORE_ALPHABETS = [17, 24, 25, 32, 33, 48, 60, 62, 63, 64]
+
+
+@pytest.mark.parametrize("states", MATRIX_CORE_ALPHABETS)
+@pytest.mark.parametrize("coded", [True, False])
+def test_every_alphabet_up_to_64_states_runs_on_the_matrix_cores(product, oracle, states, coded):
+    """multistate alphabets up to 64 states (src/util/models_mult.c:92-97) and the 60 / 62 / 63-codon genetic
+    codes: no state count falls back to the one-thread-per-element kernels; CLVs, scalers, lnL, root lnL,
+    sumtable and derivatives (single and multi-length) against the oracle, with and without per-rate scalers"""
+    name = None
+    for attributes in (0, pc.PLL_ATTRIB_RATE_SCALERS):
+        ntips, nsites = (9, 257) if states > 32 else (14, 517)
+        a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=ntips, nsites=nsites, coded=coded,
+                     attributes=attributes)
+        with a, b:
+            name = product.lib.pllhip_partials_kernel_name(a.p).decode()
+            assert name != "generic", (states, name)
+            la, lb = pc.full_traversal(a), pc.full_traversal(b)
+            tol = 5e-8 * a.N if states > 32 else max(REL_LNL * abs(lb), PER_SITE * a.N)
+            assert abs(la - lb) <= tol, (la, lb)
+            t = a.tree
+            for op in t.ops:
+                ca, cb = a.get_clv(op[0]), b.get_clv(op[0])
+                err = site_err(ca, cb)
+                assert err < (1e-8 if states <= 32 else CLV_SITE_61), (op[0], err)
+                assert np.array_equal(a.get_scaler(op[1]), b.get_scaler(op[1]))
+            sa, sb = t.scaler_of(t.root_a), t.scaler_of(t.root_b)
+            ra, rb = a.root_lnl(t.root_a, sa), b.root_lnl(t.root_a, sa)
+            assert abs(ra - rb) <= tol
+            sta, stb = a.alloc_sumtable(), b.alloc_sumtable()
+            a.update_sumtable(t.root_a, t.root_b, sa, sb, sta)
+            b.update_sumtable(t.root_a, t.root_b, sa, sb, stb)
+            lens = [1e-3, 0.05, 0.4, 3.0]
+            rtol = 1e-9 if states <= 32 else 1e-5
+            mdf, mddf = a.derivatives_multi(sa, sb, lens, sta)
+            for k, bl in enumerate(lens):
+                da, db = a.derivatives(sa, sb, bl, sta), b.derivatives(sa, sb, bl, stb)
+                assert np.allclose(da, db, rtol=rtol, atol=1e-9 * a.N), (bl, da, db)
+                assert np.allclose([mdf[k], mddf[k]], db, rtol=rtol, atol=1e-9 * a.N)
+            a.free_sumtable(sta); b.free_sumtable(stb)
+
+
+@pytest.mark.parametrize("states,ntips", [(24, 300), (32, 300), (48, 140), (64, 140)])
+def test_deep_trees_scale_bit_exactly_at_the_new_alphabets(product, oracle, states, ntips):
+    a, b = _pair(product, oracle, states=states, rate_cats=4, ntips=ntips, nsites=97, coded=True)
+    with a, b:
+        la, lb = pc.full_traversal(a), pc.full_traversal(b)
+        assert abs(la - lb) <= (5e-8 if states > 32 else 2e-9) * a.N * max(1.0, ntips / 50)
+        top = 0
+        for op in a.tree.ops:
+            sa_, sb_ = a.get_scaler(op[1]), b.get_scaler(op[1])
+            assert np.array_equal(sa_, sb_)
+            top = max(top, int(sa_.max()))
+        assert top >= 1
+
+
 def test_specialised_kernels_are_the_ones_running(product):
     for states, name in ((4, b"s4-valu"), (20, b"s20-mfma"), (61, b"s61-mfma"), (5, b"s16-mfma"), (2, b"s16-mfma"),
                          (10, b"s16-mfma"), (16, b"s16-mfma"), (17, b"generic"), (33, b"generic")):
