@@ -25,6 +25,7 @@
 namespace pllhip {
 
 constexpr unsigned S16_LUT_LDS = 3072;       // doubles of LDS a tip lookup table may take per child
+constexpr int S16_MAX_LDS_BYTES = 160 * 1024 - 512;   // dynamic LDS a kernel of the family may ask for (it has a few static words)
 
 constexpr unsigned s16_mt(unsigned KS) { return (KS + 3) / 4; }            // 16-row M tiles
 constexpr unsigned s16_fr(unsigned KS) { return s16_mt(KS) * KS * 64; }     // fragment doubles per (child, rate)
@@ -572,7 +573,7 @@ static unsigned s16_frags(const Engine * e) { const unsigned ks = s16_ks(e); ret
 static bool s16_supported(unsigned S, unsigned R)
 {
   const unsigned ks = (S + 3) / 4;
-  return S >= 2 && S <= 32 && (size_t)2 * R * ((ks + 3) / 4) * ks * 64 * sizeof(double) <= 160 * 1024;
+  return S >= 2 && S <= 32 && (size_t)2 * R * ((ks + 3) / 4) * ks * 64 * sizeof(double) <= (size_t)S16_MAX_LDS_BYTES;
 }
 
 static unsigned s16_grid(const Engine * e, unsigned blocks_per_cu)
@@ -596,8 +597,8 @@ static int s16_allow_lds(Engine * e)
   if (attr_set) return PLL_SUCCESS;
 #define PLLHIP_ATTR(KK) \
   do { \
-    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_partials_s16<KK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_lnl_s16<KK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_partials_s16<KK>), hipFuncAttributeMaxDynamicSharedMemorySize, S16_MAX_LDS_BYTES)); \
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_lnl_s16<KK>), hipFuncAttributeMaxDynamicSharedMemorySize, S16_MAX_LDS_BYTES)); \
   } while (0)
   PLLHIP_ATTR(5); PLLHIP_ATTR(6); PLLHIP_ATTR(7); PLLHIP_ATTR(8);
 #undef PLLHIP_ATTR
@@ -619,7 +620,16 @@ static int launch_partials_s16(Engine * e, const OpBatch & batch, unsigned nops)
 }
 
 // one-launch traversals: four rate categories
-static bool chains_supported_s16(const Engine * e) { return e->R == 4; }
+// (per-site scaling keeps the block of ALL rates in registers until the vote: 4 x KS x 4 VGPRs; beyond
+// 20 states that spills -- 51 / 135 / 302 registers at 24 / 28 / 32 states -- and the level schedule with its
+// store-unscaled-and-fix-up kernel is the faster form at 32 states (500 k sites, 50 taxa: 12.8 against 14.7 ms;
+// 24 / 28 states: chains 6.4 / 10.1 against 8.0 / 12.8 ms).  Per-rate scalers settle a rate at a time: no limit.
+// PLLHIP_S16_CHAIN_KS: largest KS = ceil(S / 4) that takes chains with per-site scaling.)
+static bool chains_supported_s16(const Engine * e)
+{
+  static const unsigned max_ks = getenv("PLLHIP_S16_CHAIN_KS") ? (unsigned)atoi(getenv("PLLHIP_S16_CHAIN_KS")) : 7u;
+  return e->R == 4 && (e->rate_scalers || (e->S + 3) / 4 <= max_ks);
+}
 
 static bool s16_chain_lut_lds(const Engine * e) { return e->R * e->lut_codes * e->S <= S16_LUT_LDS; }
 

@@ -1,4 +1,7 @@
-// kernels_s61.hpp -- 61-state (codon) kernel family on the fp64 matrix cores.
+// kernels_s61.hpp -- 33 .. 64 states on the fp64 matrix cores: the 61-state codon models it was written for
+// (state count a compile-time constant there), the 60 / 62 / 63-codon genetic codes and multistate alphabets up
+// to 64 states (src/util/models_mult.c:92-97) with the state count as a run-time value S (P-matrix rows Sp
+// apart); units always have 64 rows.
 //
 // Same blocked device layout and lane mapping as the 20-state family
 // (kernels_s20.hpp): clv[site_block][rate][state row][32 sites], a (block, rate)
@@ -34,14 +37,14 @@ constexpr unsigned S61_FRAGS = S61_MT * S61_KS * 64; // A-fragment doubles per (
 
 // A fragments of rate r of a [R][61][64] row-major matrix set:
 //   frag[(mt*16 + ks)*64 + lane] = M[r][(lane&15) + 16*mt][4*ks + (lane>>4)]   (0 beyond row/col 60)
-__device__ inline void s61_fill_frags(double * frag, const double * mats, unsigned r)
+__device__ inline void s61_fill_frags(double * frag, const double * mats, unsigned r, unsigned S, unsigned Sp)
 {
-  const double * M = mats + (size_t)r * S61_S * S61_SP;
+  const double * M = mats + (size_t)r * S * Sp;
   for (unsigned e = threadIdx.x; e < S61_FRAGS; e += blockDim.x)
   {
     const unsigned lane = e & 63, f = e >> 6, ks = f & 15, mt = f >> 4;
     const unsigned i = (lane & 15) + 16 * mt, j = 4 * ks + (lane >> 4);
-    frag[e] = (i < S61_S && j < S61_S) ? M[(size_t)i * S61_SP + j] : 0.0;
+    frag[e] = (i < S && j < S) ? M[(size_t)i * Sp + j] : 0.0;
   }
 }
 
@@ -86,14 +89,14 @@ __device__ inline void s61_child_inner(const double * unit, const double * frag,
 
 // LUT row layout [code][61]
 __device__ inline void s61_child_tip(const double * lut_r, unsigned code_e, unsigned code_o,
-                                     unsigned q, double2 t[S61_KS])
+                                     unsigned q, double2 t[S61_KS], unsigned S)
 {
-  const double * le = lut_r + code_e * S61_S, * lo = lut_r + code_o * S61_S;
+  const double * le = lut_r + code_e * S, * lo = lut_r + code_o * S;
 #pragma unroll
   for (unsigned k = 0; k < S61_KS; ++k)
   {
     const unsigned i = 4 * k + q;
-    t[k] = (i < S61_S) ? make_double2(le[i], lo[i]) : make_double2(0.0, 0.0);
+    t[k] = (i < S) ? make_double2(le[i], lo[i]) : make_double2(0.0, 0.0);
   }
 }
 
@@ -112,13 +115,13 @@ __device__ inline void s61_store_d(double * unit, unsigned lane, const double2 t
 }
 
 __device__ inline void s61_tip_d(unsigned long long mask_e, unsigned long long mask_o, unsigned q,
-                                 double2 t[S61_KS])
+                                 double2 t[S61_KS], unsigned S)
 {
 #pragma unroll
   for (unsigned k = 0; k < S61_KS; ++k)
   {
     const unsigned i = 4 * k + q;
-    t[k] = (i < S61_S) ? make_double2((double)((mask_e >> i) & 1ULL), (double)((mask_o >> i) & 1ULL))
+    t[k] = (i < S) ? make_double2((double)((mask_e >> i) & 1ULL), (double)((mask_o >> i) & 1ULL))
                        : make_double2(0.0, 0.0);
   }
 }
@@ -140,14 +143,14 @@ __device__ inline void s61_tip_d(unsigned long long mask_e, unsigned long long m
 // ---------------------------------------------------------------------------
 constexpr unsigned S61_CHUNK = 128;      // blocks per workgroup pass: 4 waves x 32 flag bits
 
-__device__ inline void s61_fill_frags_v3(double * frag, const double * mats, unsigned r)
+__device__ inline void s61_fill_frags_v3(double * frag, const double * mats, unsigned r, unsigned S, unsigned Sp)
 {
-  const double * M = mats + (size_t)r * S61_S * S61_SP;
+  const double * M = mats + (size_t)r * S * Sp;
   for (unsigned e = threadIdx.x; e < S61_FRAGS; e += blockDim.x)
   {
     const unsigned h = e & 1, lane = (e >> 1) & 63, f = e >> 7, mp = f & 1, ks = f >> 1;
     const unsigned i = (lane & 15) + 16 * (2 * mp + h), j = 4 * ks + (lane >> 4);
-    frag[e] = (i < S61_S && j < S61_S) ? M[(size_t)i * S61_SP + j] : 0.0;
+    frag[e] = (i < S && j < S) ? M[(size_t)i * Sp + j] : 0.0;
   }
 }
 
@@ -204,11 +207,8 @@ __device__ inline void s61_finish_unit(double * dst, unsigned lane, unsigned q, 
   {
     t1[k].x *= t2[k].x;
     t1[k].y *= t2[k].y;
-    if (4 * k + q < S61_S)
-    {
-      se &= (t1[k].x < SCALE_THRESHOLD);
-      so &= (t1[k].y < SCALE_THRESHOLD);
-    }
+    se &= (t1[k].x < SCALE_THRESHOLD);        // rows >= S are zero (padded fragments and table rows): they never veto
+    so &= (t1[k].y < SCALE_THRESHOLD);
     t1[k].x *= fe;
     t1[k].y *= fo;
   }
@@ -229,11 +229,8 @@ __device__ inline void s61_finish_unit_rs(const OpDesc & op, unsigned blk, unsig
   {
     t1[k].x *= t2[k].x;
     t1[k].y *= t2[k].y;
-    if (4 * k + q < S61_S)
-    {
-      se &= (t1[k].x < SCALE_THRESHOLD);
-      so &= (t1[k].y < SCALE_THRESHOLD);
-    }
+    se &= (t1[k].x < SCALE_THRESHOLD);        // rows >= S are zero: they never veto
+    so &= (t1[k].y < SCALE_THRESHOLD);
   }
   if (op.parent_scaler)
   {
@@ -323,7 +320,7 @@ __device__ inline void s61_rate_ii(const OpDesc & op, const double * frag, const
 __device__ inline void s61_rate_ti(const OpDesc & op, const double * clv, const double * fragi,
                                    const unsigned char * codes, const double * lut_r,
                                    unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
-                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred, bool rs, unsigned W = 4)
+                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred, bool rs, unsigned S, unsigned W = 4)
 {
   const double2 * f1 = reinterpret_cast<const double2 *>(fragi);
   const unsigned q = lane >> 4, n = lane & 15;
@@ -348,7 +345,7 @@ __device__ inline void s61_rate_ti(const OpDesc & op, const double * clv, const 
     s61_mfma_half<1>(bB, f1, lane, acc);
     S61_SCHED_FENCE();
     s61_acc_to_t(acc, t1);
-    s61_child_tip(lut_r, ce, co, q, t2);
+    s61_child_tip(lut_r, ce, co, q, t2, S);
     if (rs) { s61_finish_unit_rs(op, blk, r, R, op.parent + ub, lane, t1, t2); continue; }
     double fe, fo;
     s61_pred_factors(pred, blk, lane, fe, fo);
@@ -358,7 +355,7 @@ __device__ inline void s61_rate_ti(const OpDesc & op, const double * clv, const 
 
 __device__ inline void s61_rate_tt(const OpDesc & op, const double * lut1_r, const double * lut2_r,
                                    unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
-                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred, bool rs, unsigned W = 4)
+                                   unsigned & small_e, unsigned & small_o, const uint8_t * pred, bool rs, unsigned S, unsigned W = 4)
 {
   const unsigned q = lane >> 4, n = lane & 15;
   // the tip codes of block i+1 are fetched while block i is looked up and stored
@@ -372,8 +369,8 @@ __device__ inline void s61_rate_tt(const OpDesc & op, const double * lut1_r, con
     const unsigned n1e = op.codes1[siten], n1o = op.codes1[siten + 1];
     const unsigned n2e = op.codes2[siten], n2o = op.codes2[siten + 1];
     double2 t1[S61_KS], t2[S61_KS];
-    s61_child_tip(lut1_r, c1e, c1o, q, t1);
-    s61_child_tip(lut2_r, c2e, c2o, q, t2);
+    s61_child_tip(lut1_r, c1e, c1o, q, t1, S);
+    s61_child_tip(lut2_r, c2e, c2o, q, t2, S);
     if (rs) s61_finish_unit_rs(op, blk, r, R, op.parent + ((size_t)blk * R + r) * S61_UNIT, lane, t1, t2);
     else
     {
@@ -389,10 +386,12 @@ __device__ inline void s61_rate_tt(const OpDesc & op, const double * lut1_r, con
 // Rate-parallel launches (gridDim.z = R, used when a GPU has few blocks per wave):
 // a workgroup handles ONE rate, writes its per-site "all entries small" vote to
 // votes[(op*R + r)*Nalloc + site], and k_s61_scale_fixup combines the votes.
+template <unsigned SC>      // the state count, 0 = a run-time value (S_rt, rows of the matrices Sp_rt apart)
 __global__ __launch_bounds__(256, 2) void k_partials_s61v3(OpBatch batch, unsigned nblk, unsigned R,
                                                            unsigned lut_codes, uint8_t * votes, PredBatch preds,
-                                                           unsigned rate_scalers)
+                                                           unsigned rate_scalers, unsigned S_rt, unsigned Sp_rt)
 {
+  const unsigned S = SC ? SC : S_rt, Sp = SC ? S61_SP : Sp_rt;
   const bool rs = rate_scalers != 0;
   extern __shared__ double frag[];
   double * const frag2 = frag + S61_FRAGS;
@@ -400,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void k_partials_s61v3(OpBatch batch, unsign
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned q = lane >> 4, n = lane & 15;
   const bool scaling = op.parent_scaler != nullptr && !rs;     // per-rate scalers are settled unit by unit
-  const bool lut_lds = lut_codes * S61_S <= S61_FRAGS;
+  const bool lut_lds = lut_codes * S <= S61_FRAGS;
   const bool tip1 = op.codes1 != nullptr, tip2 = op.codes2 != nullptr;
   const unsigned beg = (unsigned)(((unsigned long long)nblk * blockIdx.x) / gridDim.x);
   const unsigned end = (unsigned)(((unsigned long long)nblk * (blockIdx.x + 1)) / gridDim.x);
@@ -420,22 +419,22 @@ __global__ __launch_bounds__(256, 2) void k_partials_s61v3(OpBatch batch, unsign
     for (unsigned r = r_begin; r < r_end; ++r)
     {
       __syncthreads();            // every wave is done reading the previous rate's fragments
-      if (!tip1) s61_fill_frags_v3(frag, op.pmat1, r);
+      if (!tip1) s61_fill_frags_v3(frag, op.pmat1, r, S, Sp);
       else if (lut_lds)
-        for (unsigned e = threadIdx.x; e < lut_codes * S61_S; e += blockDim.x)
-          frag[e] = op.lut1[(size_t)r * lut_codes * S61_S + e];
-      if (!tip2) s61_fill_frags_v3(frag2, op.pmat2, r);
+        for (unsigned e = threadIdx.x; e < lut_codes * S; e += blockDim.x)
+          frag[e] = op.lut1[(size_t)r * lut_codes * S + e];
+      if (!tip2) s61_fill_frags_v3(frag2, op.pmat2, r, S, Sp);
       else if (lut_lds)
-        for (unsigned e = threadIdx.x; e < lut_codes * S61_S; e += blockDim.x)
-          frag2[e] = op.lut2[(size_t)r * lut_codes * S61_S + e];
+        for (unsigned e = threadIdx.x; e < lut_codes * S; e += blockDim.x)
+          frag2[e] = op.lut2[(size_t)r * lut_codes * S + e];
       __syncthreads();
       if (nb == 0) continue;
-      const double * l1 = lut_lds ? frag : op.lut1 + (size_t)r * lut_codes * S61_S;
-      const double * l2 = lut_lds ? frag2 : op.lut2 + (size_t)r * lut_codes * S61_S;
-      if (tip1 && tip2) s61_rate_tt(op, l1, l2, r, R, first, nb, lane, small_e, small_o, pred, rs);
+      const double * l1 = lut_lds ? frag : op.lut1 + (size_t)r * lut_codes * S;
+      const double * l2 = lut_lds ? frag2 : op.lut2 + (size_t)r * lut_codes * S;
+      if (tip1 && tip2) s61_rate_tt(op, l1, l2, r, R, first, nb, lane, small_e, small_o, pred, rs, S);
       else if (!tip1 && !tip2) s61_rate_ii(op, frag, frag2, r, R, first, nb, lane, small_e, small_o, pred, rs);
-      else if (tip1) s61_rate_ti(op, op.clv2, frag2, op.codes1, l1, r, R, first, nb, lane, small_e, small_o, pred, rs);
-      else s61_rate_ti(op, op.clv1, frag, op.codes2, l2, r, R, first, nb, lane, small_e, small_o, pred, rs);
+      else if (tip1) s61_rate_ti(op, op.clv2, frag2, op.codes1, l1, r, R, first, nb, lane, small_e, small_o, pred, rs, S);
+      else s61_rate_ti(op, op.clv1, frag, op.codes2, l2, r, R, first, nb, lane, small_e, small_o, pred, rs, S);
     }
 
     if (scaling && rate_parallel)
@@ -522,10 +521,10 @@ struct CherryScaleBatch
 
 // grid = (ceil(codes^2 / 1024), cherries), block = 1024, dynamic LDS = 2 x codes x 61 doubles: the two
 // tables of a rate are staged with coalesced loads, a thread then owns one pair of codes
-__global__ __launch_bounds__(1024) void k_s61_cherry_scale(CherryScaleBatch batch, unsigned lut_codes, unsigned R)
+__global__ __launch_bounds__(1024) void k_s61_cherry_scale(CherryScaleBatch batch, unsigned lut_codes, unsigned R, unsigned S)
 {
   extern __shared__ double tabs[];
-  const unsigned len = lut_codes * S61_S, pairs = lut_codes * lut_codes;
+  const unsigned len = lut_codes * S, pairs = lut_codes * lut_codes;
   double * ta = tabs, * tb = tabs + len;
   const double * l1 = batch.lut1[blockIdx.y], * l2 = batch.lut2[blockIdx.y];
   const unsigned pr = blockIdx.x * 1024u + threadIdx.x;
@@ -540,9 +539,9 @@ __global__ __launch_bounds__(1024) void k_s61_cherry_scale(CherryScaleBatch batc
       tb[e] = l2[(size_t)r * len + e];
     }
     __syncthreads();
-    const double * ra = ta + ca * S61_S, * rb = tb + cb * S61_S;
+    const double * ra = ta + ca * S, * rb = tb + cb * S;
     unsigned small = 1u;
-    for (unsigned i = 0; i < S61_S; ++i) small &= (ra[i] * rb[i] < SCALE_THRESHOLD) ? 1u : 0u;
+    for (unsigned i = 0; i < S; ++i) small &= (ra[i] * rb[i] < SCALE_THRESHOLD) ? 1u : 0u;
     mask |= small << r;
   }
   if (pr < pairs) batch.out[blockIdx.y][pr] = (uint8_t)mask;
@@ -552,14 +551,14 @@ __global__ __launch_bounds__(1024) void k_s61_cherry_scale(CherryScaleBatch batc
 // scaling factor, stored to the cherry's vector and kept as B operand
 template <unsigned HALF>
 __device__ inline void s61_cherry_half(const double * ae, const double * ao, const double * be, const double * bo,
-                                       unsigned q, double fe, double fo, double * unit, unsigned lane, double2 b[8])
+                                       unsigned q, double fe, double fo, double * unit, unsigned lane, double2 b[8], unsigned S)
 {
 #pragma unroll
   for (unsigned k = 0; k < 8; ++k)
   {
     const unsigned i = 4 * (HALF * 8 + k) + q;
     double2 v = make_double2(0.0, 0.0);
-    if (i < S61_S)
+    if (i < S)
     {
       v.x = ae[i] * be[i];
       v.y = ao[i] * bo[i];
@@ -578,7 +577,7 @@ __device__ inline void s61_rate_cherry(const OpDesc & op, const OpDesc & tt, con
                                        const double * frag1, const double * frag2, const double * lut2_r,
                                        const double * luta_r, const double * lutb_r, bool tip2,
                                        unsigned r, unsigned R, unsigned first, unsigned nb, unsigned lane,
-                                       unsigned & small_e, unsigned & small_o, const uint8_t * pred, unsigned W)
+                                       unsigned & small_e, unsigned & small_o, const uint8_t * pred, unsigned W, unsigned S)
 {
   const unsigned all_rates = (1u << R) - 1u;
   const double2 * f1 = reinterpret_cast<const double2 *>(frag1);
@@ -619,18 +618,18 @@ __device__ inline void s61_rate_cherry(const OpDesc & op, const OpDesc & tt, con
       tt.parent_scaler[io] = co;
     }
     const double tfe = de ? SCALE_FACTOR : 1.0, tfo = dd ? SCALE_FACTOR : 1.0;
-    const double * ae = luta_r + cae * S61_S, * ao = luta_r + cao * S61_S;
-    const double * be = lutb_r + cbe * S61_S, * bo = lutb_r + cbo * S61_S;
+    const double * ae = luta_r + cae * S, * ao = luta_r + cao * S;
+    const double * be = lutb_r + cbe * S, * bo = lutb_r + cbo * S;
 
     v4d acc[S61_MT][2];
     double2 t1[S61_KS], t2[S61_KS];
     s61_acc_zero(acc);
     if (!tip2) s61_issue_half<1>(op.clv2 + ub, lane, bB);
-    s61_cherry_half<0>(ae, ao, be, bo, q, tfe, tfo, tt.parent + ub, lane, bC);
+    s61_cherry_half<0>(ae, ao, be, bo, q, tfe, tfo, tt.parent + ub, lane, bC, S);
     S61_SCHED_FENCE();
     s61_mfma_half<0>(bC, f1, lane, acc);
     S61_SCHED_FENCE();
-    s61_cherry_half<1>(ae, ao, be, bo, q, tfe, tfo, tt.parent + ub, lane, bC);
+    s61_cherry_half<1>(ae, ao, be, bo, q, tfe, tfo, tt.parent + ub, lane, bC, S);
     S61_SCHED_FENCE();
     s61_mfma_half<1>(bC, f1, lane, acc);
     S61_SCHED_FENCE();
@@ -646,7 +645,7 @@ __device__ inline void s61_rate_cherry(const OpDesc & op, const OpDesc & tt, con
       S61_SCHED_FENCE();
       s61_acc_to_t(acc, t2);
     }
-    else s61_child_tip(lut2_r, c2e, c2o, q, t2);
+    else s61_child_tip(lut2_r, c2e, c2o, q, t2, S);
     if (rs) s61_finish_unit_rs(op, blk, r, R, op.parent + ub, lane, t1, t2);
     else
     {
@@ -659,10 +658,12 @@ __device__ inline void s61_rate_cherry(const OpDesc & op, const OpDesc & tt, con
 }
 
 // grid = (<= CUs / R, ops, R), block = 512, dynamic LDS = 4 x 32 KiB
-template <bool rs>          // PLL_ATTRIB_RATE_SCALERS (a template parameter: as a run-time flag it cost the per-site form 54 spilled VGPRs)
+template <bool rs, unsigned SC>   // rs: PLL_ATTRIB_RATE_SCALERS (a template parameter: as a run-time flag it cost the per-site form 54 spilled VGPRs); SC: see k_partials_s61v3
 __global__ __launch_bounds__(64 * S61_V4_WAVES, 1) void k_partials_s61v4(S61Batch batch, unsigned nblk, unsigned R,
-                                                                         unsigned lut_codes, uint8_t * votes)
+                                                                         unsigned lut_codes, uint8_t * votes,
+                                                                         unsigned S_rt, unsigned Sp_rt)
 {
+  const unsigned S = SC ? SC : S_rt, Sp = SC ? S61_SP : Sp_rt;
   extern __shared__ double frag[];
   double * const frag2 = frag + S61_FRAGS, * const luta = frag + 2 * S61_FRAGS, * const lutb = frag + 3 * S61_FRAGS;
   const OpDesc & op = batch.op[blockIdx.y];
@@ -676,11 +677,11 @@ __global__ __launch_bounds__(64 * S61_V4_WAVES, 1) void k_partials_s61v4(S61Batc
   const unsigned end = (unsigned)(((unsigned long long)nblk * (blockIdx.x + 1)) / gridDim.x);
   const uint8_t * pred = scaling ? batch.pred_in[blockIdx.y] : nullptr;
   const unsigned r = blockIdx.z;
-  const size_t lut_len = (size_t)lut_codes * S61_S;
+  const size_t lut_len = (size_t)lut_codes * S;
 
-  if (!tip1) s61_fill_frags_v3(frag, op.pmat1, r);
+  if (!tip1) s61_fill_frags_v3(frag, op.pmat1, r, S, Sp);
   else for (unsigned e = threadIdx.x; e < lut_len; e += blockDim.x) frag[e] = op.lut1[r * lut_len + e];
-  if (!tip2) s61_fill_frags_v3(frag2, op.pmat2, r);
+  if (!tip2) s61_fill_frags_v3(frag2, op.pmat2, r, S, Sp);
   else for (unsigned e = threadIdx.x; e < lut_len; e += blockDim.x) frag2[e] = op.lut2[r * lut_len + e];
   if (cherry)
     for (unsigned e = threadIdx.x; e < lut_len; e += blockDim.x)
@@ -699,11 +700,11 @@ __global__ __launch_bounds__(64 * S61_V4_WAVES, 1) void k_partials_s61v4(S61Batc
     unsigned small_e = ~0u, small_o = ~0u;
     if (nb == 0) continue;
     if (cherry) s61_rate_cherry<rs>(op, tt, batch.ttscale[blockIdx.y], lut_codes, frag, frag2, frag2, luta, lutb, tip2,
-                                    r, R, first, nb, lane, small_e, small_o, pred, W);
-    else if (tip1 && tip2) s61_rate_tt(op, frag, frag2, r, R, first, nb, lane, small_e, small_o, pred, rs, W);
+                                    r, R, first, nb, lane, small_e, small_o, pred, W, S);
+    else if (tip1 && tip2) s61_rate_tt(op, frag, frag2, r, R, first, nb, lane, small_e, small_o, pred, rs, S, W);
     else if (!tip1 && !tip2) s61_rate_ii(op, frag, frag2, r, R, first, nb, lane, small_e, small_o, pred, rs, W);
-    else if (tip1) s61_rate_ti(op, op.clv2, frag2, op.codes1, frag, r, R, first, nb, lane, small_e, small_o, pred, rs, W);
-    else s61_rate_ti(op, op.clv1, frag, op.codes2, frag2, r, R, first, nb, lane, small_e, small_o, pred, rs, W);
+    else if (tip1) s61_rate_ti(op, op.clv2, frag2, op.codes1, frag, r, R, first, nb, lane, small_e, small_o, pred, rs, S, W);
+    else s61_rate_ti(op, op.clv1, frag, op.codes2, frag2, r, R, first, nb, lane, small_e, small_o, pred, rs, S, W);
 
     if (scaling)
     {
@@ -790,6 +791,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_lnl_s61(ModelView mv, ParamIdx 
 {
   extern __shared__ double frag[];
   __shared__ double scratch[4];
+  const unsigned S = mv.S, Sp = mv.Sp;
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned q = lane >> 4, n = lane & 15;
   const unsigned ntiles = (nblk + 3) / 4;
@@ -824,7 +826,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_lnl_s61(ModelView mv, ParamIdx 
     for (unsigned r = 0; r < R; ++r)
     {
       __syncthreads();
-      if (pmat && !child.codes) s61_fill_frags(frag, pmat, r);
+      if (pmat && !child.codes) s61_fill_frags(frag, pmat, r, S, Sp);
       __syncthreads();
       if (!live) continue;
       const size_t ubase = ((size_t)blk * R + r) * S61_UNIT;
@@ -836,16 +838,16 @@ __global__ __launch_bounds__(256, 2) void k_edge_lnl_s61(ModelView mv, ParamIdx 
 #pragma unroll
         for (unsigned k = 0; k < S61_KS; ++k) t[k] = make_double2(1.0, 1.0);
       }
-      else if (child.codes) s61_child_tip(lut + (size_t)r * lut_codes * S61_S, cce, cco, q, t);
+      else if (child.codes) s61_child_tip(lut + (size_t)r * lut_codes * S, cce, cco, q, t, S);
       else s61_child_inner(child.clv + ubase, frag, lane, t);
-      if (parent.codes) s61_tip_d(pme, pmo, q, pv);
+      if (parent.codes) s61_tip_d(pme, pmo, q, pv, S);
       else s61_load_d(parent.clv + ubase, lane, pv);
       double le = 0.0, lo = 0.0;
 #pragma unroll
       for (unsigned k = 0; k < S61_KS; ++k)
       {
         const unsigned i = 4 * k + q;
-        const double f = (i < S61_S) ? pi[i] : 0.0;
+        const double f = (i < S) ? pi[i] : 0.0;
         le += f * pv[k].x * t[k].x;
         lo += f * pv[k].y * t[k].y;
       }
@@ -916,9 +918,9 @@ __global__ __launch_bounds__(256, 1) void k_edge_lnl_s61_r4(ModelView mv, ParamI
   const unsigned beg = (unsigned)(((unsigned long long)nblk * blockIdx.x) / gridDim.x);
   const unsigned end = (unsigned)(((unsigned long long)nblk * (blockIdx.x + 1)) / gridDim.x);
 
-  for (unsigned r = 0; r < R; ++r) s61_fill_frags_v3(frag + (size_t)r * S61_FRAGS, pmat, r);
+  for (unsigned r = 0; r < R; ++r) s61_fill_frags_v3(frag + (size_t)r * S61_FRAGS, pmat, r, mv.S, mv.Sp);
   for (unsigned e = threadIdx.x; e < R * 64; e += blockDim.x)
-    fq[e] = ((e & 63) < S61_S) ? mv.freqs(fidx.v[e >> 6])[e & 63] : 0.0;
+    fq[e] = ((e & 63) < mv.S) ? mv.freqs(fidx.v[e >> 6])[e & 63] : 0.0;
   __syncthreads();
 
   double acc_lnl = 0.0;
@@ -951,7 +953,7 @@ __global__ __launch_bounds__(256, 1) void k_edge_lnl_s61_r4(ModelView mv, ParamI
       double2 pv[S61_KS];
       s61_acc_zero(acc);
       s61_issue_half<1>(child_clv + ub, lane, bB);
-      if (parent.codes) s61_tip_d(pme, pmo, q, pv);
+      if (parent.codes) s61_tip_d(pme, pmo, q, pv, mv.S);
       else s61_load_d(parent.clv + ub, lane, pv);
       S61_SCHED_FENCE();
       s61_mfma_half<0>(bA, fr, lane, acc);
@@ -1019,7 +1021,7 @@ __global__ __launch_bounds__(256, 1) void k_edge_lnl_s61_r4(ModelView mv, ParamI
 }
 
 // sumtable preparation: Lm[r][k][i] = pi_i V[i][k], Rm[r][k][j] = V^-1[k][j] in
-// [r][61][64] row-major form, plus tip lookup tables [r][code][61]
+// [r][S][Sp] row-major form, plus tip lookup tables [r][code][S]
 __global__ __launch_bounds__(256) void k_sumtable_prep_s61(ModelView mv, ParamIdx params,
                                                            const unsigned long long * tipmap,
                                                            unsigned lut_codes, bool want_lut,
@@ -1027,24 +1029,25 @@ __global__ __launch_bounds__(256) void k_sumtable_prep_s61(ModelView mv, ParamId
                                                            double * lutL, double * lutR)
 {
   const unsigned r = blockIdx.x, pi_ = params.v[r];
+  const unsigned S = mv.S, Sp = mv.Sp;
   const double * pi = mv.freqs(pi_), * V = mv.evecs(pi_), * Vi = mv.ievecs(pi_);
-  double * L = Lm + (size_t)r * S61_S * S61_SP, * Rr = Rm + (size_t)r * S61_S * S61_SP;
-  for (unsigned e = threadIdx.x; e < S61_S * S61_SP; e += blockDim.x)
+  double * L = Lm + (size_t)r * S * Sp, * Rr = Rm + (size_t)r * S * Sp;
+  for (unsigned e = threadIdx.x; e < S * Sp; e += blockDim.x)
   {
-    const unsigned k = e / S61_SP, i = e % S61_SP;
-    L[e] = (i < S61_S) ? pi[i] * V[i * S61_SP + k] : 0.0;
-    Rr[e] = (i < S61_S) ? Vi[k * S61_SP + i] : 0.0;
+    const unsigned k = e / Sp, i = e % Sp;
+    L[e] = (i < S) ? pi[i] * V[i * Sp + k] : 0.0;
+    Rr[e] = (i < S) ? Vi[k * Sp + i] : 0.0;
   }
   if (!want_lut) return;
-  for (unsigned e = threadIdx.x; e < lut_codes * S61_S; e += blockDim.x)
+  for (unsigned e = threadIdx.x; e < lut_codes * S; e += blockDim.x)
   {
-    const unsigned c = e / S61_S, k = e % S61_S;
+    const unsigned c = e / S, k = e % S;
     const unsigned long long mask = tipmap[c];
     double a = 0.0, b = 0.0;
-    for (unsigned i = 0; i < S61_S; ++i)
-      if ((mask >> i) & 1ULL) { a += pi[i] * V[i * S61_SP + k]; b += Vi[k * S61_SP + i]; }
-    lutL[((size_t)r * lut_codes + c) * S61_S + k] = a;
-    lutR[((size_t)r * lut_codes + c) * S61_S + k] = b;
+    for (unsigned i = 0; i < S; ++i)
+      if ((mask >> i) & 1ULL) { a += pi[i] * V[i * Sp + k]; b += Vi[k * Sp + i]; }
+    lutL[((size_t)r * lut_codes + c) * S + k] = a;
+    lutR[((size_t)r * lut_codes + c) * S + k] = b;
   }
 }
 
@@ -1068,7 +1071,7 @@ static bool s61_cherries_supported(const Engine * e)
 {
   static const int env = getenv("PLLHIP_S61_CHERRIES") ? atoi(getenv("PLLHIP_S61_CHERRIES")) : 1;
   // (per-rate scalers are carried as well: C5 --rate-scalers 8.93 -> 7.86 ms)
-  return env && e->coded_tips && s61_rate_parallel(e) && e->lut_codes * S61_S <= S61_FRAGS && e->R <= 8;
+  return env && e->coded_tips && s61_rate_parallel(e) && e->lut_codes * e->S <= S61_FRAGS && e->R <= 8;
 }
 
 // last scaling decisions per parent vector, double-buffered (the fix-up kernel reads the
@@ -1123,9 +1126,14 @@ static int launch_partials_s61(Engine * e, const OpBatch & batch, unsigned nops)
   static const int env_mul = getenv("PLLHIP_S61_GXMUL") ? atoi(getenv("PLLHIP_S61_GXMUL")) : 1;
   const unsigned per = (rate_parallel ? std::max(1u, slots / e->R) : slots) * (unsigned)std::max(1, env_mul);
   const unsigned gx = std::max(1u, std::min((e->nblk + 3) / 4, per));
-  hipLaunchKernelGGL(k_partials_s61v3, dim3(gx, nops, rate_parallel ? e->R : 1u), dim3(256), lds, e->stream,
-                     batch, e->nblk, e->R, e->lut_codes, rate_parallel ? e->d_s61_votes : (uint8_t *)nullptr, preds,
-                     e->rate_scalers ? 1u : 0u);
+  if (e->S == S61_S)
+    hipLaunchKernelGGL(k_partials_s61v3<S61_S>, dim3(gx, nops, rate_parallel ? e->R : 1u), dim3(256), lds, e->stream,
+                       batch, e->nblk, e->R, e->lut_codes, rate_parallel ? e->d_s61_votes : (uint8_t *)nullptr, preds,
+                       e->rate_scalers ? 1u : 0u, e->S, e->Sp);
+  else
+    hipLaunchKernelGGL(k_partials_s61v3<0>, dim3(gx, nops, rate_parallel ? e->R : 1u), dim3(256), lds, e->stream,
+                       batch, e->nblk, e->R, e->lut_codes, rate_parallel ? e->d_s61_votes : (uint8_t *)nullptr, preds,
+                       e->rate_scalers ? 1u : 0u, e->S, e->Sp);
   PLLHIP_TRY(hipGetLastError());
   if (rate_parallel && scaling)
   {
@@ -1147,9 +1155,13 @@ static int launch_partials_s61_cherries(Engine * e, const OpBatch & batch, const
   bool & attr_set = attr_set_dev[e->device & 63];
   if (!attr_set)
   {
-    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_partials_s61v4<false>),
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_partials_s61v4<false, S61_S>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_partials_s61v4<true>),
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_partials_s61v4<true, S61_S>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_partials_s61v4<false, 0>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_partials_s61v4<true, 0>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -1176,12 +1188,12 @@ static int launch_partials_s61_cherries(Engine * e, const OpBatch & batch, const
   unsigned per = env_per > 0 ? (unsigned)env_per : std::max(1u, e->cu_count / e->R);
   if (env_fill > 0) per = std::min(per, std::max(1u, (unsigned)env_fill * e->cu_count / (nops * e->R)));
   const unsigned gx = std::max(1u, std::min((e->nblk + S61_V4_WAVES - 1) / S61_V4_WAVES, per));
-  if (e->rate_scalers)
-    hipLaunchKernelGGL(k_partials_s61v4<true>, dim3(gx, nops, e->R), dim3(64 * S61_V4_WAVES), lds, e->stream,
-                       sb, e->nblk, e->R, e->lut_codes, e->d_s61_votes);
-  else
-    hipLaunchKernelGGL(k_partials_s61v4<false>, dim3(gx, nops, e->R), dim3(64 * S61_V4_WAVES), lds, e->stream,
-                       sb, e->nblk, e->R, e->lut_codes, e->d_s61_votes);
+#define PLLHIP_CALL(RS, SCV) \
+  hipLaunchKernelGGL((k_partials_s61v4<RS, SCV>), dim3(gx, nops, e->R), dim3(64 * S61_V4_WAVES), lds, e->stream, \
+                     sb, e->nblk, e->R, e->lut_codes, e->d_s61_votes, e->S, e->Sp)
+  if (e->S == S61_S) { if (e->rate_scalers) PLLHIP_CALL(true, S61_S); else PLLHIP_CALL(false, S61_S); }
+  else { if (e->rate_scalers) PLLHIP_CALL(true, 0); else PLLHIP_CALL(false, 0); }
+#undef PLLHIP_CALL
   PLLHIP_TRY(hipGetLastError());
   if (scaling)
   {
@@ -1195,9 +1207,9 @@ static int launch_partials_s61_cherries(Engine * e, const OpBatch & batch, const
 // scaling tables of `count` cherries (CherryScaleBatch): out[i] = [codes][codes]
 static int launch_cherry_scale_s61(Engine * e, const CherryScaleBatch & batch, unsigned count)
 {
-  const size_t lds = sizeof(double) * 2 * e->lut_codes * S61_S;      // <= 64 KiB (s61_cherries_supported)
+  const size_t lds = sizeof(double) * 2 * e->lut_codes * e->S;      // <= 64 KiB (s61_cherries_supported)
   hipLaunchKernelGGL(k_s61_cherry_scale, dim3((e->lut_codes * e->lut_codes + 1023u) / 1024u, count), dim3(1024), lds, e->stream,
-                     batch, e->lut_codes, e->R);
+                     batch, e->lut_codes, e->R, e->S);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }
@@ -1240,11 +1252,11 @@ static int launch_edge_lnl_s61(Engine * e, const ModelView & mv, const ParamIdx 
 static int launch_sumtable_s61(Engine * e, const ModelView & mv, const ParamIdx & params,
                                const NodeRef & parent, const NodeRef & child, double * d_sum)
 {
-  const size_t mats = (size_t)e->R * S61_S * S61_SP, luts = (size_t)e->R * std::max(1u, e->lut_codes) * S61_S;
+  const size_t mats = (size_t)e->R * e->S * e->Sp, luts = (size_t)e->R * std::max(1u, e->lut_codes) * e->S;
   if (!e->d_sum_scratch)
   {
     hipError_t err = hipMalloc(reinterpret_cast<void **>(&e->d_sum_scratch),
-                               sizeof(double) * 2 * (mats + (size_t)e->R * PLL_ASCII_SIZE * S61_S));
+                               sizeof(double) * 2 * (mats + (size_t)e->R * PLL_ASCII_SIZE * e->S));
     if (err != hipSuccess)
     {
       set_error(PLL_ERROR_MEM_ALLOC, "hipMalloc for sumtable scratch failed");
@@ -1272,7 +1284,7 @@ static int launch_derivatives_s61(Engine * e, const ModelView & mv, const ParamI
                                   unsigned nblocks)
 {
   const size_t lds = sizeof(double) * e->R * S61_KS * 64;
-  if (lds > 160 * 1024)
+  if (lds > 160 * 1024 - 512)
   {
     set_error(PLL_ERROR_PARAM_INVALID, "derivatives: %u rate categories exceed the LDS operand tables", e->R);
     return PLL_FAILURE;
@@ -1284,13 +1296,20 @@ static int launch_derivatives_s61(Engine * e, const ModelView & mv, const ParamI
     if (!attr_set)
     {
       PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_derivatives_mfma<S61_KS, S61_S>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+      PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_derivatives_mfma<S61_KS, 0>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
       attr_set = true;
     }
   }
-  hipLaunchKernelGGL((k_derivatives_mfma<S61_KS, S61_S>), dim3(nblocks), dim3(256), lds, e->stream,
-                     mv, params, tl, count, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, reduce_out(e),
-                     e->rate_scalers ? 1u : 0u);
+  if (e->S == S61_S)
+    hipLaunchKernelGGL((k_derivatives_mfma<S61_KS, S61_S>), dim3(nblocks), dim3(256), lds, e->stream,
+                       mv, params, tl, count, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, reduce_out(e),
+                       e->rate_scalers ? 1u : 0u);
+  else
+    hipLaunchKernelGGL((k_derivatives_mfma<S61_KS, 0>), dim3(nblocks), dim3(256), lds, e->stream,
+                       mv, params, tl, count, d_sum, ps, cs, e->d_weights, e->d_invariant, e->N, e->nblk, e->R, reduce_out(e),
+                       e->rate_scalers ? 1u : 0u);
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;
 }

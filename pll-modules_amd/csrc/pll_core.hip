@@ -228,12 +228,14 @@ Engine * engine_create(pll_partition_t * p)
   else if (e->rate_scalers && e->S <= 16) e->family = no_s16 ? KernelFamily::Generic : KernelFamily::S16;
   else if (e->S == 4 && (e->R & (e->R - 1)) == 0) e->family = KernelFamily::S4;
   else if (e->S == 20 && e->R <= 8) e->family = KernelFamily::S20;
-  else if (e->S == 61) e->family = KernelFamily::S61;
+  // 33 .. 64 states: the codon family (61 states: its own instantiation with the state count at compile time)
+  else if (e->S >= 33 && e->S <= 64) e->family = KernelFamily::S61;
   // 2 .. 32 states (17 .. 32: two M tiles): every alphabet the 4- and 20-state families do not take
   else if (s16_supported(e->S, e->R) && !no_s16) e->family = KernelFamily::S16;
   else e->family = KernelFamily::Generic;
   e->blocked = (e->family == KernelFamily::S20 || e->family == KernelFamily::S61 || e->family == KernelFamily::S16);
-  e->rows = !e->blocked ? 0u : (e->family == KernelFamily::S16) ? 4u * ((e->S + 3u) / 4u) : e->Sp;
+  e->rows = !e->blocked ? 0u : (e->family == KernelFamily::S16) ? 4u * ((e->S + 3u) / 4u)
+                               : (e->family == KernelFamily::S61) ? S61_SP : e->Sp;
   e->nblk = (e->N + S20_BS - 1) / S20_BS;
   e->Nalloc = e->blocked ? e->nblk * S20_BS : e->N;
   e->sc_len = (size_t)e->Nalloc * (e->rate_scalers ? e->R : 1);
@@ -650,7 +652,7 @@ static int ensure_luts(pll_partition_t * p)
     // grow with head-room so that a few late codes do not re-allocate
     // (but never past the size the 20-/61-state kernels can stage in LDS: 30 / 67 codes)
     unsigned cap = std::min<unsigned>(PLL_ASCII_SIZE, std::max(want, (e->S == 4) ? 16u : want + 8u));
-    if (e->family == KernelFamily::S61 && want <= 67u) cap = std::min(cap, 67u);
+    if (e->family == KernelFamily::S61 && want <= S61_FRAGS / e->S) cap = std::min(cap, S61_FRAGS / e->S);   // 67 at 61 states
     if (e->family == KernelFamily::S20 && want <= 30u) cap = std::min(cap, 30u);
     if (e->d_lut) { PLLHIP_TRY(hipStreamSynchronize(e->stream)); (void)hipFree(e->d_lut); e->d_lut = nullptr; }
     e->plan.key.clear();                            // cached schedules point into the old tables

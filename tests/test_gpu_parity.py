@@ -593,12 +593,15 @@ def test_deep_trees_scale_bit_exactly_at_the_new_alphabets(product, oracle, stat
 
 def test_specialised_kernels_are_the_ones_running(product):
     for states, name in ((4, b"s4-valu"), (20, b"s20-mfma"), (61, b"s61-mfma"), (5, b"s16-mfma"), (2, b"s16-mfma"),
-                         (10, b"s16-mfma"), (16, b"s16-mfma"), (17, b"generic"), (33, b"generic")):
+                         (10, b"s16-mfma"), (16, b"s16-mfma"), (17, b"s16-mfma"), (32, b"s16-mfma"), (33, b"s61-mfma"),
+                         (62, b"s61-mfma"), (64, b"s61-mfma")):
         with pc.Instance(product, 3, states, 8, 4) as a:
             assert product.lib.pllhip_partials_kernel_name(a.p) == name
     with pc.Instance(product, 3, 4, 8, 3) as a:                      # 4 states, odd rate count
         assert product.lib.pllhip_partials_kernel_name(a.p) == b"s16-mfma"
-    for states, name in ((4, b"s16-mfma"), (10, b"s16-mfma"), (20, b"s20-mfma"), (61, b"s61-mfma"), (33, b"generic")):
+    with pc.Instance(product, 3, 32, 8, 16) as a:                    # the tables of 16 rates do not fit the LDS
+        assert product.lib.pllhip_partials_kernel_name(a.p) == b"generic"
+    for states, name in ((4, b"s16-mfma"), (10, b"s16-mfma"), (20, b"s20-mfma"), (61, b"s61-mfma"), (33, b"s61-mfma")):
         with pc.Instance(product, 3, states, 8, 4, attributes=pc.PLL_ATTRIB_RATE_SCALERS) as a:
             assert product.lib.pllhip_partials_kernel_name(a.p) == name
 
