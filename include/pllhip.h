@@ -199,6 +199,28 @@ PLL_EXPORT int pllhip_compute_likelihood_derivatives_multi(pll_partition_t * par
    lengths (include/pllhip_eval.h) use it to decide whether speculation is free. */
 PLL_EXPORT unsigned int pllhip_free_trial_lengths(const pll_partition_t * partition);
 
+/* Newton-Raphson on one branch, entirely on the device: the loop the reference runs around
+   pll_compute_likelihood_derivatives (src/optimize/opt_algorithms.c:133-261: evaluate {f, f'} at the iterate,
+   bracket, clamp the step to +-bl_max / max_newton and to the bracket, stop at |f| or |step| < tolerance; the
+   target function is src/optimize/pll_optimize.c:1223-1287) for ONE partition whose sumtable is current
+   (pll_update_sumtable), in ONE launch: scan, in-launch reduction, step rule, next scan.  The iterates are the
+   host loop's, bit for bit (same scan, same summation order, the same fp64 expressions without contraction).
+   Returns PLL_SUCCESS with *length = the length the loop ended at and *iterations = scans made; `trail`
+   (NULL, or room for 96 doubles) receives the iterate after every scan.  PLL_FAILURE with pll_errno =
+   PLLHIP_ERROR_NEWTON_LIMIT (more than max_newton iterations) / PLLHIP_ERROR_NEWTON_DERIVATIVES (a non-finite
+   derivative) -- the reference's two failure modes -- or PLLHIP_ERROR_NEWTON_UNSUPPORTED: this partition cannot
+   run the loop on the device (4-state / generic kernel family, ascertainment-bias correction, a partition spread
+   over devices, a scan grid larger than the chip holds at once); the caller then iterates itself. */
+#define PLLHIP_ERROR_NEWTON_LIMIT        910
+#define PLLHIP_ERROR_NEWTON_DERIVATIVES  911
+#define PLLHIP_ERROR_NEWTON_UNSUPPORTED  912
+PLL_EXPORT int pllhip_newton_branch(pll_partition_t * partition,
+                                    int parent_scaler_index, int child_scaler_index,
+                                    const unsigned int * params_indices, const double * sumtable,
+                                    double start, double bl_min, double bl_max, double tolerance,
+                                    unsigned int max_newton,
+                                    double * length, unsigned int * iterations, double * trail);
+
 /* pll_update_partials for several partitions that are evaluated on ONE tree: the result is what
    pll_update_partials(partitions[i], operations, count) stores for every non-NULL partitions[i], bit for
    bit.  pll-modules walks the partitions of an analysis one after the other

@@ -229,6 +229,13 @@ struct Engine
   // the mapped result buffer + its sequence word, or a slot of a deferred result group
   struct Sink { double * dst = nullptr; unsigned long long * flag = nullptr; unsigned long long seq = 0; unsigned nq = 0; } sink;
   double * d_persite = nullptr;       // [N], allocated on first per-site request
+  // device-resident Newton-Raphson (pllhip_newton_branch): control block in device memory, results + iterate
+  // trail in mapped host memory (allocated on first use)
+  void * d_newton = nullptr;
+  double * h_newton = nullptr;        // pinned + mapped: [0..7] results, [8..103] trail, [112] sequence word
+  double * hd_newton = nullptr;
+  unsigned long long newton_seq = 0;
+  int newton_capacity = -1;           // co-resident workgroups of the loop kernel (-1: not asked yet)
 
   // caller-keyed device sumtables (pointer value is the key)
   std::list<std::pair<const void *, double *>> sumtables;

@@ -7,6 +7,7 @@
 #include "pllhip_eval_internal.h"
 #include "pllhip.h"
 #pragma weak pllhip_eval_attach_comm   /* HIP engine only (pllhip_comm.hip) */
+#pragma weak pllhip_newton_branch      /* HIP engine only (pll_core.hip) */
 #include <stdarg.h>
 
 static __thread pllhip_eval_t * cb_self;   /* pll_utree_traverse callbacks carry no user pointer */
@@ -77,6 +78,10 @@ pllhip_eval_t * pllhip_eval_create(pll_utree_t * tree, unsigned int partition_co
     } while (s && s != n);
   }
   ev->root = tree->vroot->next ? tree->vroot : tree->vroot->back;
+  {
+    const char * env = getenv("PLLHIP_EVAL_DEVICE_NEWTON");
+    ev->device_newton = (pllhip_newton_branch && (!env || atoi(env))) ? 1 : 0;
+  }
   /* Several partitions: leave every partition's lnL / derivative totals on the device and wait ONCE per
      evaluation / Newton round (include/pllhip.h, pllhip_results_*) instead of once per partition -- the
      reference's per-partition loop (src/tree/treeinfo.c:1020-1056) with the waits taken out.  Only where the
@@ -640,6 +645,37 @@ static int newton(const blo_t * b, const pll_unode_t * e, double * x)
   double xl = b->bl_min, xh = b->bl_max, f, df, dx;
   double t[PLLHIP_EVAL_MAX_TRIALS], tf[PLLHIP_EVAL_MAX_TRIALS], tdf[PLLHIP_EVAL_MAX_TRIALS];
   unsigned int nt = 0, k, iter = 0;
+  /* One partition, one worker, the tree's own lengths: the whole loop runs on the device (include/pllhip.h,
+     pllhip_newton_branch: the same iterates, one launch and one wait per branch instead of one per iterate).
+     With several partitions or workers the sums of their derivatives have to meet between two iterates:
+     the loop below. */
+  if (ev->device_newton && ev->nparts == 1 && ev->parts[0] && !ev->reduce_cb && !ev->part_brlens &&
+      ev->brlen_scalers[0] == 1.0)
+  {
+    unsigned int its = 0;
+    double len = *x;
+    if (pllhip_newton_branch(ev->parts[0], e->scaler_index, e->back->scaler_index, ev->params[0], ev->sumtables[0],
+                             *x, b->bl_min, b->bl_max, b->tolerance, b->max_newton, &len, &its, NULL))
+    {
+      *x = len;
+      ev->n_newton += its;
+      ev->n_deriv += its;
+      return PLL_SUCCESS;
+    }
+    if (pll_errno == PLLHIP_ERROR_NEWTON_LIMIT)
+    {
+      pllhip_eval_error(PLLHIP_EVAL_ERROR_NEWTON_LIMIT, "Exceeded maximum number of iterations");
+      return PLL_FAILURE;
+    }
+    if (pll_errno == PLLHIP_ERROR_NEWTON_DERIVATIVES)
+    {
+      pllhip_eval_error(PLLHIP_EVAL_ERROR_NEWTON_DERIV, "Wrong likelihood derivatives");
+      return PLL_FAILURE;
+    }
+    if (pll_errno != PLLHIP_ERROR_NEWTON_UNSUPPORTED) return PLL_FAILURE;
+    pll_errno = 0;
+    ev->device_newton = 0;                     /* this partition iterates on the host */
+  }
   *x = PLL_MAX(PLL_MIN(*x, b->bl_max), b->bl_min);
   for (;;)
   {

@@ -28,6 +28,7 @@ struct pllhip_eval
   unsigned long n_ops, n_pmat, n_deriv, n_newton;
   pllhip_eval_fused_t fused;      /* fused.fetch != NULL: deferred results */
   int fused_auto;                 /* the result group was attached by pllhip_eval_create itself */
+  int device_newton;              /* 1: try pllhip_newton_branch; 0: the library said it cannot (or PLLHIP_EVAL_DEVICE_NEWTON=0) */
   double * slot_buf;              /* [nparts * 2 * PLLHIP_EVAL_MAX_TRIALS] */
   unsigned int spec_trials;       /* trial lengths per scan; 0 = not decided yet */
   int linkage;                    /* PLLHIP_EVAL_BRLEN_* */

@@ -141,8 +141,10 @@ __device__ inline void publish_result(const ReduceOut & ro)
 // tests/test_gpu_results.py::test_single_launch_reduction_equals_two_launch_form compares it bit for bit with
 // the two-launch form (PLLHIP_FUSED_FINISH=0), which needs no such argument, and a port to another target
 // must re-derive it (or set fused_finish = false).
-template <int Q>
-__device__ inline void grid_reduce_tail(const ReduceOut & ro, double * scratch)
+// LOOP: the launch goes on after the sum (k_newton_mfma): the caller resets the tickets and tells the other
+// blocks itself; returns whether this block drew the last ticket (thread 0 then finds the totals in ro.dst)
+template <int Q, bool LOOP = false>
+__device__ inline bool grid_reduce_tail(const ReduceOut & ro, double * scratch)
 {
   const unsigned G = gridDim.x, b = blockIdx.x;
   unsigned * s_last = reinterpret_cast<unsigned *>(scratch);   // block_sum_256 left it free
@@ -165,7 +167,7 @@ __device__ inline void grid_reduce_tail(const ReduceOut & ro, double * scratch)
   __syncthreads();
   const unsigned last = *s_last;
   __syncthreads();
-  if (!last) return;                      // block-uniform
+  if (!last) return false;                // block-uniform
   if (threadIdx.x == 0)
   {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -196,10 +198,12 @@ __device__ inline void grid_reduce_tail(const ReduceOut & ro, double * scratch)
     const double t = block_sum_256(a[q], scratch);
     if (threadIdx.x == 0) ro.dst[q] = t;
   }
+  if (LOOP) return true;
   if (threadIdx.x <= REDUCE_SHARDS)       // tickets back to zero for the next launch on this stream
     __hip_atomic_store(ro.counter + threadIdx.x * REDUCE_SHARD_STRIDE, 0u, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 0) publish_result(ro);
+  return true;
 }
 
 // block totals in thread 0 (tot[0 .. Q))
@@ -228,8 +232,8 @@ __device__ inline void grid_reduce_finish(const double (&tot)[Q], const ReduceOu
 
 // block total of quantity t in thread t (t < Q <= 64: all of them lanes of wave 0, whose one
 // wait covers every store)
-template <int Q>
-__device__ inline void grid_reduce_finish_lanes(double mine, const ReduceOut & ro, double * scratch)
+template <int Q, bool LOOP = false>
+__device__ inline bool grid_reduce_finish_lanes(double mine, const ReduceOut & ro, double * scratch)
 {
   const unsigned G = gridDim.x, b = blockIdx.x;
   if (threadIdx.x < 64)
@@ -242,7 +246,8 @@ __device__ inline void grid_reduce_finish_lanes(double mine, const ReduceOut & r
     }
     if (ro.fused) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  if (ro.fused) grid_reduce_tail<Q>(ro, scratch);
+  if (ro.fused) return grid_reduce_tail<Q, LOOP>(ro, scratch);
+  return false;
 }
 
 // two-launch form: block_out[q][nblocks] -> dst[q]; one block of 256 threads

@@ -845,17 +845,15 @@ __global__ __launch_bounds__(256) void k_sumtable_prep_s20(ModelView mv, ParamId
 // dynamic LDS = R * KS * 64 doubles (the left operands as per-lane fragments)
 // totals: df[0], ddf[0], df[1], ddf[1], ...
 // ---------------------------------------------------------------------------
+// the scan of one launch: block totals of {df, ddf} of trial length j in threads 2 j, 2 j + 1 (< 8) of the block
 template <unsigned KS, unsigned SREAL>
-__global__ __launch_bounds__(256) void k_derivatives_mfma(ModelView mv, ParamIdx params, TrialLengths tl,
-                                                          unsigned ntrial,
-                                                          const double * sumtable,
-                                                          const unsigned * ps, const unsigned * cs,
-                                                          const unsigned * weights, const int * invariant,
-                                                          unsigned N, unsigned nblk, unsigned R,
-                                                          ReduceOut block_out, unsigned rate_scalers)
+__device__ inline double deriv_block_totals(const ModelView & mv, const ParamIdx & params, const TrialLengths & tl,
+                                            unsigned ntrial, const double * sumtable,
+                                            const unsigned * ps, const unsigned * cs,
+                                            const unsigned * weights, const int * invariant,
+                                            unsigned N, unsigned nblk, unsigned R, unsigned rate_scalers,
+                                            double * frag)
 {
-  extern __shared__ double frag[];        // [r][ks][lane]
-  __shared__ double scratch[4];
   constexpr unsigned UNIT = 4 * KS * S20_BS;
   const unsigned SR = SREAL ? SREAL : mv.S;       // SREAL = 0: the state count is a run-time value
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -988,7 +986,154 @@ __global__ __launch_bounds__(256) void k_derivatives_mfma(ModelView mv, ParamIdx
   double mine = 0.0;
   if (threadIdx.x < 8) mine = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
   __syncthreads();
+  return mine;
+}
+
+template <unsigned KS, unsigned SREAL>
+__global__ __launch_bounds__(256) void k_derivatives_mfma(ModelView mv, ParamIdx params, TrialLengths tl,
+                                                          unsigned ntrial,
+                                                          const double * sumtable,
+                                                          const unsigned * ps, const unsigned * cs,
+                                                          const unsigned * weights, const int * invariant,
+                                                          unsigned N, unsigned nblk, unsigned R,
+                                                          ReduceOut block_out, unsigned rate_scalers)
+{
+  extern __shared__ double frag[];        // [r][ks][lane]
+  __shared__ double scratch[4];
+  const double mine = deriv_block_totals<KS, SREAL>(mv, params, tl, ntrial, sumtable, ps, cs, weights, invariant,
+                                                    N, nblk, R, rate_scalers, frag);
   grid_reduce_finish_lanes<8>(mine, block_out, scratch);
+}
+
+// ---------------------------------------------------------------------------
+// Newton-Raphson on one branch where the data is.  The reference's minimiser evaluates {f, f'} =
+// {d(-lnL)/dt, d2(-lnL)/dt2} once per iterate (src/optimize/opt_algorithms.c:133-261 calls the target function,
+// src/optimize/pll_optimize.c:1223-1287, which scans the sumtable); through the C ABI every iterate is a launch,
+// a completion the host waits for, and host arithmetic in between: 44 us per iterate around a 23 us scan at the
+// per-GPU slice of an 8-way split.  Here ONE launch runs the whole loop: all workgroups (co-resident: the grid is
+// the scan's own grid, bounded by what the chip holds at once) scan the sumtable at the current length, the block
+// that draws the last ticket of the in-launch reduction adds the block totals in block order (the very sum of
+// k_derivatives_mfma: same grid, same order, same bits), applies the step rule -- the expressions of the host loop
+// (csrc/host/pllhip_eval.c, newton(); fp64, no contraction: -ffp-contract=off) -- and releases the next iterate
+// to the others, which wait for it on a word in device memory.  The iterate trail goes to mapped host memory as it
+// is made; the host waits once, for the final length.
+// Every wait is bounded (NEWTON_SPIN_LIMIT polls): a workgroup that gives up marks the run as failed, so the
+// grid always drains.
+// ---------------------------------------------------------------------------
+struct NewtonControl          // device memory, one per engine
+{
+  double x;                   // the iterate the next scan evaluates
+  double xl, xh;              // bracket
+  unsigned iter;              // scans completed (what the other blocks wait for)
+  unsigned status;            // NEWTON_RUNNING, or how the loop ended
+  double tot[8];              // totals of the scan (grid reduction sink)
+};
+
+struct NewtonParams { double x0, bl_min, bl_max, tolerance, dxmax; unsigned max_newton; };
+
+// mapped host memory: [0] final length, [1] iterations, [2] status, [3] last f, [4] last df, [8 ...] the trail
+constexpr unsigned NEWTON_RUNNING = 0, NEWTON_CONVERGED = 1, NEWTON_LIMIT = 2, NEWTON_NONFINITE = 3, NEWTON_STUCK = 4;
+constexpr unsigned NEWTON_TRAIL_SLOT = 8, NEWTON_TRAIL_MAX = 96;
+constexpr unsigned NEWTON_SPIN_LIMIT = 1u << 24;
+
+template <unsigned KS, unsigned SREAL>
+__global__ __launch_bounds__(256) void k_newton_mfma(ModelView mv, ParamIdx params, NewtonParams np,
+                                                     const double * sumtable,
+                                                     const unsigned * ps, const unsigned * cs,
+                                                     const unsigned * weights, const int * invariant,
+                                                     unsigned N, unsigned nblk, unsigned R,
+                                                     ReduceOut ro, unsigned rate_scalers,
+                                                     NewtonControl * ctl, double * host_out,
+                                                     unsigned long long * host_flag, unsigned long long host_seq)
+{
+  extern __shared__ double frag[];
+  __shared__ double scratch[4];
+  __shared__ double s_x;
+  __shared__ unsigned s_status;
+  double x = np.x0;                                     // (clamped by the host, as newton() does first)
+  for (unsigned it = 0; ; ++it)
+  {
+    TrialLengths tl;
+#pragma unroll
+    for (unsigned i = 0; i < MAX_TRIAL_LENGTHS; ++i) tl.t[i] = x;
+    const double mine = deriv_block_totals<KS, SREAL>(mv, params, tl, 1u, sumtable, ps, cs, weights, invariant,
+                                                      N, nblk, R, rate_scalers, frag);
+    const bool last = grid_reduce_finish_lanes<8, true>(mine, ro, scratch);
+    if (last && threadIdx.x == 0)
+    {
+      // the step rule of newton() (csrc/host/pllhip_eval.c), expression by expression
+      const double f = ro.dst[0], df = ro.dst[1];
+      double xl = ctl->xl, xh = ctl->xh, dx;
+      unsigned status = NEWTON_RUNNING;
+      if (it > np.max_newton) status = NEWTON_LIMIT;                  // (the host loop counts the same way)
+      else if (!isfinite(f) || !isfinite(df)) status = NEWTON_NONFINITE;
+      else
+      {
+        if (df > 0.0)
+        {
+          if (fabs(f) < np.tolerance) status = NEWTON_CONVERGED;
+          else
+          {
+            if (f < 0.0) xl = x; else xh = x;
+            dx = -f / df;
+          }
+        }
+        else
+          dx = -f / fabs(df);
+        if (status == NEWTON_RUNNING)
+        {
+          dx = fmax(fmin(dx, np.dxmax), -np.dxmax);
+          if (x + dx < xl) dx = xl - x;
+          if (x + dx > xh) dx = xh - x;
+          if (fabs(dx) < np.tolerance) status = NEWTON_CONVERGED;
+          else
+          {
+            x += dx;
+            x = fmax(fmin(x, np.bl_max), np.bl_min);
+          }
+        }
+      }
+      if (it < NEWTON_TRAIL_MAX) host_out[NEWTON_TRAIL_SLOT + it] = x;       // the iterate after this scan
+      ctl->xl = xl;
+      ctl->xh = xh;
+      ctl->x = x;
+      ctl->status = status;
+      for (unsigned k = 0; k <= REDUCE_SHARDS; ++k)                          // tickets back to zero for the next scan
+        __hip_atomic_store(ro.counter + k * REDUCE_SHARD_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (status != NEWTON_RUNNING)
+      {
+        host_out[0] = x;
+        host_out[1] = (double)(it + 1);
+        host_out[2] = (double)status;
+        host_out[3] = f;
+        host_out[4] = df;
+        __threadfence_system();
+        __hip_atomic_store(host_flag, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      __hip_atomic_store(&ctl->iter, it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0)
+    {
+      unsigned spins = 0;
+      while (__hip_atomic_load(&ctl->iter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != it + 1)
+      {
+        if (++spins > NEWTON_SPIN_LIMIT)
+        {
+          __hip_atomic_store(&ctl->status, NEWTON_STUCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      s_status = (spins > NEWTON_SPIN_LIMIT) ? NEWTON_STUCK
+                                             : __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_x = __hip_atomic_load(&ctl->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned status = s_status;
+    x = s_x;
+    __syncthreads();
+    if (status != NEWTON_RUNNING) return;
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -348,6 +348,8 @@ void engine_destroy(Engine * e)
   (void)hipFree(e->d_model);
   (void)hipFree(e->d_partials);
   (void)hipFree(e->d_persite);
+  (void)hipFree(e->d_newton);
+  if (e->h_newton) (void)hipHostFree(e->h_newton);
   (void)hipFree(e->d_sum_scratch);
   if (e->h_result) (void)hipHostFree(e->h_result);
   if (e->h_asc) (void)hipHostFree(e->h_asc);
@@ -2381,6 +2383,120 @@ int pll_compute_likelihood_derivatives(pll_partition_t * p,
                               sumtable, d_f, dd_f);
   return derivatives_impl(p, parent_scaler_index, child_scaler_index, &branch_length, 1, params_indices,
                           sumtable, nullptr, d_f, dd_f);
+}
+
+int pllhip_newton_branch(pll_partition_t * p, int parent_scaler_index, int child_scaler_index,
+                         const unsigned int * params_indices, const double * sumtable,
+                         double start, double bl_min, double bl_max, double tolerance, unsigned int max_newton,
+                         double * length, unsigned int * iterations, double * trail)
+{
+  Engine * e = engine_of(p);
+  static const int enabled = getenv("PLLHIP_DEVICE_NEWTON") ? atoi(getenv("PLLHIP_DEVICE_NEWTON")) : 1;
+  const bool family_ok = e->family == KernelFamily::S20 || e->family == KernelFamily::S16 || e->family == KernelFamily::S61;
+  if (!enabled || !e->shards.empty() || !family_ok || e->N > e->Nreal || !e->fused_finish || !max_newton)
+  {
+    set_error(PLLHIP_ERROR_NEWTON_UNSUPPORTED, "this partition does not run the Newton-Raphson loop on the device");
+    return PLL_FAILURE;
+  }
+  PLLHIP_TRY(hipSetDevice(e->device));
+  if (!check_scaler_index(e, parent_scaler_index) || !check_scaler_index(e, child_scaler_index)) return PLL_FAILURE;
+  double * d_sum = sumtable_device(e, sumtable, false);
+  if (!d_sum)
+  {
+    set_error(PLL_ERROR_PARAM_INVALID, "pllhip_newton_branch: no sumtable was computed for this buffer");
+    return PLL_FAILURE;
+  }
+  if (!sync_model(p) || !ensure_invariant(p)) return PLL_FAILURE;
+  // the scan's own grid (derivatives_impl): the block totals, and with them every bit of the sums, are the same
+  const unsigned nblocks = std::min(reduce_grid(e), 4u * e->cu_count);
+  const unsigned ks = e->family == KernelFamily::S20 ? 5u : e->family == KernelFamily::S61 ? S61_KS : s16_ks(e);
+  const size_t lds = sizeof(double) * e->R * ks * 64;
+  const void * fn = nullptr;
+#define PLLHIP_PICK(KK, SS) fn = reinterpret_cast<const void *>(k_newton_mfma<KK, SS>)
+  if (e->family == KernelFamily::S20) PLLHIP_PICK(5, 20);
+  else if (e->family == KernelFamily::S61) { if (e->S == S61_S) PLLHIP_PICK(S61_KS, S61_S); else PLLHIP_PICK(S61_KS, 0); }
+#undef PLLHIP_PICK
+  if (e->family == KernelFamily::S16)
+  {
+    switch (ks)
+    {
+      case 1: fn = reinterpret_cast<const void *>(k_newton_mfma<1, 0>); break;
+      case 2: fn = reinterpret_cast<const void *>(k_newton_mfma<2, 0>); break;
+      case 3: fn = reinterpret_cast<const void *>(k_newton_mfma<3, 0>); break;
+      case 4: fn = reinterpret_cast<const void *>(k_newton_mfma<4, 0>); break;
+      case 5: fn = reinterpret_cast<const void *>(k_newton_mfma<5, 0>); break;
+      case 6: fn = reinterpret_cast<const void *>(k_newton_mfma<6, 0>); break;
+      case 7: fn = reinterpret_cast<const void *>(k_newton_mfma<7, 0>); break;
+      default: fn = reinterpret_cast<const void *>(k_newton_mfma<8, 0>); break;
+    }
+  }
+  if (e->newton_capacity < 0)
+  {
+    if (lds > 64 * 1024) PLLHIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+    int per_cu = 0;
+    PLLHIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
+    e->newton_capacity = std::max(0, per_cu) * (int)e->cu_count;
+  }
+  // every workgroup waits for the others inside the launch: all of them have to be on the chip at once
+  if ((int)nblocks > e->newton_capacity || lds > 160 * 1024 - 512)
+  {
+    set_error(PLLHIP_ERROR_NEWTON_UNSUPPORTED, "the scan grid (%u workgroups) does not fit the chip at once (%d)",
+              nblocks, e->newton_capacity);
+    return PLL_FAILURE;
+  }
+  if (!e->d_newton)
+  {
+    if (!dev_alloc(reinterpret_cast<NewtonControl **>(&e->d_newton), 1, "Newton-Raphson control block")) return PLL_FAILURE;
+    PLLHIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_newton), 128 * sizeof(double), hipHostMallocMapped));
+    memset(e->h_newton, 0, 128 * sizeof(double));
+    PLLHIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->hd_newton), e->h_newton, 0));
+  }
+  NewtonParams np;
+  np.bl_min = bl_min; np.bl_max = bl_max; np.tolerance = tolerance;
+  np.dxmax = bl_max / max_newton;
+  np.max_newton = max_newton;
+  np.x0 = std::max(std::min(start, bl_max), bl_min);
+  NewtonControl init;
+  memset(&init, 0, sizeof(init));
+  init.x = np.x0; init.xl = bl_min; init.xh = bl_max; init.iter = 0; init.status = NEWTON_RUNNING;
+  NewtonControl * ctl = static_cast<NewtonControl *>(e->d_newton);
+  // (pageable source: staged by the runtime before the call returns)
+  PLLHIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, e->stream));
+  ReduceOut ro;
+  ro.block_out = e->d_partials;
+  ro.counter = e->d_counter;
+  ro.dst = ctl->tot;
+  ro.flag = nullptr;
+  ro.seq = 0;
+  ro.fused = 1;
+  ro.nq = 2;
+  const unsigned long long seq = ++e->newton_seq;
+  unsigned long long * host_flag = reinterpret_cast<unsigned long long *>(e->hd_newton + 112);
+  const ModelView mv = model_view(e);
+  const ParamIdx params = make_params(p, params_indices);
+  const unsigned * ps = scaler_ptr(e, parent_scaler_index), * cs = scaler_ptr(e, child_scaler_index);
+  void * args[] = {(void *)&mv, (void *)&params, (void *)&np, (void *)&d_sum, (void *)&ps, (void *)&cs,
+                   (void *)&e->d_weights, (void *)&e->d_invariant, (void *)&e->N, (void *)&e->nblk, (void *)&e->R,
+                   (void *)&ro, nullptr, (void *)&ctl, (void *)&e->hd_newton, (void *)&host_flag, (void *)&seq};
+  unsigned rs = e->rate_scalers ? 1u : 0u;
+  args[12] = &rs;
+  PLLHIP_TRY(hipLaunchKernel(fn, dim3(nblocks), dim3(256), args, lds, e->stream));
+  e->counters.derivative_calls++;
+  const volatile unsigned long long * flag = reinterpret_cast<const volatile unsigned long long *>(e->h_newton + 112);
+  if (!wait_sequence(e->stream, flag, seq)) return PLL_FAILURE;
+  const unsigned its = (unsigned)e->h_newton[1], status = (unsigned)e->h_newton[2];
+  e->counters.derivative_points += its;
+  if (length) *length = e->h_newton[0];
+  if (iterations) *iterations = its;
+  if (trail) for (unsigned i = 0; i < its && i < NEWTON_TRAIL_MAX; ++i) trail[i] = e->h_newton[NEWTON_TRAIL_SLOT + i];
+  switch (status)
+  {
+    case NEWTON_CONVERGED: return PLL_SUCCESS;
+    case NEWTON_LIMIT: set_error(PLLHIP_ERROR_NEWTON_LIMIT, "Exceeded maximum number of iterations"); return PLL_FAILURE;
+    case NEWTON_NONFINITE: set_error(PLLHIP_ERROR_NEWTON_DERIVATIVES, "Wrong likelihood derivatives"); return PLL_FAILURE;
+    default: set_error(PLL_ERROR_HIP_RUNTIME, "the device-resident Newton-Raphson loop did not complete (status %u)", status);
+             return PLL_FAILURE;
+  }
 }
 
 unsigned int pllhip_free_trial_lengths(const pll_partition_t * p)

@@ -138,7 +138,7 @@ pllhip_profile_partials pllhip_profile_read pllhip_comm_rank pllhip_comm_size
 pllhip_compute_likelihood_derivatives_multi pllhip_free_trial_lengths pllhip_set_sharding
 pllhip_shard_count pllhip_results_create pllhip_results_destroy
 pllhip_results_edge_loglikelihood pllhip_results_derivatives pllhip_results_fetch
-pllhip_eval_attach_comm pllhip_update_partials_batch pllhip_results_poison""".split()
+pllhip_eval_attach_comm pllhip_update_partials_batch pllhip_results_poison pllhip_newton_branch""".split()
 
 
 def _u32(a):
@@ -288,6 +288,9 @@ class PllLib:
             L.pllhip_results_fetch.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_int, c_double_p]
             L.pllhip_results_poison.argtypes = [C.c_void_p]
             L.pllhip_results_poison.restype = None
+        if hasattr(L, "pllhip_newton_branch"):
+            L.pllhip_newton_branch.argtypes = [pp, C.c_int, C.c_int, c_uint_p, c_double_p, C.c_double, C.c_double,
+                                               C.c_double, C.c_double, C.c_uint, c_double_p, c_uint_p, c_double_p]
         if hasattr(L, "pllhip_update_partials_batch"):
             L.pllhip_update_partials_batch.argtypes = [C.POINTER(pp), C.c_uint, C.POINTER(Operation), C.c_uint]
         if hasattr(L, "pllhip_compute_likelihood_derivatives_multi"):
@@ -465,6 +468,17 @@ class Instance:
                                                          C.byref(df), C.byref(ddf)):
             raise RuntimeError(self.lib.errmsg)
         return df.value, ddf.value
+
+    def newton_branch(self, psc, csc, st, start, bl_min, bl_max, tolerance, max_newton):
+        """pllhip_newton_branch: (length, iterations, trail) or raises with the library's message"""
+        length, its = C.c_double(), C.c_uint()
+        trail = np.zeros(96)
+        self.lib.errno = 0
+        ok = self.L.pllhip_newton_branch(self.p, psc, csc, self.params_p, st, start, bl_min, bl_max, tolerance,
+                                         max_newton, C.byref(length), C.byref(its), trail.ctypes.data_as(c_double_p))
+        if not ok:
+            raise RuntimeError(f"[{self.lib.errno}] {self.lib.errmsg}")
+        return length.value, its.value, trail[:its.value]
 
     def derivatives_multi(self, psc, csc, ts, st):
         """(df[], ddf[]) at several branch lengths from one sumtable scan"""

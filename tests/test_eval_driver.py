@@ -386,3 +386,110 @@ def test_scaled_and_unlinked_lengths_on_gpu_match_oracle(product, oracle, linkag
     for x, y, z in zip(g, c, f):
         assert abs(x - y) < 1e-7 * max(1.0, abs(y))
         assert abs(z - x) < 1e-9 * max(1.0, abs(x))
+
+
+# ---------------------------------------------------------------------------
+# Newton-Raphson on the device (include/pllhip.h, pllhip_newton_branch)
+# ---------------------------------------------------------------------------
+def _host_newton(deriv, x, bl_min, bl_max, tol, max_newton):
+    """the step rule of newton() (csrc/host/pllhip_eval.c; reference: src/optimize/opt_algorithms.c:133-261)
+    in Python floats (IEEE doubles, no contraction): the iterate after every scan"""
+    dxmax = bl_max / max_newton
+    xl, xh = bl_min, bl_max
+    x = max(min(x, bl_max), bl_min)
+    trail = []
+    it = 0
+    while True:
+        assert it <= max_newton
+        it += 1
+        f, df = deriv(x)
+        if df > 0.0:
+            if abs(f) < tol:
+                trail.append(x)
+                return x, trail
+            if f < 0.0:
+                xl = x
+            else:
+                xh = x
+            dx = -f / df
+        else:
+            dx = -f / abs(df)
+        dx = max(min(dx, dxmax), -dxmax)
+        if x + dx < xl:
+            dx = xl - x
+        if x + dx > xh:
+            dx = xh - x
+        if abs(dx) < tol:
+            trail.append(x)
+            return x, trail
+        x += dx
+        x = max(min(x, bl_max), bl_min)
+        trail.append(x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("states,nsites,pinv", [(20, 5000, 0.0), (20, 333, 0.1), (61, 700, 0.0), (10, 2000, 0.0),
+                                                (24, 1500, 0.0), (62, 300, 0.0), (2, 4000, 0.0)])
+def test_device_newton_makes_the_host_loop_s_iterates(product, states, nsites, pinv):
+    """one launch runs the whole Newton-Raphson loop of a branch: every iterate is, bit for bit, the one the
+    host loop reaches by calling pll_compute_likelihood_derivatives once per iterate"""
+    with pc.build_instance(product, states=states, rate_cats=4, ntips=9, nsites=nsites, coded=True, pinv=pinv) as a:
+        pc.full_traversal(a)
+        t = a.tree
+        st = a.alloc_sumtable()
+        # every edge of the tree would need re-rooting; the root edge and, after re-rooting, two more
+        for root_edge in (t.root_matrix, 0, t.nedges // 2):
+            t2 = pc.Tree(9, 42, 43)
+            t2.set_root_edge(root_edge)
+            a.tree = t2
+            pc.full_traversal(a)
+            if t2.root_b < t2.ntips and t2.root_a < t2.ntips:
+                continue
+            sa, sb = t2.scaler_of(t2.root_a), t2.scaler_of(t2.root_b)
+            a.update_sumtable(t2.root_a, t2.root_b, sa, sb, st)
+            for start in (float(t2.brlens[root_edge]), 1e-4, 5.0):
+                want_x, want_trail = _host_newton(lambda x: a.derivatives(sa, sb, x, st), start, 1e-4, 10.0, 1e-5, 32)
+                got_x, its, trail = a.newton_branch(sa, sb, st, start, 1e-4, 10.0, 1e-5, 32)
+                assert its == len(want_trail), (states, root_edge, start, its, len(want_trail))
+                assert list(trail) == want_trail
+                assert got_x == want_x
+        a.free_sumtable(st)
+
+
+@pytest.mark.gpu
+def test_device_newton_says_when_it_cannot(product):
+    with pc.build_instance(product, states=4, rate_cats=4, ntips=6, nsites=500, coded=True) as a:
+        pc.full_traversal(a)
+        t = a.tree
+        st = a.alloc_sumtable()
+        a.update_sumtable(t.root_a, t.root_b, t.scaler_of(t.root_a), t.scaler_of(t.root_b), st)
+        with pytest.raises(RuntimeError, match="912"):
+            a.newton_branch(t.scaler_of(t.root_a), t.scaler_of(t.root_b), st, 0.1, 1e-4, 10.0, 1e-5, 32)
+        a.free_sumtable(st)
+    with pc.build_instance(product, states=20, rate_cats=4, ntips=6, nsites=500, coded=True) as a:
+        pc.full_traversal(a)
+        t = a.tree
+        st = a.alloc_sumtable()
+        a.update_sumtable(t.root_a, t.root_b, t.scaler_of(t.root_a), t.scaler_of(t.root_b), st)
+        with pytest.raises(RuntimeError, match="910"):       # an iteration limit the loop cannot meet
+            a.newton_branch(t.scaler_of(t.root_a), t.scaler_of(t.root_b), st, 9.0, 1e-4, 10.0, 1e-12, 1)
+        a.free_sumtable(st)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("states", [20, 61, 10])
+def test_driver_with_device_newton_equals_driver_with_host_loop(product, states):
+    """pllhip_eval_optimize_branches on one partition: the device loop and the host loop give the same tree,
+    the same lnL and the same number of Newton iterations"""
+    import os
+    out = []
+    for flag in ("0", "1"):
+        os.environ["PLLHIP_EVAL_DEVICE_NEWTON"] = flag
+        try:
+            with build_search(product, states, ntips=12, nsites=400 if states < 61 else 150) as ev:
+                l0 = ev.loglh()
+                l1 = ev.optimize_branches(1e-4, 10.0, 0.01, 3, -1)
+                out.append((l0, l1, ev.newick(), ev.newton_iterations()))
+        finally:
+            del os.environ["PLLHIP_EVAL_DEVICE_NEWTON"]
+    assert out[0] == out[1]
