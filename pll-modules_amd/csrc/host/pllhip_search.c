@@ -9,8 +9,12 @@
  * and the CPU oracle alike; tests/test_dropin_modules.py runs the reference's
  * function and this one on the same data and compares the resulting trees.
  *
- * Scope: linked branch lengths, no topological constraint, incremental CLV
- * updates (the reference's fast_clv_updates = 1).
+ * Scope: linked, scaled and unlinked branch lengths, no topological constraint, incremental CLV
+ * updates (the reference's fast_clv_updates = 1).  With unlinked lengths every length the round saves,
+ * joins, halves, clamps or restores is a vector -- the tree's own length plus one per partition, kept by
+ * P-matrix index (src/algorithm/algo_search.c:399-565: algo_unode_fix_length, algo_utree_prune,
+ * algo_utree_regraft, and the pllmod_treeinfo_get / set_branch_length_all calls of best_reinsert_edge,
+ * src/algorithm/algo_search.c:639-641, 756, 811-813).
  *
  * Why the validity flags stay truthful through the scan: every scan starts with
  * an evaluation rooted at the pruned record, after which every CLV slot of the
@@ -30,23 +34,28 @@ static int trace_on(void)
 }
 #define TRACE(...) do { if (trace_on()) fprintf(stderr, "[spr] " __VA_ARGS__); } while (0)
 
+/* a branch length as the round handles it: v[0] the tree's, v[1 + p] partition p's own (unlinked only);
+   LV(s) values */
+#define LV(s) ((s)->nl)
+
 typedef struct
 {
   pll_unode_t * p, * r;
-  double b1, b2, b3, lh;
+  double * b1, * b2, * b3;     /* [LV] each */
+  double lh;
   unsigned int undo_pos;       /* number of moves applied before this placement was scored */
 } placement_t;
 
 typedef struct
 {
   pll_unode_t * p, * home;     /* home: p->next->back before the move */
-  double p_len, left_len, right_len, regraft_len;
+  double * p_len, * left_len, * right_len, * regraft_len;     /* [LV] each */
 } undo_t;
 
 typedef struct
 {
   unsigned int left, right, pmatrix_index;
-  double length;
+  double * length;             /* [LV] */
 } saved_edge_t;
 
 typedef struct
@@ -56,6 +65,7 @@ typedef struct
   pllhip_spr_cutoff_t * cut;
   pllhip_spr_stats_t * st;
   int thorough;
+  unsigned int nl;             /* 1, or 1 + partitions with unlinked branch lengths */
   undo_t * ring;               /* applied moves, newest at cur - 1 (wraps) */
   size_t ring_size, ring_cur;
   unsigned int ring_round;
@@ -64,7 +74,11 @@ typedef struct
   pll_unode_t ** records;      /* by node_index */
   pll_unode_t ** queue;        /* breadth-first regraft candidates */
   unsigned int * qdist;
+  double * pool;               /* the length vectors of all of the above + scratch */
+  double * tmp;                /* [8][LV] scratch vectors */
 } search_t;
+
+#define TMP(s, k) ((s)->tmp + (size_t)(k) * LV(s))
 
 /* ---- graph surgery; index rule of the reference: the second record of a new
    edge takes the P-matrix index of the first (utree_operations.c:359-374) ---- */
@@ -77,30 +91,71 @@ static void connect(pll_unode_t * a, pll_unode_t * b, double length)
   b->pmatrix_index = a->pmatrix_index;
 }
 
-/* utree_operations.c:184-207: neighbours joined, lengths added; returns the joined edge */
-static pll_unode_t * detach(pll_unode_t * p)
+/* the length vector of an edge / an edge takes a length vector */
+static void get_lens(const search_t * s, const pll_unode_t * e, double * out)
+{
+  unsigned int p;
+  out[0] = e->length;
+  for (p = 0; p + 1 < LV(s); ++p) out[1 + p] = s->ev->part_brlens[p][e->pmatrix_index];
+}
+
+static void set_lens(search_t * s, pll_unode_t * e, const double * in)
+{
+  unsigned int p;
+  e->length = e->back->length = in[0];
+  for (p = 0; p + 1 < LV(s); ++p) s->ev->part_brlens[p][e->pmatrix_index] = in[1 + p];
+}
+
+static void copy_lens(const search_t * s, double * dst, const double * src) { memcpy(dst, src, sizeof(double) * LV(s)); }
+
+/* utree_operations.c:184-207 / algo_search.c:495-524: neighbours joined, lengths added (every partition's own
+   as well); returns the joined edge */
+static pll_unode_t * detach(search_t * s, pll_unode_t * p)
 {
   pll_unode_t * u = p->next->back, * v = p->next->next->back;
-  connect(u, v, u->length + v->length);
+  double * a = TMP(s, 6), * b = TMP(s, 7);
+  unsigned int k;
+  get_lens(s, u, a);
+  get_lens(s, v, b);
+  for (k = 0; k < LV(s); ++k) a[k] += b[k];
+  connect(u, v, a[0]);
+  set_lens(s, u, a);
   p->next->back = p->next->next->back = NULL;
   return u;
 }
 
-/* utree_operations.c:229-257: the target edge is split in half */
-static void attach(pll_unode_t * p, pll_unode_t * r)
+/* utree_operations.c:229-257 / algo_search.c:527-565: the target edge is split in half */
+static void attach(search_t * s, pll_unode_t * p, pll_unode_t * r)
 {
   pll_unode_t * r2 = r->back;
-  const double half = r->length / 2;
-  connect(r, p->next, half);
-  connect(p->next->next, r2, half);
+  double * a = TMP(s, 6);
+  unsigned int k;
+  get_lens(s, r, a);
+  for (k = 0; k < LV(s); ++k) a[k] = a[k] / 2;
+  connect(r, p->next, a[0]);
+  connect(p->next->next, r2, a[0]);
+  set_lens(s, r, a);
+  set_lens(s, r2, a);
 }
 
-static void set_len(pll_unode_t * e, double length) { e->length = e->back->length = length; }
-
+/* algo_search.c:421-459 (algo_unode_fix_length): every length of the edge into [bl_min, bl_max] */
 static void clamp_len(search_t * s, pll_unode_t * e)
 {
-  if (e->length < s->prm->bl_min) { set_len(e, s->prm->bl_min); pllhip_eval_invalidate_pmatrix(s->ev, e); }
-  else if (e->length > s->prm->bl_max) { set_len(e, s->prm->bl_max); pllhip_eval_invalidate_pmatrix(s->ev, e); }
+  unsigned int p;
+  int changed = 0;
+  if (LV(s) == 1)
+  {
+    if (e->length < s->prm->bl_min) { e->length = e->back->length = s->prm->bl_min; changed = 1; }
+    else if (e->length > s->prm->bl_max) { e->length = e->back->length = s->prm->bl_max; changed = 1; }
+  }
+  else
+    for (p = 0; p + 1 < LV(s); ++p)
+    {
+      double * len = &s->ev->part_brlens[p][e->pmatrix_index];
+      if (*len < s->prm->bl_min) { *len = s->prm->bl_min; changed = 1; }
+      else if (*len > s->prm->bl_max) { *len = s->prm->bl_max; changed = 1; }
+    }
+  if (changed) pllhip_eval_invalidate_pmatrix(s->ev, e);
 }
 
 static void root_at(search_t * s, pll_unode_t * n) { s->ev->root = n->next ? n : n->back; }
@@ -131,13 +186,20 @@ static undo_t * ring_prev(search_t * s)
   return s->ring + s->ring_cur;
 }
 
+/* the list owns its length vectors: an insertion rotates the vectors of the entry that drops out to the new slot */
 static void best_save(search_t * s, const placement_t * e)
 {
   size_t i = 0, j;
+  placement_t spare;
   while (i < s->best_size && s->best[i].p && e->lh < s->best[i].lh) ++i;
   if (i >= s->best_size) return;
+  spare = s->best[s->best_size - 1];
   for (j = s->best_size - 1; j > i; --j) s->best[j] = s->best[j - 1];
-  s->best[i] = *e;
+  s->best[i].p = e->p; s->best[i].r = e->r; s->best[i].lh = e->lh; s->best[i].undo_pos = e->undo_pos;
+  s->best[i].b1 = spare.b1; s->best[i].b2 = spare.b2; s->best[i].b3 = spare.b3;
+  copy_lens(s, s->best[i].b1, e->b1);
+  copy_lens(s, s->best[i].b2, e->b2);
+  copy_lens(s, s->best[i].b3, e->b3);
 }
 
 static int best_next(const search_t * s, size_t pos, int i)
@@ -183,7 +245,7 @@ static void save_topology(const search_t * s, saved_edge_t * out, unsigned int *
       out[k].left = n->node_index;
       out[k].right = n->back->node_index;
       out[k].pmatrix_index = n->pmatrix_index;
-      out[k].length = n->length;
+      get_lens(s, n, out[k].length);
       ++k;
     }
   }
@@ -196,8 +258,9 @@ static void load_topology(search_t * s, const saved_edge_t * in, unsigned int ro
   for (k = 0; k < s->ev->edges; ++k)
   {
     pll_unode_t * a = s->records[in[k].left], * b = s->records[in[k].right];
-    connect(a, b, in[k].length);
+    connect(a, b, in[k].length[0]);
     a->pmatrix_index = b->pmatrix_index = in[k].pmatrix_index;
+    set_lens(s, a, in[k].length);
   }
   s->ev->root = s->records[root_index];
   pllhip_eval_invalidate_all(s->ev);
@@ -220,10 +283,12 @@ static int scan_placements(search_t * s, placement_t * entry)
 {
   pllhip_eval_t * ev = s->ev;
   pll_unode_t * p = entry->p, * home, * r;
-  const double z1 = p->length, z2 = p->next->length, z3 = p->next->next->length;
+  double * z1 = TMP(s, 0), * z2 = TMP(s, 1), * z3 = TMP(s, 2);
+  double * b1 = TMP(s, 3), * b2 = TMP(s, 4), * b3 = TMP(s, 5);
   unsigned int count = 0, j;
   double lh;
 
+  get_lens(s, p, z1); get_lens(s, p->next, z2); get_lens(s, p->next->next, z3);
   entry->r = NULL;
   entry->lh = -INFINITY;
 
@@ -232,7 +297,7 @@ static int scan_placements(search_t * s, placement_t * entry)
   pllhip_eval_invalidate_clv(ev, p);
   if (isnan(pllhip_eval_loglh(ev, 1))) return PLL_FAILURE;
 
-  home = detach(p);
+  home = detach(s, p);
   clamp_len(s, home);
   root_at(s, home);
   pllhip_eval_invalidate_clv(ev, home);
@@ -246,15 +311,15 @@ static int scan_placements(search_t * s, placement_t * entry)
 
   for (j = 0; (r = s->queue[j]) != NULL; ++j)
   {
-    double regraft_len, b1, b2, b3;
+    double * regraft_len = s->tmp + (size_t)8 * LV(s);
     int descend;
     if (r == home || r == home->back) continue;
 
-    regraft_len = r->length;
-    attach(p, r);
+    get_lens(s, r, regraft_len);
+    attach(s, p, r);
     root_at(s, p);
     pllhip_eval_invalidate_clv(ev, p);
-    b1 = p->length; b2 = p->next->length; b3 = p->next->next->length;
+    get_lens(s, p, b1); get_lens(s, p->next, b2); get_lens(s, p->next->next, b3);
     clamp_len(s, p->next);
     clamp_len(s, p->next->next);
     pllhip_eval_invalidate_pmatrix(ev, p->next);
@@ -276,15 +341,15 @@ static int scan_placements(search_t * s, placement_t * entry)
     {
       entry->lh = lh;
       entry->r = r;
-      entry->b1 = p->length; entry->b2 = p->next->length; entry->b3 = p->next->next->length;
+      get_lens(s, p, entry->b1); get_lens(s, p->next, entry->b2); get_lens(s, p->next->next, entry->b3);
     }
 
     /* back to the lengths before the insertion, then take the subtree out again */
-    set_len(p, b1); set_len(p->next, b2); set_len(p->next->next, b3);
+    set_lens(s, p, b1); set_lens(s, p->next, b2); set_lens(s, p->next->next, b3);
     invalidate_triplet(s, p);
     {
-      pll_unode_t * gap = detach(p);
-      set_len(gap, regraft_len);
+      pll_unode_t * gap = detach(s, p);
+      set_lens(s, gap, regraft_len);
       pllhip_eval_invalidate_pmatrix(ev, gap);
     }
 
@@ -307,8 +372,8 @@ static int scan_placements(search_t * s, placement_t * entry)
   TRACE("scan p=%u: %u candidates, best lh %.6f at r=%d\n", p->node_index, j, entry->lh,
         entry->r ? (int)entry->r->node_index : -1);
   /* back home, original lengths, everything looks at p again */
-  attach(p, home);
-  set_len(p, z1); set_len(p->next, z2); set_len(p->next->next, z3);
+  attach(s, p, home);
+  set_lens(s, p, z1); set_lens(s, p->next, z2); set_lens(s, p->next->next, z3);
   invalidate_triplet(s, p);
   root_at(s, p);
   pllhip_eval_invalidate_clv(ev, p);
@@ -332,6 +397,7 @@ static double scan_nodes(search_t * s, pll_unode_t ** nodes, unsigned int count)
     /* a two-taxon remainder has nowhere to go */
     if (!p->next->back->next && !p->next->next->back->next) continue;
     entry.p = p;
+    entry.b1 = s->tmp + (size_t)9 * LV(s); entry.b2 = s->tmp + (size_t)10 * LV(s); entry.b3 = s->tmp + (size_t)11 * LV(s);
     if (s->cut) s->cut->lh_start = best_lh;
     if (!scan_placements(s, &entry)) return 0.0;
     r = entry.r;
@@ -342,12 +408,12 @@ static double scan_nodes(search_t * s, pll_unode_t ** nodes, unsigned int count)
       pll_unode_t * home = p->next->back;
       slot->p = p;
       slot->home = home;
-      slot->p_len = p->length;
-      slot->left_len = p->next->length;
-      slot->right_len = p->next->next->length;
-      slot->regraft_len = r->length;
-      detach(p);
-      attach(p, r);
+      get_lens(s, p, slot->p_len);
+      get_lens(s, p->next, slot->left_len);
+      get_lens(s, p->next->next, slot->right_len);
+      get_lens(s, r, slot->regraft_len);
+      detach(s, p);
+      attach(s, p, r);
       clamp_len(s, home);
       pllhip_eval_invalidate_pmatrix(ev, home);
       if (s->st)
@@ -363,7 +429,7 @@ static double scan_nodes(search_t * s, pll_unode_t ** nodes, unsigned int count)
       slot = ring_next(s);
       if (s->thorough)
       {
-        set_len(p, entry.b1); set_len(p->next, entry.b2); set_len(p->next->next, entry.b3);
+        set_lens(s, p, entry.b1); set_lens(s, p->next, entry.b2); set_lens(s, p->next->next, entry.b3);
       }
       else
       {
@@ -392,6 +458,8 @@ double pllhip_eval_spr_round(pllhip_eval_t * ev, const pllhip_spr_params_t * prm
                              pllhip_spr_cutoff_t * cut, pllhip_spr_stats_t * st)
 {
   search_t s;
+  undo_t redo;
+  double * topol_lens = NULL;
   pll_unode_t ** nodes = NULL, * initial_root;
   saved_edge_t * best_topol = NULL;
   unsigned int i, k = 0, best_root = 0, nrec;
@@ -405,32 +473,49 @@ double pllhip_eval_spr_round(pllhip_eval_t * ev, const pllhip_spr_params_t * prm
     pllhip_eval_error(PLL_ERROR_PARAM_INVALID, "Invalid SPR round parameters");
     return 0.0;
   }
-  if (ev->linkage == PLLHIP_EVAL_BRLEN_UNLINKED)
-  {
-    /* the round saves and restores ONE length per branch (the tree's); per-partition
-       lengths would need the reference's topology snapshots (src/tree/treeinfo.c:570-700) */
-    pllhip_eval_error(PLL_ERROR_NOT_IMPLEMENTED, "SPR rounds need linked or scaled branch lengths");
-    return 0.0;
-  }
   pll_errno = 0;
   memset(&s, 0, sizeof(s));
+  memset(&redo, 0, sizeof(redo));
   s.ev = ev; s.prm = prm; s.cut = cut; s.st = st;
   s.thorough = prm->thorough;
+  s.nl = (ev->linkage == PLLHIP_EVAL_BRLEN_UNLINKED && ev->part_brlens) ? 1 + ev->nparts : 1;
   s.ring_size = prm->ntopol_keep;
   s.best_size = prm->thorough ? prm->ntopol_keep : (size_t)prm->ntopol_keep * 3;
   nrec = ev->inner * 3;
   s.ring = (undo_t *)calloc(s.ring_size ? s.ring_size : 1, sizeof(undo_t));
   s.best = (placement_t *)calloc(s.best_size ? s.best_size : 1, sizeof(placement_t));
+  {
+    /* length vectors: 4 per remembered move (+ one spare move for re-applying a listed placement), 3 per listed
+       placement, 1 per edge of the best topology, 12 scratch */
+    const size_t ring_n = s.ring_size ? s.ring_size : 1, best_n = s.best_size ? s.best_size : 1;
+    const size_t vectors = 4 * (ring_n + 1) + 3 * best_n + ev->edges + 12;
+    s.pool = (double *)calloc(vectors * s.nl, sizeof(double));
+    if (s.pool && s.ring && s.best)
+    {
+      double * v = s.pool;
+      size_t x;
+      for (x = 0; x < ring_n; ++x)
+      {
+        s.ring[x].p_len = v; v += s.nl; s.ring[x].left_len = v; v += s.nl;
+        s.ring[x].right_len = v; v += s.nl; s.ring[x].regraft_len = v; v += s.nl;
+      }
+      redo.p_len = v; v += s.nl; redo.left_len = v; v += s.nl; redo.right_len = v; v += s.nl; redo.regraft_len = v; v += s.nl;
+      for (x = 0; x < best_n; ++x) { s.best[x].b1 = v; v += s.nl; s.best[x].b2 = v; v += s.nl; s.best[x].b3 = v; v += s.nl; }
+      topol_lens = v; v += (size_t)ev->edges * s.nl;
+      s.tmp = v;
+    }
+  }
   s.records = (pll_unode_t **)calloc(ev->records, sizeof(*s.records));
   s.queue = (pll_unode_t **)calloc((size_t)ev->edges * 2 + 2, sizeof(*s.queue));
   s.qdist = (unsigned int *)calloc((size_t)ev->edges * 2 + 2, sizeof(unsigned int));
   nodes = (pll_unode_t **)calloc(nrec ? nrec : 1, sizeof(*nodes));
   best_topol = (saved_edge_t *)calloc(ev->edges, sizeof(saved_edge_t));
-  if (!s.ring || !s.best || !s.records || !s.queue || !s.qdist || !nodes || !best_topol)
+  if (!s.ring || !s.best || !s.records || !s.queue || !s.qdist || !nodes || !best_topol || !s.pool)
   {
     pllhip_eval_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate SPR round buffers");
     goto done;
   }
+  for (i = 0; i < ev->edges; ++i) best_topol[i].length = topol_lens + (size_t)i * s.nl;
   for (i = 0; i < ev->tips + ev->inner; ++i)
   {
     pll_unode_t * n = ev->tree->nodes[i], * t = n;
@@ -462,7 +547,6 @@ double pllhip_eval_spr_round(pllhip_eval_t * ev, const pllhip_spr_params_t * prm
   while (undone < s.ring_size)
   {
     const size_t pos = ring_pos(&s);
-    undo_t redo;
     int applied_listed = 0;
     li = best_next(&s, pos, li);
     if (li < 0)
@@ -472,12 +556,12 @@ double pllhip_eval_spr_round(pllhip_eval_t * ev, const pllhip_spr_params_t * prm
       if (!u || !u->p) break;
       cur1 = u->p->next->back;
       cur2 = u->home->back;
-      detach(u->p);
-      attach(u->p, u->home);
-      set_len(cur1, u->regraft_len);
-      set_len(u->p, u->p_len);
-      set_len(u->home, u->left_len);
-      set_len(cur2, u->right_len);
+      detach(&s, u->p);
+      attach(&s, u->p, u->home);
+      set_lens(&s, cur1, u->regraft_len);
+      set_lens(&s, u->p, u->p_len);
+      set_lens(&s, u->home, u->left_len);
+      set_lens(&s, cur2, u->right_len);
       undone++;
     }
     else
@@ -487,16 +571,16 @@ double pllhip_eval_spr_round(pllhip_eval_t * ev, const pllhip_spr_params_t * prm
       e = &s.best[li];
       redo.p = e->p;
       redo.home = e->p->next->back;
-      redo.p_len = e->p->length;
-      redo.left_len = e->p->next->length;
-      redo.right_len = e->p->next->next->length;
-      redo.regraft_len = e->r->length;
-      detach(e->p);
-      attach(e->p, e->r);
+      get_lens(&s, e->p, redo.p_len);
+      get_lens(&s, e->p->next, redo.left_len);
+      get_lens(&s, e->p->next->next, redo.right_len);
+      get_lens(&s, e->r, redo.regraft_len);
+      detach(&s, e->p);
+      attach(&s, e->p, e->r);
       clamp_len(&s, redo.home);
       if (prm->thorough)
       {
-        set_len(e->p, e->b1); set_len(e->p->next, e->b2); set_len(e->p->next->next, e->b3);
+        set_lens(&s, e->p, e->b1); set_lens(&s, e->p->next, e->b2); set_lens(&s, e->p->next->next, e->b3);
       }
       else
       {
@@ -517,12 +601,12 @@ double pllhip_eval_spr_round(pllhip_eval_t * ev, const pllhip_spr_params_t * prm
     if (applied_listed)
     {
       pll_unode_t * cur1 = redo.p->next->back, * cur2 = redo.home->back;
-      detach(redo.p);
-      attach(redo.p, redo.home);
-      set_len(cur1, redo.regraft_len);
-      set_len(redo.p, redo.p_len);
-      set_len(redo.home, redo.left_len);
-      set_len(cur2, redo.right_len);
+      detach(&s, redo.p);
+      attach(&s, redo.p, redo.home);
+      set_lens(&s, cur1, redo.regraft_len);
+      set_lens(&s, redo.p, redo.p_len);
+      set_lens(&s, redo.home, redo.left_len);
+      set_lens(&s, cur2, redo.right_len);
     }
   }
 
@@ -541,7 +625,7 @@ double pllhip_eval_spr_round(pllhip_eval_t * ev, const pllhip_spr_params_t * prm
   result = lh;
 
 done:
-  free(s.ring); free(s.best); free(s.records); free(s.queue); free(s.qdist);
+  free(s.ring); free(s.best); free(s.records); free(s.queue); free(s.qdist); free(s.pool);
   free(nodes); free(best_topol);
   return result;
 }

@@ -2191,6 +2191,56 @@ double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsigned cc
   return total;
 }
 
+// the loop kernel of pllhip_newton_branch for this partition's family, its LDS, and how many of its workgroups
+// the chip holds at once (-1: HIP error).  derivatives_impl sizes its scan grid with the same number, so that the
+// device loop and the host loop add the same block totals in the same order.
+static int newton_capacity(Engine * e, const void ** fn_out, size_t * lds_out)
+{
+  const unsigned ks = e->family == KernelFamily::S20 ? 5u : e->family == KernelFamily::S61 ? S61_KS : s16_ks(e);
+  const size_t lds = sizeof(double) * e->R * ks * 64;
+  const void * fn = nullptr;
+#define PLLHIP_PICK(KK, SS) fn = reinterpret_cast<const void *>(k_newton_mfma<KK, SS>)
+  if (e->family == KernelFamily::S20) PLLHIP_PICK(5, 20);
+  else if (e->family == KernelFamily::S61) { if (e->S == S61_S) PLLHIP_PICK(S61_KS, S61_S); else PLLHIP_PICK(S61_KS, 0); }
+  else
+    switch (ks)
+    {
+      case 1: PLLHIP_PICK(1, 0); break;
+      case 2: PLLHIP_PICK(2, 0); break;
+      case 3: PLLHIP_PICK(3, 0); break;
+      case 4: PLLHIP_PICK(4, 0); break;
+      case 5: PLLHIP_PICK(5, 0); break;
+      case 6: PLLHIP_PICK(6, 0); break;
+      case 7: PLLHIP_PICK(7, 0); break;
+      default: PLLHIP_PICK(8, 0); break;
+    }
+#undef PLLHIP_PICK
+  if (fn_out) *fn_out = fn;
+  if (lds_out) *lds_out = lds;
+  if (e->newton_capacity < 0)
+  {
+    if (lds > 160 * 1024 - 512) { e->newton_capacity = 0; return 0; }
+    if (lds > 64 * 1024 && !hip_ok(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512), "hipFuncSetAttribute"))
+      return -1;
+    int per_cu = 0;
+    if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor"))
+      return -1;
+    e->newton_capacity = std::max(0, per_cu) * (int)e->cu_count;
+  }
+  return e->newton_capacity;
+}
+
+// workgroups of a derivative scan on the matrix cores: long-lived ones (the scan pipelines its loads across the
+// units a wave walks; tables built, totals reduced and published less often), and no more than the chip holds at
+// once, so that pllhip_newton_branch can run the very same grid as a loop
+static unsigned scan_grid(Engine * e)
+{
+  unsigned nblocks = std::min(reduce_grid(e), 4u * e->cu_count);
+  const int cap = newton_capacity(e, nullptr, nullptr);
+  if (cap > 0) nblocks = std::min(nblocks, (unsigned)cap);
+  return nblocks;
+}
+
 // K = up to MAX_TRIAL_LENGTHS trial branch lengths per sumtable scan; totals in the order
 // df[0], ddf[0], df[1], ddf[1], ...  (to out_df / out_ddf, or left at deferred->dst)
 int derivatives_impl(pll_partition_t * p, int parent_scaler_index, int child_scaler_index,
@@ -2215,10 +2265,7 @@ int derivatives_impl(pll_partition_t * p, int parent_scaler_index, int child_sca
     return PLL_FAILURE;
   }
   if (!sync_model(p) || !ensure_invariant(p)) return PLL_FAILURE;
-  unsigned nblocks = reduce_grid(e);
-  // the matrix-core scan pipelines its loads across the units a wave walks: a few long-lived
-  // workgroups per CU (tables built, totals reduced and published less often)
-  if (e->blocked) nblocks = std::min(nblocks, 4u * e->cu_count);
+  const unsigned nblocks = e->blocked ? scan_grid(e) : reduce_grid(e);
   const ModelView mv = model_view(e);
   const ParamIdx params = make_params(p, params_indices);
   // lengths per launch: the matrix-core kernel (20 / 61 states) takes four; the others are
@@ -2408,37 +2455,13 @@ int pllhip_newton_branch(pll_partition_t * p, int parent_scaler_index, int child
   }
   if (!sync_model(p) || !ensure_invariant(p)) return PLL_FAILURE;
   // the scan's own grid (derivatives_impl): the block totals, and with them every bit of the sums, are the same
-  const unsigned nblocks = std::min(reduce_grid(e), 4u * e->cu_count);
-  const unsigned ks = e->family == KernelFamily::S20 ? 5u : e->family == KernelFamily::S61 ? S61_KS : s16_ks(e);
-  const size_t lds = sizeof(double) * e->R * ks * 64;
+  const unsigned nblocks = scan_grid(e);
   const void * fn = nullptr;
-#define PLLHIP_PICK(KK, SS) fn = reinterpret_cast<const void *>(k_newton_mfma<KK, SS>)
-  if (e->family == KernelFamily::S20) PLLHIP_PICK(5, 20);
-  else if (e->family == KernelFamily::S61) { if (e->S == S61_S) PLLHIP_PICK(S61_KS, S61_S); else PLLHIP_PICK(S61_KS, 0); }
-#undef PLLHIP_PICK
-  if (e->family == KernelFamily::S16)
-  {
-    switch (ks)
-    {
-      case 1: fn = reinterpret_cast<const void *>(k_newton_mfma<1, 0>); break;
-      case 2: fn = reinterpret_cast<const void *>(k_newton_mfma<2, 0>); break;
-      case 3: fn = reinterpret_cast<const void *>(k_newton_mfma<3, 0>); break;
-      case 4: fn = reinterpret_cast<const void *>(k_newton_mfma<4, 0>); break;
-      case 5: fn = reinterpret_cast<const void *>(k_newton_mfma<5, 0>); break;
-      case 6: fn = reinterpret_cast<const void *>(k_newton_mfma<6, 0>); break;
-      case 7: fn = reinterpret_cast<const void *>(k_newton_mfma<7, 0>); break;
-      default: fn = reinterpret_cast<const void *>(k_newton_mfma<8, 0>); break;
-    }
-  }
-  if (e->newton_capacity < 0)
-  {
-    if (lds > 64 * 1024) PLLHIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-    int per_cu = 0;
-    PLLHIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
-    e->newton_capacity = std::max(0, per_cu) * (int)e->cu_count;
-  }
+  size_t lds = 0;
+  const int capacity = newton_capacity(e, &fn, &lds);
+  if (capacity < 0) return PLL_FAILURE;
   // every workgroup waits for the others inside the launch: all of them have to be on the chip at once
-  if ((int)nblocks > e->newton_capacity || lds > 160 * 1024 - 512)
+  if ((int)nblocks > capacity || capacity == 0)
   {
     set_error(PLLHIP_ERROR_NEWTON_UNSUPPORTED, "the scan grid (%u workgroups) does not fit the chip at once (%d)",
               nblocks, e->newton_capacity);

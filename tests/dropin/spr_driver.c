@@ -5,7 +5,7 @@
  * data, both on the library the test links (the CPU oracle build), and prints
  * what each one ends with.  Only public pll-modules / include/pll.h calls.
  *
- * usage: spr_driver <newick file> <alignment file> fast|thorough <radius_max> <rounds> <ntopol>
+ * usage: spr_driver <newick file> <alignment file> fast|thorough <radius_max> <rounds> <ntopol> [linked|scaled|unlinked]
  * alignment file: one "<label> <sequence over acgt->" line per taxon; columns are
  * split into two partitions (first 60 % / rest) with different models.
  */
@@ -87,6 +87,11 @@ int main(int argc, char ** argv)
   const unsigned int radius_max = (unsigned int)atoi(argv[4]);
   const int rounds = atoi(argv[5]);
   const unsigned int ntopol = (unsigned int)atoi(argv[6]);
+  const char * linkage = argc > 7 ? argv[7] : "linked";
+  const int ref_linkage = !strcmp(linkage, "unlinked") ? PLLMOD_COMMON_BRLEN_UNLINKED
+                        : !strcmp(linkage, "scaled") ? PLLMOD_COMMON_BRLEN_SCALED : PLLMOD_COMMON_BRLEN_LINKED;
+  const int own_linkage = !strcmp(linkage, "unlinked") ? PLLHIP_EVAL_BRLEN_UNLINKED
+                        : !strcmp(linkage, "scaled") ? PLLHIP_EVAL_BRLEN_SCALED : PLLHIP_EVAL_BRLEN_LINKED;
   int round;
   read_alignment(argv[2]);
   pll_utree_t * tree = pll_utree_parse_newick_string(slurp(argv[1]));
@@ -101,13 +106,14 @@ int main(int argc, char ** argv)
   parts[1] = make_partition(tree, cut, nsites - cut, 1.1, 4.0);
 
   /* ---- the reference ---- */
-  pllmod_treeinfo_t * ti = pllmod_treeinfo_create(tree->vroot, ntaxa, 2, PLLMOD_COMMON_BRLEN_LINKED);
+  pllmod_treeinfo_t * ti = pllmod_treeinfo_create(tree->vroot, ntaxa, 2, ref_linkage);
   if (!ti) { fprintf(stderr, "treeinfo: %s\n", pll_errmsg); return 1; }
   if (!pllmod_treeinfo_init_partition(ti, 0, parts[0], PLLMOD_OPT_PARAM_BRANCHES_ITERATIVE,
                                       PLL_GAMMA_RATES_MEAN, 0.6, params_indices, sym) ||
       !pllmod_treeinfo_init_partition(ti, 1, parts[1], PLLMOD_OPT_PARAM_BRANCHES_ITERATIVE,
                                       PLL_GAMMA_RATES_MEAN, 1.1, params_indices, sym))
   { fprintf(stderr, "init_partition: %s\n", pll_errmsg); return 1; }
+  if (ref_linkage == PLLMOD_COMMON_BRLEN_SCALED) { ti->brlen_scalers[0] = 0.8; ti->brlen_scalers[1] = 1.3; }
   cutoff_info_t rc;
   memset(&rc, 0, sizeof(rc));
   rc.lh_cutoff = 1e30;       /* first round: no cutoff yet, as raxml-ng starts it */
@@ -122,6 +128,17 @@ int main(int argc, char ** argv)
   char * nw = pll_utree_export_newick(ti->root, NULL);
   printf("ref tree: %s\n", nw);
   free(nw);
+  {
+    /* per-partition tree lengths (the newick lengths mean nothing with unlinked branch lengths) */
+    unsigned int p, k;
+    for (p = 0; p < 2; ++p)
+    {
+      double tot = 0.0;
+      const unsigned int src = (ref_linkage == PLLMOD_COMMON_BRLEN_UNLINKED) ? p : 0;
+      for (k = 0; k < 2 * ntaxa - 3; ++k) tot += ti->branch_lengths[src][k];
+      printf("ref plen %u: %.8f\n", p, tot);
+    }
+  }
   pllmod_treeinfo_destroy(ti);
 
   /* ---- this repository's round, from the same start ---- */
@@ -129,6 +146,9 @@ int main(int argc, char ** argv)
   if (!ev || !pllhip_eval_set_partition(ev, 0, parts[0], params_indices) ||
       !pllhip_eval_set_partition(ev, 1, parts[1], params_indices))
   { fprintf(stderr, "eval: %s\n", pll_errmsg); return 1; }
+  if (!pllhip_eval_set_brlen_linkage(ev, own_linkage)) { fprintf(stderr, "linkage: %s\n", pll_errmsg); return 1; }
+  if (own_linkage == PLLHIP_EVAL_BRLEN_SCALED)
+  { pllhip_eval_set_brlen_scaler(ev, 0, 0.8); pllhip_eval_set_brlen_scaler(ev, 1, 1.3); }
   pllhip_spr_params_t prm;
   memset(&prm, 0, sizeof(prm));
   prm.radius_min = 1; prm.radius_max = radius_max; prm.ntopol_keep = ntopol; prm.thorough = thorough;
@@ -150,6 +170,23 @@ int main(int argc, char ** argv)
   nw = pll_utree_export_newick(pllhip_eval_root(ev), NULL);
   printf("own tree: %s\n", nw);
   free(nw);
+  {
+    unsigned int p, k;
+    for (p = 0; p < 2; ++p)
+    {
+      double tot = 0.0;
+      for (k = 0; k < copy->tip_count + copy->inner_count; ++k)
+      {
+        pll_unode_t * n = copy->nodes[k], * t = n;
+        do
+        {
+          if (t->node_index < t->back->node_index) tot += pllhip_eval_get_partition_branch_length(ev, p, t);
+          t = t->next;
+        } while (t && t != n);
+      }
+      printf("own plen %u: %.8f\n", p, tot);
+    }
+  }
   pllhip_eval_destroy(ev);
   pll_utree_destroy(copy, NULL);
   pll_partition_destroy(parts[0]);

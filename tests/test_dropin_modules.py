@@ -196,26 +196,35 @@ def spr_driver(oracle, tmp_path_factory):
     return str(exe)
 
 
-@pytest.mark.parametrize("mode,ntaxa,radius,rounds,ntopol,seed", [
-    ("fast", 14, 5, 2, 5, 1),
-    ("thorough", 12, 4, 1, 3, 2),
-    ("fast", 20, 7, 2, 8, 3),
-    ("thorough", 16, 3, 2, 4, 4),
+@pytest.mark.parametrize("mode,ntaxa,radius,rounds,ntopol,seed,linkage", [
+    ("fast", 14, 5, 2, 5, 1, "linked"),
+    ("thorough", 12, 4, 1, 3, 2, "linked"),
+    ("fast", 20, 7, 2, 8, 3, "linked"),
+    ("thorough", 16, 3, 2, 4, 4, "linked"),
+    # per-partition branch lengths (src/algorithm/algo_search.c:399-565, 639-641, 756, 811-813)
+    ("fast", 14, 5, 2, 5, 5, "unlinked"),
+    ("thorough", 12, 4, 2, 3, 6, "unlinked"),
+    ("fast", 18, 6, 1, 6, 7, "scaled"),
 ])
 def test_own_spr_round_makes_the_reference_s_moves(spr_driver, tmp_path, mode, ntaxa, radius, rounds,
-                                                   ntopol, seed):
+                                                   ntopol, seed, linkage):
     nwk, aln = _simulate(ntaxa, 600, seed)
     (tmp_path / "start.nwk").write_text(nwk)
     (tmp_path / "aln.txt").write_text(aln)
     out = subprocess.run([spr_driver, str(tmp_path / "start.nwk"), str(tmp_path / "aln.txt"), mode,
-                          str(radius), str(rounds), str(ntopol)],
+                          str(radius), str(rounds), str(ntopol), linkage],
                          check=True, capture_output=True, text=True, timeout=900).stdout
     ref_tree = re.search(r"^ref tree: (.*)$", out, re.M).group(1)
     own_tree = re.search(r"^own tree: (.*)$", out, re.M).group(1)
     assert _splits(ref_tree) != _splits(nwk), "the round should have changed the starting topology"
     assert _splits(own_tree) == _splits(ref_tree)
-    for a, b in zip(_brlens(own_tree), _brlens(ref_tree)):
-        assert abs(a - b) < 1e-5
+    if linkage != "unlinked":            # (with per-partition lengths the tree's own lengths are not maintained)
+        for a, b in zip(_brlens(own_tree), _brlens(ref_tree)):
+            assert abs(a - b) < 1e-5
+    for p in range(2):
+        ref = float(re.search(rf"^ref plen {p}: (\S+)$", out, re.M).group(1))
+        own = float(re.search(rf"^own plen {p}: (\S+)$", out, re.M).group(1))
+        assert abs(ref - own) < 1e-4, (p, ref, own)
     for r in range(rounds):
         ref = float(re.search(rf"^ref round {r} lnL: (\S+)$", out, re.M).group(1))
         own = float(re.search(rf"^own round {r} lnL: (\S+)$", out, re.M).group(1))
