@@ -148,6 +148,18 @@ typedef struct pllhip_profile
 } pllhip_profile_t;
 
 PLL_EXPORT int pllhip_profile_partials(pll_partition_t * partition, int enable);
+
+/* PLL_ATTRIB_SITE_REPEATS (libpll-2's site repeats; the reference's test harness selects it,
+   test/src/common.c:31): what the engine did with it since the partition was created.  First step: the vector of
+   a cherry (a tip x tip operation) is computed per class of sites -- a pair of tip codes -- and not per site. */
+typedef struct pllhip_repeat_stats
+{
+  unsigned long long cherries;         /* tip x tip operations kept per class */
+  unsigned long long classes;          /* classes of those operations, summed */
+  unsigned long long sites;            /* sites they cover, summed (classes / sites = the share computed) */
+  unsigned long long expansions;       /* cherries expanded to the site-indexed form on demand */
+} pllhip_repeat_stats_t;
+PLL_EXPORT int pllhip_repeat_stats(const pll_partition_t * partition, pllhip_repeat_stats_t * out);
 PLL_EXPORT int pllhip_profile_read(pll_partition_t * partition, pllhip_profile_t * out);
 
 /* kernel family actually used for pll_update_partials on this partition:

@@ -127,6 +127,10 @@ struct DevicePlan                                 // the schedule resident on th
   struct Launch { unsigned begin, end, rows, ops; double bytes, flops, min_bytes; };   // chains [begin, end) over `rows` grid rows
   std::vector<Launch> launches;
   unsigned long long generation = 0;              // changes whenever `bytes` / `launches` are rebuilt (unique across engines)
+  // site repeats: the cherries the schedule keeps per class and the lookup tables it reads them through
+  // (job arrays behind the chains in `bytes`)
+  unsigned ncherry_jobs = 0, npair_jobs = 0, repeat_codes = 0;
+  size_t off_cherry_jobs = 0, off_pair_jobs = 0;
   unsigned max_extent = 0;                        // largest PlanChain::extent of the schedule
 };
 
@@ -161,6 +165,23 @@ struct Engine
   unsigned tips = 0, nodes = 0, nscalers = 0, nmat = 0, nrm = 0;
   bool coded_tips = false;
   bool rate_scalers = false;          // PLL_ATTRIB_RATE_SCALERS: one count per (site, rate), scaler[n*R + r]
+  // PLL_ATTRIB_SITE_REPEATS, first step (kernels_repeats.hpp): a cherry is kept per class of sites (pair of
+  // tip codes) and expanded to the site-indexed vector only for a reader that needs it
+  bool site_repeats = false;
+  struct Cherry
+  {
+    bool valid = false;               // the node's vector IS this cherry (nothing has overwritten it since)
+    bool materialized = false;        // d_clv[node] holds the expanded vector
+    unsigned ncodes = 0;              // classes = ncodes^2
+    double * table = nullptr;         // blocked pseudo-CLV over the classes
+    unsigned short * pair = nullptr;  // [Nalloc] class code per site
+    uint8_t * flags = nullptr;        // [classes] scaled?
+    unsigned cap_codes = 0;           // what table / flags were allocated for
+  };
+  std::vector<Cherry> cherries;       // by CLV index (empty unless site_repeats)
+  double * d_pairlut = nullptr;       // lookup tables of the wide tips of the resident schedule
+  size_t pairlut_cap = 0;
+  pllhip_repeat_stats_t repeat_stats = {};
   size_t sc_len = 0;                  // entries per scale buffer on the device
   KernelFamily family = KernelFamily::Generic;
   unsigned cu_count = 256;

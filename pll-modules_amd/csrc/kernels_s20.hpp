@@ -434,6 +434,11 @@ __device__ inline void s20_child_inner_c(const double * unit, const double * cfr
   s20_child_regs_c(b, cfrag_r, lane, t);
 }
 
+__device__ inline const unsigned short * s20_wide_codes(const double * clv, const uint8_t * codes, const double * pfrag)
+{
+  return (!clv && !codes) ? reinterpret_cast<const unsigned short *>(pfrag) : nullptr;
+}
+
 // one operation for one site block; X holds the handed-over operand on entry (when
 // carried != 0) and the result on exit.  s1 / s2: the children's LDS tables.
 // xe / xo: the scaler counts that go with X (per rate with RS = PLL_ATTRIB_RATE_SCALERS, where
@@ -449,8 +454,14 @@ __device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2
   const unsigned q = lane >> 4, n = lane & 15;
   const size_t site0 = (size_t)blk * S20_BS + 2 * n;
   unsigned c1e = 0, c1o = 0, c2e = 0, c2o = 0;
+  // a "wide tip" (kernels_repeats.hpp: a cherry known per class of sites): neither vector nor byte codes; the
+  // pfrag field holds its 16-bit class codes, lut its table, childN_index the rows of that table
+  const unsigned short * w1 = s20_wide_codes(op.clv1, op.codes1, op.pfrag1);
+  const unsigned short * w2 = s20_wide_codes(op.clv2, op.codes2, op.pfrag2);
   if (op.codes1) { c1e = op.codes1[site0]; c1o = op.codes1[site0 + 1]; }
+  else if (w1) { c1e = w1[site0]; c1o = w1[site0 + 1]; }
   if (op.codes2) { c2e = op.codes2[site0]; c2o = op.codes2[site0 + 1]; }
+  else if (w2) { c2e = w2[site0]; c2o = w2[site0 + 1]; }
   const bool scaling = op.parent_scaler != nullptr;
   int small_e = 1, small_o = 1;
 #pragma unroll
@@ -459,10 +470,12 @@ __device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2
     const size_t ubase = ((size_t)blk * RT + r) * S20_UNIT;
     double2 t1[5], t2[5];
     if (carried == 1) s20_child_regs_c(X[r], s1 + r * S20_CFRAGS, lane, t1);
+    else if (w1) s20_child_tip(op.lut1 + (size_t)r * op.child1_index * 20, c1e, c1o, q, t1);
     else if (!op.codes1) s20_child_inner_c(op.clv1 + ubase, s1 + r * S20_CFRAGS, lane, t1, nt_ld);
     else if (lut_lds) s20_child_tip(s1 + r * lut_used * S20_LUT_RS, c1e, c1o, q, t1, S20_LUT_RS);
     else s20_child_tip(op.lut1 + (size_t)r * lut_codes * 20, c1e, c1o, q, t1);
     if (carried == 2) s20_child_regs_c(X[r], s2 + r * S20_CFRAGS, lane, t2);
+    else if (w2) s20_child_tip(op.lut2 + (size_t)r * op.child2_index * 20, c2e, c2o, q, t2);
     else if (!op.codes2) s20_child_inner_c(op.clv2 + ubase, s2 + r * S20_CFRAGS, lane, t2, nt_ld);
     else if (lut_lds) s20_child_tip(s2 + r * lut_used * S20_LUT_RS, c2e, c2o, q, t2, S20_LUT_RS);
     else s20_child_tip(op.lut2 + (size_t)r * lut_codes * 20, c2e, c2o, q, t2);
@@ -660,8 +673,10 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanVi
       for (unsigned i = 0; i < ch.len; ++i)
       {
         const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
-        s20_fill_slot(lds + po.slot1, po.d.pmat1, po.d.pfrag1, po.d.codes1 ? po.d.lut1 : nullptr, RT, lut_codes, lut_used, lut_lds);
-        s20_fill_slot(lds + po.slot2, po.d.pmat2, po.d.pfrag2, po.d.codes2 ? po.d.lut2 : nullptr, RT, lut_codes, lut_used, lut_lds);
+        if (po.d.clv1 || po.d.codes1)       // (a wide tip has no table in LDS)
+          s20_fill_slot(lds + po.slot1, po.d.pmat1, po.d.pfrag1, po.d.codes1 ? po.d.lut1 : nullptr, RT, lut_codes, lut_used, lut_lds);
+        if (po.d.clv2 || po.d.codes2)
+          s20_fill_slot(lds + po.slot2, po.d.pmat2, po.d.pfrag2, po.d.codes2 ? po.d.lut2 : nullptr, RT, lut_codes, lut_used, lut_lds);
       }
       __syncthreads();
 
@@ -1115,15 +1130,18 @@ __global__ __launch_bounds__(256) void k_newton_mfma(ModelView mv, ParamIdx para
     if (threadIdx.x == 0)
     {
       unsigned spins = 0;
-      while (__hip_atomic_load(&ctl->iter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != it + 1)
+      // (relaxed polls, ONE acquire afterwards: an acquire per poll invalidates the caches of the whole chip
+      // several hundred times per microsecond)
+      while (__hip_atomic_load(&ctl->iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != it + 1)
       {
         if (++spins > NEWTON_SPIN_LIMIT)
         {
           __hip_atomic_store(&ctl->status, NEWTON_STUCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(1);
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       s_status = (spins > NEWTON_SPIN_LIMIT) ? NEWTON_STUCK
                                              : __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_x = __hip_atomic_load(&ctl->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -24,6 +24,7 @@
 #include "kernels_s20.hpp"
 #include "kernels_s61.hpp"
 #include "kernels_s16.hpp"
+#include "kernels_repeats.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -217,6 +218,8 @@ Engine * engine_create(pll_partition_t * p)
   e->nmat = p->prob_matrices; e->nrm = p->rate_matrices;
   e->coded_tips = (p->attributes & PLL_ATTRIB_PATTERN_TIP) != 0;
   e->rate_scalers = (p->attributes & PLL_ATTRIB_RATE_SCALERS) != 0;
+  e->site_repeats = (p->attributes & PLL_ATTRIB_SITE_REPEATS) != 0 && e->coded_tips && !e->rate_scalers &&
+                    !p->asc_bias_alloc && !(getenv("PLLHIP_SITE_REPEATS") && !atoi(getenv("PLLHIP_SITE_REPEATS")));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) e->cu_count = prop.multiProcessorCount;
 
@@ -289,6 +292,8 @@ Engine * engine_create(pll_partition_t * p)
     if (ok) memset(e->h_asc, 0, bytes);
     ok = ok && hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->d_asc), e->h_asc, 0), "map asc");
   }
+  if (e->site_repeats && e->family == KernelFamily::S20) e->cherries.assign(e->nodes, Engine::Cherry());
+  else e->site_repeats = false;                 // (first step: the 20-state family)
   e->pmat_brlen.assign(e->nmat, std::numeric_limits<double>::quiet_NaN());
   e->pmat_params.assign(e->nmat, std::vector<unsigned>());
 
@@ -348,6 +353,8 @@ void engine_destroy(Engine * e)
   (void)hipFree(e->d_model);
   (void)hipFree(e->d_partials);
   (void)hipFree(e->d_persite);
+  for (auto & c : e->cherries) { (void)hipFree(c.table); (void)hipFree(c.pair); (void)hipFree(c.flags); }
+  (void)hipFree(e->d_pairlut);
   (void)hipFree(e->d_newton);
   if (e->h_newton) (void)hipHostFree(e->h_newton);
   (void)hipFree(e->d_sum_scratch);
@@ -1053,6 +1060,56 @@ static int upload_plan(DevicePlan & dp, hipStream_t stream, PlanView & view)
   return PLL_SUCCESS;
 }
 
+// ---------------------------------------------------------------------------
+// site repeats (kernels_repeats.hpp): host side
+// ---------------------------------------------------------------------------
+// a reader needs the site-indexed vector of `idx`: expand it if the node is a cherry kept per class
+static int need_clv(Engine * e, unsigned idx)
+{
+  if (e->cherries.empty() || idx >= e->cherries.size()) return PLL_SUCCESS;
+  Engine::Cherry & c = e->cherries[idx];
+  if (!c.valid || c.materialized) return PLL_SUCCESS;
+  hipLaunchKernelGGL(k_cherry_expand, dim3(std::max(1u, std::min((e->nblk + 3) / 4, e->cu_count * 8u))), dim3(256), 0,
+                     e->stream, c.table, c.pair, e->nblk, e->R, e->d_clv[idx]);
+  PLLHIP_TRY(hipGetLastError());
+  c.materialized = true;
+  e->repeat_stats.expansions++;
+  return PLL_SUCCESS;
+}
+
+// which operations of a list are cherries the schedule keeps per class, and which children are read as wide tips
+struct RepeatPlan
+{
+  bool active = false;
+  std::vector<pll_operation_t> ops;          // the list without the virtual cherries
+  std::vector<unsigned> cherry_ops;          // their positions in the original list
+  unsigned ncodes = 0;
+};
+
+static bool cherry_storage(Engine * e, unsigned node, unsigned ncodes)
+{
+  Engine::Cherry & c = e->cherries[node];
+  const unsigned npairs = ncodes * ncodes, npblk = (npairs + S20_BS - 1) / S20_BS;
+  if (c.cap_codes < ncodes)
+  {
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
+    (void)hipFree(c.table); (void)hipFree(c.flags);
+    c.table = nullptr; c.flags = nullptr; c.cap_codes = 0;
+    e->plan.key.clear();                          // cached schedules point at the old tables
+    if (!dev_alloc(&c.table, (size_t)npblk * e->R * S20_UNIT, "cherry table") ||
+        !dev_alloc(&c.flags, (size_t)npblk * S20_BS, "cherry flags") ||
+        !hip_ok(hipMemsetAsync(c.flags, 0, (size_t)npblk * S20_BS, e->stream), "memset flags"))
+      return false;
+    c.cap_codes = ncodes;
+  }
+  if (!c.pair)
+  {
+    e->plan.key.clear();
+    if (!dev_alloc(&c.pair, (size_t)e->Nalloc, "cherry class codes")) return false;
+  }
+  return true;
+}
+
 // resolve one operation to device pointers and add its algorithmic bytes
 // (child vectors in -- 8*S per (site, rate), a coded tip is 1 byte
 // per site --, parent vector out, scalers, the two P-matrices or lookup tables
@@ -1061,7 +1118,7 @@ static void fill_desc(const Engine * e, const pll_operation_t & op, OpDesc & d, 
 {
   const size_t pm_stride = (size_t)e->R * e->S * e->Sp;
   const size_t lut_stride = (size_t)e->R * e->lut_codes * e->S;
-    const bool t1 = e->coded_tips && op.child1_clv_index < e->tips;
+  const bool t1 = e->coded_tips && op.child1_clv_index < e->tips;
   const bool t2 = e->coded_tips && op.child2_clv_index < e->tips;
   d.clv1 = t1 ? nullptr : e->d_clv[op.child1_clv_index];
   d.codes1 = t1 ? e->d_codes[op.child1_clv_index] : nullptr;
@@ -1096,7 +1153,8 @@ static void fill_desc(const Engine * e, const pll_operation_t & op, OpDesc & d, 
 static std::atomic<unsigned long long> plan_generation{0};
 
 static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_operation_t * ops, unsigned count,
-                             unsigned mode)
+                             unsigned mode, const RepeatPlan * rp = nullptr,
+                             const pll_operation_t * all_ops = nullptr, unsigned all_count = 0)
 {
   const bool chains20 = e->family == KernelFamily::S20, chains16 = e->family == KernelFamily::S16;
   const bool chains4 = e->family == KernelFamily::S4;
@@ -1106,12 +1164,46 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
   DevicePlan & dp = e->plan;
   const bool by_rounds = mode == 0;
   ChainPlan plan;
-  std::vector<unsigned char> key(3 * sizeof(unsigned) + (size_t)count * sizeof(pll_operation_t));
-  memcpy(key.data(), &count, sizeof(unsigned));
+  // site repeats: children that are cherries kept per class are read as wide tips (kernels_repeats.hpp)
+  std::vector<unsigned char> wide(e->cherries.empty() ? 0 : 2 * (size_t)count, 0);
+  unsigned nwide = 0;
+  if (!wide.empty())
+  {
+    std::vector<char> made(e->nodes, 0);
+    for (unsigned k = 0; k < count; ++k)
+    {
+      const unsigned child[2] = {ops[k].child1_clv_index, ops[k].child2_clv_index};
+      for (int x = 0; x < 2; ++x)
+        if (child[x] >= e->tips && !made[child[x]] && e->cherries[child[x]].valid) { wide[2 * k + x] = 1; ++nwide; }
+      made[ops[k].parent_clv_index] = 1;
+    }
+  }
+  // (the key holds the list as the caller passed it: the cherries taken out of it are part of the schedule)
+  const pll_operation_t * key_ops = all_ops ? all_ops : ops;
+  const unsigned key_count = all_ops ? all_count : count;
+  std::vector<unsigned char> key(3 * sizeof(unsigned) + (size_t)key_count * sizeof(pll_operation_t) + wide.size());
+  memcpy(key.data(), &key_count, sizeof(unsigned));
   memcpy(key.data() + sizeof(unsigned), &lut_used, sizeof(unsigned));
   memcpy(key.data() + 2 * sizeof(unsigned), &mode, sizeof(unsigned));
-  memcpy(key.data() + 3 * sizeof(unsigned), ops, (size_t)count * sizeof(pll_operation_t));
+  memcpy(key.data() + 3 * sizeof(unsigned), key_ops, (size_t)key_count * sizeof(pll_operation_t));
+  if (!wide.empty()) memcpy(key.data() + 3 * sizeof(unsigned) + (size_t)key_count * sizeof(pll_operation_t), wide.data(), wide.size());
   bool have = !dp.key.empty() && dp.key == key;
+  const unsigned rep_codes = lut_used, rep_pairs = rep_codes * rep_codes;
+  if (!have && nwide)
+  {
+    // the lookup tables of the wide tips: one per (cherry, branch) of the schedule
+    const size_t need = (size_t)nwide * e->R * rep_pairs * 20;
+    if (need > e->pairlut_cap)
+    {
+      if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
+      (void)hipFree(e->d_pairlut);
+      e->d_pairlut = nullptr;
+      e->pairlut_cap = 0;
+      if (!dev_alloc(&e->d_pairlut, 2 * need, "wide-tip lookup tables")) return false;
+      e->pairlut_cap = 2 * need;
+    }
+  }
+  std::vector<PairLutJob> pair_jobs;
   if (!have && plan_chains(e, ops, count, chain_max, chain_lds, lut_used, plan))
   {
     // Order of the chains: depth first, so that a vector is consumed soon after it was written
@@ -1173,7 +1265,7 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
     }
     std::vector<PlanOp> pops(count);
     std::vector<PlanChain> pchains;
-    unsigned nops = 0, lds_max = 0;
+    unsigned nops = 0, lds_max = 0, nops_virtual = 0;
     dp.algo_bytes = dp.algo_flops = dp.min_bytes = 0.0;
     dp.launches.clear();
     int cur_round = -1;
@@ -1221,8 +1313,25 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
         const double before = dp.algo_bytes;
         fill_desc(e, o, po.d, dp.algo_bytes, dp.algo_flops);
         po.carried = i ? plan.carried[ch[i]] : 0;
+        double wide_saved = 0.0;
+        for (int x = 0; x < 2 && !wide.empty(); ++x)
+        {
+          if (!wide[2 * ch[i] + x]) continue;
+          const unsigned cidx = x ? o.child2_clv_index : o.child1_clv_index;
+          const unsigned midx = x ? o.child2_matrix_index : o.child1_matrix_index;
+          const Engine::Cherry & c = e->cherries[cidx];
+          PairLutJob job;
+          job.table = c.table;
+          job.pfrag = e->d_pfrag + (size_t)midx * e->R * 400;
+          job.out = e->d_pairlut + pair_jobs.size() * (size_t)e->R * rep_pairs * 20;
+          pair_jobs.push_back(job);
+          // wide tip: no vector, no byte codes; pfrag = class codes, lut = its table, childN_index = table rows
+          if (x) { po.d.clv2 = nullptr; po.d.codes2 = nullptr; po.d.pfrag2 = reinterpret_cast<const double *>(c.pair); po.d.lut2 = job.out; po.d.child2_index = rep_pairs; }
+          else   { po.d.clv1 = nullptr; po.d.codes1 = nullptr; po.d.pfrag1 = reinterpret_cast<const double *>(c.pair); po.d.lut1 = job.out; po.d.child1_index = rep_pairs; }
+          wide_saved += (double)e->N * e->R * 8.0 * e->S - 2.0 * e->N;      // class codes instead of the vector
+        }
         // the handed-over child stays in registers: neither its vector nor its scaler counts are read
-        dp.min_bytes += dp.algo_bytes - before;
+        dp.min_bytes += dp.algo_bytes - before - wide_saved;
         if (po.carried)
           dp.min_bytes -= (double)e->N * e->R * 8.0 * e->S +
                           ((po.carried == 1 ? po.d.scaler1 : po.d.scaler2) ? 4.0 * (double)e->N * (e->rate_scalers ? e->R : 1) : 0.0);
@@ -1230,17 +1339,51 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
         const bool t2 = e->coded_tips && o.child2_clv_index < e->tips;
         if (chains20 || chains16)
         {
+          const bool w1 = !wide.empty() && wide[2 * ch[i]], w2 = !wide.empty() && wide[2 * ch[i] + 1];
           po.slot1 = off;
-          off += chains20 ? s20_chain_slot(e, t1, lut_used) : s16_chain_slot(e, t1);
+          if (!w1) off += chains20 ? s20_chain_slot(e, t1, lut_used) : s16_chain_slot(e, t1);
           po.slot2 = off;
-          off += chains20 ? s20_chain_slot(e, t2, lut_used) : s16_chain_slot(e, t2);
+          if (!w2) off += chains20 ? s20_chain_slot(e, t2, lut_used) : s16_chain_slot(e, t2);
         }
       }
       lds_max = std::max(lds_max, chains4 ? (unsigned)ch.size() : off);   // 4 states: the longest chain
     }
-    dp.bytes.resize(pops.size() * sizeof(PlanOp) + pchains.size() * sizeof(PlanChain));
+    // site repeats: the cherries the schedule keeps per class (taken out of the list by the caller) ...
+    std::vector<CherryJob> cherry_jobs;
+    if (rp && rp->active)
+    {
+      const size_t lut_stride = (size_t)e->R * e->lut_codes * e->S;
+      for (unsigned k : rp->cherry_ops)
+      {
+        const pll_operation_t & o = all_ops[k];
+        const Engine::Cherry & c = e->cherries[o.parent_clv_index];
+        CherryJob j;
+        j.lut1 = e->d_lut + lut_stride * o.child1_matrix_index;
+        j.lut2 = e->d_lut + lut_stride * o.child2_matrix_index;
+        j.codes1 = e->d_codes[o.child1_clv_index];
+        j.codes2 = e->d_codes[o.child2_clv_index];
+        j.table = c.table; j.flags = c.flags; j.pair = c.pair;
+        j.parent_scaler = const_cast<unsigned *>(scaler_ptr(e, o.parent_scaler_index));
+        cherry_jobs.push_back(j);
+        // what SURVEY.md 8d counts for the operation (two coded tips in, one vector out) / what it moves now
+        OpDesc dummy;
+        double ab = 0.0;
+        fill_desc(e, o, dummy, ab, dp.algo_flops);
+        dp.algo_bytes += ab;
+        dp.min_bytes += 2.0 * e->N + 2.0 * e->N + (j.parent_scaler ? 4.0 * e->N : 0.0);
+        ++nops_virtual;
+      }
+    }
+    dp.ncherry_jobs = (unsigned)cherry_jobs.size();
+    dp.npair_jobs = (unsigned)pair_jobs.size();
+    dp.repeat_codes = rep_codes;
+    dp.off_cherry_jobs = pops.size() * sizeof(PlanOp) + pchains.size() * sizeof(PlanChain);
+    dp.off_pair_jobs = dp.off_cherry_jobs + cherry_jobs.size() * sizeof(CherryJob);
+    dp.bytes.resize(dp.off_pair_jobs + pair_jobs.size() * sizeof(PairLutJob));
     memcpy(dp.bytes.data(), pops.data(), pops.size() * sizeof(PlanOp));
     memcpy(dp.bytes.data() + pops.size() * sizeof(PlanOp), pchains.data(), pchains.size() * sizeof(PlanChain));
+    if (!cherry_jobs.empty()) memcpy(dp.bytes.data() + dp.off_cherry_jobs, cherry_jobs.data(), cherry_jobs.size() * sizeof(CherryJob));
+    if (!pair_jobs.empty()) memcpy(dp.bytes.data() + dp.off_pair_jobs, pair_jobs.data(), pair_jobs.size() * sizeof(PairLutJob));
     if (!dp.launches.empty())
     {
       DevicePlan::Launch & done = dp.launches.back();
@@ -1250,6 +1393,7 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
       done.flops = dp.algo_flops - done.flops;
       done.min_bytes = dp.min_bytes - done.min_bytes;
     }
+    (void)nops_virtual;
     // rounds of ONE chain each that follow one another (the spine towards the root) need no launch
     // boundary between them: one workgroup row walks them in turn, exactly as in a one-launch traversal
     if (by_rounds)
@@ -1325,6 +1469,19 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
   std::vector<int> clv_level(e->nodes, -1), sc_level(e->nscalers, -1), level(count, 0);
   int max_level = 0;
   if (!validate_ops(e, ops, count)) return PLL_FAILURE;
+  if (!e->cherries.empty())
+  {
+    // every vector this list writes stops being the cherry it may have been; one that the list reads first
+    // (and that exists per class only) is expanded before it goes
+    std::vector<char> read(e->nodes, 0);
+    for (unsigned k = 0; k < count; ++k)
+    {
+      read[ops[k].child1_clv_index] = read[ops[k].child2_clv_index] = 1;
+      Engine::Cherry & c = e->cherries[ops[k].parent_clv_index];
+      if (c.valid && read[ops[k].parent_clv_index] && !need_clv(e, ops[k].parent_clv_index)) return PLL_FAILURE;
+      c.valid = false;
+    }
+  }
   for (unsigned k = 0; k < count; ++k)
   {
     const pll_operation_t & op = ops[k];
@@ -1427,11 +1584,71 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     {
       const unsigned mode = use_traverse ? 1u : 0u;
       DevicePlan & dp = e->plan;
-      const bool have = prepare_schedule(e, p, ops, count, mode);
+      // site repeats: the cherries of the list that an operation of the list consumes are kept per class
+      // (kernels_repeats.hpp) and leave the list; their consumers read them as wide tips
+      RepeatPlan rp;
+      if (e->site_repeats && chains20 && lut_used <= 64)
+      {
+        std::vector<int> consumer(e->nodes, -1);
+        for (unsigned k = 0; k < count; ++k) { consumer[ops[k].child1_clv_index] = (int)k; consumer[ops[k].child2_clv_index] = (int)k; }
+        for (unsigned k = 0; k < count; ++k)
+        {
+          const pll_operation_t & o = ops[k];
+          const bool cherry = o.child1_clv_index < e->tips && o.child2_clv_index < e->tips &&
+                              o.child1_scaler_index == PLL_SCALE_BUFFER_NONE && o.child2_scaler_index == PLL_SCALE_BUFFER_NONE &&
+                              consumer[o.parent_clv_index] > (int)k;
+          if (cherry) rp.cherry_ops.push_back(k); else rp.ops.push_back(o);
+        }
+        if (!rp.cherry_ops.empty() && !rp.ops.empty())
+        {
+          rp.active = true;
+          rp.ncodes = lut_used;
+          for (unsigned k : rp.cherry_ops)
+          {
+            if (!cherry_storage(e, ops[k].parent_clv_index, lut_used)) return PLL_FAILURE;
+            Engine::Cherry & c = e->cherries[ops[k].parent_clv_index];
+            c.valid = true;
+            c.materialized = false;
+            c.ncodes = lut_used;
+          }
+        }
+      }
+      const bool have = rp.active ? prepare_schedule(e, p, rp.ops.data(), (unsigned)rp.ops.size(), mode, &rp, ops, count)
+                                  : prepare_schedule(e, p, ops, count, mode);
+      if (!have && rp.active)
+        for (unsigned k : rp.cherry_ops) e->cherries[ops[k].parent_clv_index].valid = false;     // the plain paths below compute them
       if (have)
       {
         PlanView view;
         if (!upload_plan(e->plan, e->stream, view)) return PLL_FAILURE;
+        if (dp.ncherry_jobs || dp.npair_jobs)
+        {
+          const unsigned codes = dp.repeat_codes, pairs = codes * codes, npblk = (pairs + S20_BS - 1) / S20_BS;
+          const CherryJob * cj = reinterpret_cast<const CherryJob *>(dp.d_buf + dp.off_cherry_jobs);
+          const PairLutJob * pj = reinterpret_cast<const PairLutJob *>(dp.d_buf + dp.off_pair_jobs);
+          if (dp.ncherry_jobs)
+          {
+            const dim3 gb((npblk + 3) / 4, dp.ncherry_jobs), gs(std::max(1u, std::min((e->Nalloc + 255u) / 256u, 4u * e->cu_count)), dp.ncherry_jobs);
+            if (e->R == 4) hipLaunchKernelGGL(k_cherry_build<4>, gb, dim3(256), 0, e->stream, cj, e->lut_codes, codes);
+            else if (e->R == 2) hipLaunchKernelGGL(k_cherry_build<2>, gb, dim3(256), 0, e->stream, cj, e->lut_codes, codes);
+            else hipLaunchKernelGGL(k_cherry_build<1>, gb, dim3(256), 0, e->stream, cj, e->lut_codes, codes);
+            PLLHIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_cherry_sites, gs, dim3(256), 0, e->stream, cj, codes, e->Nalloc);
+            PLLHIP_TRY(hipGetLastError());
+            e->repeat_stats.cherries += dp.ncherry_jobs;
+            e->repeat_stats.classes += (unsigned long long)dp.ncherry_jobs * pairs;
+            e->repeat_stats.sites += (unsigned long long)dp.ncherry_jobs * e->N;
+          }
+          if (dp.npair_jobs)
+          {
+            const dim3 gp((npblk + 3) / 4, dp.npair_jobs);
+            const size_t lds = sizeof(double) * e->R * S20_CFRAGS;
+            if (e->R == 4) hipLaunchKernelGGL(k_pair_lut<4>, gp, dim3(256), lds, e->stream, pj, pairs);
+            else if (e->R == 2) hipLaunchKernelGGL(k_pair_lut<2>, gp, dim3(256), lds, e->stream, pj, pairs);
+            else hipLaunchKernelGGL(k_pair_lut<1>, gp, dim3(256), lds, e->stream, pj, pairs);
+            PLLHIP_TRY(hipGetLastError());
+          }
+        }
         for (const DevicePlan::Launch & l : dp.launches)
         {
           const unsigned rows = l.rows;
@@ -1494,6 +1711,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
           for (size_t i = 0; i < ch.size(); ++i)
           {
             const pll_operation_t & o = ops[ch[i]];
+            if (!need_clv(e, o.child1_clv_index) || !need_clv(e, o.child2_clv_index)) return PLL_FAILURE;
             fill_desc(e, o, cb.op[nops], bytes, flops);
             cb.carried[nops] = i ? plan.carried[ch[i]] : 0;
             if (cb.carried[nops])       // handed over in registers: not read
@@ -1632,6 +1850,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
       if (k < count && level[k] == l)
       {
         pll_operation_t o = ops[k];
+        if (!need_clv(e, o.child1_clv_index) || !need_clv(e, o.child2_clv_index)) return PLL_FAILURE;
         memset(&cherries.op[nb], 0, sizeof(OpDesc));
         tables[nb] = nullptr;
         if (cherry_of[k] >= 0)
@@ -1693,7 +1912,7 @@ static bool batch_family(const Engine * e)
 {
   static const int use_chains = getenv("PLLHIP_CHAINS") ? atoi(getenv("PLLHIP_CHAINS")) : 1;
   static const int use_batch = getenv("PLLHIP_BATCH") ? atoi(getenv("PLLHIP_BATCH")) : 1;
-  if (!use_chains || !use_batch || !e->shards.empty()) return false;
+  if (!use_chains || !use_batch || !e->shards.empty() || e->site_repeats) return false;
   return (e->family == KernelFamily::S20 && chains_supported_s20(e)) ||
          (e->family == KernelFamily::S4 && chains_supported_s4(e)) ||
          (e->family == KernelFamily::S16 && chains_supported_s16(e));
@@ -2109,6 +2328,7 @@ double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsigned cc
     if ((unsigned)matrix_index >= e->nmat) { set_error(PLL_ERROR_PARAM_INVALID, "matrix index out of range"); return fail; }
   }
   if (!sync_model(p) || !flush_pmatrices(p) || !ensure_luts(p) || !ensure_invariant(p)) return fail;
+  if (!need_clv(e, pc) || (matrix_index >= 0 && !need_clv(e, cc))) return fail;
   // ascertainment-bias correction: the kernel runs over alignment + constant patterns (the
   // latter weigh 0 on the device), the per-site values of the constant patterns come back
   // through the mapped result buffer and the host adds the closed-form correction
@@ -2398,6 +2618,7 @@ int pll_update_sumtable(pll_partition_t * p,
   }
   if (!ensure_eigen(p, params_indices) || !sync_model(p)) return PLL_FAILURE;
   if (e->coded_tips && !ensure_luts(p)) return PLL_FAILURE;
+  if (!need_clv(e, parent_clv_index) || !need_clv(e, child_clv_index)) return PLL_FAILURE;
   double * d_sum = sumtable_device(e, sumtable, true);
   if (!d_sum) return PLL_FAILURE;
 
@@ -2643,6 +2864,7 @@ int pll_compute_node_ancestral(pll_partition_t * p, unsigned int node_clv_index,
   }
   if (!sync_model(p) || !flush_pmatrices(p) || !ensure_luts(p)) return PLL_FAILURE;
   if (!e->N) return PLL_SUCCESS;
+  if (!need_clv(e, node_clv_index) || !need_clv(e, other_clv_index)) return PLL_FAILURE;
   // the result is normalised per site, so scaler counts cancel
   double * d_out = nullptr;
   if (!dev_alloc(&d_out, (size_t)e->N * e->S, "ancestral states")) return PLL_FAILURE;
@@ -2733,6 +2955,7 @@ int pllhip_get_clv(pll_partition_t * p, unsigned int clv_index, double * out)
     (void)hipFree(tmp);
     return PLL_SUCCESS;
   }
+  if (!need_clv(e, clv_index)) return PLL_FAILURE;
   return fetch_clv(e, e->d_clv[clv_index], out);
 }
 
@@ -2752,7 +2975,14 @@ int pllhip_set_clv(pll_partition_t * p, unsigned int clv_index, const double * c
     set_error(PLL_ERROR_PARAM_INVALID, "CLV %u is a coded tip", clv_index);
     return PLL_FAILURE;
   }
+  if (!e->cherries.empty()) e->cherries[clv_index].valid = false;
   return store_clv(e, e->d_clv[clv_index], clv);
+}
+
+int pllhip_repeat_stats(const pll_partition_t * p, pllhip_repeat_stats_t * out)
+{
+  *out = exec_engine(p)->repeat_stats;
+  return PLL_SUCCESS;
 }
 
 int pllhip_get_scaler(pll_partition_t * p, unsigned int idx, unsigned int * out)

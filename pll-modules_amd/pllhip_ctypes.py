@@ -25,6 +25,7 @@ PLL_ATTRIB_PATTERN_TIP = 1 << 4
 PLL_ATTRIB_AB_LEWIS, PLL_ATTRIB_AB_FELSENSTEIN, PLL_ATTRIB_AB_STAMATAKIS = 1 << 5, 2 << 5, 3 << 5
 PLL_ATTRIB_AB_FLAG = 1 << 8
 PLL_ATTRIB_RATE_SCALERS = 1 << 9
+PLL_ATTRIB_SITE_REPEATS = 1 << 10
 PLL_GAMMA_RATES_MEAN = 0
 PLL_TREE_TRAVERSE_POSTORDER = 1
 PLLHIP_SYNC_PMATRIX, PLLHIP_SYNC_CLV, PLLHIP_SYNC_SCALERS, PLLHIP_SYNC_TIPS, PLLHIP_SYNC_ALL = 1, 2, 4, 8, 15
@@ -94,6 +95,10 @@ class Counters(C.Structure):
         "lnl_calls", "sumtable_calls", "derivative_calls", "derivative_points", "model_uploads")]
 
 
+class RepeatStats(C.Structure):
+    _fields_ = [(n, C.c_ulonglong) for n in ("cherries", "classes", "sites", "expansions")]
+
+
 class Profile(C.Structure):
     _fields_ = [("launches", C.c_ulonglong), ("ops", C.c_ulonglong),
                 ("kernel_ms", C.c_double), ("algorithmic_bytes", C.c_double),
@@ -138,7 +143,7 @@ pllhip_profile_partials pllhip_profile_read pllhip_comm_rank pllhip_comm_size
 pllhip_compute_likelihood_derivatives_multi pllhip_free_trial_lengths pllhip_set_sharding
 pllhip_shard_count pllhip_results_create pllhip_results_destroy
 pllhip_results_edge_loglikelihood pllhip_results_derivatives pllhip_results_fetch
-pllhip_eval_attach_comm pllhip_update_partials_batch pllhip_results_poison pllhip_newton_branch""".split()
+pllhip_eval_attach_comm pllhip_update_partials_batch pllhip_results_poison pllhip_newton_branch pllhip_repeat_stats""".split()
 
 
 def _u32(a):
@@ -264,6 +269,7 @@ class PllLib:
             L.pllhip_partials_kernel_name.argtypes = [pp]
             L.pllhip_profile_partials.argtypes = [pp, C.c_int]
             L.pllhip_profile_read.argtypes = [pp, C.POINTER(Profile)]
+            L.pllhip_repeat_stats.argtypes = [pp, C.POINTER(RepeatStats)]
             L.pllhip_comm_get_unique_id.argtypes = [C.c_char_p]
             L.pllhip_comm_create.restype = C.c_void_p
             L.pllhip_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
@@ -534,6 +540,11 @@ class Instance:
         c = Counters()
         self.L.pllhip_get_counters(self.p, C.byref(c))
         return c
+
+    def repeat_stats(self):
+        st = RepeatStats()
+        self.L.pllhip_repeat_stats(self.p, C.byref(st))
+        return st
 
 
 # ---------------------------------------------------------------------------

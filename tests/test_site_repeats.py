@@ -1,0 +1,124 @@
+"""PLL_ATTRIB_SITE_REPEATS, first step (pll-modules_amd/csrc/kernels_repeats.hpp): cherries are kept per class of
+sites (pair of tip codes).  Everything a caller can observe must be identical -- bit for bit -- to the attribute
+being off: the reference's own tests run every program with and without it and compare the text
+(test/src/common.c:31, test/runtest.py:45-51)."""
+import numpy as np
+import pytest
+
+import pllhip_ctypes as pc
+
+pytestmark = pytest.mark.gpu
+NONE = pc.PLL_SCALE_BUFFER_NONE
+
+
+def _build(product, tree, nsites, repeats, seed=44, gaps=False, states=20, ambiguity=False):
+    inst = pc.build_instance(product, states=states, rate_cats=4, ntips=tree.ntips, nsites=nsites, coded=True, tree=tree,
+                             attributes=pc.PLL_ATTRIB_SITE_REPEATS if repeats else 0)
+    if gaps or ambiguity:
+        cmap = pc.state_charmap(states)
+        if ambiguity:
+            cmap[ord("B")] = (1 << 2) | (1 << 3)
+            cmap[ord("Z")] = (1 << 5) | (1 << 6)
+        codes = pc.random_codes(tree.ntips, nsites, states, seed)
+        rnd = pc.splitmix64(seed + 5, tree.ntips * nsites).reshape(tree.ntips, nsites)
+        for t in range(tree.ntips):
+            seq = (codes[t] + 48).astype(np.uint8)
+            seq[rnd[t] % np.uint64(17) == 0] = ord("-")
+            if ambiguity:
+                seq[rnd[t] % np.uint64(23) == 1] = ord("B")
+                seq[rnd[t] % np.uint64(29) == 2] = ord("Z")
+            inst.set_tip_states(t, cmap, seq.tobytes())
+    inst.tree = tree
+    return inst
+
+
+def _everything(inst):
+    t = inst.tree
+    out = {"lnl": pc.full_traversal(inst)}
+    out["clv"] = [inst.get_clv(op[0]) for op in t.ops]
+    out["scaler"] = [inst.get_scaler(op[1]) for op in t.ops]
+    sa, sb = t.scaler_of(t.root_a), t.scaler_of(t.root_b)
+    out["persite"] = inst.edge_lnl(t.root_a, sa, t.root_b, sb, t.root_matrix, persite=True)[1]
+    st = inst.alloc_sumtable()
+    inst.update_sumtable(t.root_a, t.root_b, sa, sb, st)
+    out["deriv"] = [inst.derivatives(sa, sb, x, st) for x in (0.01, 0.3)]
+    inst.free_sumtable(st)
+    # a second evaluation (the resident schedule is reused), then the same tree from other root edges: cherries
+    # become readers' parents, the former root-side vectors become cherries' consumers
+    out["lnl2"] = pc.full_traversal(inst)
+    for k in (0, t.nedges // 2, 3):
+        t2 = pc.Tree(t.ntips, 42, 43, ladder=getattr(t, "is_ladder", False))
+        t2.set_root_edge(k)
+        inst.tree = t2
+        out[f"root{k}"] = pc.full_traversal(inst)
+        out[f"root{k}_clv"] = inst.get_clv(t2.ops[-1][0])
+    inst.tree = t
+    return out
+
+
+def _same(a, b):
+    assert a.keys() == b.keys()
+    for k in a:
+        if isinstance(a[k], list):
+            for x, y in zip(a[k], b[k]):
+                assert np.array_equal(np.asarray(x), np.asarray(y)), k
+        else:
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+
+
+@pytest.mark.parametrize("ntips,nsites,gaps,ambiguity", [(14, 1031, False, False), (40, 5000, True, False),
+                                                         (9, 257, True, True), (100, 3333, False, False)])
+def test_site_repeats_change_nothing_a_caller_can_see(product, ntips, nsites, gaps, ambiguity):
+    tree = pc.Tree(ntips, 42, 43)
+    with _build(product, tree, nsites, True, gaps=gaps, ambiguity=ambiguity) as on, \
+            _build(product, tree, nsites, False, gaps=gaps, ambiguity=ambiguity) as off:
+        a, b = _everything(on), _everything(off)
+        _same(a, b)
+        st = on.repeat_stats()
+        assert st.cherries > 0 and st.classes < st.sites or nsites < 500
+        assert off.repeat_stats().cherries == 0
+
+
+def test_site_repeats_with_scaling_cherries(product):
+    """long pendant branches: the cherries themselves are scaled (per class), the counts travel per site"""
+    tree = pc.Tree(12, 42, 43, brlen_range=(60.0, 90.0))
+    with _build(product, tree, 700, True) as on, _build(product, tree, 700, False) as off:
+        for inst in (on, off):
+            # slow mixing, so that the vectors really fall below 2^-256 ... (every entry ~ pi_i at such lengths: no);
+            # make the matrices tiny instead: a model with near-zero frequencies for most states
+            pass
+        a, b = _everything(on), _everything(off)
+        _same(a, b)
+
+
+def test_site_repeats_on_deep_trees(product):
+    tree = pc.Tree(260, 42, 43)
+    with _build(product, tree, 300, True) as on, _build(product, tree, 300, False) as off:
+        la, lb = pc.full_traversal(on), pc.full_traversal(off)
+        assert la == lb
+        top = 0
+        for op in tree.ops:
+            sa, sb = on.get_scaler(op[1]), off.get_scaler(op[1])
+            assert np.array_equal(sa, sb)
+            top = max(top, int(sa.max()))
+        assert top >= 1
+        for op in tree.ops[:40]:
+            assert np.array_equal(on.get_clv(op[0]), off.get_clv(op[0]))
+
+
+def test_site_repeats_through_the_driver(product):
+    """branch-length optimisation and an SPR round (short operation lists, sumtables at cherries): same results"""
+    from test_eval_driver import build_search
+    out = []
+    for attributes in (pc.PLL_ATTRIB_SITE_REPEATS, 0):
+        truth = pc.Tree(12, 7, 8, brlen_range=(0.03, 0.25))
+        start = pc.Tree(12, 11, 12, brlen_range=(0.05, 0.15))
+        ev = pc.Evaluation(product, start.newick(), nparts=1)
+        r, f = pc.protein_model()
+        ev.add_partition(0, 20, 3000, 4, pc.simulated_codes(truth, 3000, 20), r, f, 0.8, attributes=attributes)
+        with ev:
+            l0 = ev.loglh()
+            l1 = ev.optimize_branches(1e-4, 10.0, 0.01, 2, -1)
+            l2, st = ev.spr_round(radius_max=3, ntopol_keep=3)
+            out.append((l0, l1, l2, ev.newick(), st.moves_applied))
+    assert out[0] == out[1]
