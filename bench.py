@@ -66,6 +66,10 @@ def parse_args():
     ap.add_argument("--pmatrix-calls", default="per-branch", choices=["per-branch", "batched"],
                     help="per-branch = one pll_update_prob_matrices call per branch, as treeinfo issues "
                          "them (src/tree/treeinfo.c:845-865); batched = one call with count = 2n-3")
+    ap.add_argument("--site-repeats", action="store_true",
+                    help="PLL_ATTRIB_SITE_REPEATS (first step: cherries are computed per class of sites, not per site)")
+    ap.add_argument("--data", default="random", choices=["random", "simulated"],
+                    help="random: iid uniform tip states (seed 44); simulated: states evolved along the tree (SURVEY.md 8d, seed 45)")
     ap.add_argument("--rate-scalers", action="store_true",
                     help="PLL_ATTRIB_RATE_SCALERS: one scaling count per (site, rate) instead of per site")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
@@ -362,7 +366,12 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
             ev.add_remote_partition(k)
             continue
         subst, freqs, alpha = model_of(pc, p_[0])
-        codes = pc.random_codes(tree.ntips, p_[1], p_[0], 44 + 101 * k, first_site=first_sites[k])
+        if args.data == "simulated":
+            if world > 1:
+                raise SystemExit("bench.py: --data simulated is a one-GPU data set")
+            codes = pc.simulated_codes(tree, p_[1], p_[0], seed=45 + k)
+        else:
+            codes = pc.random_codes(tree.ntips, p_[1], p_[0], 44 + 101 * k, first_site=first_sites[k])
         insts.append(ev.add_partition(k, p_[0], p_[1], rate_cats, codes, subst, freqs, alpha, coded=True,
                                       attributes=ATTRIBUTES))
         del codes
@@ -422,6 +431,14 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
         for f, _ in pc.Profile._fields_:
             setattr(prof, f, getattr(prof, f) + getattr(one, f))
     counters = [i.counters() for i in insts]
+    repeats = None
+    if args.site_repeats:
+        st = [i.repeat_stats() for i in insts]
+        repeats = {"cherries_per_step": sum(x.cherries for x in st) // max(1, steps + warmup),
+                   "classes": sum(x.classes for x in st), "sites": sum(x.sites for x in st),
+                   "classes_over_sites": (sum(x.classes for x in st) / max(1, sum(x.sites for x in st))),
+                   "expansions": sum(x.expansions for x in st),
+                   "what": "tip x tip operations computed per class of sites (pair of tip codes) instead of per site"}
     partial_launches = sum(c.partial_launches for c in counters)
     pmatrix_launches = sum(c.pmatrix_launches for c in counters)
 
@@ -450,7 +467,8 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
     traffic = None
     traffic_source = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and world == 1 and not sites and not taxa and not args.rate_scalers:
+    if os.path.exists(tpath) and world == 1 and not sites and not taxa and not args.rate_scalers and not args.site_repeats \
+            and args.data == "random":
         try:
             tj = json.load(open(tpath))
             per_step = tj.get(f"{config}:{kernel}:per_step")
@@ -540,7 +558,8 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
                                      if balanced else "every rank holds a contiguous 1/N site range of every partition"),
             "tips": "1-byte codes",
             "scalers": ("per (site, rate)" if args.rate_scalers else "per-site") + ", one buffer per inner node",
-            "pmatrix_calls": args.pmatrix_calls,
+            "pmatrix_calls": args.pmatrix_calls, "alignment": args.data,
+            "site_repeats": repeats,
             "pmatrix_launches_per_step": pmatrix_launches // evals,
             "partial_launches_per_step": partial_launches // evals,
             "parallelism": (f"one process, every partition spread over {args.gpus} devices inside the engine, "
@@ -638,6 +657,8 @@ def main():
     global ATTRIBUTES
     if args.rate_scalers:
         ATTRIBUTES = pc.PLL_ATTRIB_RATE_SCALERS
+    if args.site_repeats:
+        ATTRIBUTES |= pc.PLL_ATTRIB_SITE_REPEATS
     product = pc.PllLib(pc.PRODUCT_LIB)
     if product.lib.pllhip_device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible; the engine has no CPU fallback")
@@ -691,7 +712,8 @@ def main():
     out["runtime"] = {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG"),
                       "torch_loaded_before_engine": world > 1}
     default_run = (world == 1 and not internal and args.config == "c3" and not args.sites and not args.taxa and
-                   not args.rate_scalers and not args.no_also and not args.no_cpu_baseline)
+                   not args.rate_scalers and not args.no_also and not args.no_cpu_baseline and not args.site_repeats and
+                   args.data == "random")
     if default_run:
         t0 = time.perf_counter()
         out["also"] = also_legs(ctx)

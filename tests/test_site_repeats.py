@@ -80,15 +80,25 @@ def test_site_repeats_change_nothing_a_caller_can_see(product, ntips, nsites, ga
 
 
 def test_site_repeats_with_scaling_cherries(product):
-    """long pendant branches: the cherries themselves are scaled (per class), the counts travel per site"""
-    tree = pc.Tree(12, 42, 43, brlen_range=(60.0, 90.0))
+    """a cherry only ever scales when its entries are exact zeros: pendant branches of length 0 (identity
+    matrices) make every site with two different states an all-zero, scaled site.  The scaling decision is taken
+    per class, the counts travel per site; identical to the attribute being off (lnL is -inf on both sides)."""
+    tree = pc.Tree(24, 42, 43)
+    cherries = [op for op in tree.ops if op[2] < tree.ntips and op[5] < tree.ntips]
+    assert len(cherries) >= 3
+    for k, op in enumerate(cherries):
+        if k % 3 != 2:
+            tree.brlens[op[3]] = 0.0
+            tree.brlens[op[6]] = 0.0 if k % 3 == 0 else 0.05
     with _build(product, tree, 700, True) as on, _build(product, tree, 700, False) as off:
-        for inst in (on, off):
-            # slow mixing, so that the vectors really fall below 2^-256 ... (every entry ~ pi_i at such lengths: no);
-            # make the matrices tiny instead: a model with near-zero frequencies for most states
-            pass
-        a, b = _everything(on), _everything(off)
-        _same(a, b)
+        for rep in range(2):
+            la, lb = pc.full_traversal(on), pc.full_traversal(off)
+            assert la == lb == -np.inf
+            for op in tree.ops:
+                assert np.array_equal(on.get_scaler(op[1]), off.get_scaler(op[1]))
+                assert np.array_equal(on.get_clv(op[0]), off.get_clv(op[0]))
+        assert sum(int(off.get_scaler(op[1]).sum()) for op in cherries) > 0
+        assert on.repeat_stats().cherries > 0
 
 
 def test_site_repeats_on_deep_trees(product):
