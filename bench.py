@@ -129,6 +129,33 @@ def evaluate_with_persite(ev, plan):
     return lnl, persite
 
 
+def usable_cores():
+    """cores this process may really use: the affinity mask and the cgroup CPU quota (a one-GPU box gets a
+    16-core share of a 256-core host; 256 OpenMP threads on it run slower than 16)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def _omp_set_threads(n):
     try:
         C.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
@@ -163,7 +190,8 @@ def cpu_baseline(pc, product, tree, config, states, rate_cats, nsites_gpu, cpu_s
     sized for a few seconds.  The 16-thread sample is then evaluated on the GPU: |dlnL| per site on
     identical inputs (BASELINE.json's metric, second half).  quick: parity sample only (no timing legs)."""
     host_cores = os.cpu_count() or 1
-    threads = min(host_cores, 16)      # the 1-GPU box share of host cores
+    usable = usable_cores()
+    threads = min(usable, 16)          # the 1-GPU box share of host cores
     os.environ.setdefault("OMP_NUM_THREADS", str(threads))
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("ORC_FAST", "1")      # the oracle's AVX2-vectorised partials (4 / 20 / 61 states)
@@ -195,15 +223,16 @@ def cpu_baseline(pc, product, tree, config, states, rate_cats, nsites_gpu, cpu_s
     if quick:
         return None, parity
     base = {"value": rate, "unit": "CLV site-updates/s", "cores": threads, "kind": "port",
-            "host_cores": host_cores, "threads": threads, "sample_sites": cpu_sites, "sample_evaluations": reps,
+            "host_cores": host_cores, "usable_cores": usable, "threads": threads, "sample_sites": cpu_sites,
+            "sample_evaluations": reps,
             "lnl_per_site": lnl_cpu / cpu_sites,
             "sample": f"{reps} full evaluations of the same tree/model on the first {cpu_sites} sites of the "
                       f"benchmark alignment (oracle/, plain C + OpenMP over sites, AVX2-vectorised partials, "
                       f"{threads} threads on a host with {host_cores} cores)"}
     # one thread, and every core of the host: a few seconds each, own sample sizes
     if can_set:
-        for label, nthreads in (("one_thread", 1), ("all_cores", host_cores)):
-            if label == "all_cores" and host_cores == threads:
+        for label, nthreads in (("one_thread", 1), ("all_cores", usable)):
+            if label == "all_cores" and usable == threads:
                 base[label] = {"value": rate, "threads": threads, "sample_sites": cpu_sites, "same_as": "value"}
                 continue
             _omp_set_threads(nthreads)

@@ -226,12 +226,38 @@ def alphabets(lib, out):
                                               "algorithmic_GBps": nb / dt / 1e9}
 
 
+def alphabets32(lib, out):
+    """the alphabets that left the generic kernels in round 3: 17 .. 32 states on the two-tile 2..32-state family,
+    33 .. 64 states on the codon family with a run-time state count; 20 and 61 states next to them"""
+    for S, N in ((17, 500_000), (20, 500_000), (24, 500_000), (28, 500_000), (32, 500_000), (48, 200_000),
+                 (60, 200_000), (61, 200_000), (62, 200_000), (64, 200_000)):
+        inst = pc.build_instance(lib, states=S, rate_cats=4, ntips=50, nsites=N, coded=True)
+        with inst:
+            pc.full_traversal(inst)
+            lib.lib.pllhip_synchronize(inst.p)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                lnl = pc.full_traversal(inst)
+            dt = (time.perf_counter() - t0) / 5
+            t = inst.tree
+            nb = 0.0
+            for op in t.ops:
+                tips = (op[2] < t.ntips) + (op[5] < t.ntips)
+                nb += N * 4 * 8.0 * S * (3 - tips) + N * tips + 12.0 * N
+            out[f"ALPHABET_{S}states_{N}"] = {"kernel": lib.lib.pllhip_partials_kernel_name(inst.p).decode(),
+                                              "ms_per_traversal": dt * 1e3, "lnl": lnl,
+                                              "site_updates_per_s": len(t.ops) * N * 4 / dt,
+                                              "algorithmic_GBps": nb / dt / 1e9}
+
+
 def main():
     lib = pc.PllLib(pc.PRODUCT_LIB)
     out = {}
     which = sys.argv[1:] or ["w2", "w3", "c4", "blo"]
     if "alphabets" in which:
         alphabets(lib, out)
+    if "alphabets32" in which:
+        alphabets32(lib, out)
     if "blo125" in which:
         blo(lib, "c3", out, nsites=125_000)
     if "blo_c2" in which:
