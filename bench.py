@@ -77,6 +77,9 @@ def parse_args():
                          "torch = the reduce callback through torch.distributed (a rehearsal path: with "
                          "PLLHIP_BENCH_DIST_BACKEND=gloo and PLLHIP_ALLOW_DEVICE_WRAP=1 all ranks can share one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--as-rank", default="",
+                    help="R/N: run, on ONE GPU and without a reduction, the share rank R of N would hold (the cost-balanced "
+                         "partition assignment of --config c4); `value` then counts that share only")
     ap.add_argument("--no-also", action="store_true",
                     help="default run only: skip the C2 / C4 / C5 / branch-length / SPR legs behind the C3 line")
     ap.add_argument("--also-steps", type=int, default=5)
@@ -378,7 +381,16 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
     # large slices go to few ranks each, balanced by cost (assign_partitions); the others are NULL slots there.
     job_plan = partition_plan(config, states, nsites * (world if args.scaling == "weak" else 1))
     balanced = world > 1 and len(job_plan) > 1 and os.environ.get("PLLHIP_BENCH_BALANCE", "1") != "0"
-    if balanced:
+    emulate = None
+    if args.as_rank and world == 1:
+        er, en = (int(x) for x in args.as_rank.split("/"))
+        emulate = (er, en)
+        balanced = len(job_plan) > 1 and os.environ.get("PLLHIP_BENCH_BALANCE", "1") != "0"
+    if emulate and balanced:
+        mine = assign_partitions(job_plan, rate_cats, emulate[0], emulate[1])
+    elif emulate:
+        mine = [(n_ * emulate[0] // emulate[1], n_ * (emulate[0] + 1) // emulate[1] - n_ * emulate[0] // emulate[1]) for _, n_ in job_plan]
+    elif balanced:
         mine = assign_partitions(job_plan, rate_cats, rank, world)
     else:
         mine = [(n_ * rank // world, n_ * (rank + 1) // world - n_ * rank // world) for _, n_ in job_plan]
@@ -478,7 +490,7 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
         elapsed = float(tt.item())
 
     kernel = product.lib.pllhip_partials_kernel_name(inst.p).decode()
-    updates_per_step = nops * total_sites * rate_cats
+    updates_per_step = nops * (local_sites if emulate else total_sites) * rate_cats
     value = updates_per_step * steps / elapsed
 
     # roofline of the dominant kernel (pll_update_partials), from the HIP events
@@ -556,7 +568,7 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
 
     ev.close()                   # frees the CLVs: the parity sample below gets its own partitions
     cpu_base = parity = None
-    if rank == 0 and world == 1 and not ctx.internal and cpu:
+    if rank == 0 and world == 1 and not ctx.internal and cpu and not emulate:
         cpu_base, parity = cpu_baseline(pc, product, tree, config, states, rate_cats, local_sites,
                                         args.cpu_sites, per_branch, quick=(cpu == "parity"))
     names = {"c2": "C2 DNA GTR+G4", "c4": "C4 mixed: 2 DNA GTR+G4 + 2 protein GTR20+G4 partitions, linked branch lengths",
@@ -583,6 +595,7 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
             "partitions": [({"states": p_[0], "first_site": f_, "sites_on_rank0": p_[1]} if p_ else
                             {"states": job_plan[k][0], "sites_on_rank0": 0, "remote": True})
                            for k, (p_, f_) in enumerate(zip(plan, first_sites))],
+            "emulated_rank": (f"{emulate[0]}/{emulate[1]}" if emulate else None),
             "partition_assignment": ("cost-balanced: whole partitions / large slices per rank, NULL slots elsewhere"
                                      if balanced else "every rank holds a contiguous 1/N site range of every partition"),
             "tips": "1-byte codes",

@@ -52,12 +52,16 @@ __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, 
     const double rt = mv.rates()[r] * t / (1.0 - mv.pinv()[pi_]);
     const unsigned arows = (Sp == 64) ? 64u : S;          // 64 columns: whole 64 x 64 operands, zero beyond S
     double * A = lds, * B = lds + arows * Sp;
+    // one exp per eigenvalue (B's first row is free until the loop below fills it), not one per matrix entry
+    if (threadIdx.x < S) B[threadIdx.x] = exp(L[threadIdx.x] * rt);
+    __syncthreads();
     for (unsigned e = threadIdx.x; e < arows * Sp; e += blockDim.x)
     {
       const unsigned k = e % Sp;
-      A[e] = (e < S * Sp && k < S) ? V[e] * exp(L[k] * rt) : 0.0;
-      B[e] = (e < S * Sp) ? Vi[e] : 0.0;
+      A[e] = (e < S * Sp && k < S) ? V[e] * B[k] : 0.0;
     }
+    __syncthreads();
+    for (unsigned e = threadIdx.x; e < arows * Sp; e += blockDim.x) B[e] = (e < S * Sp) ? Vi[e] : 0.0;
     __syncthreads();
     double res[16];
     if (Sp == 64)

@@ -553,8 +553,15 @@ __global__ __launch_bounds__(256) void k_sumtable_prep_s16(ModelView mv, ParamId
     const unsigned c = e / S, k = e % S;
     const unsigned long long mask = tipmap[c];
     double a = 0.0, b = 0.0;
-    for (unsigned i = 0; i < S; ++i)
-      if ((mask >> i) & 1ULL) { a += pi[i] * V[i * Sp + k]; b += Vi[k * Sp + i]; }
+    if (mask && !(mask & (mask - 1)))                 // one state (most codes): no walk over the alphabet
+    {
+      const unsigned i = (unsigned)__ffsll((long long)mask) - 1;
+      a += pi[i] * V[i * Sp + k];
+      b += Vi[k * Sp + i];
+    }
+    else
+      for (unsigned i = 0; i < S; ++i)
+        if ((mask >> i) & 1ULL) { a += pi[i] * V[i * Sp + k]; b += Vi[k * Sp + i]; }
     lutL[((size_t)r * lut_codes + c) * S + k] = a;
     lutR[((size_t)r * lut_codes + c) * S + k] = b;
   }

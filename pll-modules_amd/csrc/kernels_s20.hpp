@@ -838,8 +838,15 @@ __global__ __launch_bounds__(256) void k_sumtable_prep_s20(ModelView mv, ParamId
     const unsigned c = e / 20, k = e % 20;
     const unsigned long long mask = tipmap[c];
     double a = 0.0, b = 0.0;
-    for (unsigned i = 0; i < 20; ++i)
-      if ((mask >> i) & 1ULL) { a += pi[i] * V[i * 20 + k]; b += Vi[k * 20 + i]; }
+    if (mask && !(mask & (mask - 1)))                 // one state (most codes): no walk over the alphabet
+    {
+      const unsigned i = (unsigned)__ffsll((long long)mask) - 1;
+      a += pi[i] * V[i * 20 + k];
+      b += Vi[k * 20 + i];
+    }
+    else
+      for (unsigned i = 0; i < 20; ++i)
+        if ((mask >> i) & 1ULL) { a += pi[i] * V[i * 20 + k]; b += Vi[k * 20 + i]; }
     lutL[((size_t)r * lut_codes + c) * 20 + k] = a;
     lutR[((size_t)r * lut_codes + c) * 20 + k] = b;
   }
