@@ -325,35 +325,69 @@ def launch_probe(args, rank, world):
 
 def partition_cost(states, rate_cats):
     """relative cost of one site of a partition: bytes per site across one operation for the HBM-bound
-    families (24 S per rate), flops over the ridge (~10 flop/B) where the matrix pipe bounds it"""
-    return rate_cats * max(24.0 * states, 2.0 * states * states / 10.2)
+    families (24 S per rate; 20 % on top where the matrix pipe works next to the memory system:
+    measured 6.0 : 1 between 20 and 4 states at the slice sizes of an 8-way split), flops over the ridge
+    (~10 flop/B) where the matrix pipe bounds it"""
+    per_rate = 24.0 * states * (1.2 if states > 16 else 1.0)
+    return rate_cats * max(per_rate, 2.0 * states * states / 10.2)
+
+
+# what a further slice on a rank costs (its own launches, tables, lnL kernel), in units of partition_cost(4, 4) sites:
+# measured at the C4 slices of an 8-way split (two slices of one family on a rank: +0.15 ms of 1.04)
+SLICE_OVERHEAD_SITES = 30000.0
 
 
 def assign_partitions(job_plan, rate_cats, rank, world):
     """Cost-balanced assignment of the partitions of a job to the ranks: all partitions are
-    laid end to end, every site weighted with its partition's cost, and cut into `world` pieces of equal
-    cost -- a rank gets the (few, large) partition slices inside its piece and NULL slots for the rest
-    (src/tree/treeinfo.c:1024-1031), instead of a 1/world slice of EVERY partition.  Slice borders sit on whole
-    32-site blocks.  Returns [(first_site, sites) or None per partition]."""
-    costs = [partition_cost(s_, rate_cats) * n_ for s_, n_ in job_plan]
-    total = sum(costs)
-    lo_c, hi_c = total * rank / world, total * (rank + 1) / world
-    out, start = [], 0.0
-    for (s_, n_), c in zip(job_plan, costs):
-        end = start + c
-        a, b = max(lo_c, start), min(hi_c, end)
-        if b <= a or c <= 0:
-            out.append(None)
+    laid end to end, every site weighted with its partition's cost, and cut into `world` consecutive pieces --
+    a rank gets the (few, large) partition slices inside its piece and NULL slots for the rest
+    (src/tree/treeinfo.c:1024-1031), instead of a 1/world slice of EVERY partition.  The cuts minimise the load
+    of the busiest rank, a slice costing a fixed overhead on top of its sites (so that no rank is left with a
+    sliver of a second partition): the smallest budget with which a greedy walk places everything on `world`
+    ranks, found by bisection.  Slice borders sit on whole 32-site blocks.  Returns [(first_site, sites) or None
+    per partition]."""
+    unit = partition_cost(4, rate_cats)
+    cost = [partition_cost(s_, rate_cats) / unit for s_, _ in job_plan]
+    sizes = [n_ for _, n_ in job_plan]
+
+    def walk(budget):
+        """greedy: [per rank: [(partition, first, sites)]] or None if `world` ranks do not suffice"""
+        ranks, cur, load = [], [], 0.0
+        for k, n_ in enumerate(sizes):
+            first = 0
+            while first < n_:
+                room = budget - load - (SLICE_OVERHEAD_SITES if cur else 0.0)
+                take = int(room / cost[k]) // 32 * 32
+                if take >= n_ - first:
+                    take = n_ - first
+                if take <= 0 or (take < 32 and take < n_ - first):
+                    if not cur:
+                        return None                    # the budget does not even hold one block
+                    ranks.append(cur)
+                    cur, load = [], 0.0
+                    if len(ranks) >= world:
+                        return None
+                    continue
+                load += (SLICE_OVERHEAD_SITES if cur else 0.0) + take * cost[k]
+                cur.append((k, first, take))
+                first += take
+        if cur:
+            ranks.append(cur)
+        return ranks if len(ranks) <= world else None
+
+    total = sum(c * n_ for c, n_ in zip(cost, sizes))
+    lo, hi = total / world, total + SLICE_OVERHEAD_SITES * len(sizes)
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if walk(mid) is None:
+            lo = mid
         else:
-            def cut(x, last):
-                if last:
-                    return n_
-                v = int(round((x - start) / c * n_ / 32.0)) * 32
-                return max(0, min(n_, v))
-            first = cut(a, False) if a > start else 0
-            stop = cut(b, b >= end)
-            out.append((first, stop - first) if stop > first else None)
-        start = end
+            hi = mid
+    ranks = walk(hi) or []
+    out = [None] * len(sizes)
+    if rank < len(ranks):
+        for k, first, take in ranks[rank]:
+            out[k] = (first, take)
     return out
 
 
