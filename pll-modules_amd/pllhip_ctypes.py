@@ -567,6 +567,16 @@ def uniform01(seed, n):
     return (splitmix64(seed, n) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
+def _balanced_pick(t):
+    """the tip whose pendant edge tip t splits in a balanced tree: tips 0, 1, 2, 3, ... in turn, starting over
+    whenever every existing tip has been split once (3 -> 6 -> 12 -> ... tips: a complete binary tree)"""
+    start, size = 3, 3
+    while t >= start + size:
+        start += size
+        size *= 2
+    return t - start
+
+
 class Tree:
     """Unrooted binary tree as index arrays.
 
@@ -575,20 +585,33 @@ class Tree:
     operation list towards the root edge (root_a, root_b, root_matrix).
     """
 
-    def __init__(self, ntips, seed_topology=42, seed_brlen=43, brlen_range=(0.01, 0.2), ladder=False):
+    def __init__(self, ntips, seed_topology=42, seed_brlen=43, brlen_range=(0.01, 0.2), ladder=False, balanced=False):
         assert ntips >= 3
         self.ntips = ntips
+        self.is_ladder = ladder
         rnd = splitmix64(seed_topology, ntips)
         # edges as [u, v]; start with a star on tips 0,1,2 around inner node n
         edges = [[0, ntips], [1, ntips], [2, ntips]]
+        pendant = {0: 0, 1: 1, 2: 2}            # tip -> index of its pendant edge
         for t in range(3, ntips):
-            # ladder: always split the pendant edge of the tip added last (a caterpillar)
-            e = len(edges) - 1 if ladder else int(rnd[t] % np.uint64(len(edges)))
+            # ladder: always split the pendant edge of the tip added last (a caterpillar);
+            # balanced: the pendant edges of the tips in turn (every tip becomes a cherry before any is split twice)
+            if ladder:
+                e = len(edges) - 1
+            elif balanced:
+                e = pendant[_balanced_pick(t)]
+            else:
+                e = int(rnd[t] % np.uint64(len(edges)))
             u, v = edges[e]
             w = ntips + (t - 2)          # new inner node
             edges[e] = [u, w]
             edges.append([w, v])
             edges.append([t, w])
+            if u < ntips:                # the split edge was the pendant edge of tip u: it still is (u -- w)
+                pendant[u] = e
+            elif v < ntips:
+                pendant[v] = len(edges) - 2
+            pendant[t] = len(edges) - 1
         self.edges = edges
         lo, hi = brlen_range
         self.brlens = lo + (hi - lo) * uniform01(seed_brlen, len(edges))

@@ -243,7 +243,10 @@ sys.path.insert(0, %r)
 import numpy as np
 import pllhip_ctypes as pc
 lib = pc.PllLib(pc.PRODUCT_LIB)
-with pc.build_instance(lib, states=%d, rate_cats=4, ntips=%d, nsites=1531, coded=True) as a:
+import os
+shape = os.environ.get("TEST_TREE_SHAPE", "random")
+tree = pc.Tree(%d, 42, 43, ladder=(shape == "ladder"), balanced=(shape == "balanced"))
+with pc.build_instance(lib, states=%d, rate_cats=4, ntips=tree.ntips, nsites=1531, coded=True, tree=tree) as a:
     out = []
     t = a.tree
     for rep in range(4):
@@ -263,14 +266,38 @@ with pc.build_instance(lib, states=%d, rate_cats=4, ntips=%d, nsites=1531, coded
         out.append("%%.17g %%s" %% (l, h.hexdigest()))
     print("\n".join(out))
     print(a.counters().partial_launches)
-""" % (os.path.dirname(pc.__file__), states, ntips)
-    runs = []
-    for mode in ("1", "0"):
-        env = dict(os.environ, PLLHIP_TRAVERSE=mode)
-        runs.append(subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True,
-                                   text=True, timeout=300).stdout.splitlines())
-    assert runs[0][:4] == runs[1][:4] and len(runs[0]) == 5
-    assert int(runs[0][4]) == 4 and int(runs[1][4]) > 8        # one launch per traversal / several
+""" % (os.path.dirname(pc.__file__), ntips, states)
+    for shape in ("random", "balanced"):
+        runs = []
+        for mode in ("1", "0"):
+            env = dict(os.environ, PLLHIP_TRAVERSE=mode, TEST_TREE_SHAPE=shape)
+            runs.append(subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True,
+                                       text=True, timeout=300).stdout.splitlines())
+        assert runs[0][:4] == runs[1][:4] and len(runs[0]) == 5
+        assert int(runs[0][4]) == 4 and int(runs[1][4]) > 8        # one launch per traversal / several
+
+
+@pytest.mark.parametrize("shape", ["random", "ladder", "balanced"])
+@pytest.mark.parametrize("states", [4, 20, 10, 61])
+def test_tree_shapes_against_the_oracle(product, oracle, states, shape):
+    """the chain / round / one-launch schedules are cut from the tree: a caterpillar (one chain after the other),
+    a complete binary tree (half of the operations are cherries, 13 levels for 100 taxa) and the random
+    stepwise-addition trees of the benchmarks; vectors, scaler counts and lnL against the oracle, operation by
+    operation, with site repeats on top at 20 states"""
+    ntips, nsites = (40, 130) if states > 20 else (100, 777)
+    tree = pc.Tree(ntips, 42, 43, ladder=(shape == "ladder"), balanced=(shape == "balanced"))
+    for attributes in ((0, pc.PLL_ATTRIB_SITE_REPEATS) if states == 20 else (0,)):
+        a = pc.build_instance(product, states=states, rate_cats=4, ntips=ntips, nsites=nsites, coded=True, tree=tree,
+                              attributes=attributes)
+        b = pc.build_instance(oracle, states=states, rate_cats=4, ntips=ntips, nsites=nsites, coded=True, tree=tree)
+        with a, b:
+            # (61 states: a cherry site whose two codons differ in all three positions is made of P-matrix entries
+            # at the 1e-16 absolute floor of the two eigen-solvers -- 2e-7 of that site's largest entry, the class of
+            # deviation tests/test_expm_fixtures.py pins; vectors are compared up to 20 states, scaler counts and lnL always)
+            _compare_full(a, b, check_clvs=states <= 20)
+            for op in tree.ops:
+                assert np.array_equal(a.get_scaler(op[1]), b.get_scaler(op[1]))
+            _compare_full(a, b, check_clvs=False)          # the resident schedule once more
 
 
 @pytest.mark.parametrize("states,nsites,ntips,launches", [(4, 900_000, 8, 1), (4, 70_000, 14, None), (20, 120_000, 10, 1),
