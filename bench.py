@@ -77,6 +77,8 @@ def parse_args():
                          "torch = the reduce callback through torch.distributed (a rehearsal path: with "
                          "PLLHIP_BENCH_DIST_BACKEND=gloo and PLLHIP_ALLOW_DEVICE_WRAP=1 all ranks can share one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tree", default="random", choices=["random", "ladder", "balanced"],
+                    help="tree shape: random stepwise addition (seed 42, the benchmark's), a caterpillar, a complete binary tree")
     ap.add_argument("--as-rank", default="",
                     help="R/N: run, on ONE GPU and without a reduction, the share rank R of N would hold (the cost-balanced "
                          "partition assignment of --config c4); `value` then counts that share only")
@@ -408,7 +410,7 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
     if taxa:
         ntips = taxa
     per_branch = args.pmatrix_calls == "per-branch"
-    tree = pc.Tree(ntips, 42, 43)
+    tree = pc.Tree(ntips, 42, 43, ladder=(args.tree == "ladder"), balanced=(args.tree == "balanced"))
 
     # ONE alignment for the whole job (strong: the configured site count is split; weak: it is the per-GPU share).
     # One partition: rank r owns a contiguous site range.  Several partitions on several ranks: whole partitions /
@@ -543,7 +545,7 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
     traffic_source = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and world == 1 and not sites and not taxa and not args.rate_scalers and not args.site_repeats \
-            and args.data == "random":
+            and args.data == "random" and args.tree == "random":
         try:
             tj = json.load(open(tpath))
             per_step = tj.get(f"{config}:{kernel}:per_step")
@@ -634,7 +636,7 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
                                      if balanced else "every rank holds a contiguous 1/N site range of every partition"),
             "tips": "1-byte codes",
             "scalers": ("per (site, rate)" if args.rate_scalers else "per-site") + ", one buffer per inner node",
-            "pmatrix_calls": args.pmatrix_calls, "alignment": args.data,
+            "pmatrix_calls": args.pmatrix_calls, "alignment": args.data, "tree": args.tree,
             "site_repeats": repeats,
             "pmatrix_launches_per_step": pmatrix_launches // evals,
             "partial_launches_per_step": partial_launches // evals,
@@ -789,7 +791,7 @@ def main():
                       "torch_loaded_before_engine": world > 1}
     default_run = (world == 1 and not internal and args.config == "c3" and not args.sites and not args.taxa and
                    not args.rate_scalers and not args.no_also and not args.no_cpu_baseline and not args.site_repeats and
-                   args.data == "random")
+                   args.data == "random" and args.tree == "random")
     if default_run:
         t0 = time.perf_counter()
         out["also"] = also_legs(ctx)
