@@ -37,4 +37,43 @@ for S, N, n in ((4, 70_000, 14), (4, 900_000, 8), (20, 40_000, 12), (20, 120_000
             ok = abs(la - lb) <= 1e-11 * abs(lb) + 2e-9 * N and \
                 all(np.array_equal(a.get_scaler(op[1]), b.get_scaler(op[1])) for op in tr.ops)
             if not ok: bad += 1; print("big", S, N, n, la, lb)
+# round 3: every alphabet up to 64 states, mixtures, balanced trees, site repeats, partitions sharing launches
+for trial in range(36):
+    S = [17, 24, 32, 33, 48, 62, 64, 20, 4, 61, 28, 5][trial % 12]; R = 4
+    n = int(rng.integers(5, 40)) if S <= 32 else int(rng.integers(5, 12)); N = int(rng.integers(1, 500))
+    tr = pc.Tree(n, 300 + trial, 400 + trial, ladder=(trial % 3 == 1), balanced=(trial % 3 == 2))
+    mix = [None, [0, 1, 0, 1], [0, 1, 2, 3]][(trial // 3) % 3]
+    attrs = pc.PLL_ATTRIB_SITE_REPEATS if (S == 20 and trial % 2 == 0) else 0
+    kw = dict(states=S, rate_cats=R, ntips=n, nsites=N, coded=bool(trial % 5 != 4) or bool(attrs), tree=tr, mixture=mix,
+              attributes=attrs)
+    with pc.build_instance(product, **kw) as a, pc.build_instance(oracle, **{**kw, "attributes": 0}) as b:
+        for rep in range(2):
+            la, lb = pc.full_traversal(a, one_by_one_pmatrices=bool(rep)), pc.full_traversal(b, one_by_one_pmatrices=bool(rep))
+            tol = (2e-6 if S > 32 else 1e-11) * abs(lb) + 2e-9 * N
+            ok = abs(la - lb) <= tol and all(np.array_equal(a.get_scaler(op[1]), b.get_scaler(op[1])) for op in tr.ops)
+            if not ok: bad += 1; print("r3 trav", S, n, N, mix, attrs, la, lb)
+for trial in range(6):
+    n = int(rng.integers(6, 50))
+    tr = pc.Tree(n, 500 + trial, 600 + trial, balanced=bool(trial % 2))
+    spec = [(S, int(rng.integers(1, 3000))) for S in ([20, 20, 20, 4, 4, 10, 10, 61][:int(rng.integers(2, 9))])]
+    def members(lib):
+        out = []
+        for k, (S, N) in enumerate(spec):
+            m = pc.build_instance(lib, states=S, rate_cats=4, ntips=n, nsites=N, coded=True, tree=tr, seed_shift=0)
+            m.tree = tr
+            out.append(m)
+        return out
+    ga, gb, oc = members(product), members(product), members(oracle)
+    for m in ga + gb + oc:
+        m.update_pmatrices(np.arange(tr.nedges), tr.brlens)
+    pc.update_partials_batch(product, ga, tr.ops_with_scalers(True))
+    for m in gb + oc:
+        m.update_partials(tr.ops_with_scalers(True))
+    for x, y, z in zip(ga, gb, oc):
+        sa, sb = tr.scaler_of(tr.root_a), tr.scaler_of(tr.root_b)
+        lx, ly, lz = (i.edge_lnl(tr.root_a, sa, tr.root_b, sb, tr.root_matrix) for i in (x, y, z))
+        if lx != ly or abs(lx - lz) > (2e-6 if x.S > 32 else 1e-11) * abs(lz) + 2e-9 * x.N:
+            bad += 1; print("batch", spec, lx, ly, lz)
+    for m in ga + gb + oc:
+        m.close()
 print("stress done, failures:", bad)
