@@ -568,6 +568,7 @@ int sync_model(pll_partition_t * p, bool light)
   // queued P-matrix requests belong to the model state they were issued under,
   // which is the one still on the device
   if (!flush_pmatrices(p)) return PLL_FAILURE;
+  PLLHIP_TRY(hipSetDevice(e->device));
   // pageable source: the runtime stages it before returning, so `cur` may die
   PLLHIP_TRY(hipMemcpyAsync(e->d_model, cur.data(), sizeof(double) * e->model_len,
                             hipMemcpyHostToDevice, e->stream));
@@ -588,6 +589,7 @@ int flush_pmatrices(pll_partition_t * p)
 {
   Engine * e = engine_of(p);
   if (e->pend_midx.empty()) return PLL_SUCCESS;
+  PLLHIP_TRY(hipSetDevice(e->device));
   if (e->coded_tips)
   {
     // LUT storage must exist so that the kernel can fill it in the same pass
@@ -2256,7 +2258,8 @@ int pll_update_prob_matrices(pll_partition_t * p,
     }
     return PLL_SUCCESS;
   }
-  PLLHIP_TRY(hipSetDevice(e->device));
+  // (no HIP call on the queueing path: the reference issues one call per branch and partition -- 6 304 per
+  // evaluation of 32 partitions on 100 taxa --; the device is selected where something is launched or copied)
   if (!ensure_eigen(p, params_indices)) return PLL_FAILURE;
   if (!sync_model(p, e->pmatrix_burst)) return PLL_FAILURE;
   e->pmatrix_burst = true;                    // until another entry point looks at the model
