@@ -1176,7 +1176,13 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
     {
       const unsigned child[2] = {ops[k].child1_clv_index, ops[k].child2_clv_index};
       for (int x = 0; x < 2; ++x)
-        if (child[x] >= e->tips && !made[child[x]] && e->cherries[child[x]].valid) { wide[2 * k + x] = 1; ++nwide; }
+      {
+        if (child[x] < e->tips || made[child[x]] || !e->cherries[child[x]].valid) continue;
+        // (a cherry built under another code table -- a tip has taken a new ambiguity code since -- is read
+        // through its expanded vector: its classes are not the ones this schedule indexes)
+        if (e->cherries[child[x]].ncodes == lut_used) { wide[2 * k + x] = 1; ++nwide; }
+        else if (!need_clv(e, child[x])) return false;
+      }
       made[ops[k].parent_clv_index] = 1;
     }
   }

@@ -132,3 +132,27 @@ def test_site_repeats_through_the_driver(product):
             l2, st = ev.spr_round(radius_max=3, ntopol_keep=3)
             out.append((l0, l1, l2, ev.newick(), st.moves_applied))
     assert out[0] == out[1]
+
+
+def test_cherry_built_under_an_older_code_table(product):
+    """a tip takes a new ambiguity code after a traversal (the code table grows); a later partial traversal reads
+    the cherries built before that: through their expanded vectors, with the same result as without site repeats"""
+    tree = pc.Tree(30, 42, 43)
+    out = []
+    for repeats in (True, False):
+        with _build(product, tree, 900, repeats) as a:
+            l0 = pc.full_traversal(a)
+            cmap = pc.state_charmap(20)
+            cmap[ord("B")] = (1 << 2) | (1 << 3)
+            cherry_tips = {op[2] for op in tree.ops if op[2] < 30 and op[5] < 30} | {op[5] for op in tree.ops if op[2] < 30 and op[5] < 30}
+            other = next(t for t in range(30) if t not in cherry_tips)
+            seq = (a.codes[other] + 48).astype(np.uint8)
+            seq[::7] = ord("B")
+            a.set_tip_states(other, cmap, seq.tobytes())
+            ops = [op for op in tree.ops_with_scalers(True) if not (op[2] < 30 and op[5] < 30)]      # everything but the cherries
+            a.update_pmatrices(np.arange(tree.nedges), tree.brlens)
+            a.update_partials(ops)
+            l1 = a.edge_lnl(tree.root_a, tree.scaler_of(tree.root_a), tree.root_b, tree.scaler_of(tree.root_b), tree.root_matrix)
+            out.append((l0, l1, [a.get_clv(op[0]).tobytes() for op in tree.ops]))
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1] and out[0][1] != out[0][0]
+    assert out[0][2] == out[1][2]
