@@ -4,7 +4,8 @@
 // subtree below it (the reference selects the attribute in its test harness, test/src/common.c:31, and carries
 // the per-node class tables through its checkpoints, src/binary/binary_io_operations.c:231-282).  For a cherry --
 // a tip x tip operation -- the class of a site is simply its pair of tip codes: at most codes^2 classes (a few
-// hundred) however long the alignment is.  With the attribute set the 20-state family therefore
+// hundred) however long the alignment is.  With the attribute set the 20-state family (and, with scalar kernels of
+// the same structure at the end of this file, the 4-state family) therefore
 //   * computes a cherry's vector per code pair (k_cherry_build: the arithmetic of the tip x tip operation on a
 //     "pseudo alignment" whose sites are the pairs; a few hundred KiB that stay in the caches) and writes per site
 //     only the 16-bit class code and the scaler count (k_cherry_sites: 6 B instead of 640 B per site);
@@ -168,6 +169,72 @@ __global__ __launch_bounds__(256) void k_cherry_expand(const double * table, con
       for (int k = 0; k < 5; ++k) t[k] = make_double2(ue[k * 128], uo[k * 128]);
       s20_store_d(clv + ((size_t)blk * R + r) * S20_UNIT, lane, t);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// the same for the 4-state family (kernels_s4.hpp; vectors in the API layout [site][rate][4], tip tables
+// [rate][16 codes][4]): at most 256 classes per cherry
+// ---------------------------------------------------------------------------
+// grid = (ceil(pairs / 256), jobs), block = 256: a thread per class
+__global__ __launch_bounds__(256) void k_cherry_build_s4(const CherryJob * jobs, unsigned R, unsigned ncodes)
+{
+  const CherryJob job = plan_fetch(jobs + blockIdx.y);
+  const unsigned npairs = ncodes * ncodes;
+  const unsigned p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= npairs) return;
+  const double * lut1 = as_global(job.lut1), * lut2 = as_global(job.lut2);
+  double * table = as_global(job.table);
+  const unsigned a = p / ncodes, b = p % ncodes;
+  bool small = true;
+  for (unsigned r = 0; r < R; ++r)
+    for (unsigned i = 0; i < 4; ++i)
+    {
+      const double v = lut1[(r * 16 + a) * 4 + i] * lut2[(r * 16 + b) * 4 + i];
+      table[((size_t)p * R + r) * 4 + i] = v;
+      small = small && (v < SCALE_THRESHOLD);
+    }
+  if (job.parent_scaler)
+  {
+    as_global(job.flags)[p] = small ? 1 : 0;
+    if (small)
+      for (unsigned e = 0; e < R * 4; ++e) table[(size_t)p * R * 4 + e] *= SCALE_FACTOR;
+  }
+}
+
+// [rate][class][4] = P(rate) . vector(class), with the association of s4_half_matvec:
+// (P_i0 x_0 + P_i1 x_1) + (P_i2 x_2 + P_i3 x_3).  grid = (ceil(pairs * R / 256), jobs), block = 256;
+// job.pfrag holds the branch's matrices [rate][4][4]
+__global__ __launch_bounds__(256) void k_pair_lut_s4(const PairLutJob * jobs, unsigned npairs, unsigned R)
+{
+  const PairLutJob job = plan_fetch(jobs + blockIdx.y);
+  const unsigned x = blockIdx.x * 256u + threadIdx.x;
+  if (x >= npairs * R) return;
+  const unsigned p = x / R, r = x % R;
+  const double * P = as_global(job.pfrag) + r * 16;
+  const double * v = as_global(job.table) + ((size_t)p * R + r) * 4;
+  double * out = as_global(job.out) + ((size_t)r * npairs + p) * 4;
+  for (unsigned i = 0; i < 4; ++i)
+  {
+    const double lo = P[i * 4 + 0] * v[0] + P[i * 4 + 1] * v[1];
+    const double hi = P[i * 4 + 2] * v[2] + P[i * 4 + 3] * v[3];
+    out[i] = (i < 2) ? lo + hi : hi + lo;
+  }
+}
+
+// the site-indexed vector of a cherry: grid-stride over (site, rate) columns
+__global__ __launch_bounds__(256) void k_cherry_expand_s4(const double * table, const unsigned short * pair,
+                                                          unsigned N, unsigned R, double * clv)
+{
+  const unsigned long long total = (unsigned long long)N * R;
+  for (unsigned long long c = (unsigned long long)blockIdx.x * 256u + threadIdx.x; c < total;
+       c += (unsigned long long)gridDim.x * 256u)
+  {
+    const unsigned long long n = c / R;
+    const unsigned r = (unsigned)(c % R);
+    const double * src = table + ((size_t)pair[n] * R + r) * 4;
+    double * dst = clv + c * 4;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
   }
 }
 

@@ -269,9 +269,14 @@ __device__ inline void s4_chain_step(const OpDesc & op, unsigned carried, const 
 {
   constexpr unsigned group = 2 * R, spi = 64 / group;
   constexpr unsigned T2 = R * S4_LUT_RS, M1 = 2 * R * S4_LUT_RS, M2 = 2 * R * S4_LUT_RS + R * 16;
+  // a "wide tip" (kernels_repeats.hpp: a cherry known per class of sites): neither vector nor byte codes; pfrag
+  // holds its 16-bit class codes, lut its table [rate][class][4], childN_index the classes
+  const unsigned short * w1 = (!op.clv1 && !op.codes1) ? reinterpret_cast<const unsigned short *>(op.pfrag1) : nullptr;
+  const unsigned short * w2 = (!op.clv2 && !op.codes2) ? reinterpret_cast<const unsigned short *>(op.pfrag2) : nullptr;
+  const bool tip1 = op.codes1 || w1, tip2 = op.codes2 || w2;
   HalfP p1 = {}, p2 = {};
-  if (!op.codes1) p1 = s4_load_half_p(base + M1, r, h);
-  if (!op.codes2) p2 = s4_load_half_p(base + M2, r, h);
+  if (!tip1) p1 = s4_load_half_p(base + M1, r, h);
+  if (!tip2) p2 = s4_load_half_p(base + M2, r, h);
   unsigned child_cnt = 0;
   if (op.parent_scaler && nsc < N)
   {
@@ -283,8 +288,8 @@ __device__ inline void s4_chain_step(const OpDesc & op, unsigned carried, const 
   // site l of the chunk); an iteration picks its site's code with a lane shuffle, so no
   // global load sits in front of the table lookup
   const unsigned long long ncode = nsc < N ? nsc : 0ULL;
-  const int cb1 = op.codes1 ? (int)op.codes1[ncode] : 0;
-  const int cb2 = op.codes2 ? (int)op.codes2[ncode] : 0;
+  const int cb1 = op.codes1 ? (int)op.codes1[ncode] : w1 ? (int)w1[ncode] : 0;
+  const int cb2 = op.codes2 ? (int)op.codes2[ncode] : w2 ? (int)w2[ncode] : 0;
 #pragma unroll
   for (unsigned k0 = 0; k0 < group; k0 += U)
   {
@@ -297,15 +302,19 @@ __device__ inline void s4_chain_step(const OpDesc & op, unsigned carried, const 
       const int src = (int)((k0 + u) * spi + lane / group);       // this lane's site within the chunk
       live[u] = gu < total;
       in1[u] = in2[u] = make_double2(0.0, 0.0);
-      const int code1 = op.codes1 ? __shfl(cb1, src, 64) : 0;
-      const int code2 = op.codes2 ? __shfl(cb2, src, 64) : 0;
+      const int code1 = tip1 ? __shfl(cb1, src, 64) : 0;
+      const int code2 = tip2 ? __shfl(cb2, src, 64) : 0;
       if (live[u])
       {
         if (op.codes1)
           in1[u] = *reinterpret_cast<const double2 *>(&base[r * S4_LUT_RS + code1 * 4 + 2 * h]);
+        else if (w1)
+          in1[u] = *reinterpret_cast<const double2 *>(&op.lut1[((size_t)r * op.child1_index + (unsigned)code1) * 4 + 2 * h]);
         else if (carried != 1) in1[u] = s4_ld2<NT == 2>(op.clv1 + gu * 2);
         if (op.codes2)
           in2[u] = *reinterpret_cast<const double2 *>(&base[T2 + r * S4_LUT_RS + code2 * 4 + 2 * h]);
+        else if (w2)
+          in2[u] = *reinterpret_cast<const double2 *>(&op.lut2[((size_t)r * op.child2_index + (unsigned)code2) * 4 + 2 * h]);
         else if (carried != 2) in2[u] = s4_ld2<NT == 2>(op.clv2 + gu * 2);
       }
     }
@@ -314,8 +323,8 @@ __device__ inline void s4_chain_step(const OpDesc & op, unsigned carried, const 
     {
       const unsigned k = k0 + u;
       const unsigned long long gu = hc0 + (unsigned long long)k * 64ULL;
-      const double2 a = op.codes1 ? in1[u] : s4_half_matvec(p1, carried == 1 ? X[k] : in1[u]);
-      const double2 b = op.codes2 ? in2[u] : s4_half_matvec(p2, carried == 2 ? X[k] : in2[u]);
+      const double2 a = tip1 ? in1[u] : s4_half_matvec(p1, carried == 1 ? X[k] : in1[u]);
+      const double2 b = tip2 ? in2[u] : s4_half_matvec(p2, carried == 2 ? X[k] : in2[u]);
       double2 v = make_double2(a.x * b.x, a.y * b.y);
       if (op.parent_scaler)
       {

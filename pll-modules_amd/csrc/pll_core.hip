@@ -292,8 +292,9 @@ Engine * engine_create(pll_partition_t * p)
     if (ok) memset(e->h_asc, 0, bytes);
     ok = ok && hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->d_asc), e->h_asc, 0), "map asc");
   }
-  if (e->site_repeats && e->family == KernelFamily::S20) e->cherries.assign(e->nodes, Engine::Cherry());
-  else e->site_repeats = false;                 // (first step: the 20-state family)
+  if (e->site_repeats && (e->family == KernelFamily::S20 || e->family == KernelFamily::S4))
+    e->cherries.assign(e->nodes, Engine::Cherry());
+  else e->site_repeats = false;                 // (first step: the 20- and the 4-state family)
   e->pmat_brlen.assign(e->nmat, std::numeric_limits<double>::quiet_NaN());
   e->pmat_params.assign(e->nmat, std::vector<unsigned>());
 
@@ -1071,8 +1072,12 @@ static int need_clv(Engine * e, unsigned idx)
   if (e->cherries.empty() || idx >= e->cherries.size()) return PLL_SUCCESS;
   Engine::Cherry & c = e->cherries[idx];
   if (!c.valid || c.materialized) return PLL_SUCCESS;
-  hipLaunchKernelGGL(k_cherry_expand, dim3(std::max(1u, std::min((e->nblk + 3) / 4, e->cu_count * 8u))), dim3(256), 0,
-                     e->stream, c.table, c.pair, e->nblk, e->R, e->d_clv[idx]);
+  if (e->family == KernelFamily::S4)
+    hipLaunchKernelGGL(k_cherry_expand_s4, dim3(std::max(1u, std::min((e->N * e->R + 255u) / 256u, e->cu_count * 8u))), dim3(256), 0,
+                       e->stream, c.table, c.pair, e->N, e->R, e->d_clv[idx]);
+  else
+    hipLaunchKernelGGL(k_cherry_expand, dim3(std::max(1u, std::min((e->nblk + 3) / 4, e->cu_count * 8u))), dim3(256), 0,
+                       e->stream, c.table, c.pair, e->nblk, e->R, e->d_clv[idx]);
   PLLHIP_TRY(hipGetLastError());
   c.materialized = true;
   e->repeat_stats.expansions++;
@@ -1092,13 +1097,15 @@ static bool cherry_storage(Engine * e, unsigned node, unsigned ncodes)
 {
   Engine::Cherry & c = e->cherries[node];
   const unsigned npairs = ncodes * ncodes, npblk = (npairs + S20_BS - 1) / S20_BS;
+  // (20 states: blocked like a vector over the classes; 4 states: [class][rate][4])
+  const size_t table_doubles = e->family == KernelFamily::S4 ? (size_t)npairs * e->R * 4 : (size_t)npblk * e->R * S20_UNIT;
   if (c.cap_codes < ncodes)
   {
     if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
     (void)hipFree(c.table); (void)hipFree(c.flags);
     c.table = nullptr; c.flags = nullptr; c.cap_codes = 0;
     e->plan.key.clear();                          // cached schedules point at the old tables
-    if (!dev_alloc(&c.table, (size_t)npblk * e->R * S20_UNIT, "cherry table") ||
+    if (!dev_alloc(&c.table, table_doubles, "cherry table") ||
         !dev_alloc(&c.flags, (size_t)npblk * S20_BS, "cherry flags") ||
         !hip_ok(hipMemsetAsync(c.flags, 0, (size_t)npblk * S20_BS, e->stream), "memset flags"))
       return false;
@@ -1200,7 +1207,7 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
   if (!have && nwide)
   {
     // the lookup tables of the wide tips: one per (cherry, branch) of the schedule
-    const size_t need = (size_t)nwide * e->R * rep_pairs * 20;
+    const size_t need = (size_t)nwide * e->R * rep_pairs * e->S;
     if (need > e->pairlut_cap)
     {
       if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
@@ -1330,8 +1337,8 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
           const Engine::Cherry & c = e->cherries[cidx];
           PairLutJob job;
           job.table = c.table;
-          job.pfrag = e->d_pfrag + (size_t)midx * e->R * 400;
-          job.out = e->d_pairlut + pair_jobs.size() * (size_t)e->R * rep_pairs * 20;
+          job.pfrag = chains4 ? e->d_pmat + (size_t)midx * e->R * 16 : e->d_pfrag + (size_t)midx * e->R * 400;
+          job.out = e->d_pairlut + pair_jobs.size() * (size_t)e->R * rep_pairs * e->S;
           pair_jobs.push_back(job);
           // wide tip: no vector, no byte codes; pfrag = class codes, lut = its table, childN_index = table rows
           if (x) { po.d.clv2 = nullptr; po.d.codes2 = nullptr; po.d.pfrag2 = reinterpret_cast<const double *>(c.pair); po.d.lut2 = job.out; po.d.child2_index = rep_pairs; }
@@ -1595,7 +1602,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
       // site repeats: the cherries of the list that an operation of the list consumes are kept per class
       // (kernels_repeats.hpp) and leave the list; their consumers read them as wide tips
       RepeatPlan rp;
-      if (e->site_repeats && chains20 && lut_used <= 64)
+      if (e->site_repeats && (chains20 || chains4) && lut_used <= 64)
       {
         std::vector<int> consumer(e->nodes, -1);
         for (unsigned k = 0; k < count; ++k) { consumer[ops[k].child1_clv_index] = (int)k; consumer[ops[k].child2_clv_index] = (int)k; }
@@ -1637,7 +1644,8 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
           if (dp.ncherry_jobs)
           {
             const dim3 gb((npblk + 3) / 4, dp.ncherry_jobs), gs(std::max(1u, std::min((e->Nalloc + 255u) / 256u, 4u * e->cu_count)), dp.ncherry_jobs);
-            if (e->R == 4) hipLaunchKernelGGL(k_cherry_build<4>, gb, dim3(256), 0, e->stream, cj, e->lut_codes, codes);
+            if (chains4) hipLaunchKernelGGL(k_cherry_build_s4, dim3((pairs + 255) / 256, dp.ncherry_jobs), dim3(256), 0, e->stream, cj, e->R, codes);
+            else if (e->R == 4) hipLaunchKernelGGL(k_cherry_build<4>, gb, dim3(256), 0, e->stream, cj, e->lut_codes, codes);
             else if (e->R == 2) hipLaunchKernelGGL(k_cherry_build<2>, gb, dim3(256), 0, e->stream, cj, e->lut_codes, codes);
             else hipLaunchKernelGGL(k_cherry_build<1>, gb, dim3(256), 0, e->stream, cj, e->lut_codes, codes);
             PLLHIP_TRY(hipGetLastError());
@@ -1651,7 +1659,8 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
           {
             const dim3 gp((npblk + 3) / 4, dp.npair_jobs);
             const size_t lds = sizeof(double) * e->R * S20_CFRAGS;
-            if (e->R == 4) hipLaunchKernelGGL(k_pair_lut<4>, gp, dim3(256), lds, e->stream, pj, pairs);
+            if (chains4) hipLaunchKernelGGL(k_pair_lut_s4, dim3((pairs * e->R + 255) / 256, dp.npair_jobs), dim3(256), 0, e->stream, pj, pairs, e->R);
+            else if (e->R == 4) hipLaunchKernelGGL(k_pair_lut<4>, gp, dim3(256), lds, e->stream, pj, pairs);
             else if (e->R == 2) hipLaunchKernelGGL(k_pair_lut<2>, gp, dim3(256), lds, e->stream, pj, pairs);
             else hipLaunchKernelGGL(k_pair_lut<1>, gp, dim3(256), lds, e->stream, pj, pairs);
             PLLHIP_TRY(hipGetLastError());

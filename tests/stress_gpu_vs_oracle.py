@@ -43,7 +43,7 @@ for trial in range(36):
     n = int(rng.integers(5, 40)) if S <= 32 else int(rng.integers(5, 12)); N = int(rng.integers(1, 500))
     tr = pc.Tree(n, 300 + trial, 400 + trial, ladder=(trial % 3 == 1), balanced=(trial % 3 == 2))
     mix = [None, [0, 1, 0, 1], [0, 1, 2, 3]][(trial // 3) % 3]
-    attrs = pc.PLL_ATTRIB_SITE_REPEATS if (S == 20 and trial % 2 == 0) else 0
+    attrs = pc.PLL_ATTRIB_SITE_REPEATS if (S in (20, 4) and trial % 2 == 0) else 0
     kw = dict(states=S, rate_cats=R, ntips=n, nsites=N, coded=bool(trial % 5 != 4) or bool(attrs), tree=tr, mixture=mix,
               attributes=attrs)
     with pc.build_instance(product, **kw) as a, pc.build_instance(oracle, **{**kw, "attributes": 0}) as b:

@@ -18,7 +18,7 @@ def _build(product, tree, nsites, repeats, seed=44, gaps=False, states=20, ambig
         cmap = pc.state_charmap(states)
         if ambiguity:
             cmap[ord("B")] = (1 << 2) | (1 << 3)
-            cmap[ord("Z")] = (1 << 5) | (1 << 6)
+            cmap[ord("Z")] = (1 << 5) | (1 << 6) if states > 4 else (1 << 1) | (1 << 2)
         codes = pc.random_codes(tree.ntips, nsites, states, seed)
         rnd = pc.splitmix64(seed + 5, tree.ntips * nsites).reshape(tree.ntips, nsites)
         for t in range(tree.ntips):
@@ -66,12 +66,13 @@ def _same(a, b):
             assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
 
 
+@pytest.mark.parametrize("states", [20, 4])
 @pytest.mark.parametrize("ntips,nsites,gaps,ambiguity", [(14, 1031, False, False), (40, 5000, True, False),
                                                          (9, 257, True, True), (100, 3333, False, False)])
-def test_site_repeats_change_nothing_a_caller_can_see(product, ntips, nsites, gaps, ambiguity):
+def test_site_repeats_change_nothing_a_caller_can_see(product, ntips, nsites, gaps, ambiguity, states):
     tree = pc.Tree(ntips, 42, 43)
-    with _build(product, tree, nsites, True, gaps=gaps, ambiguity=ambiguity) as on, \
-            _build(product, tree, nsites, False, gaps=gaps, ambiguity=ambiguity) as off:
+    with _build(product, tree, nsites, True, gaps=gaps, ambiguity=ambiguity, states=states) as on, \
+            _build(product, tree, nsites, False, gaps=gaps, ambiguity=ambiguity, states=states) as off:
         a, b = _everything(on), _everything(off)
         _same(a, b)
         st = on.repeat_stats()
@@ -79,7 +80,22 @@ def test_site_repeats_change_nothing_a_caller_can_see(product, ntips, nsites, ga
         assert off.repeat_stats().cherries == 0
 
 
-def test_site_repeats_with_scaling_cherries(product):
+def test_site_repeats_dna_one_launch_and_rounds(product):
+    """4 states at a size where the whole traversal is one launch (and, forced, by rounds): wide tips in both forms"""
+    tree = pc.Tree(30, 42, 43)
+    with _build(product, tree, 800_000, True, states=4, gaps=True) as on, \
+            _build(product, tree, 800_000, False, states=4, gaps=True) as off:
+        for rep in range(2):
+            assert pc.full_traversal(on) == pc.full_traversal(off)
+        for op in tree.ops[::5]:
+            assert np.array_equal(on.get_scaler(op[1]), off.get_scaler(op[1]))
+            assert np.array_equal(on.get_clv(op[0]), off.get_clv(op[0]))
+        st = on.repeat_stats()
+        assert st.cherries > 0 and st.classes * 1000 < st.sites
+
+
+@pytest.mark.parametrize("states", [20, 4])
+def test_site_repeats_with_scaling_cherries(product, states):
     """a cherry only ever scales when its entries are exact zeros: pendant branches of length 0 (identity
     matrices) make every site with two different states an all-zero, scaled site.  The scaling decision is taken
     per class, the counts travel per site; identical to the attribute being off (lnL is -inf on both sides)."""
@@ -90,7 +106,7 @@ def test_site_repeats_with_scaling_cherries(product):
         if k % 3 != 2:
             tree.brlens[op[3]] = 0.0
             tree.brlens[op[6]] = 0.0 if k % 3 == 0 else 0.05
-    with _build(product, tree, 700, True) as on, _build(product, tree, 700, False) as off:
+    with _build(product, tree, 700, True, states=states) as on, _build(product, tree, 700, False, states=states) as off:
         for rep in range(2):
             la, lb = pc.full_traversal(on), pc.full_traversal(off)
             assert la == lb == -np.inf
@@ -101,9 +117,10 @@ def test_site_repeats_with_scaling_cherries(product):
         assert on.repeat_stats().cherries > 0
 
 
-def test_site_repeats_on_deep_trees(product):
-    tree = pc.Tree(260, 42, 43)
-    with _build(product, tree, 300, True) as on, _build(product, tree, 300, False) as off:
+@pytest.mark.parametrize("states,ntips", [(20, 260), (4, 900)])
+def test_site_repeats_on_deep_trees(product, states, ntips):
+    tree = pc.Tree(ntips, 42, 43)
+    with _build(product, tree, 300, True, states=states) as on, _build(product, tree, 300, False, states=states) as off:
         la, lb = pc.full_traversal(on), pc.full_traversal(off)
         assert la == lb
         top = 0
