@@ -73,6 +73,32 @@ __device__ inline double block_sum_256(double v, double * scratch)
 //   `__threadfence()` in every block serialises on the L2 write-back (measured 3x slower
 //   in round 1; MI355X_MICROARCH.md, hand-off forms).
 // fused == 0 keeps the two-launch form (block totals, then k_final_sum).
+// Staging loops (global memory -> LDS / global): out(e, in(e)) for e = threadIdx.x, + blockDim.x, ... < n with U
+// loads of a thread in flight.  The plain form "for (e = tid; e < n; e += blockDim.x) lds[e] = g[e]" compiles to
+// load -> s_waitcnt vmcnt(0) -> ds_write per iteration: one memory round trip per 256 doubles, 16 in a row for the
+// fragments of one 61-state matrix -- 20 us at the head of every workgroup, which is all a single operation on a
+// 25 k-site partition takes otherwise.  in(e) must be a load that is valid for every e < n (no branch around it).
+template <unsigned U, class In, class Out>
+__device__ inline void staged_loop(unsigned n, In in, Out out)
+{
+  const unsigned T = blockDim.x;
+  for (unsigned base = threadIdx.x; base < n; base += U * T)
+  {
+    decltype(in(0u)) v[U];
+#pragma unroll
+    for (unsigned u = 0; u < U; ++u) { const unsigned e = base + u * T; v[u] = in(e < n ? e : base); }
+#pragma unroll
+    for (unsigned u = 0; u < U; ++u) { const unsigned e = base + u * T; if (e < n) out(e, v[u]); }
+  }
+}
+
+// dst[e] = src[e], e < n
+template <unsigned U = 8>
+__device__ inline void staged_copy(double * dst, const double * src, unsigned n)
+{
+  staged_loop<U>(n, [=](unsigned e) { return src[e]; }, [=](unsigned e, double v) { dst[e] = v; });
+}
+
 constexpr unsigned REDUCE_SHARDS = 8;
 constexpr unsigned REDUCE_SHARD_STRIDE = 1024;   // unsigned words: 4 KiB apart
 constexpr unsigned REDUCE_MAX_Q = 16;            // quantities per launch (8 trial lengths x {df, ddf})

@@ -55,13 +55,12 @@ __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, 
     // one exp per eigenvalue (B's first row is free until the loop below fills it), not one per matrix entry
     if (threadIdx.x < S) B[threadIdx.x] = exp(L[threadIdx.x] * rt);
     __syncthreads();
-    for (unsigned e = threadIdx.x; e < arows * Sp; e += blockDim.x)
-    {
-      const unsigned k = e % Sp;
-      A[e] = (e < S * Sp && k < S) ? V[e] * B[k] : 0.0;
-    }
+    // (staged_loop: the loads of a thread go out together -- one memory round trip per operand, not sixteen)
+    staged_loop<16>(arows * Sp, [=](unsigned e) { return V[e < S * Sp ? e : 0]; },
+                    [=](unsigned e, double v) { const unsigned k = e % Sp; A[e] = (e < S * Sp && k < S) ? v * B[k] : 0.0; });
     __syncthreads();
-    for (unsigned e = threadIdx.x; e < arows * Sp; e += blockDim.x) B[e] = (e < S * Sp) ? Vi[e] : 0.0;
+    staged_loop<16>(arows * Sp, [=](unsigned e) { return Vi[e < S * Sp ? e : 0]; },
+                    [=](unsigned e, double v) { B[e] = (e < S * Sp) ? v : 0.0; });
     __syncthreads();
     double res[16];
     if (Sp == 64)
@@ -151,10 +150,9 @@ __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, 
   if (lut)
   {
     double * T = lut + ((size_t)m * R + r) * lut_codes * S;
-    for (unsigned e = threadIdx.x; e < lut_codes * S; e += blockDim.x)
+    staged_loop<16>(lut_codes * S, [=](unsigned e) { return tipmap[e / S]; }, [=](unsigned e, unsigned long long mask)
     {
-      const unsigned c = e / S, i = e % S;
-      const unsigned long long mask = tipmap[c];
+      const unsigned i = e % S;
       double acc = 0.0;
       if (mask && !(mask & (mask - 1)))               // one state: a column of P
         acc = Pl[i * Sp + (unsigned)__ffsll((long long)mask) - 1];
@@ -162,7 +160,7 @@ __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, 
         for (unsigned j = 0; j < S; ++j)
           if ((mask >> j) & 1ULL) acc += Pl[i * Sp + j];
       T[e] = acc;
-    }
+    });
   }
 }
 

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_pair_lut(const PairLutJob * jobs, unsig
   extern __shared__ double cfrag[];
   const PairLutJob job = plan_fetch(jobs + blockIdx.y);
   const double * pf = as_global(job.pfrag);
-  for (unsigned e = threadIdx.x; e < RT * S20_CFRAGS; e += blockDim.x) cfrag[e] = pf[e];
+  staged_copy<8>(cfrag, pf, RT * S20_CFRAGS);
   __syncthreads();
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned q = lane >> 4, n = lane & 15;

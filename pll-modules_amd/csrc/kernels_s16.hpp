@@ -36,12 +36,15 @@ template <unsigned KS>
 __device__ inline void s16_fill_frags(double * frag, const double * mats, unsigned R, unsigned S, unsigned Sp)
 {
   constexpr unsigned MT = s16_mt(KS);
-  for (unsigned e = threadIdx.x; e < R * MT * KS * 64; e += blockDim.x)
+  // (staged_loop, kernels_common.hpp: the loads of a thread go out together)
+  staged_loop<8>(R * MT * KS * 64, [=](unsigned e)
   {
     const unsigned lane = e & 63, f = e >> 6, ks = f % KS, mt = (f / KS) % MT, r = f / (KS * MT);
     const unsigned i = 16 * mt + (lane & 15), j = 4 * ks + (lane >> 4);
-    frag[e] = (i < S && j < S) ? mats[((size_t)r * S + i) * Sp + j] : 0.0;
-  }
+    const bool in = i < S && j < S;
+    const double x = mats[in ? ((size_t)r * S + i) * Sp + j : 0];
+    return in ? x : 0.0;
+  }, [=](unsigned e, double x) { frag[e] = x; });
 }
 
 // child term from a B operand in registers (b[ks] = rows 4 ks + q of the child vector), D layout out:
@@ -157,10 +160,10 @@ __global__ __launch_bounds__(256) void k_partials_s16(OpBatch batch, unsigned nb
   const bool lut_lds = R * lut_codes * S <= table;
   if (!op.codes1) s16_fill_frags<KS>(tab1, op.pmat1, R, S, Sp);
   else if (lut_lds)
-    for (unsigned e = threadIdx.x; e < R * lut_codes * S; e += blockDim.x) tab1[e] = op.lut1[e];
+    staged_copy<8>(tab1, op.lut1, R * lut_codes * S);
   if (!op.codes2) s16_fill_frags<KS>(tab2, op.pmat2, R, S, Sp);
   else if (lut_lds)
-    for (unsigned e = threadIdx.x; e < R * lut_codes * S; e += blockDim.x) tab2[e] = op.lut2[e];
+    staged_copy<8>(tab2, op.lut2, R * lut_codes * S);
   __syncthreads();
   const double * l1 = lut_lds ? tab1 : op.lut1, * l2 = lut_lds ? tab2 : op.lut2;
 
@@ -392,10 +395,10 @@ __global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanVi
       const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
       if (!po.d.codes1) s16_fill_frags<KS>(lds + po.slot1, po.d.pmat1, RT, S, Sp);
       else if (lut_lds)
-        for (unsigned e = threadIdx.x; e < RT * lut_codes * S; e += blockDim.x) lds[po.slot1 + e] = po.d.lut1[e];
+        staged_copy<8>(lds + po.slot1, po.d.lut1, RT * lut_codes * S);
       if (!po.d.codes2) s16_fill_frags<KS>(lds + po.slot2, po.d.pmat2, RT, S, Sp);
       else if (lut_lds)
-        for (unsigned e = threadIdx.x; e < RT * lut_codes * S; e += blockDim.x) lds[po.slot2 + e] = po.d.lut2[e];
+        staged_copy<8>(lds + po.slot2, po.d.lut2, RT * lut_codes * S);
     }
     __syncthreads();
     for (unsigned blk = blockIdx.x * S16_CHAIN_WAVES + wave; blk < nblk; blk += wstride)

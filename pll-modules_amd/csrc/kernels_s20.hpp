@@ -76,12 +76,14 @@ __device__ inline unsigned s20_row(unsigned k, unsigned q) { return (k < 4) ? q 
 //   frag[((r*2 + mt)*5 + ks)*64 + lane] = M[r][ (lane&15)+16*mt ][ 4*ks + (lane>>4) ]  (0 beyond row 19)
 __device__ inline void s20_fill_frags(double * frag, const double * mats, unsigned R)
 {
-  for (unsigned e = threadIdx.x; e < R * S20_FRAGS; e += blockDim.x)
+  // (staged_loop, kernels_common.hpp: the loads of a thread go out together)
+  staged_loop<10>(R * S20_FRAGS, [=](unsigned e)
   {
     const unsigned lane = e & 63, f = e >> 6, ks = f % 5, mt = (f / 5) & 1, r = f / 10;
     const unsigned i = (lane & 15) + 16 * mt, j = 4 * ks + (lane >> 4);
-    frag[e] = (i < 20) ? mats[((size_t)r * 20 + i) * 20 + j] : 0.0;
-  }
+    const double x = mats[((size_t)r * 20 + (i < 20 ? i : 0)) * 20 + j];
+    return (i < 20) ? x : 0.0;
+  }, [=](unsigned e, double x) { frag[e] = x; });
 }
 
 // child term in D layout: t[k] = {even site, odd site} for row s20_row(k, q)
@@ -190,10 +192,10 @@ __device__ inline void s20_op_body(const OpDesc & op, unsigned nblk, unsigned Rr
   double * const frag2 = frag + R * S20_FRAGS;
   if (!op.codes1) s20_fill_frags(frag, op.pmat1, R);
   else if (lut_lds)
-    for (unsigned e = threadIdx.x; e < R * lut_codes * 20; e += blockDim.x) frag[(e / 20) * S20_LUT_RS + e % 20] = op.lut1[e];
+    staged_loop<8>(R * lut_codes * 20, [=](unsigned e) { return op.lut1[e]; }, [=](unsigned e, double x) { frag[(e / 20) * S20_LUT_RS + e % 20] = x; });
   if (!op.codes2) s20_fill_frags(frag2, op.pmat2, R);
   else if (lut_lds)
-    for (unsigned e = threadIdx.x; e < R * lut_codes * 20; e += blockDim.x) frag2[(e / 20) * S20_LUT_RS + e % 20] = op.lut2[e];
+    staged_loop<8>(R * lut_codes * 20, [=](unsigned e) { return op.lut2[e]; }, [=](unsigned e, double x) { frag2[(e / 20) * S20_LUT_RS + e % 20] = x; });
   __syncthreads();
 
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -388,14 +390,14 @@ constexpr unsigned S20_CHAIN_WAVES = 8;
 // cfrag[r*400 + 320 + ks*16 + q*4 + n] (n < 4) = M[r][16 + n][4 ks + q]
 __device__ inline void s20_fill_cfrags(double * cfrag, const double * mats, unsigned R)
 {
-  for (unsigned e = threadIdx.x; e < R * S20_CFRAGS; e += blockDim.x)
+  staged_loop<8>(R * S20_CFRAGS, [=](unsigned e)
   {
     const unsigned r = e / S20_CFRAGS, x = e % S20_CFRAGS;
     unsigned i, j;
     if (x < 320) { i = x & 15; j = 4 * (x >> 6) + ((x & 63) >> 4); }
     else { const unsigned y = x - 320; i = 16 + (y & 3); j = 4 * (y >> 4) + ((y >> 2) & 3); }
-    cfrag[e] = mats[((size_t)r * 20 + i) * 20 + j];
-  }
+    return mats[((size_t)r * 20 + i) * 20 + j];
+  }, [=](unsigned e, double x) { cfrag[e] = x; });
 }
 
 // child term from a B operand in registers (b[ks] = rows 4 ks + q of the child vector)
@@ -586,8 +588,8 @@ __device__ inline void s20_fill_slot(double * slot, const double * pmat, const d
   if (!lut)
   {
     if (pfrag)        // written in fragment order by k_pmatrix: a plain, coalesced copy
-      for (unsigned e = threadIdx.x; e < R * S20_CFRAGS / 2; e += blockDim.x)
-        reinterpret_cast<double2 *>(slot)[e] = reinterpret_cast<const double2 *>(pfrag)[e];
+      staged_loop<4>(R * S20_CFRAGS / 2, [=](unsigned e) { return reinterpret_cast<const double2 *>(pfrag)[e]; },
+                     [=](unsigned e, double2 v) { reinterpret_cast<double2 *>(slot)[e] = v; });
     else s20_fill_cfrags(slot, pmat, R);
   }
   else if (lut_lds)
@@ -598,8 +600,15 @@ __device__ inline void s20_fill_slot(double * slot, const double * pmat, const d
     for (unsigned x = threadIdx.x; x < per_rate; x += blockDim.x)
     {
       const unsigned c = x / 20, i = x - c * 20;
-      for (unsigned r = 0; r < R; ++r)
-        slot[(r * lut_used + c) * S20_LUT_RS + i] = lut[(size_t)r * lut_codes * 20 + x];
+      for (unsigned r0 = 0; r0 < R; r0 += 4)          // the loads of (up to) four rates go out together
+      {
+        double v[4];
+#pragma unroll
+        for (unsigned u = 0; u < 4; ++u) v[u] = lut[(size_t)(r0 + u < R ? r0 + u : r0) * lut_codes * 20 + x];
+#pragma unroll
+        for (unsigned u = 0; u < 4; ++u)
+          if (r0 + u < R) slot[((r0 + u) * lut_used + c) * S20_LUT_RS + i] = v[u];
+      }
     }
   }
 }

@@ -40,12 +40,14 @@ constexpr unsigned S61_FRAGS = S61_MT * S61_KS * 64; // A-fragment doubles per (
 __device__ inline void s61_fill_frags(double * frag, const double * mats, unsigned r, unsigned S, unsigned Sp)
 {
   const double * M = mats + (size_t)r * S * Sp;
-  for (unsigned e = threadIdx.x; e < S61_FRAGS; e += blockDim.x)
+  staged_loop<16>(S61_FRAGS, [=](unsigned e)
   {
     const unsigned lane = e & 63, f = e >> 6, ks = f & 15, mt = f >> 4;
     const unsigned i = (lane & 15) + 16 * mt, j = 4 * ks + (lane >> 4);
-    frag[e] = (i < S && j < S) ? M[(size_t)i * Sp + j] : 0.0;
-  }
+    const bool in = i < S && j < S;
+    const double x = M[in ? (size_t)i * Sp + j : 0];
+    return in ? x : 0.0;
+  }, [=](unsigned e, double x) { frag[e] = x; });
 }
 
 // child term in D layout: t[k] = {even site, odd site} for row 4k + q
@@ -146,12 +148,14 @@ constexpr unsigned S61_CHUNK = 128;      // blocks per workgroup pass: 4 waves x
 __device__ inline void s61_fill_frags_v3(double * frag, const double * mats, unsigned r, unsigned S, unsigned Sp)
 {
   const double * M = mats + (size_t)r * S * Sp;
-  for (unsigned e = threadIdx.x; e < S61_FRAGS; e += blockDim.x)
+  staged_loop<16>(S61_FRAGS, [=](unsigned e)
   {
     const unsigned h = e & 1, lane = (e >> 1) & 63, f = e >> 7, mp = f & 1, ks = f >> 1;
     const unsigned i = (lane & 15) + 16 * (2 * mp + h), j = 4 * ks + (lane >> 4);
-    frag[e] = (i < S && j < S) ? M[(size_t)i * Sp + j] : 0.0;
-  }
+    const bool in = i < S && j < S;
+    const double x = M[in ? (size_t)i * Sp + j : 0];
+    return in ? x : 0.0;
+  }, [=](unsigned e, double x) { frag[e] = x; });
 }
 
 #define S61_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -420,13 +424,9 @@ __global__ __launch_bounds__(256, 2) void k_partials_s61v3(OpBatch batch, unsign
     {
       __syncthreads();            // every wave is done reading the previous rate's fragments
       if (!tip1) s61_fill_frags_v3(frag, op.pmat1, r, S, Sp);
-      else if (lut_lds)
-        for (unsigned e = threadIdx.x; e < lut_codes * S; e += blockDim.x)
-          frag[e] = op.lut1[(size_t)r * lut_codes * S + e];
+      else if (lut_lds) staged_copy<16>(frag, op.lut1 + (size_t)r * lut_codes * S, lut_codes * S);
       if (!tip2) s61_fill_frags_v3(frag2, op.pmat2, r, S, Sp);
-      else if (lut_lds)
-        for (unsigned e = threadIdx.x; e < lut_codes * S; e += blockDim.x)
-          frag2[e] = op.lut2[(size_t)r * lut_codes * S + e];
+      else if (lut_lds) staged_copy<16>(frag2, op.lut2 + (size_t)r * lut_codes * S, lut_codes * S);
       __syncthreads();
       if (nb == 0) continue;
       const double * l1 = lut_lds ? frag : op.lut1 + (size_t)r * lut_codes * S;
@@ -533,11 +533,8 @@ __global__ __launch_bounds__(1024) void k_s61_cherry_scale(CherryScaleBatch batc
   for (unsigned r = 0; r < R; ++r)
   {
     __syncthreads();
-    for (unsigned e = threadIdx.x; e < len; e += blockDim.x)
-    {
-      ta[e] = l1[(size_t)r * len + e];
-      tb[e] = l2[(size_t)r * len + e];
-    }
+    staged_loop<4>(len, [=](unsigned e) { return make_double2(l1[(size_t)r * len + e], l2[(size_t)r * len + e]); },
+                   [=](unsigned e, double2 v) { ta[e] = v.x; tb[e] = v.y; });
     __syncthreads();
     const double * ra = ta + ca * S, * rb = tb + cb * S;
     unsigned small = 1u;
@@ -680,15 +677,14 @@ __global__ __launch_bounds__(64 * S61_V4_WAVES, 1) void k_partials_s61v4(S61Batc
   const size_t lut_len = (size_t)lut_codes * S;
 
   if (!tip1) s61_fill_frags_v3(frag, op.pmat1, r, S, Sp);
-  else for (unsigned e = threadIdx.x; e < lut_len; e += blockDim.x) frag[e] = op.lut1[r * lut_len + e];
+  else staged_copy<8>(frag, op.lut1 + r * lut_len, (unsigned)lut_len);
   if (!tip2) s61_fill_frags_v3(frag2, op.pmat2, r, S, Sp);
-  else for (unsigned e = threadIdx.x; e < lut_len; e += blockDim.x) frag2[e] = op.lut2[r * lut_len + e];
+  else staged_copy<8>(frag2, op.lut2 + r * lut_len, (unsigned)lut_len);
   if (cherry)
-    for (unsigned e = threadIdx.x; e < lut_len; e += blockDim.x)
-    {
-      luta[e] = tt.lut1[r * lut_len + e];
-      lutb[e] = tt.lut2[r * lut_len + e];
-    }
+  {
+    staged_copy<8>(luta, tt.lut1 + r * lut_len, (unsigned)lut_len);
+    staged_copy<8>(lutb, tt.lut2 + r * lut_len, (unsigned)lut_len);
+  }
   __syncthreads();
 
   constexpr unsigned W = S61_V4_WAVES;
@@ -919,8 +915,8 @@ __global__ __launch_bounds__(256, 1) void k_edge_lnl_s61_r4(ModelView mv, ParamI
   const unsigned end = (unsigned)(((unsigned long long)nblk * (blockIdx.x + 1)) / gridDim.x);
 
   for (unsigned r = 0; r < R; ++r) s61_fill_frags_v3(frag + (size_t)r * S61_FRAGS, pmat, r, mv.S, mv.Sp);
-  for (unsigned e = threadIdx.x; e < R * 64; e += blockDim.x)
-    fq[e] = ((e & 63) < mv.S) ? mv.freqs(fidx.v[e >> 6])[e & 63] : 0.0;
+  staged_loop<4>(R * 64, [=](unsigned e) { const bool in = (e & 63) < mv.S; const double x = mv.freqs(fidx.v[e >> 6])[in ? (e & 63) : 0]; return in ? x : 0.0; },
+                 [=](unsigned e, double x) { fq[e] = x; });
   __syncthreads();
 
   double acc_lnl = 0.0;
@@ -1032,12 +1028,12 @@ __global__ __launch_bounds__(256) void k_sumtable_prep_s61(ModelView mv, ParamId
   const unsigned S = mv.S, Sp = mv.Sp;
   const double * pi = mv.freqs(pi_), * V = mv.evecs(pi_), * Vi = mv.ievecs(pi_);
   double * L = Lm + (size_t)r * S * Sp, * Rr = Rm + (size_t)r * S * Sp;
-  for (unsigned e = threadIdx.x; e < S * Sp; e += blockDim.x)
+  staged_loop<8>(S * Sp, [=](unsigned e)
   {
-    const unsigned k = e / Sp, i = e % Sp;
-    L[e] = (i < S) ? pi[i] * V[i * Sp + k] : 0.0;
-    Rr[e] = (i < S) ? Vi[k * Sp + i] : 0.0;
-  }
+    const unsigned k = e / Sp, i = e % Sp, ic = i < S ? i : 0;
+    const double a = pi[ic] * V[ic * Sp + k], b = Vi[k * Sp + ic];
+    return (i < S) ? make_double2(a, b) : make_double2(0.0, 0.0);
+  }, [=](unsigned e, double2 v) { L[e] = v.x; Rr[e] = v.y; });
   if (!want_lut) return;
   for (unsigned e = threadIdx.x; e < lut_codes * S; e += blockDim.x)
   {
