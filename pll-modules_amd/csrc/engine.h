@@ -193,6 +193,13 @@ struct Engine
   size_t clv_len = 0;                 // doubles per CLV / sumtable buffer
   unsigned Nalloc = 0;                // per-site array length (N, or nblk*32)
   double * d_sum_scratch = nullptr;   // eigen-basis matrices + LUTs of the sumtable kernel
+  // ... which depend on the model, the parameter indices and the code table only, not on the branch: what the
+  // scratch area was last prepared for (sum_prep_needed)
+  unsigned long long model_generation = 0;          // uploads of the model block
+  unsigned long long sum_prep_model = ~0ULL;
+  unsigned sum_prep_params[16] = {0};
+  unsigned sum_prep_lut_codes = 0, sum_prep_tipmap = 0;
+  bool sum_prep_has_lut = false;
 
   // --- device-resident data ---
   std::vector<double *> d_clv;        // [nodes], nullptr for coded tips

@@ -412,6 +412,24 @@ __device__ inline PlanOp plan_fetch_op(const PlanOp * p)
 // rounds of many partitions in one launch, pllhip_update_partials_batch) a row gets few workgroups and each
 // of them many blocks, and the staging is paid once per row instead of once per eight blocks.
 // PLLHIP_ROUND_WGS: workgroups per CU the launch aims for (0: a row takes what its partition could use alone).
+// The eigen-basis operands of the sumtable kernels (k_sumtable_prep_*: pi V and V^-1 per rate, and their tip
+// tables) depend on the model, the parameter indices and the code table, not on the branch: true when the scratch
+// area has to be prepared (again) -- once per model change instead of once per sumtable (a branch-length pass at
+// 125 k protein sites: 397 launches of 20 us; an SPR round at 61 states: 1 372 of 36 us)
+static bool sum_prep_needed(Engine * e, const ParamIdx & params, bool want_lut)
+{
+  bool same = e->sum_prep_model == e->model_generation && e->sum_prep_lut_codes == e->lut_codes &&
+              e->sum_prep_tipmap == e->tipmap_codes_uploaded && (e->sum_prep_has_lut || !want_lut);
+  for (unsigned r = 0; same && r < e->R && r < 16; ++r) same = e->sum_prep_params[r] == params.v[r];
+  if (same) return false;
+  e->sum_prep_model = e->model_generation;
+  e->sum_prep_lut_codes = e->lut_codes;
+  e->sum_prep_tipmap = e->tipmap_codes_uploaded;
+  e->sum_prep_has_lut = want_lut;
+  for (unsigned r = 0; r < e->R && r < 16; ++r) e->sum_prep_params[r] = params.v[r];
+  return true;
+}
+
 static unsigned round_grid(const Engine * e, unsigned gx, unsigned rows, unsigned per_cu_default = 4u)
 {
   static const int env = getenv("PLLHIP_ROUND_WGS") ? atoi(getenv("PLLHIP_ROUND_WGS")) : -1;

@@ -41,11 +41,14 @@ __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, 
   const double * V = mv.evecs(pi_), * Vi = mv.ievecs(pi_), * L = mv.evals(pi_);
   double * P = pmat + ((size_t)m * R + r) * S * Sp;
   double * Pl = staged ? lds : lds + Sp;
+  // rows of the result in LDS: Sp + 1 doubles apart when Sp = 64, so that lanes walking down a column (the tip-table
+  // build below) meet in different banks instead of one
+  const unsigned PS = (staged && Sp == 64) ? 65u : Sp;
 
   if (t == 0.0)
   {
     for (unsigned e = threadIdx.x; e < S * Sp; e += blockDim.x)
-      Pl[e] = (e / Sp == e % Sp) ? 1.0 : 0.0;
+      Pl[(e / Sp) * PS + e % Sp] = (e / Sp == e % Sp) ? 1.0 : 0.0;
   }
   else if (staged)
   {
@@ -53,14 +56,32 @@ __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, 
     const unsigned arows = (Sp == 64) ? 64u : S;          // 64 columns: whole 64 x 64 operands, zero beyond S
     double * A = lds, * B = lds + arows * Sp;
     // one exp per eigenvalue (B's first row is free until the loop below fills it), not one per matrix entry
+    // every operand load of the thread goes out before anything waits: V and V^-1 (arows * Sp <= 4096 = 16 per
+    // thread of the 256) and the eigenvalue -- one memory round trip at the head of the kernel instead of one per
+    // operand (or, written as plain loops, one per 256 doubles: kernels_common.hpp, staged_loop)
+    double v[16], vi[16];
+#pragma unroll
+    for (unsigned u = 0; u < 16; ++u)
+    {
+      const unsigned e = threadIdx.x + u * 256u, ec = e < S * Sp ? e : 0u;
+      v[u] = V[ec];
+      vi[u] = Vi[ec];
+    }
     if (threadIdx.x < S) B[threadIdx.x] = exp(L[threadIdx.x] * rt);
     __syncthreads();
-    // (staged_loop: the loads of a thread go out together -- one memory round trip per operand, not sixteen)
-    staged_loop<16>(arows * Sp, [=](unsigned e) { return V[e < S * Sp ? e : 0]; },
-                    [=](unsigned e, double v) { const unsigned k = e % Sp; A[e] = (e < S * Sp && k < S) ? v * B[k] : 0.0; });
+#pragma unroll
+    for (unsigned u = 0; u < 16; ++u)
+    {
+      const unsigned e = threadIdx.x + u * 256u, k = e % Sp;
+      if (e < arows * Sp) A[e] = (e < S * Sp && k < S) ? v[u] * B[k] : 0.0;
+    }
     __syncthreads();
-    staged_loop<16>(arows * Sp, [=](unsigned e) { return Vi[e < S * Sp ? e : 0]; },
-                    [=](unsigned e, double v) { B[e] = (e < S * Sp) ? v : 0.0; });
+#pragma unroll
+    for (unsigned u = 0; u < 16; ++u)
+    {
+      const unsigned e = threadIdx.x + u * 256u;
+      if (e < arows * Sp) B[e] = (e < S * Sp) ? vi[u] : 0.0;
+    }
     __syncthreads();
     double res[16];
     if (Sp == 64)
@@ -87,7 +108,7 @@ __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, 
         for (unsigned v = 0; v < 4; ++v)
         {
           const unsigned i = 16 * mt + 4 * v + q, j = 16 * nt + n;
-          if (i < S) Pl[i * Sp + j] = (j < S && acc[nt][v] > 0.0) ? acc[nt][v] : 0.0;
+          if (i < S) Pl[i * PS + j] = (j < S && acc[nt][v] > 0.0) ? acc[nt][v] : 0.0;
         }
     }
     else
@@ -133,7 +154,7 @@ __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, 
     }
   }
   __syncthreads();
-  for (unsigned e = threadIdx.x; e < S * Sp; e += blockDim.x) P[e] = Pl[e];
+  for (unsigned e = threadIdx.x; e < S * Sp; e += blockDim.x) P[e] = Pl[(e / Sp) * PS + e % Sp];
   if (pfrag)
   {
     // 20 states: the matrix once more as compact MFMA A fragments (kernels_s20.hpp, s20_fill_cfrags),
@@ -144,7 +165,7 @@ __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, 
       unsigned i, j;
       if (x < 320) { i = x & 15; j = 4 * (x >> 6) + ((x & 63) >> 4); }
       else { const unsigned y = x - 320; i = 16 + (y & 3); j = 4 * (y >> 4) + ((y >> 2) & 3); }
-      F[x] = Pl[i * Sp + j];
+      F[x] = Pl[i * PS + j];
     }
   }
   if (lut)
@@ -155,10 +176,10 @@ __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, 
       const unsigned i = e % S;
       double acc = 0.0;
       if (mask && !(mask & (mask - 1)))               // one state: a column of P
-        acc = Pl[i * Sp + (unsigned)__ffsll((long long)mask) - 1];
+        acc = Pl[i * PS + (unsigned)__ffsll((long long)mask) - 1];
       else
         for (unsigned j = 0; j < S; ++j)
-          if ((mask >> j) & 1ULL) acc += Pl[i * Sp + j];
+          if ((mask >> j) & 1ULL) acc += Pl[i * PS + j];
       T[e] = acc;
     });
   }

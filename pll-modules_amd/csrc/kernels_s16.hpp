@@ -722,9 +722,12 @@ static int launch_sumtable_s16(Engine * e, const ModelView & mv, const ParamIdx 
   }
   double * Lm = e->d_sum_scratch, * Rm = Lm + mats, * lutL = Rm + mats, * lutR = lutL + luts;
   const bool want_lut = parent.codes || child.codes;
-  hipLaunchKernelGGL(k_sumtable_prep_s16, dim3(e->R), dim3(256), 0, e->stream,
-                     mv, params, e->d_tipmap, e->lut_codes, want_lut, Lm, Rm, lutL, lutR);
-  PLLHIP_TRY(hipGetLastError());
+  if (sum_prep_needed(e, params, want_lut))
+  {
+    hipLaunchKernelGGL(k_sumtable_prep_s16, dim3(e->R), dim3(256), 0, e->stream,
+                       mv, params, e->d_tipmap, e->lut_codes, want_lut, Lm, Rm, lutL, lutR);
+    PLLHIP_TRY(hipGetLastError());
+  }
   OpBatch batch;
   OpDesc & d = batch.op[0];
   d.clv1 = parent.clv; d.codes1 = parent.codes; d.pmat1 = Lm; d.lut1 = lutL;

@@ -387,6 +387,54 @@ __device__ inline void s61_rate_tt(const OpDesc & op, const double * lut1_r, con
   }
 }
 
+// Second half of a rate-parallel launch: combine the R votes of every site of blocks beg, beg + nwaves, ... < end,
+// correct the units of the sites whose vote differs from the prediction they were stored with (a vector is usually
+// re-evaluated many times -- branch-length optimisation, SPR scoring -- and its scaling pattern rarely changes),
+// write the parent scalers and the new prediction.  One wave per block.
+__device__ inline void s61_fixup_range(const OpDesc & op, unsigned opi, unsigned beg, unsigned end, unsigned nwaves,
+                                       unsigned nblk, unsigned R, const uint8_t * votes, const uint8_t * pred_in,
+                                       uint8_t * pred_out, unsigned lane)
+{
+  const unsigned q = lane >> 4, n = lane & 15;
+  const size_t nsite = (size_t)nblk * S20_BS;
+  for (unsigned blk = beg; blk < end; blk += nwaves)
+  {
+    const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+    int se = 1, so = 1;
+    for (unsigned r = 0; r < R; ++r)
+    {
+      const uint8_t * v = votes + ((size_t)opi * R + r) * nsite;
+      se &= v[site0];
+      so &= v[site0 + 1];
+    }
+    const int pe = pred_in[site0], po = pred_in[site0 + 1];
+    if (__any((se != pe) | (so != po)))
+    {
+      const double fe = (se == pe) ? 1.0 : (se ? SCALE_FACTOR : 1.0 / SCALE_FACTOR);
+      const double fo = (so == po) ? 1.0 : (so ? SCALE_FACTOR : 1.0 / SCALE_FACTOR);
+      for (unsigned r = 0; r < R; ++r)
+      {
+        double * unit = op.parent + ((size_t)blk * R + r) * S61_UNIT;
+        double2 t[S61_KS];
+        s61_load_d(unit, lane, t);
+#pragma unroll
+        for (unsigned k = 0; k < S61_KS; ++k) { t[k].x *= fe; t[k].y *= fo; }
+        s61_store_d(unit, lane, t);
+      }
+    }
+    if (q == 0)
+    {
+      unsigned ce = se ? 1u : 0u, co = so ? 1u : 0u;
+      if (op.scaler1) { ce += op.scaler1[site0]; co += op.scaler1[site0 + 1]; }
+      if (op.scaler2) { ce += op.scaler2[site0]; co += op.scaler2[site0 + 1]; }
+      op.parent_scaler[site0] = ce;
+      op.parent_scaler[site0 + 1] = co;
+      pred_out[site0] = (uint8_t)se;
+      pred_out[site0 + 1] = (uint8_t)so;
+    }
+  }
+}
+
 // Rate-parallel launches (gridDim.z = R, used when a GPU has few blocks per wave):
 // a workgroup handles ONE rate, writes its per-site "all entries small" vote to
 // votes[(op*R + r)*Nalloc + site], and k_s61_scale_fixup combines the votes.
@@ -719,55 +767,18 @@ __global__ __launch_bounds__(64 * S61_V4_WAVES, 1) void k_partials_s61v4(S61Batc
   }
 }
 
-// second half of a rate-parallel launch: combine the R votes of every site, correct the
-// units of the sites whose vote differs from the prediction they were stored with (a
-// vector is usually re-evaluated many times -- branch-length optimisation, SPR scoring --
-// and its scaling pattern rarely changes), write the parent scalers and the new
-// prediction.  One wave per block (with predictions a correction is the exception, so the
-// rates are not spread over workgroups): grid = (blocks/4, ops), block = 256
+// grid = (blocks/4, ops), block = 256.  (Run by the last-arriving rate workgroup of a range inside the partials
+// kernel instead -- one launch per operation -- it was twice as slow: the release / acquire fences around the
+// arrival counter write back and invalidate the L2 of the XCD, which holds the units just written: SPR round at
+// 25 k sites 0.93 -> 1.83 s, a 50-taxon traversal at 200 k sites 7.5 -> 10.8 ms.)
 __global__ __launch_bounds__(256) void k_s61_scale_fixup(OpBatch batch, unsigned nblk, unsigned R,
                                                          const uint8_t * votes, PredBatch preds)
 {
   const OpDesc & op = batch.op[blockIdx.y];
   if (!op.parent_scaler) return;
-  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned q = lane >> 4, n = lane & 15;
-  const unsigned blk = blockIdx.x * 4 + wave;
+  const unsigned blk = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blk >= nblk) return;
-  const size_t site0 = (size_t)blk * S20_BS + 2 * n;
-  const size_t nsite = (size_t)nblk * S20_BS;
-  int se = 1, so = 1;
-  for (unsigned r = 0; r < R; ++r)
-  {
-    const uint8_t * v = votes + ((size_t)blockIdx.y * R + r) * nsite;
-    se &= v[site0];
-    so &= v[site0 + 1];
-  }
-  const int pe = preds.in[blockIdx.y][site0], po = preds.in[blockIdx.y][site0 + 1];
-  if (__any((se != pe) | (so != po)))
-  {
-    const double fe = (se == pe) ? 1.0 : (se ? SCALE_FACTOR : 1.0 / SCALE_FACTOR);
-    const double fo = (so == po) ? 1.0 : (so ? SCALE_FACTOR : 1.0 / SCALE_FACTOR);
-    for (unsigned r = 0; r < R; ++r)
-    {
-      double * unit = op.parent + ((size_t)blk * R + r) * S61_UNIT;
-      double2 t[S61_KS];
-      s61_load_d(unit, lane, t);
-#pragma unroll
-      for (unsigned k = 0; k < S61_KS; ++k) { t[k].x *= fe; t[k].y *= fo; }
-      s61_store_d(unit, lane, t);
-    }
-  }
-  if (q == 0)
-  {
-    unsigned ce = se ? 1u : 0u, co = so ? 1u : 0u;
-    if (op.scaler1) { ce += op.scaler1[site0]; co += op.scaler1[site0 + 1]; }
-    if (op.scaler2) { ce += op.scaler2[site0]; co += op.scaler2[site0 + 1]; }
-    op.parent_scaler[site0] = ce;
-    op.parent_scaler[site0 + 1] = co;
-    preds.out[blockIdx.y][site0] = (uint8_t)se;
-    preds.out[blockIdx.y][site0 + 1] = (uint8_t)so;
-  }
+  s61_fixup_range(op, blockIdx.y, blk, blk + 1, 1, nblk, R, votes, preds.in[blockIdx.y], preds.out[blockIdx.y], threadIdx.x & 63);
 }
 
 // ---------------------------------------------------------------------------
@@ -1091,24 +1102,37 @@ static int s61_prepare_preds(Engine * e, const OpBatch & batch, unsigned nops, P
     if (!d.parent_scaler) continue;
     const unsigned long long lo = std::min(d.child1_index, d.child2_index), hi = std::max(d.child1_index, d.child2_index);
     const unsigned long long key = (hi << 32) | lo;
-    Engine::PredSlot * slot = nullptr, * victim = &e->s61_pred[3 * (size_t)d.parent_index];
+    Engine::PredSlot * slot = nullptr, * victim = &e->s61_pred[3 * (size_t)d.parent_index], * latest = nullptr;
     for (int w = 0; w < 3; ++w)
     {
       Engine::PredSlot & c = e->s61_pred[3 * (size_t)d.parent_index + w];
       if (c.key == key) { slot = &c; break; }
       if (c.used < victim->used) victim = &c;
+      if (c.used && c.buf[c.cur] && (!latest || c.used > latest->used)) latest = &c;
     }
+    const uint8_t * from = nullptr;
     if (!slot)
     {
-      slot = victim;                      // new orientation (or topology): start from "no site scales"
+      // new orientation (or topology).  Start from what the vector's last evaluation decided, whatever its
+      // children were: in an SPR round the scratch vectors near the root are re-evaluated over subtrees that
+      // differ by the pruned part only, and about half of their sites scale -- "no site scales" made the
+      // fix-up kernel rewrite most blocks there.  (The launch reads that slot's buffer in place; first
+      // evaluation ever: no site scales.)
+      from = latest ? latest->buf[latest->cur] : nullptr;
+      slot = victim;
       slot->key = key;
-      slot->cur = 0;
       for (int w = 0; w < 2; ++w)
         if (!slot->buf[w]) PLLHIP_TRY(hipMalloc((void **)&slot->buf[w], bytes));
-      PLLHIP_TRY(hipMemsetAsync(slot->buf[0], 0, bytes, e->stream));
+      if (!from)
+      {
+        slot->cur = 0;
+        PLLHIP_TRY(hipMemsetAsync(slot->buf[0], 0, bytes, e->stream));
+      }
+      else if (from == slot->buf[0] || from == slot->buf[1]) from = nullptr;      // the victim's own last decision
+      else slot->cur = 1;                       // written into buf[0] below
     }
     slot->used = ++e->s61_pred_clock;
-    preds.in[i] = slot->buf[slot->cur];
+    preds.in[i] = from ? from : slot->buf[slot->cur];
     preds.out[i] = slot->buf[slot->cur ^ 1u];
     slot->cur ^= 1u;
   }
@@ -1268,9 +1292,12 @@ static int launch_sumtable_s61(Engine * e, const ModelView & mv, const ParamIdx 
   }
   double * Lm = e->d_sum_scratch, * Rm = Lm + mats, * lutL = Rm + mats, * lutR = lutL + luts;
   const bool want_lut = parent.codes || child.codes;
-  hipLaunchKernelGGL(k_sumtable_prep_s61, dim3(e->R), dim3(256), 0, e->stream,
-                     mv, params, e->d_tipmap, e->lut_codes, want_lut, Lm, Rm, lutL, lutR);
-  PLLHIP_TRY(hipGetLastError());
+  if (sum_prep_needed(e, params, want_lut))
+  {
+    hipLaunchKernelGGL(k_sumtable_prep_s61, dim3(e->R), dim3(256), 0, e->stream,
+                       mv, params, e->d_tipmap, e->lut_codes, want_lut, Lm, Rm, lutL, lutR);
+    PLLHIP_TRY(hipGetLastError());
+  }
   OpBatch batch;
   OpDesc & d = batch.op[0];
   d.clv1 = parent.clv; d.codes1 = parent.codes; d.pmat1 = Lm; d.lut1 = lutL;

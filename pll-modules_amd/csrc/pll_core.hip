@@ -576,6 +576,7 @@ int sync_model(pll_partition_t * p, bool light)
   PLLHIP_TRY(hipStreamSynchronize(e->stream));
   e->model_shadow.swap(cur);
   e->counters.model_uploads++;
+  e->model_generation++;
   // pattern weights (4*N bytes) are NOT re-compared here: pll-modules changes them
   // only through pll_set_pattern_weights (SURVEY.md section 0.3 lists the fields it
   // pokes directly; weights are not among them), which uploads them itself.
