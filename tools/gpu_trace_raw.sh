@@ -24,8 +24,12 @@ for r in rows:
     by[key][0].append((e - s) / 1e3)
     if prev_end is not None: by[key][1].append((s - prev_end) / 1e3)
     prev_end = e
+span = (max(int(r["End_Timestamp"]) for r in rows) - int(rows[0]["Start_Timestamp"])) / 1e6
+busy = sum(sum(d) for d, g in by.values()) / 1e3
+print(f"span {span:.1f} ms, kernels {busy:.1f} ms, idle before a kernel (gaps > 0, < 1 ms) {sum(x for d, g in by.values() for x in g if 0 < x < 1000) / 1e3:.1f} ms")
 for (name, grid), (d, g) in sorted(by.items(), key=lambda kv: -sum(kv[1][0])):
-    print(f"{name:60s} grid/wg/lds/scratch/vgpr={grid} n={len(d):5d} dur min {min(d):7.1f} med {st.median(d):7.1f} max {max(d):7.1f}  gap med {st.median(g) if g else 0:6.1f}")
+    pos = [x for x in g if 0 < x < 1000]
+    print(f"{name:60s} grid/wg/lds/scratch/vgpr={grid} n={len(d):5d} dur min {min(d):7.1f} med {st.median(d):7.1f} max {max(d):7.1f} sum {sum(d) / 1e3:7.1f} ms  gap med {st.median(g) if g else 0:6.1f} sum {sum(pos) / 1e3:6.1f} ms")
 PY
 head -40 "$ROOT/gpurun_out/traceraw_${label}.txt" | cut -c1-230
 rm -rf "$d"
