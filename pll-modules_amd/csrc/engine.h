@@ -131,6 +131,12 @@ struct DevicePlan                                 // the schedule resident on th
   // (job arrays behind the chains in `bytes`)
   unsigned ncherry_jobs = 0, npair_jobs = 0, repeat_codes = 0;
   size_t off_cherry_jobs = 0, off_pair_jobs = 0;
+  // the class operations run level by level (a node's table needs the tables below it): per level the row tables
+  // of its class children (pair jobs), then the tables (class jobs); the last entry holds the row tables of the
+  // wide tips of the chains (no class jobs)
+  struct RepeatLevel { unsigned job_begin, job_end, pair_begin, pair_end, max_classes, max_rows; };
+  std::vector<RepeatLevel> repeat_levels;
+  unsigned long long repeat_classes = 0;          // classes of all class operations (statistics)
   unsigned max_extent = 0;                        // largest PlanChain::extent of the schedule
 };
 
@@ -168,17 +174,32 @@ struct Engine
   // PLL_ATTRIB_SITE_REPEATS, first step (kernels_repeats.hpp): a cherry is kept per class of sites (pair of
   // tip codes) and expanded to the site-indexed vector only for a reader that needs it
   bool site_repeats = false;
-  struct Cherry
+  struct Cherry                       // a node known per class of sites (a cherry, or a node above class nodes / tips)
   {
-    bool valid = false;               // the node's vector IS this cherry (nothing has overwritten it since)
+    bool valid = false;               // the node's vector IS this table (nothing has overwritten it since)
     bool materialized = false;        // d_clv[node] holds the expanded vector
-    unsigned ncodes = 0;              // classes = ncodes^2
+    unsigned ncodes = 0;              // size of the tip code table the class map was made under
+    unsigned nclasses = 0;
     double * table = nullptr;         // blocked pseudo-CLV over the classes
-    unsigned short * pair = nullptr;  // [Nalloc] class code per site
+    unsigned short * pair = nullptr;  // [Nalloc] class per site
     uint8_t * flags = nullptr;        // [classes] scaled?
-    unsigned cap_codes = 0;           // what table / flags were allocated for
+    unsigned cap_classes = 0;         // what table / flags were allocated for
+    unsigned * rep = nullptr;         // [2 * classes] the children's classes of each class (null: a cherry, class = code1 * ncodes + code2)
+    unsigned rep_cap = 0;
+    // the class map (pair, rep, nclasses) depends on the topology below and the tips' codes only: kept while
+    // the children and their maps are the ones it was made from
+    bool map_valid = false;
+    bool trackable = false;           // map_valid: the node is worth keeping per class (few enough classes)
+    unsigned child[2] = {~0u, ~0u};
+    unsigned long long child_version[2] = {0, 0};
+    unsigned long long version = 0;   // changes with the map
   };
   std::vector<Cherry> cherries;       // by CLV index (empty unless site_repeats)
+  std::vector<unsigned long long> tip_version;    // changes with a tip's codes
+  unsigned long long class_clock = 0;
+  unsigned * d_class_seen = nullptr;  // [pairs of child classes] scratch of the class numbering, + tile sums + total
+  size_t class_seen_cap = 0;
+  unsigned * h_class_total = nullptr; // pinned: the class count read back once per new map
   double * d_pairlut = nullptr;       // lookup tables of the wide tips of the resident schedule
   size_t pairlut_cap = 0;
   pllhip_repeat_stats_t repeat_stats = {};

@@ -16,7 +16,15 @@
 //   * expands the vector to the site-indexed form only for a reader that needs it (k_cherry_expand: an edge lnL
 //     or a sumtable AT the cherry, pllhip_get_clv, a checkpoint).
 // What a caller can observe -- vectors, scaler counts, likelihoods, derivatives -- is identical to the attribute
-// being off (tests/test_site_repeats.py).  Deeper classes (tip x cherry, ...) are the next step.
+// being off (tests/test_site_repeats.py).
+//
+// Second step: classes of whole subtrees.  A node both of whose children are known per class (tips, cherries, or
+// nodes of this kind) is known per class itself: the class of a site is the pair (class below child 1, class below
+// child 2).  The pairs that occur are numbered densely on the device once per topology (k_class_mark, a prefix sum,
+// k_class_assign: what libpll's pll_update_repeats does with its lookup table, and like there only while the table
+// of possible pairs stays small), and the node's table is rows1[class of child 1] * rows2[class of child 2], where
+// the rows of a tip are its lookup table and the rows of a class node are P . its table (k_pair_lut again).  The
+// frontier -- the first operation above that is computed per site -- reads its class children as wide tips.
 #pragma once
 
 #include "kernels_common.hpp"
@@ -25,50 +33,57 @@
 
 namespace pllhip {
 
-// one virtual cherry of a traversal (device memory, part of the resident schedule)
+// one operation of a traversal that is computed per class (device memory, part of the resident schedule)
 struct CherryJob
 {
-  const double * lut1, * lut2;       // the two tips' lookup tables [rate][lut_codes][20]
-  const uint8_t * codes1, * codes2;
-  double * table;                    // blocked pseudo-CLV [pair block][rate][unit]
-  uint8_t * flags;                   // per pair: the vector was scaled
-  unsigned short * pair;             // per site: class code
+  const double * lut1, * lut2;       // row tables of the two children, [rate][rows][states]: a tip's lookup table, or P . table of a class node
+  const unsigned * rep;              // [2 * classes]: the children's classes of each class; null = a cherry (class = code1 * codes + code2)
+  unsigned rows1, rows2;             // rows per rate of the two tables
+  unsigned nclasses;
+  double * table;                    // blocked pseudo-CLV [class block][rate][unit] (4 states: [class][rate][4])
+  uint8_t * flags;                   // per class: the vector was scaled
+  const unsigned short * pair;       // per site: class
   unsigned * parent_scaler;          // per site, or null
+  const unsigned * scaler1, * scaler2;   // per-site counts of the children (class nodes), or null
 };
 
-// one lookup table of a traversal: table(cherry) seen through the P-matrix of the consumer's branch
+// one row table of a traversal: the table of a class node seen through the P-matrix of the branch above it
 struct PairLutJob
 {
   const double * table;
-  const double * pfrag;              // compact A fragments [rate][400] of the branch's matrices
-  double * out;                      // [rate][pairs][20]
+  const double * pfrag;              // compact A fragments [rate][400] of the branch's matrices (4 states: the matrices)
+  double * out;                      // [rate][rows][states]
+  unsigned nrows;
 };
 
-// the cherry per code pair.  grid = (pair blocks / 4, jobs), block = 256 (a wave per 32-pair block)
+// the table of a class operation.  grid = (class blocks of the largest job / 4, jobs), block = 256 (a wave per
+// 32-class block)
 template <unsigned RT>
-__global__ __launch_bounds__(256) void k_cherry_build(const CherryJob * jobs, unsigned lut_codes, unsigned ncodes)
+__global__ __launch_bounds__(256) void k_cherry_build(const CherryJob * jobs, unsigned ncodes)
 {
   const CherryJob job = plan_fetch(jobs + blockIdx.y);
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned q = lane >> 4, n = lane & 15;
-  const unsigned npairs = ncodes * ncodes, npblk = (npairs + S20_BS - 1) / S20_BS;
+  const unsigned npairs = job.nclasses, npblk = (npairs + S20_BS - 1) / S20_BS;
   const unsigned blk = blockIdx.x * 4 + wave;
   if (blk >= npblk) return;
   const double * lut1 = as_global(job.lut1), * lut2 = as_global(job.lut2);
+  const unsigned * rep = as_global(job.rep);
   double * table = as_global(job.table);
   uint8_t * flags = as_global(job.flags);
   const unsigned pe = blk * S20_BS + 2 * n, po = pe + 1;
-  // pairs beyond the table repeat pair 0: their columns are never read
-  const unsigned ae = pe < npairs ? pe / ncodes : 0, be = pe < npairs ? pe % ncodes : 0;
-  const unsigned ao = po < npairs ? po / ncodes : 0, bo = po < npairs ? po % ncodes : 0;
+  // classes beyond the table repeat class 0: their columns are never read
+  const unsigned ce = pe < npairs ? pe : 0, co = po < npairs ? po : 0;
+  const unsigned ae = rep ? rep[2 * ce] : ce / ncodes, be = rep ? rep[2 * ce + 1] : ce % ncodes;
+  const unsigned ao = rep ? rep[2 * co] : co / ncodes, bo = rep ? rep[2 * co + 1] : co % ncodes;
   double2 X[RT][5];
   int small_e = 1, small_o = 1;
 #pragma unroll
   for (unsigned r = 0; r < RT; ++r)
   {
     double2 t2[5];
-    s20_child_tip(lut1 + (size_t)r * lut_codes * 20, ae, ao, q, X[r]);
-    s20_child_tip(lut2 + (size_t)r * lut_codes * 20, be, bo, q, t2);
+    s20_child_tip(lut1 + (size_t)r * job.rows1 * 20, ae, ao, q, X[r]);
+    s20_child_tip(lut2 + (size_t)r * job.rows2 * 20, be, bo, q, t2);
 #pragma unroll
     for (int k = 0; k < 5; ++k)
     {
@@ -100,30 +115,128 @@ __global__ __launch_bounds__(256) void k_cherry_build(const CherryJob * jobs, un
   }
 }
 
-// class code and scaler count per site.  grid = (chunks, jobs), block = 256
-__global__ __launch_bounds__(256) void k_cherry_sites(const CherryJob * jobs, unsigned ncodes, unsigned nalloc)
+// scaler counts per site: the class's own decision plus the counts below.  The jobs are in post-order and a thread
+// walks them for its sites, so the counts of a class child are there when its parent adds them.
+// grid = chunks, block = 256
+__global__ __launch_bounds__(256) void k_cherry_sites(const CherryJob * jobs, unsigned njobs, unsigned nalloc)
 {
-  const CherryJob job = plan_fetch(jobs + blockIdx.y);
-  const uint8_t * c1 = as_global(job.codes1), * c2 = as_global(job.codes2);
-  const uint8_t * flags = as_global(job.flags);
-  unsigned short * pair = as_global(job.pair);
-  unsigned * ps = as_global(job.parent_scaler);
   for (unsigned s = blockIdx.x * 256u + threadIdx.x; s < nalloc; s += gridDim.x * 256u)
+    for (unsigned j = 0; j < njobs; ++j)
+    {
+      const CherryJob & job = jobs[j];
+      unsigned * ps = job.parent_scaler;
+      if (!ps) continue;
+      unsigned cnt = job.flags[job.pair[s]];
+      if (job.scaler1) cnt += job.scaler1[s];
+      if (job.scaler2) cnt += job.scaler2[s];
+      ps[s] = cnt;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// class maps (once per topology and orientation of a node; cached on the host side)
+// ---------------------------------------------------------------------------
+// classes of the two children per site: a tip's codes (bytes) or a class node's classes (16 bit)
+struct ClassMapArgs
+{
+  const uint8_t * codes1, * codes2;          // tip children
+  const unsigned short * cls1, * cls2;       // class-node children
+  unsigned n1, n2;                           // classes of the children
+};
+
+__device__ inline unsigned class_key(const ClassMapArgs & a, unsigned s)
+{
+  unsigned k1 = a.codes1 ? a.codes1[s] : a.cls1[s], k2 = a.codes2 ? a.codes2[s] : a.cls2[s];
+  if (k1 >= a.n1) k1 = 0;
+  if (k2 >= a.n2) k2 = 0;
+  return k1 * a.n2 + k2;
+}
+
+// a cherry: every code pair is a class.  grid = chunks, block = 256
+__global__ __launch_bounds__(256) void k_class_cherry(ClassMapArgs a, unsigned nalloc, unsigned short * pair)
+{
+  for (unsigned s = blockIdx.x * 256u + threadIdx.x; s < nalloc; s += gridDim.x * 256u)
+    pair[s] = (unsigned short)class_key(a, s);            // (padding sites carry code 0)
+}
+
+// which pairs occur.  grid = chunks, block = 256; `seen` zeroed [n1 * n2]
+__global__ __launch_bounds__(256) void k_class_mark(ClassMapArgs a, unsigned N, unsigned * seen)
+{
+  for (unsigned s = blockIdx.x * 256u + threadIdx.x; s < N; s += gridDim.x * 256u) seen[class_key(a, s)] = 1u;
+}
+
+// exclusive prefix sum of `seen` (n <= 1024 * 4096), three small launches: sums of 4096-entry tiles, their prefix
+// in one workgroup, then the entries
+__global__ __launch_bounds__(1024) void k_class_scan_tiles(const unsigned * seen, unsigned n, unsigned * tile_sum)
+{
+  __shared__ unsigned part[16];
+  unsigned v = 0;
+  const unsigned base = blockIdx.x * 4096u + threadIdx.x * 4u;
+  for (unsigned u = 0; u < 4; ++u) if (base + u < n) v += seen[base + u];
+  for (int off = 32; off; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { unsigned t = 0; for (int w = 0; w < 16; ++w) t += part[w]; tile_sum[blockIdx.x] = t; }
+}
+
+__global__ __launch_bounds__(1024) void k_class_scan_top(unsigned * tile_sum, unsigned ntiles, unsigned * total)
+{
+  __shared__ unsigned buf[1024];
+  const unsigned v = threadIdx.x < ntiles ? tile_sum[threadIdx.x] : 0u;
+  buf[threadIdx.x] = v;
+  __syncthreads();
+  for (unsigned off = 1; off < 1024; off <<= 1)
   {
-    const unsigned a = c1[s], b = c2[s];
-    const unsigned p = (a < ncodes && b < ncodes) ? a * ncodes + b : 0u;       // (padding sites carry code 0)
-    pair[s] = (unsigned short)p;
-    if (ps) ps[s] = flags[p];
+    const unsigned add = threadIdx.x >= off ? buf[threadIdx.x - off] : 0u;
+    __syncthreads();
+    buf[threadIdx.x] += add;
+    __syncthreads();
   }
+  if (threadIdx.x < ntiles) tile_sum[threadIdx.x] = buf[threadIdx.x] - v;       // exclusive
+  if (threadIdx.x == 1023) *total = buf[1023];
+}
+
+// seen[k] becomes the class number of pair k (for pairs that occur); the children's classes of every class
+__global__ __launch_bounds__(1024) void k_class_scan_apply(unsigned * seen, unsigned n, const unsigned * tile_sum,
+                                                           unsigned n2, unsigned * rep, unsigned rep_cap)
+{
+  __shared__ unsigned part[16];
+  const unsigned base = blockIdx.x * 4096u + threadIdx.x * 4u;
+  unsigned f[4], v = 0;
+  for (unsigned u = 0; u < 4; ++u) { f[u] = (base + u < n) ? seen[base + u] : 0u; v += f[u]; }
+  // exclusive prefix of v over the workgroup
+  unsigned incl = v;
+  for (int off = 1; off < 64; off <<= 1) { const unsigned t = __shfl_up(incl, off, 64); if ((threadIdx.x & 63) >= (unsigned)off) incl += t; }
+  if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  unsigned before = tile_sum[blockIdx.x];
+  for (unsigned w = 0; w < (threadIdx.x >> 6); ++w) before += part[w];
+  unsigned id = before + incl - v;
+  for (unsigned u = 0; u < 4; ++u)
+    if (base + u < n)
+    {
+      seen[base + u] = id;
+      if (f[u] && id < rep_cap) { rep[2 * id] = (base + u) / n2; rep[2 * id + 1] = (base + u) % n2; }
+      id += f[u];
+    }
+}
+
+// the class of every site.  grid = chunks, block = 256
+__global__ __launch_bounds__(256) void k_class_assign(ClassMapArgs a, unsigned N, unsigned nalloc, const unsigned * ids,
+                                                      unsigned short * pair)
+{
+  for (unsigned s = blockIdx.x * 256u + threadIdx.x; s < nalloc; s += gridDim.x * 256u)
+    pair[s] = s < N ? (unsigned short)ids[class_key(a, s)] : (unsigned short)0;
 }
 
 // lookup tables of the wide tips of a traversal.  grid = (pair blocks / 4, jobs), block = 256,
 // dynamic LDS = RT * 400 doubles (the compact fragments of the branch's matrices)
 template <unsigned RT>
-__global__ __launch_bounds__(256) void k_pair_lut(const PairLutJob * jobs, unsigned npairs)
+__global__ __launch_bounds__(256) void k_pair_lut(const PairLutJob * jobs)
 {
   extern __shared__ double cfrag[];
   const PairLutJob job = plan_fetch(jobs + blockIdx.y);
+  const unsigned npairs = job.nrows;
   const double * pf = as_global(job.pfrag);
   staged_copy<8>(cfrag, pf, RT * S20_CFRAGS);
   __syncthreads();
@@ -180,17 +293,18 @@ __global__ __launch_bounds__(256) void k_cherry_expand(const double * table, con
 __global__ __launch_bounds__(256) void k_cherry_build_s4(const CherryJob * jobs, unsigned R, unsigned ncodes)
 {
   const CherryJob job = plan_fetch(jobs + blockIdx.y);
-  const unsigned npairs = ncodes * ncodes;
+  const unsigned npairs = job.nclasses;
   const unsigned p = blockIdx.x * 256u + threadIdx.x;
   if (p >= npairs) return;
   const double * lut1 = as_global(job.lut1), * lut2 = as_global(job.lut2);
+  const unsigned * rep = as_global(job.rep);
   double * table = as_global(job.table);
-  const unsigned a = p / ncodes, b = p % ncodes;
+  const unsigned a = rep ? rep[2 * p] : p / ncodes, b = rep ? rep[2 * p + 1] : p % ncodes;
   bool small = true;
   for (unsigned r = 0; r < R; ++r)
     for (unsigned i = 0; i < 4; ++i)
     {
-      const double v = lut1[(r * 16 + a) * 4 + i] * lut2[(r * 16 + b) * 4 + i];
+      const double v = lut1[((size_t)r * job.rows1 + a) * 4 + i] * lut2[((size_t)r * job.rows2 + b) * 4 + i];
       table[((size_t)p * R + r) * 4 + i] = v;
       small = small && (v < SCALE_THRESHOLD);
     }
@@ -205,9 +319,10 @@ __global__ __launch_bounds__(256) void k_cherry_build_s4(const CherryJob * jobs,
 // [rate][class][4] = P(rate) . vector(class), with the association of s4_half_matvec:
 // (P_i0 x_0 + P_i1 x_1) + (P_i2 x_2 + P_i3 x_3).  grid = (ceil(pairs * R / 256), jobs), block = 256;
 // job.pfrag holds the branch's matrices [rate][4][4]
-__global__ __launch_bounds__(256) void k_pair_lut_s4(const PairLutJob * jobs, unsigned npairs, unsigned R)
+__global__ __launch_bounds__(256) void k_pair_lut_s4(const PairLutJob * jobs, unsigned R)
 {
   const PairLutJob job = plan_fetch(jobs + blockIdx.y);
+  const unsigned npairs = job.nrows;
   const unsigned x = blockIdx.x * 256u + threadIdx.x;
   if (x >= npairs * R) return;
   const unsigned p = x / R, r = x % R;

@@ -293,7 +293,10 @@ Engine * engine_create(pll_partition_t * p)
     ok = ok && hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->d_asc), e->h_asc, 0), "map asc");
   }
   if (e->site_repeats && (e->family == KernelFamily::S20 || e->family == KernelFamily::S4))
+  {
     e->cherries.assign(e->nodes, Engine::Cherry());
+    e->tip_version.assign(e->tips, 0);
+  }
   else e->site_repeats = false;                 // (first step: the 20- and the 4-state family)
   e->pmat_brlen.assign(e->nmat, std::numeric_limits<double>::quiet_NaN());
   e->pmat_params.assign(e->nmat, std::vector<unsigned>());
@@ -354,7 +357,9 @@ void engine_destroy(Engine * e)
   (void)hipFree(e->d_model);
   (void)hipFree(e->d_partials);
   (void)hipFree(e->d_persite);
-  for (auto & c : e->cherries) { (void)hipFree(c.table); (void)hipFree(c.pair); (void)hipFree(c.flags); }
+  for (auto & c : e->cherries) { (void)hipFree(c.table); (void)hipFree(c.pair); (void)hipFree(c.flags); (void)hipFree(c.rep); }
+  (void)hipFree(e->d_class_seen);
+  if (e->h_class_total) (void)hipHostFree(e->h_class_total);
   (void)hipFree(e->d_pairlut);
   (void)hipFree(e->d_newton);
   if (e->h_newton) (void)hipHostFree(e->h_newton);
@@ -454,6 +459,7 @@ int upload_tip_codes(pll_partition_t * p, unsigned tip)
   if (e->N)
     PLLHIP_TRY(hipMemcpyAsync(e->d_codes[tip], p->tipchars[tip], (size_t)e->N,
                               hipMemcpyHostToDevice, e->stream));
+  if (tip < e->tip_version.size()) e->tip_version[tip] = ++e->class_clock;     // class maps above this tip are stale
   return upload_tipmap(p);
 }
 
@@ -1085,38 +1091,131 @@ static int need_clv(Engine * e, unsigned idx)
   return PLL_SUCCESS;
 }
 
-// which operations of a list are cherries the schedule keeps per class, and which children are read as wide tips
+// which operations of a list the schedule keeps per class (cherries and the class nodes above them), and which
+// children the others read as wide tips
 struct RepeatPlan
 {
   bool active = false;
-  std::vector<pll_operation_t> ops;          // the list without the virtual cherries
-  std::vector<unsigned> cherry_ops;          // their positions in the original list
+  std::vector<pll_operation_t> ops;          // the list without the class operations
+  std::vector<unsigned> cherry_ops;          // positions of the class operations in the original list (post-order)
   unsigned ncodes = 0;
 };
 
-static bool cherry_storage(Engine * e, unsigned node, unsigned ncodes)
+// limits of the class numbering: pairs of child classes (libpll's PLL_REPEATS_LOOKUP_SIZE plays this role in
+// pll_update_repeats), classes of a node (16-bit class codes per site), and how much smaller than the alignment a
+// class table has to be for the node to be worth it
+constexpr unsigned long long CLASS_MAX_PAIRS = 1024ULL * 4096ULL;
+constexpr unsigned CLASS_MAX = 65536u;
+constexpr unsigned CLASS_MIN_RATIO = 4u;
+
+static bool cherry_storage(Engine * e, unsigned node, unsigned nclasses)
 {
   Engine::Cherry & c = e->cherries[node];
-  const unsigned npairs = ncodes * ncodes, npblk = (npairs + S20_BS - 1) / S20_BS;
+  const unsigned npblk = (nclasses + S20_BS - 1) / S20_BS;
   // (20 states: blocked like a vector over the classes; 4 states: [class][rate][4])
-  const size_t table_doubles = e->family == KernelFamily::S4 ? (size_t)npairs * e->R * 4 : (size_t)npblk * e->R * S20_UNIT;
-  if (c.cap_codes < ncodes)
+  const size_t table_doubles = e->family == KernelFamily::S4 ? (size_t)nclasses * e->R * 4 : (size_t)npblk * e->R * S20_UNIT;
+  if (c.cap_classes < nclasses)
   {
     if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
     (void)hipFree(c.table); (void)hipFree(c.flags);
-    c.table = nullptr; c.flags = nullptr; c.cap_codes = 0;
+    c.table = nullptr; c.flags = nullptr; c.cap_classes = 0;
     e->plan.key.clear();                          // cached schedules point at the old tables
-    if (!dev_alloc(&c.table, table_doubles, "cherry table") ||
-        !dev_alloc(&c.flags, (size_t)npblk * S20_BS, "cherry flags") ||
+    if (!dev_alloc(&c.table, table_doubles, "class table") ||
+        !dev_alloc(&c.flags, (size_t)npblk * S20_BS, "class flags") ||
         !hip_ok(hipMemsetAsync(c.flags, 0, (size_t)npblk * S20_BS, e->stream), "memset flags"))
       return false;
-    c.cap_codes = ncodes;
+    c.cap_classes = nclasses;
   }
-  if (!c.pair)
+  return true;
+}
+
+static unsigned long long class_child_version(const Engine * e, unsigned idx)
+{
+  return idx < e->tips ? e->tip_version[idx] : e->cherries[idx].version;
+}
+
+// classes below a child of a class operation: a coded tip's codes, or the classes of a class node
+static unsigned class_child_count(const Engine * e, unsigned idx, unsigned lut_used)
+{
+  return idx < e->tips ? lut_used : e->cherries[idx].nclasses;
+}
+
+// The class map of `node` as the parent of (c1, c2) -- both coded tips or class nodes with current maps -- :
+// kept if it was made from these children, made on the device otherwise (one wait for the class count per new
+// map of a node above cherries; a cherry needs none).  True if the node is worth keeping per class.
+static bool class_map(Engine * e, unsigned node, unsigned c1, unsigned c2, unsigned lut_used, bool & failed)
+{
+  Engine::Cherry & c = e->cherries[node];
+  failed = false;
+  if (c.map_valid && c.ncodes == lut_used && c.child[0] == c1 && c.child[1] == c2 &&
+      c.child_version[0] == class_child_version(e, c1) && c.child_version[1] == class_child_version(e, c2))
+    return c.trackable;
+  const unsigned n1 = class_child_count(e, c1, lut_used), n2 = class_child_count(e, c2, lut_used);
+  const unsigned long long pairs = (unsigned long long)n1 * n2;
+  c.map_valid = true;
+  c.trackable = false;
+  c.ncodes = lut_used;
+  c.child[0] = c1; c.child[1] = c2;
+  c.child_version[0] = class_child_version(e, c1); c.child_version[1] = class_child_version(e, c2);
+  c.version = ++e->class_clock;
+  e->plan.key.clear();
+  if (!pairs || pairs > CLASS_MAX_PAIRS) return false;
+  failed = true;
+  if (!c.pair && !dev_alloc(&c.pair, (size_t)e->Nalloc, "class codes")) return false;
+  ClassMapArgs a;
+  a.codes1 = c1 < e->tips ? e->d_codes[c1] : nullptr;
+  a.codes2 = c2 < e->tips ? e->d_codes[c2] : nullptr;
+  a.cls1 = c1 < e->tips ? nullptr : e->cherries[c1].pair;
+  a.cls2 = c2 < e->tips ? nullptr : e->cherries[c2].pair;
+  a.n1 = n1; a.n2 = n2;
+  const dim3 gs(std::max(1u, std::min((e->Nalloc + 255u) / 256u, 8u * e->cu_count)));
+  if (c1 < e->tips && c2 < e->tips)
   {
-    e->plan.key.clear();
-    if (!dev_alloc(&c.pair, (size_t)e->Nalloc, "cherry class codes")) return false;
+    // a cherry: every code pair is a class
+    if (pairs > CLASS_MAX) { failed = false; return false; }
+    hipLaunchKernelGGL(k_class_cherry, gs, dim3(256), 0, e->stream, a, e->Nalloc, c.pair);
+    if (hipGetLastError() != hipSuccess) { set_error(PLL_ERROR_HIP_RUNTIME, "class map launch failed"); return false; }
+    c.nclasses = (unsigned)pairs;
+    (void)hipFree(c.rep); c.rep = nullptr; c.rep_cap = 0;
+    c.trackable = true;
+    failed = false;
+    return true;
   }
+  // scratch: seen[pairs] | tile sums [1024] | total
+  const size_t words = (size_t)pairs + 1024 + 1;
+  if (e->class_seen_cap < words)
+  {
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
+    (void)hipFree(e->d_class_seen); e->d_class_seen = nullptr; e->class_seen_cap = 0;
+    if (!dev_alloc(&e->d_class_seen, words, "class numbering scratch")) return false;
+    e->class_seen_cap = words;
+  }
+  if (!e->h_class_total && !hip_ok(hipHostMalloc(reinterpret_cast<void **>(&e->h_class_total), sizeof(unsigned), hipHostMallocDefault), "hipHostMalloc"))
+    return false;
+  const unsigned rep_cap = (unsigned)std::min<unsigned long long>(pairs, CLASS_MAX);
+  if (c.rep_cap < rep_cap)
+  {
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
+    (void)hipFree(c.rep); c.rep = nullptr; c.rep_cap = 0;
+    if (!dev_alloc(&c.rep, 2 * (size_t)rep_cap, "class children")) return false;
+    c.rep_cap = rep_cap;
+  }
+  unsigned * seen = e->d_class_seen, * tiles = seen + pairs, * total = tiles + 1024;
+  const unsigned ntiles = (unsigned)((pairs + 4095) / 4096);
+  if (!hip_ok(hipMemsetAsync(seen, 0, (size_t)pairs * sizeof(unsigned), e->stream), "memset class scratch")) return false;
+  hipLaunchKernelGGL(k_class_mark, gs, dim3(256), 0, e->stream, a, e->N, seen);
+  hipLaunchKernelGGL(k_class_scan_tiles, dim3(ntiles), dim3(1024), 0, e->stream, seen, (unsigned)pairs, tiles);
+  hipLaunchKernelGGL(k_class_scan_top, dim3(1), dim3(1024), 0, e->stream, tiles, ntiles, total);
+  hipLaunchKernelGGL(k_class_scan_apply, dim3(ntiles), dim3(1024), 0, e->stream, seen, (unsigned)pairs, tiles, n2, c.rep, c.rep_cap);
+  if (hipGetLastError() != hipSuccess) { set_error(PLL_ERROR_HIP_RUNTIME, "class map launch failed"); return false; }
+  if (!hip_ok(hipMemcpyAsync(e->h_class_total, total, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream), "class count") ||
+      !hip_ok(hipStreamSynchronize(e->stream), "class count")) return false;
+  failed = false;
+  c.nclasses = *e->h_class_total;
+  if (!c.nclasses || c.nclasses > CLASS_MAX || (unsigned long long)c.nclasses * CLASS_MIN_RATIO > e->N) return false;
+  hipLaunchKernelGGL(k_class_assign, gs, dim3(256), 0, e->stream, a, e->N, e->Nalloc, (const unsigned *)seen, c.pair);
+  if (hipGetLastError() != hipSuccess) { set_error(PLL_ERROR_HIP_RUNTIME, "class map launch failed"); failed = true; return false; }
+  c.trackable = true;
   return true;
 }
 
@@ -1197,18 +1296,35 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
   // (the key holds the list as the caller passed it: the cherries taken out of it are part of the schedule)
   const pll_operation_t * key_ops = all_ops ? all_ops : ops;
   const unsigned key_count = all_ops ? all_count : count;
-  std::vector<unsigned char> key(3 * sizeof(unsigned) + (size_t)key_count * sizeof(pll_operation_t) + wide.size());
+  // (... and which of its operations are kept per class: the same list can meet other class nodes of earlier calls)
+  std::vector<unsigned char> tracked(rp && rp->active ? key_count : 0, 0);
+  if (!tracked.empty()) for (unsigned k : rp->cherry_ops) tracked[k] = 1;
+  std::vector<unsigned char> key(3 * sizeof(unsigned) + (size_t)key_count * sizeof(pll_operation_t) + wide.size() + tracked.size());
   memcpy(key.data(), &key_count, sizeof(unsigned));
   memcpy(key.data() + sizeof(unsigned), &lut_used, sizeof(unsigned));
   memcpy(key.data() + 2 * sizeof(unsigned), &mode, sizeof(unsigned));
   memcpy(key.data() + 3 * sizeof(unsigned), key_ops, (size_t)key_count * sizeof(pll_operation_t));
   if (!wide.empty()) memcpy(key.data() + 3 * sizeof(unsigned) + (size_t)key_count * sizeof(pll_operation_t), wide.data(), wide.size());
+  if (!tracked.empty()) memcpy(key.data() + key.size() - tracked.size(), tracked.data(), tracked.size());
   bool have = !dp.key.empty() && dp.key == key;
-  const unsigned rep_codes = lut_used, rep_pairs = rep_codes * rep_codes;
-  if (!have && nwide)
+  const unsigned rep_codes = lut_used;
+  if (!have && (nwide || (rp && rp->active)))
   {
-    // the lookup tables of the wide tips: one per (cherry, branch) of the schedule
-    const size_t need = (size_t)nwide * e->R * rep_pairs * e->S;
+    // the row tables of the schedule: one per (class node, branch above it) -- the wide tips of the chains and the
+    // class children of the class operations
+    size_t rows = 0;
+    for (unsigned k = 0; k < count && !wide.empty(); ++k)
+    {
+      if (wide[2 * k]) rows += e->cherries[ops[k].child1_clv_index].nclasses;
+      if (wide[2 * k + 1]) rows += e->cherries[ops[k].child2_clv_index].nclasses;
+    }
+    if (rp && rp->active)
+      for (unsigned k : rp->cherry_ops)
+      {
+        if (all_ops[k].child1_clv_index >= e->tips) rows += e->cherries[all_ops[k].child1_clv_index].nclasses;
+        if (all_ops[k].child2_clv_index >= e->tips) rows += e->cherries[all_ops[k].child2_clv_index].nclasses;
+      }
+    const size_t need = rows * e->R * e->S;
     if (need > e->pairlut_cap)
     {
       if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
@@ -1219,7 +1335,8 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
       e->pairlut_cap = 2 * need;
     }
   }
-  std::vector<PairLutJob> pair_jobs;
+  std::vector<PairLutJob> pair_jobs;             // row tables of the wide tips of the chains
+  size_t pairlut_used = 0;
   if (!have && plan_chains(e, ops, count, chain_max, chain_lds, lut_used, plan))
   {
     // Order of the chains: depth first, so that a vector is consumed soon after it was written
@@ -1339,11 +1456,13 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
           PairLutJob job;
           job.table = c.table;
           job.pfrag = chains4 ? e->d_pmat + (size_t)midx * e->R * 16 : e->d_pfrag + (size_t)midx * e->R * 400;
-          job.out = e->d_pairlut + pair_jobs.size() * (size_t)e->R * rep_pairs * e->S;
+          job.out = e->d_pairlut + pairlut_used;
+          job.nrows = c.nclasses;
+          pairlut_used += (size_t)e->R * c.nclasses * e->S;
           pair_jobs.push_back(job);
           // wide tip: no vector, no byte codes; pfrag = class codes, lut = its table, childN_index = table rows
-          if (x) { po.d.clv2 = nullptr; po.d.codes2 = nullptr; po.d.pfrag2 = reinterpret_cast<const double *>(c.pair); po.d.lut2 = job.out; po.d.child2_index = rep_pairs; }
-          else   { po.d.clv1 = nullptr; po.d.codes1 = nullptr; po.d.pfrag1 = reinterpret_cast<const double *>(c.pair); po.d.lut1 = job.out; po.d.child1_index = rep_pairs; }
+          if (x) { po.d.clv2 = nullptr; po.d.codes2 = nullptr; po.d.pfrag2 = reinterpret_cast<const double *>(c.pair); po.d.lut2 = job.out; po.d.child2_index = c.nclasses; }
+          else   { po.d.clv1 = nullptr; po.d.codes1 = nullptr; po.d.pfrag1 = reinterpret_cast<const double *>(c.pair); po.d.lut1 = job.out; po.d.child1_index = c.nclasses; }
           wide_saved += (double)e->N * e->R * 8.0 * e->S - 2.0 * e->N;      // class codes instead of the vector
         }
         // the handed-over child stays in registers: neither its vector nor its scaler counts are read
@@ -1364,32 +1483,94 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
       }
       lds_max = std::max(lds_max, chains4 ? (unsigned)ch.size() : off);   // 4 states: the longest chain
     }
-    // site repeats: the cherries the schedule keeps per class (taken out of the list by the caller) ...
+    // site repeats: the operations the schedule keeps per class (taken out of the list by the caller), by level
     std::vector<CherryJob> cherry_jobs;
+    std::vector<PairLutJob> level_pairs;           // row tables of class children, by level of their parent
+    dp.repeat_levels.clear();
+    dp.repeat_classes = 0;
     if (rp && rp->active)
     {
       const size_t lut_stride = (size_t)e->R * e->lut_codes * e->S;
-      for (unsigned k : rp->cherry_ops)
+      const size_t nrp = rp->cherry_ops.size();
+      std::vector<int> node_level(e->nodes, -1);
+      std::vector<unsigned> lvl(nrp, 0), order(nrp);
+      unsigned max_level = 0;
+      for (size_t x = 0; x < nrp; ++x)
       {
-        const pll_operation_t & o = all_ops[k];
-        const Engine::Cherry & c = e->cherries[o.parent_clv_index];
-        CherryJob j;
-        j.lut1 = e->d_lut + lut_stride * o.child1_matrix_index;
-        j.lut2 = e->d_lut + lut_stride * o.child2_matrix_index;
-        j.codes1 = e->d_codes[o.child1_clv_index];
-        j.codes2 = e->d_codes[o.child2_clv_index];
-        j.table = c.table; j.flags = c.flags; j.pair = c.pair;
-        j.parent_scaler = const_cast<unsigned *>(scaler_ptr(e, o.parent_scaler_index));
-        cherry_jobs.push_back(j);
-        // what SURVEY.md 8d counts for the operation (two coded tips in, one vector out) / what it moves now
-        OpDesc dummy;
-        double ab = 0.0;
-        fill_desc(e, o, dummy, ab, dp.algo_flops);
-        dp.algo_bytes += ab;
-        dp.min_bytes += 2.0 * e->N + 2.0 * e->N + (j.parent_scaler ? 4.0 * e->N : 0.0);
-        ++nops_virtual;
+        const pll_operation_t & o = all_ops[rp->cherry_ops[x]];
+        unsigned l = 0;
+        if (o.child1_clv_index >= e->tips) l = std::max(l, 1u + (unsigned)std::max(node_level[o.child1_clv_index], 0));
+        if (o.child2_clv_index >= e->tips) l = std::max(l, 1u + (unsigned)std::max(node_level[o.child2_clv_index], 0));
+        lvl[x] = l;
+        node_level[o.parent_clv_index] = (int)l;
+        max_level = std::max(max_level, l);
+        order[x] = (unsigned)x;
+      }
+      std::stable_sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return lvl[a] < lvl[b]; });
+      size_t at = 0;
+      for (unsigned l = 0; l <= max_level; ++l)
+      {
+        DevicePlan::RepeatLevel L = {(unsigned)cherry_jobs.size(), 0, (unsigned)level_pairs.size(), 0, 0, 0};
+        for (; at < nrp && lvl[order[at]] == l; ++at)
+        {
+          const pll_operation_t & o = all_ops[rp->cherry_ops[order[at]]];
+          const Engine::Cherry & c = e->cherries[o.parent_clv_index];
+          CherryJob j;
+          memset(&j, 0, sizeof(j));
+          const unsigned child[2] = {o.child1_clv_index, o.child2_clv_index};
+          const unsigned matrix[2] = {o.child1_matrix_index, o.child2_matrix_index};
+          const int child_scaler[2] = {o.child1_scaler_index, o.child2_scaler_index};
+          for (int x = 0; x < 2; ++x)
+          {
+            const double * rows;
+            unsigned nrows;
+            if (child[x] < e->tips) { rows = e->d_lut + lut_stride * matrix[x]; nrows = e->lut_codes; }
+            else
+            {
+              const Engine::Cherry & cc = e->cherries[child[x]];
+              PairLutJob pj;
+              pj.table = cc.table;
+              pj.pfrag = chains4 ? e->d_pmat + (size_t)matrix[x] * e->R * 16 : e->d_pfrag + (size_t)matrix[x] * e->R * 400;
+              pj.out = e->d_pairlut + pairlut_used;
+              pj.nrows = cc.nclasses;
+              pairlut_used += (size_t)e->R * cc.nclasses * e->S;
+              level_pairs.push_back(pj);
+              L.max_rows = std::max(L.max_rows, cc.nclasses);
+              rows = pj.out; nrows = cc.nclasses;
+            }
+            if (x) { j.lut2 = rows; j.rows2 = nrows; j.scaler2 = scaler_ptr(e, child_scaler[x]); }
+            else   { j.lut1 = rows; j.rows1 = nrows; j.scaler1 = scaler_ptr(e, child_scaler[x]); }
+          }
+          j.rep = c.rep;
+          j.nclasses = c.nclasses;
+          j.table = c.table; j.flags = c.flags; j.pair = c.pair;
+          j.parent_scaler = const_cast<unsigned *>(scaler_ptr(e, o.parent_scaler_index));
+          cherry_jobs.push_back(j);
+          L.max_classes = std::max(L.max_classes, c.nclasses);
+          dp.repeat_classes += c.nclasses;
+          // what SURVEY.md 8d counts for the operation / what it moves now
+          OpDesc dummy;
+          double ab = 0.0;
+          fill_desc(e, o, dummy, ab, dp.algo_flops);
+          dp.algo_bytes += ab;
+          dp.min_bytes += 2.0 * e->N + 2.0 * e->N + (j.parent_scaler ? 4.0 * e->N * (1 + (j.scaler1 ? 1 : 0) + (j.scaler2 ? 1 : 0)) : 0.0);
+          ++nops_virtual;
+        }
+        L.job_end = (unsigned)cherry_jobs.size();
+        L.pair_end = (unsigned)level_pairs.size();
+        dp.repeat_levels.push_back(L);
       }
     }
+    if (!cherry_jobs.empty() || !pair_jobs.empty())
+    {
+      // ... and the row tables of the wide tips, after the last level
+      DevicePlan::RepeatLevel L = {(unsigned)cherry_jobs.size(), (unsigned)cherry_jobs.size(), (unsigned)level_pairs.size(),
+                                   (unsigned)(level_pairs.size() + pair_jobs.size()), 0, 0};
+      for (const PairLutJob & pj : pair_jobs) L.max_rows = std::max(L.max_rows, pj.nrows);
+      dp.repeat_levels.push_back(L);
+      level_pairs.insert(level_pairs.end(), pair_jobs.begin(), pair_jobs.end());
+    }
+    pair_jobs.swap(level_pairs);
     dp.ncherry_jobs = (unsigned)cherry_jobs.size();
     dp.npair_jobs = (unsigned)pair_jobs.size();
     dp.repeat_codes = rep_codes;
@@ -1605,29 +1786,51 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
       RepeatPlan rp;
       if (e->site_repeats && (chains20 || chains4) && lut_used <= 64)
       {
+        // an operation is kept per class if an operation of the list consumes it and both children are known per
+        // class: coded tips, class operations earlier in the list, or class nodes of earlier calls whose tables
+        // still are their vectors
         std::vector<int> consumer(e->nodes, -1);
+        std::vector<char> now(e->nodes, 0);
         for (unsigned k = 0; k < count; ++k) { consumer[ops[k].child1_clv_index] = (int)k; consumer[ops[k].child2_clv_index] = (int)k; }
         for (unsigned k = 0; k < count; ++k)
         {
           const pll_operation_t & o = ops[k];
-          const bool cherry = o.child1_clv_index < e->tips && o.child2_clv_index < e->tips &&
-                              o.child1_scaler_index == PLL_SCALE_BUFFER_NONE && o.child2_scaler_index == PLL_SCALE_BUFFER_NONE &&
-                              consumer[o.parent_clv_index] > (int)k;
-          if (cherry) rp.cherry_ops.push_back(k); else rp.ops.push_back(o);
+          const unsigned child[2] = {o.child1_clv_index, o.child2_clv_index};
+          const int child_scaler[2] = {o.child1_scaler_index, o.child2_scaler_index};
+          bool ok = consumer[o.parent_clv_index] > (int)k && child[0] != child[1];
+          for (int x = 0; x < 2 && ok; ++x)
+          {
+            if (child[x] < e->tips) ok = child_scaler[x] == PLL_SCALE_BUFFER_NONE;
+            else
+            {
+              const Engine::Cherry & cc = e->cherries[child[x]];
+              ok = (now[child[x]] || cc.valid) && cc.map_valid && cc.trackable && cc.ncodes == lut_used;
+            }
+          }
+          if (ok)
+          {
+            bool failed = false;
+            ok = class_map(e, o.parent_clv_index, child[0], child[1], lut_used, failed);
+            if (failed) return PLL_FAILURE;
+          }
+          if (ok)
+          {
+            Engine::Cherry & c = e->cherries[o.parent_clv_index];
+            if (!cherry_storage(e, o.parent_clv_index, c.nclasses)) return PLL_FAILURE;
+            c.valid = true;
+            c.materialized = false;
+            now[o.parent_clv_index] = 1;
+            rp.cherry_ops.push_back(k);
+          }
+          else rp.ops.push_back(o);
         }
         if (!rp.cherry_ops.empty() && !rp.ops.empty())
         {
           rp.active = true;
           rp.ncodes = lut_used;
-          for (unsigned k : rp.cherry_ops)
-          {
-            if (!cherry_storage(e, ops[k].parent_clv_index, lut_used)) return PLL_FAILURE;
-            Engine::Cherry & c = e->cherries[ops[k].parent_clv_index];
-            c.valid = true;
-            c.materialized = false;
-            c.ncodes = lut_used;
-          }
         }
+        else
+          for (unsigned k : rp.cherry_ops) e->cherries[ops[k].parent_clv_index].valid = false;
       }
       const bool have = rp.active ? prepare_schedule(e, p, rp.ops.data(), (unsigned)rp.ops.size(), mode, &rp, ops, count)
                                   : prepare_schedule(e, p, ops, count, mode);
@@ -1639,33 +1842,46 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
         if (!upload_plan(e->plan, e->stream, view)) return PLL_FAILURE;
         if (dp.ncherry_jobs || dp.npair_jobs)
         {
-          const unsigned codes = dp.repeat_codes, pairs = codes * codes, npblk = (pairs + S20_BS - 1) / S20_BS;
+          // level by level: the row tables of the class children of a level, then the tables of the level; the last
+          // entry holds the row tables of the wide tips of the chains.  The scaler counts follow the tables.
           const CherryJob * cj = reinterpret_cast<const CherryJob *>(dp.d_buf + dp.off_cherry_jobs);
           const PairLutJob * pj = reinterpret_cast<const PairLutJob *>(dp.d_buf + dp.off_pair_jobs);
-          if (dp.ncherry_jobs)
+          for (size_t lv = 0; lv < dp.repeat_levels.size(); ++lv)
           {
-            const dim3 gb((npblk + 3) / 4, dp.ncherry_jobs), gs(std::max(1u, std::min((e->Nalloc + 255u) / 256u, 4u * e->cu_count)), dp.ncherry_jobs);
-            if (chains4) hipLaunchKernelGGL(k_cherry_build_s4, dim3((pairs + 255) / 256, dp.ncherry_jobs), dim3(256), 0, e->stream, cj, e->R, codes);
-            else if (e->R == 4) hipLaunchKernelGGL(k_cherry_build<4>, gb, dim3(256), 0, e->stream, cj, e->lut_codes, codes);
-            else if (e->R == 2) hipLaunchKernelGGL(k_cherry_build<2>, gb, dim3(256), 0, e->stream, cj, e->lut_codes, codes);
-            else hipLaunchKernelGGL(k_cherry_build<1>, gb, dim3(256), 0, e->stream, cj, e->lut_codes, codes);
-            PLLHIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(k_cherry_sites, gs, dim3(256), 0, e->stream, cj, codes, e->Nalloc);
-            PLLHIP_TRY(hipGetLastError());
-            e->repeat_stats.cherries += dp.ncherry_jobs;
-            e->repeat_stats.classes += (unsigned long long)dp.ncherry_jobs * pairs;
-            e->repeat_stats.sites += (unsigned long long)dp.ncherry_jobs * e->N;
+            const DevicePlan::RepeatLevel & L = dp.repeat_levels[lv];
+            if (lv + 1 == dp.repeat_levels.size() && dp.ncherry_jobs)
+            {
+              hipLaunchKernelGGL(k_cherry_sites, dim3(std::max(1u, std::min((e->Nalloc + 255u) / 256u, 4u * e->cu_count))), dim3(256), 0,
+                                 e->stream, cj, dp.ncherry_jobs, e->Nalloc);
+              PLLHIP_TRY(hipGetLastError());
+            }
+            if (L.pair_end > L.pair_begin)
+            {
+              const unsigned njobs = L.pair_end - L.pair_begin, npblk = (L.max_rows + S20_BS - 1) / S20_BS;
+              const PairLutJob * jobs = pj + L.pair_begin;
+              const dim3 gp((npblk + 3) / 4, njobs);
+              const size_t lds = sizeof(double) * e->R * S20_CFRAGS;
+              if (chains4) hipLaunchKernelGGL(k_pair_lut_s4, dim3((L.max_rows * e->R + 255) / 256, njobs), dim3(256), 0, e->stream, jobs, e->R);
+              else if (e->R == 4) hipLaunchKernelGGL(k_pair_lut<4>, gp, dim3(256), lds, e->stream, jobs);
+              else if (e->R == 2) hipLaunchKernelGGL(k_pair_lut<2>, gp, dim3(256), lds, e->stream, jobs);
+              else hipLaunchKernelGGL(k_pair_lut<1>, gp, dim3(256), lds, e->stream, jobs);
+              PLLHIP_TRY(hipGetLastError());
+            }
+            if (L.job_end > L.job_begin)
+            {
+              const unsigned njobs = L.job_end - L.job_begin, npblk = (L.max_classes + S20_BS - 1) / S20_BS;
+              const CherryJob * jobs = cj + L.job_begin;
+              const dim3 gb((npblk + 3) / 4, njobs);
+              if (chains4) hipLaunchKernelGGL(k_cherry_build_s4, dim3((L.max_classes + 255) / 256, njobs), dim3(256), 0, e->stream, jobs, e->R, dp.repeat_codes);
+              else if (e->R == 4) hipLaunchKernelGGL(k_cherry_build<4>, gb, dim3(256), 0, e->stream, jobs, dp.repeat_codes);
+              else if (e->R == 2) hipLaunchKernelGGL(k_cherry_build<2>, gb, dim3(256), 0, e->stream, jobs, dp.repeat_codes);
+              else hipLaunchKernelGGL(k_cherry_build<1>, gb, dim3(256), 0, e->stream, jobs, dp.repeat_codes);
+              PLLHIP_TRY(hipGetLastError());
+            }
           }
-          if (dp.npair_jobs)
-          {
-            const dim3 gp((npblk + 3) / 4, dp.npair_jobs);
-            const size_t lds = sizeof(double) * e->R * S20_CFRAGS;
-            if (chains4) hipLaunchKernelGGL(k_pair_lut_s4, dim3((pairs * e->R + 255) / 256, dp.npair_jobs), dim3(256), 0, e->stream, pj, pairs, e->R);
-            else if (e->R == 4) hipLaunchKernelGGL(k_pair_lut<4>, gp, dim3(256), lds, e->stream, pj, pairs);
-            else if (e->R == 2) hipLaunchKernelGGL(k_pair_lut<2>, gp, dim3(256), lds, e->stream, pj, pairs);
-            else hipLaunchKernelGGL(k_pair_lut<1>, gp, dim3(256), lds, e->stream, pj, pairs);
-            PLLHIP_TRY(hipGetLastError());
-          }
+          e->repeat_stats.cherries += dp.ncherry_jobs;
+          e->repeat_stats.classes += dp.repeat_classes;
+          e->repeat_stats.sites += (unsigned long long)dp.ncherry_jobs * e->N;
         }
         for (const DevicePlan::Launch & l : dp.launches)
         {

@@ -965,7 +965,7 @@ def mixture_component(subst, freqs, m):
 
 
 def build_instance(lib, states, rate_cats, ntips, nsites, coded=True, scalers=True, alpha=None,
-                   seed_shift=0, tree=None, pinv=0.0, attributes=0, mixture=None, mixture_pinv=None):
+                   seed_shift=0, tree=None, pinv=0.0, attributes=0, mixture=None, mixture_pinv=None, codes=None):
     """partition + tree + model + tips for one synthetic configuration.
     mixture: per-rate-category rate-matrix indices (e.g. [0, 1, 0, 1]): the partition gets
     max(mixture) + 1 rate matrices, each with a model of its own (mixture_component) and, with
@@ -995,7 +995,8 @@ def build_instance(lib, states, rate_cats, ntips, nsites, coded=True, scalers=Tr
             inst.set_model(*mixture_component(subst, freqs, m), rates, idx=m)
         inst.set_params_indices(mixture)
     cmap = state_charmap(states)
-    codes = random_codes(ntips, nsites, states, 44 + seed_shift)
+    if codes is None:
+        codes = random_codes(ntips, nsites, states, 44 + seed_shift)
     for t in range(ntips):
         inst.set_tip_states(t, cmap, (codes[t] + 48).tobytes())
     if pinv > 0:
