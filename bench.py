@@ -511,11 +511,13 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
     repeats = None
     if args.site_repeats:
         st = [i.repeat_stats() for i in insts]
-        repeats = {"cherries_per_step": sum(x.cherries for x in st) // max(1, steps + warmup),
+        repeats = {"class_operations_per_step": sum(x.cherries for x in st) // max(1, steps + warmup),
+                   "operations_per_step": nops,
                    "classes": sum(x.classes for x in st), "sites": sum(x.sites for x in st),
                    "classes_over_sites": (sum(x.classes for x in st) / max(1, sum(x.sites for x in st))),
                    "expansions": sum(x.expansions for x in st),
-                   "what": "tip x tip operations computed per class of sites (pair of tip codes) instead of per site"}
+                   "what": "operations computed per class of sites (cherries: pairs of tip codes; nodes above them: pairs of "
+                           "their children's classes) instead of per site"}
     partial_launches = sum(c.partial_launches for c in counters)
     pmatrix_launches = sum(c.pmatrix_launches for c in counters)
 
