@@ -676,6 +676,23 @@ def also_legs(ctx):
             "partial_launches_per_step": d["config"]["partial_launches_per_step"],
             "leg_wall_s": round(time.perf_counter() - t0, 2),
         }
+    # the headline configuration once more with PLL_ATTRIB_SITE_REPEATS: operations computed per class of sites
+    # (same iid-uniform data as the headline: its worst case), with the same parity sample against the oracle
+    global ATTRIBUTES
+    saved = (ATTRIBUTES, ctx.args.site_repeats)
+    ATTRIBUTES |= ctx.pc.PLL_ATTRIB_SITE_REPEATS
+    ctx.args.site_repeats = True
+    try:
+        t0 = time.perf_counter()
+        d = run_leg(ctx, "c3", steps=steps, warmup=2, cpu="parity")
+        also["c3_site_repeats"] = {
+            "workload": d["config"]["workload"], "value": d["value"], "ms_per_step": d["ms_per_step"], "steps": steps,
+            "site_repeats": d["config"].get("site_repeats"),
+            "dlnl_per_site": d["dlnl_per_site"], "max_persite_dlnl": d["max_persite_dlnl"],
+            "leg_wall_s": round(time.perf_counter() - t0, 2),
+        }
+    finally:
+        ATTRIBUTES, ctx.args.site_repeats = saved
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gpu_workloads as gw
     out = {}
