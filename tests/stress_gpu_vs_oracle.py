@@ -76,4 +76,27 @@ for trial in range(6):
             bad += 1; print("batch", spec, lx, ly, lz)
     for m in ga + gb + oc:
         m.close()
+# site repeats over subtrees: simulated alignments (real repeats), random shapes and sizes, a second evaluation
+# from another root edge (class nodes of the first one under new parents); on / off must agree exactly
+for trial in range(40):
+    S = [4, 20][trial % 2]
+    n = int(rng.integers(4, 70)); N = int(rng.integers(50, 30_000))
+    shape = dict(ladder=(trial % 5 == 1), balanced=(trial % 5 == 2), brlen_range=(0.005, float(rng.uniform(0.02, 0.3))))
+    tr = pc.Tree(n, 700 + trial, 800 + trial, **shape)
+    codes = pc.simulated_codes(tr, N, S, seed=900 + trial, scale=float(rng.uniform(0.3, 2.0)))
+    edge = int(rng.integers(0, tr.nedges))
+    res = []
+    for attrs in (pc.PLL_ATTRIB_SITE_REPEATS, 0):
+        with pc.build_instance(product, states=S, rate_cats=[4, 4, 2, 1][trial % 4], ntips=n, nsites=N, coded=True, tree=tr,
+                               attributes=attrs, codes=codes) as a:
+            a.tree = tr
+            l1 = pc.full_traversal(a)
+            sc = [a.get_scaler(op[1]).tobytes() for op in tr.ops]
+            t2 = pc.Tree(n, 700 + trial, 800 + trial, **shape)
+            t2.set_root_edge(edge)
+            a.tree = t2
+            l2 = pc.full_traversal(a)
+            res.append((l1, l2, sc, [a.get_clv(op[0]).tobytes() for op in t2.ops[::4]], [a.get_scaler(op[1]).tobytes() for op in t2.ops]))
+    if res[0] != res[1]:
+        bad += 1; print("classes", S, n, N, res[0][:2], res[1][:2])
 print("stress done, failures:", bad)
