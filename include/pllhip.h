@@ -150,14 +150,15 @@ typedef struct pllhip_profile
 PLL_EXPORT int pllhip_profile_partials(pll_partition_t * partition, int enable);
 
 /* PLL_ATTRIB_SITE_REPEATS (libpll-2's site repeats; the reference's test harness selects it,
-   test/src/common.c:31): what the engine did with it since the partition was created.  First step: the vector of
-   a cherry (a tip x tip operation) is computed per class of sites -- a pair of tip codes -- and not per site. */
+   test/src/common.c:31): what the engine did with it since the partition was created.  The vector of a cherry
+   (a tip x tip operation) is computed per class of sites -- a pair of tip codes -- and not per site, and so is the
+   vector of every node whose two children are known per class (4- and 20-state families, coded tips). */
 typedef struct pllhip_repeat_stats
 {
-  unsigned long long cherries;         /* tip x tip operations kept per class */
+  unsigned long long cherries;         /* operations kept per class (the name is the first step's: cherries only) */
   unsigned long long classes;          /* classes of those operations, summed */
   unsigned long long sites;            /* sites they cover, summed (classes / sites = the share computed) */
-  unsigned long long expansions;       /* cherries expanded to the site-indexed form on demand */
+  unsigned long long expansions;       /* class nodes expanded to the site-indexed form on demand */
 } pllhip_repeat_stats_t;
 PLL_EXPORT int pllhip_repeat_stats(const pll_partition_t * partition, pllhip_repeat_stats_t * out);
 PLL_EXPORT int pllhip_profile_read(pll_partition_t * partition, pllhip_profile_t * out);
