@@ -218,8 +218,10 @@ Engine * engine_create(pll_partition_t * p)
   e->nmat = p->prob_matrices; e->nrm = p->rate_matrices;
   e->coded_tips = (p->attributes & PLL_ATTRIB_PATTERN_TIP) != 0;
   e->rate_scalers = (p->attributes & PLL_ATTRIB_RATE_SCALERS) != 0;
-  e->site_repeats = (p->attributes & PLL_ATTRIB_SITE_REPEATS) != 0 && e->coded_tips && !e->rate_scalers &&
-                    !p->asc_bias_alloc && !(getenv("PLLHIP_SITE_REPEATS") && !atoi(getenv("PLLHIP_SITE_REPEATS")));
+  // PLLHIP_SITE_REPEATS=0: never; =2: as if every partition had the attribute (the whole test suite under site repeats)
+  const int env_repeats = getenv("PLLHIP_SITE_REPEATS") ? atoi(getenv("PLLHIP_SITE_REPEATS")) : 1;
+  e->site_repeats = ((p->attributes & PLL_ATTRIB_SITE_REPEATS) != 0 || env_repeats == 2) && e->coded_tips && !e->rate_scalers &&
+                    !p->asc_bias_alloc && env_repeats != 0;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) e->cu_count = prop.multiProcessorCount;
 
