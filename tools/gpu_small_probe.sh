@@ -8,7 +8,5 @@ python tools/gpu_workloads.py spr25 blo125 > gpurun_out/wl_small.json 2> gpurun_
 grep -h "s_per_round\|lnl_after\|us_per_scan\|s_per_smoothing" gpurun_out/wl_small.json
 python tools/gpu_microbench.py 61 25000 30 2>&1 | tail -6
 python tools/gpu_microbench.py 20 125000 30 2>&1 | tail -6
-for k in 0 1; do
-  PLLHIP_S61_FIXUP_KERNEL=$k python bench.py --config c5 --no-also --no-cpu-baseline --steps 30 --warmup 5 2> gpurun_out/c5_fix$k.err | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c5 fixup_kernel=$k', d['ms_per_step'], d['dlnl_per_site'])"
-  PLLHIP_S61_FIXUP_KERNEL=$k python bench.py --config c5 --sites 25000 --no-also --no-cpu-baseline --steps 50 --warmup 5 2> gpurun_out/c5s_fix$k.err | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c5 25k fixup_kernel=$k', d['ms_per_step'], d['dlnl_per_site'])"
-done
+python bench.py --config c5 --no-also --no-cpu-baseline --steps 30 --warmup 5 2> gpurun_out/c5_small.err | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c5', d['ms_per_step'])"
+python bench.py --config c5 --sites 25000 --no-also --no-cpu-baseline --steps 50 --warmup 5 2> gpurun_out/c5s_small.err | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c5 25k', d['ms_per_step'])"
