@@ -285,6 +285,9 @@ struct Engine
   double * hd_newton = nullptr;
   unsigned long long newton_seq = 0;
   int newton_capacity = -1;           // co-resident workgroups of the loop kernel (-1: not asked yet)
+  int newton_resident = 0;            // blocks per wave that k_newton_mfma_resident keeps in registers (0: the streaming loop)
+  const void * newton_fn = nullptr;
+  size_t newton_lds = 0;
 
   // caller-keyed device sumtables (pointer value is the key)
   std::list<std::pair<const void *, double *>> sumtables;

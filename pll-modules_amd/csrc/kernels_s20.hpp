@@ -1020,6 +1020,156 @@ __device__ inline double deriv_block_totals(const ModelView & mv, const ParamIdx
   return mine;
 }
 
+// The same scan for a loop of scans over ONE sumtable (k_newton_mfma) whose share per wave -- at most NB site blocks
+// of RT rates -- fits the wave's registers: the first scan loads the units (and what belongs to their sites:
+// weights, scaler counts, the invariant-site term), every later one finds them where they are and touches no
+// memory but the model's few numbers.  Same units per wave, same order of the MFMAs and of the additions: the
+// block totals are the ones deriv_block_totals produces, bit for bit.  (No per-rate scalers: those rescale the
+// units per scan.)
+// (NBR of the NB blocks of a wave in registers, the others in LDS behind the left operands: [block][wave][rate][k-step][lane])
+template <unsigned KS, unsigned NB, unsigned NBR, unsigned RT>
+struct DerivResident
+{
+  double2 unit[NBR ? NBR : 1][RT][KS];
+  double inv_e[NB], inv_o[NB];
+  SiteSide sd[NB];
+};
+
+template <unsigned KS, unsigned SREAL, unsigned NB, unsigned NBR, unsigned RT>
+__device__ inline double deriv_block_totals_resident(const ModelView & mv, const ParamIdx & params, double t,
+                                                     const double * sumtable,
+                                                     const unsigned * ps, const unsigned * cs,
+                                                     const unsigned * weights, const int * invariant,
+                                                     unsigned N, unsigned nblk, double * frag,
+                                                     DerivResident<KS, NB, NBR, RT> & res, bool first)
+{
+  double2 * const lds_units = reinterpret_cast<double2 *>(frag + RT * KS * 64);
+  constexpr unsigned UNIT = 4 * KS * S20_BS;
+  const unsigned SR = SREAL ? SREAL : mv.S;
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, n = lane & 15;
+  const unsigned wstride = gridDim.x * 4;
+  const unsigned blk0 = blockIdx.x * 4 + wave;
+  if (first)
+  {
+#pragma unroll
+    for (unsigned b = 0; b < NB; ++b)
+    {
+      const unsigned blk = blk0 + b * wstride;
+#pragma unroll
+      for (unsigned r = 0; r < RT; ++r)
+#pragma unroll
+        for (unsigned ks = 0; ks < KS; ++ks)
+        {
+          const double2 u = blk < nblk ? *reinterpret_cast<const double2 *>(sumtable + ((size_t)blk * RT + r) * UNIT + lane * 2 + ks * 128)
+                                       : make_double2(0.0, 0.0);
+          if (b < NBR) res.unit[b < NBR ? b : 0][r][ks] = u;
+          else lds_units[((((b - NBR) * 4 + wave) * RT + r) * KS + ks) * 64 + lane] = u;
+        }
+    }
+  }
+  // left operands, as in deriv_block_totals with one trial length in all four slots
+  for (unsigned x = threadIdx.x; x < RT * KS * 64; x += blockDim.x) frag[x] = 0.0;
+  __syncthreads();
+  for (unsigned x = threadIdx.x; x < RT * SR; x += blockDim.x)
+  {
+    const unsigned k = x % SR, r = x / SR;
+    const unsigned pi_ = params.v[r];
+    const double pinv = mv.pinv()[pi_];
+    const double lam = mv.evals(pi_)[k] * mv.rates()[r] / (1.0 - pinv);
+    const double wr = mv.weights()[r] * ((pinv > 0.0) ? (1.0 - pinv) : 1.0);
+    const double ex = exp(lam * t);
+    const double e0 = wr * ex, e1 = wr * ex * lam, e2 = wr * ex * lam * lam;
+    double * f = frag + ((size_t)r * KS + (k >> 2)) * 64 + (k & 3) * 16;
+    for (unsigned jj = 0; jj < 4; ++jj)
+    {
+      f[jj] = e0;
+      f[jj + 4] = e1;
+      f[jj + 8] = e2;
+    }
+  }
+  __syncthreads();
+  if (first)
+  {
+#pragma unroll
+    for (unsigned b = 0; b < NB; ++b)
+    {
+      const unsigned blk = blk0 + b * wstride;
+      const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+      res.sd[b] = SiteSide{0u, 0u, 0u, 0u};
+      res.inv_e[b] = res.inv_o[b] = 0.0;
+      if (blk >= nblk) continue;
+      res.sd[b] = load_site_side(ps, cs, weights, site0, N, true);
+      if (invariant)
+        for (unsigned r = 0; r < RT; ++r)              // (rate by rate: the order of the additions of the streaming scan)
+        {
+          const unsigned pi_ = params.v[r];
+          const double pinv = mv.pinv()[pi_];
+          if (pinv > 0.0)
+          {
+            const double w = mv.weights()[r] * pinv;
+            if (site0 < N && invariant[site0] >= 0) res.inv_e[b] += w * mv.freqs(pi_)[invariant[site0]];
+            if (site0 + 1 < N && invariant[site0 + 1] >= 0) res.inv_o[b] += w * mv.freqs(pi_)[invariant[site0 + 1]];
+          }
+        }
+    }
+  }
+  double df = 0.0, ddf = 0.0;
+#pragma unroll
+  for (unsigned b = 0; b < NB; ++b)
+  {
+    const unsigned blk = blk0 + b * wstride;
+    if (blk >= nblk) break;
+    const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+    v4d acc_e = {0, 0, 0, 0}, acc_o = {0, 0, 0, 0};
+#pragma unroll
+    for (unsigned r = 0; r < RT; ++r)
+    {
+      const double * fr = frag + (size_t)r * KS * 64 + lane;
+#pragma unroll
+      for (unsigned ks = 0; ks < KS; ++ks)
+      {
+        const double f = fr[ks * 64];
+        const double2 u = b < NBR ? res.unit[b < NBR ? b : 0][r][ks]
+                                  : lds_units[((((b - NBR) * 4 + wave) * RT + r) * KS + ks) * 64 + lane];
+        acc_e = mfma_f64(f, u.x, acc_e);
+        acc_o = mfma_f64(f, u.y, acc_o);
+      }
+    }
+    const SiteSide sd = res.sd[b];
+    if (site0 < N)
+    {
+      double a = acc_e[0];
+      if (res.inv_e[b] > 0.0) a += (sd.cnt_e <= 3) ? ldexp(res.inv_e[b], 256 * (int)sd.cnt_e) : INFINITY;
+      const double w = (double)sd.w_e, ba = acc_e[1] / a, ca = acc_e[2] / a;
+      df -= w * ba;
+      ddf += w * (ba * ba - ca);
+    }
+    if (site0 + 1 < N)
+    {
+      double a = acc_o[0];
+      if (res.inv_o[b] > 0.0) a += (sd.cnt_o <= 3) ? ldexp(res.inv_o[b], 256 * (int)sd.cnt_o) : INFINITY;
+      const double w = (double)sd.w_o, ba = acc_o[1] / a, ca = acc_o[2] / a;
+      df -= w * ba;
+      ddf += w * (ba * ba - ca);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // block by block: interleaving them costs more registers than the units take
+  }
+  __shared__ double part[4][8];
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1)
+  {
+    df += __shfl_xor(df, off, 64);
+    ddf += __shfl_xor(ddf, off, 64);
+  }
+  if (n == 0) { part[wave][2 * q] = df; part[wave][2 * q + 1] = ddf; }
+  __syncthreads();
+  double mine = 0.0;
+  if (threadIdx.x < 8) mine = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+  __syncthreads();
+  return mine;
+}
+
 template <unsigned KS, unsigned SREAL>
 __global__ __launch_bounds__(256) void k_derivatives_mfma(ModelView mv, ParamIdx params, TrialLengths tl,
                                                           unsigned ntrial,
@@ -1067,28 +1217,38 @@ constexpr unsigned NEWTON_RUNNING = 0, NEWTON_CONVERGED = 1, NEWTON_LIMIT = 2, N
 constexpr unsigned NEWTON_TRAIL_SLOT = 8, NEWTON_TRAIL_MAX = 96;
 constexpr unsigned NEWTON_SPIN_LIMIT = 1u << 24;
 
-template <unsigned KS, unsigned SREAL>
-__global__ __launch_bounds__(256) void k_newton_mfma(ModelView mv, ParamIdx params, NewtonParams np,
-                                                     const double * sumtable,
-                                                     const unsigned * ps, const unsigned * cs,
-                                                     const unsigned * weights, const int * invariant,
-                                                     unsigned N, unsigned nblk, unsigned R,
-                                                     ReduceOut ro, unsigned rate_scalers,
-                                                     NewtonControl * ctl, double * host_out,
-                                                     unsigned long long * host_flag, unsigned long long host_seq)
+// NB > 0: the sumtable stays in the registers of the waves between the scans (deriv_block_totals_resident; four rate
+// categories, per-site scalers, at most NB blocks per wave: a 125 k-site protein slice, a 25 k-site codon slice) --
+// an iterate then costs the in-launch reduction and the hand-over, not a pass over 80 MB
+template <unsigned KS, unsigned SREAL, unsigned NB, unsigned NBR = NB>
+__device__ inline void newton_loop(const ModelView & mv, const ParamIdx & params, const NewtonParams & np,
+                                   const double * sumtable,
+                                   const unsigned * ps, const unsigned * cs,
+                                   const unsigned * weights, const int * invariant,
+                                   unsigned N, unsigned nblk, unsigned R,
+                                   const ReduceOut & ro, unsigned rate_scalers,
+                                   NewtonControl * ctl, double * host_out,
+                                   unsigned long long * host_flag, unsigned long long host_seq)
 {
   extern __shared__ double frag[];
   __shared__ double scratch[4];
   __shared__ double s_x;
   __shared__ unsigned s_status;
   double x = np.x0;                                     // (clamped by the host, as newton() does first)
+  DerivResident<KS, NB ? NB : 1, NB ? NBR : 1, NB ? 4 : 1> res;
   for (unsigned it = 0; ; ++it)
   {
-    TrialLengths tl;
+    double mine;
+    if constexpr (NB > 0)
+      mine = deriv_block_totals_resident<KS, SREAL, NB, NBR, 4>(mv, params, x, sumtable, ps, cs, weights, invariant, N, nblk, frag, res, it == 0);
+    else
+    {
+      TrialLengths tl;
 #pragma unroll
-    for (unsigned i = 0; i < MAX_TRIAL_LENGTHS; ++i) tl.t[i] = x;
-    const double mine = deriv_block_totals<KS, SREAL>(mv, params, tl, 1u, sumtable, ps, cs, weights, invariant,
-                                                      N, nblk, R, rate_scalers, frag);
+      for (unsigned i = 0; i < MAX_TRIAL_LENGTHS; ++i) tl.t[i] = x;
+      mine = deriv_block_totals<KS, SREAL>(mv, params, tl, 1u, sumtable, ps, cs, weights, invariant,
+                                           N, nblk, R, rate_scalers, frag);
+    }
     const bool last = grid_reduce_finish_lanes<8, true>(mine, ro, scratch);
     if (last && threadIdx.x == 0)
     {
@@ -1169,6 +1329,26 @@ __global__ __launch_bounds__(256) void k_newton_mfma(ModelView mv, ParamIdx para
     if (status != NEWTON_RUNNING) return;
   }
 }
+
+#define PLLHIP_NEWTON_ARGS ModelView mv, ParamIdx params, NewtonParams np, const double * sumtable,                  \
+                           const unsigned * ps, const unsigned * cs, const unsigned * weights, const int * invariant, \
+                           unsigned N, unsigned nblk, unsigned R, ReduceOut ro, unsigned rate_scalers,               \
+                           NewtonControl * ctl, double * host_out, unsigned long long * host_flag, unsigned long long host_seq
+template <unsigned KS, unsigned SREAL>
+__global__ __launch_bounds__(256) void k_newton_mfma(PLLHIP_NEWTON_ARGS)
+{
+  newton_loop<KS, SREAL, 0>(mv, params, np, sumtable, ps, cs, weights, invariant, N, nblk, R, ro, rate_scalers, ctl, host_out, host_flag, host_seq);
+}
+
+// one wave per SIMD with the whole register file: four blocks of five k-steps (20 states: 131 k sites on 256 CUs;
+// NBR = 3 of them in registers, one in LDS: four in registers spill 104) or one block of sixteen (33 .. 64 states:
+// 32 k sites).  dynamic LDS = the left operands + (NB - NBR) * 4 waves * 4 rates * KS * 64 double2
+template <unsigned KS, unsigned SREAL, unsigned NB, unsigned NBR>
+__global__ __launch_bounds__(256, 1) void k_newton_mfma_resident(PLLHIP_NEWTON_ARGS)
+{
+  newton_loop<KS, SREAL, NB, NBR>(mv, params, np, sumtable, ps, cs, weights, invariant, N, nblk, R, ro, rate_scalers, ctl, host_out, host_flag, host_seq);
+}
+#undef PLLHIP_NEWTON_ARGS
 
 // ---------------------------------------------------------------------------
 // layout converters between the API layout [site][rate][20] and the blocked

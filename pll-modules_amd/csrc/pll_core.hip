@@ -2672,7 +2672,6 @@ static int newton_capacity(Engine * e, const void ** fn_out, size_t * lds_out)
       default: PLLHIP_PICK(8, 0); break;
     }
 #undef PLLHIP_PICK
-  if (fn_out) *fn_out = fn;
   if (lds_out) *lds_out = lds;
   if (e->newton_capacity < 0)
   {
@@ -2683,7 +2682,45 @@ static int newton_capacity(Engine * e, const void ** fn_out, size_t * lds_out)
     if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor"))
       return -1;
     e->newton_capacity = std::max(0, per_cu) * (int)e->cu_count;
+    // Does the sumtable fit the registers of the waves of ONE co-resident grid (k_newton_mfma_resident)?  Then that
+    // grid is the scan grid of this partition -- for the single scans of derivatives_impl as well, so that both
+    // add the same block totals in the same order.
+    static const int env_res = getenv("PLLHIP_NEWTON_RESIDENT") ? atoi(getenv("PLLHIP_NEWTON_RESIDENT")) : 1;
+    e->newton_resident = 0;
+    e->newton_fn = nullptr;
+    const void * rfn = nullptr;
+    unsigned nb = 0;
+    size_t res_lds = lds;
+    if (env_res && e->R == 4 && !e->rate_scalers && lds <= 64 * 1024)
+    {
+      if (e->family == KernelFamily::S20) { rfn = reinterpret_cast<const void *>(k_newton_mfma_resident<5, 20, 4, 3>); nb = 4; res_lds = lds + sizeof(double2) * 4 * 4 * 5 * 64; }
+      else if (e->family == KernelFamily::S61)
+      {
+        rfn = e->S == S61_S ? reinterpret_cast<const void *>(k_newton_mfma_resident<S61_KS, S61_S, 1, 1>)
+                            : reinterpret_cast<const void *>(k_newton_mfma_resident<S61_KS, 0, 1, 1>);
+        nb = 1;
+      }
+    }
+    if (rfn)
+    {
+      int res_cu = 0;
+      if (res_lds > 64 * 1024 && !hip_ok(hipFuncSetAttribute(rfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds), "hipFuncSetAttribute"))
+        return -1;
+      if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&res_cu, rfn, 256, res_lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor"))
+        return -1;
+      const unsigned cap_res = (unsigned)std::max(0, res_cu) * e->cu_count;
+      const unsigned g = std::min({reduce_grid(e), 4u * e->cu_count, cap_res});
+      if (g && (unsigned long long)e->nblk <= (unsigned long long)nb * 4u * g)
+      {
+        e->newton_resident = (int)nb;
+        e->newton_fn = rfn;
+        e->newton_lds = res_lds;
+        e->newton_capacity = (int)cap_res;
+      }
+    }
   }
+  if (fn_out) *fn_out = e->newton_resident ? e->newton_fn : fn;
+  if (lds_out && e->newton_resident) *lds_out = e->newton_lds;
   return e->newton_capacity;
 }
 
