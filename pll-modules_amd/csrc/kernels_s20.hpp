@@ -1208,6 +1208,7 @@ struct NewtonControl          // device memory, one per engine
   unsigned iter;              // scans completed (what the other blocks wait for)
   unsigned status;            // NEWTON_RUNNING, or how the loop ended
   double tot[8];              // totals of the scan (grid reduction sink)
+  double trail[96];           // the iterates (NEWTON_TRAIL_MAX), copied to the host when the loop ends
 };
 
 struct NewtonParams { double x0, bl_min, bl_max, tolerance, dxmax; unsigned max_newton; };
@@ -1284,7 +1285,9 @@ __device__ inline void newton_loop(const ModelView & mv, const ParamIdx & params
           }
         }
       }
-      if (it < NEWTON_TRAIL_MAX) host_out[NEWTON_TRAIL_SLOT + it] = x;       // the iterate after this scan
+      // the iterate after this scan (kept on the device until the loop ends: a store to host memory would have to
+      // be acknowledged before the release below hands the iterate to the other blocks)
+      if (it < NEWTON_TRAIL_MAX) ctl->trail[it] = x;
       ctl->xl = xl;
       ctl->xh = xh;
       ctl->x = x;
@@ -1293,6 +1296,7 @@ __device__ inline void newton_loop(const ModelView & mv, const ParamIdx & params
         __hip_atomic_store(ro.counter + k * REDUCE_SHARD_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (status != NEWTON_RUNNING)
       {
+        for (unsigned k = 0; k <= it && k < NEWTON_TRAIL_MAX; ++k) host_out[NEWTON_TRAIL_SLOT + k] = ctl->trail[k];
         host_out[0] = x;
         host_out[1] = (double)(it + 1);
         host_out[2] = (double)status;
