@@ -1221,6 +1221,94 @@ constexpr unsigned NEWTON_SPIN_LIMIT = 1u << 24;
 // NB > 0: the sumtable stays in the registers of the waves between the scans (deriv_block_totals_resident; four rate
 // categories, per-site scalers, at most NB blocks per wave: a 125 k-site protein slice, a 25 k-site codon slice) --
 // an iterate then costs the in-launch reduction and the hand-over, not a pass over 80 MB
+// what follows a scan: the block that drew the last ticket of the reduction (`last`; thread 0 finds the totals in
+// ro.dst) applies the step rule and releases the next iterate; every block waits for it.  Returns the status of the
+// loop after scan `it`; x = the next iterate.  s_x / s_status: two words of LDS.
+__device__ inline unsigned newton_step_and_wait(unsigned it, bool last, double & x, const NewtonParams & np, const ReduceOut & ro,
+                                                NewtonControl * ctl, double * host_out, unsigned long long * host_flag,
+                                                unsigned long long host_seq, double * s_x, unsigned * s_status)
+{
+  if (last && threadIdx.x == 0)
+  {
+    // the step rule of newton() (csrc/host/pllhip_eval.c), expression by expression
+    const double f = ro.dst[0], df = ro.dst[1];
+    double xl = ctl->xl, xh = ctl->xh, dx;
+    unsigned status = NEWTON_RUNNING;
+    if (it > np.max_newton) status = NEWTON_LIMIT;                  // (the host loop counts the same way)
+    else if (!isfinite(f) || !isfinite(df)) status = NEWTON_NONFINITE;
+    else
+    {
+      if (df > 0.0)
+      {
+        if (fabs(f) < np.tolerance) status = NEWTON_CONVERGED;
+        else
+        {
+          if (f < 0.0) xl = x; else xh = x;
+          dx = -f / df;
+        }
+      }
+      else
+        dx = -f / fabs(df);
+      if (status == NEWTON_RUNNING)
+      {
+        dx = fmax(fmin(dx, np.dxmax), -np.dxmax);
+        if (x + dx < xl) dx = xl - x;
+        if (x + dx > xh) dx = xh - x;
+        if (fabs(dx) < np.tolerance) status = NEWTON_CONVERGED;
+        else
+        {
+          x += dx;
+          x = fmax(fmin(x, np.bl_max), np.bl_min);
+        }
+      }
+    }
+    // the iterate after this scan (kept on the device until the loop ends)
+    if (it < NEWTON_TRAIL_MAX) ctl->trail[it] = x;
+    ctl->xl = xl;
+    ctl->xh = xh;
+    ctl->x = x;
+    ctl->status = status;
+    for (unsigned k = 0; k <= REDUCE_SHARDS; ++k)                          // tickets back to zero for the next scan
+      __hip_atomic_store(ro.counter + k * REDUCE_SHARD_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (status != NEWTON_RUNNING)
+    {
+      for (unsigned k = 0; k <= it && k < NEWTON_TRAIL_MAX; ++k) host_out[NEWTON_TRAIL_SLOT + k] = ctl->trail[k];
+      host_out[0] = x;
+      host_out[1] = (double)(it + 1);
+      host_out[2] = (double)status;
+      host_out[3] = f;
+      host_out[4] = df;
+      __threadfence_system();
+      __hip_atomic_store(host_flag, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __hip_atomic_store(&ctl->iter, it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x == 0)
+  {
+    unsigned spins = 0;
+    // (relaxed polls, ONE acquire afterwards: an acquire per poll invalidates the caches of the whole chip
+    // several hundred times per microsecond)
+    while (__hip_atomic_load(&ctl->iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != it + 1)
+    {
+      if (++spins > NEWTON_SPIN_LIMIT)
+      {
+        __hip_atomic_store(&ctl->status, NEWTON_STUCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *s_status = (spins > NEWTON_SPIN_LIMIT) ? NEWTON_STUCK
+                                           : __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_x = __hip_atomic_load(&ctl->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const unsigned status = *s_status;
+  x = *s_x;
+  __syncthreads();
+  return status;
+}
+
 template <unsigned KS, unsigned SREAL, unsigned NB, unsigned NBR = NB>
 __device__ inline void newton_loop(const ModelView & mv, const ParamIdx & params, const NewtonParams & np,
                                    const double * sumtable,
@@ -1251,86 +1339,7 @@ __device__ inline void newton_loop(const ModelView & mv, const ParamIdx & params
                                            N, nblk, R, rate_scalers, frag);
     }
     const bool last = grid_reduce_finish_lanes<8, true>(mine, ro, scratch);
-    if (last && threadIdx.x == 0)
-    {
-      // the step rule of newton() (csrc/host/pllhip_eval.c), expression by expression
-      const double f = ro.dst[0], df = ro.dst[1];
-      double xl = ctl->xl, xh = ctl->xh, dx;
-      unsigned status = NEWTON_RUNNING;
-      if (it > np.max_newton) status = NEWTON_LIMIT;                  // (the host loop counts the same way)
-      else if (!isfinite(f) || !isfinite(df)) status = NEWTON_NONFINITE;
-      else
-      {
-        if (df > 0.0)
-        {
-          if (fabs(f) < np.tolerance) status = NEWTON_CONVERGED;
-          else
-          {
-            if (f < 0.0) xl = x; else xh = x;
-            dx = -f / df;
-          }
-        }
-        else
-          dx = -f / fabs(df);
-        if (status == NEWTON_RUNNING)
-        {
-          dx = fmax(fmin(dx, np.dxmax), -np.dxmax);
-          if (x + dx < xl) dx = xl - x;
-          if (x + dx > xh) dx = xh - x;
-          if (fabs(dx) < np.tolerance) status = NEWTON_CONVERGED;
-          else
-          {
-            x += dx;
-            x = fmax(fmin(x, np.bl_max), np.bl_min);
-          }
-        }
-      }
-      // the iterate after this scan (kept on the device until the loop ends: a store to host memory would have to
-      // be acknowledged before the release below hands the iterate to the other blocks)
-      if (it < NEWTON_TRAIL_MAX) ctl->trail[it] = x;
-      ctl->xl = xl;
-      ctl->xh = xh;
-      ctl->x = x;
-      ctl->status = status;
-      for (unsigned k = 0; k <= REDUCE_SHARDS; ++k)                          // tickets back to zero for the next scan
-        __hip_atomic_store(ro.counter + k * REDUCE_SHARD_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (status != NEWTON_RUNNING)
-      {
-        for (unsigned k = 0; k <= it && k < NEWTON_TRAIL_MAX; ++k) host_out[NEWTON_TRAIL_SLOT + k] = ctl->trail[k];
-        host_out[0] = x;
-        host_out[1] = (double)(it + 1);
-        host_out[2] = (double)status;
-        host_out[3] = f;
-        host_out[4] = df;
-        __threadfence_system();
-        __hip_atomic_store(host_flag, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      __hip_atomic_store(&ctl->iter, it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (threadIdx.x == 0)
-    {
-      unsigned spins = 0;
-      // (relaxed polls, ONE acquire afterwards: an acquire per poll invalidates the caches of the whole chip
-      // several hundred times per microsecond)
-      while (__hip_atomic_load(&ctl->iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != it + 1)
-      {
-        if (++spins > NEWTON_SPIN_LIMIT)
-        {
-          __hip_atomic_store(&ctl->status, NEWTON_STUCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      s_status = (spins > NEWTON_SPIN_LIMIT) ? NEWTON_STUCK
-                                             : __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_x = __hip_atomic_load(&ctl->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    const unsigned status = s_status;
-    x = s_x;
-    __syncthreads();
-    if (status != NEWTON_RUNNING) return;
+    if (newton_step_and_wait(it, last, x, np, ro, ctl, host_out, host_flag, host_seq, &s_x, &s_status) != NEWTON_RUNNING) return;
   }
 }
 

@@ -25,6 +25,7 @@
 #include "kernels_s61.hpp"
 #include "kernels_s16.hpp"
 #include "kernels_repeats.hpp"
+#include "kernels_newton_s4.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -2653,6 +2654,31 @@ double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsigned cc
 // device loop and the host loop add the same block totals in the same order.
 static int newton_capacity(Engine * e, const void ** fn_out, size_t * lds_out)
 {
+  if (e->family == KernelFamily::S4)
+  {
+    // 4 states (kernels_newton_s4.hpp): the loop with the table in registers when a thread has at most two trips
+    // on the grid that variant can hold at once; otherwise the host loop (capacity 0: a streaming loop in one
+    // launch measured no faster than one blocking call per iterate -- 59.3 against 57.7 us all-in at 1 M sites)
+    if (e->newton_capacity < 0)
+    {
+      static const int env_res = getenv("PLLHIP_NEWTON_RESIDENT") ? atoi(getenv("PLLHIP_NEWTON_RESIDENT")) : 1;
+      const void * fn2 = reinterpret_cast<const void *>(k_newton_s4<2>);
+      int cu2 = 0;
+      if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&cu2, fn2, 256, 0), "hipOccupancyMaxActiveBlocksPerMultiprocessor"))
+        return -1;
+      const unsigned cap2 = (unsigned)std::max(0, cu2) * e->cu_count;
+      const unsigned long long limit = ((unsigned long long)e->N * e->R + 63ULL) & ~63ULL;
+      const unsigned g2 = std::min(reduce_grid(e), cap2);
+      const bool resident = env_res && g2 && (limit + 1024ULL * g2 - 1) / (1024ULL * g2) <= 2;
+      e->newton_resident = resident ? 2 : 0;
+      e->newton_fn = fn2;
+      e->newton_lds = 0;
+      e->newton_capacity = resident ? (int)cap2 : 0;
+    }
+    if (fn_out) *fn_out = e->newton_fn;
+    if (lds_out) *lds_out = 0;
+    return e->newton_capacity;
+  }
   const unsigned ks = e->family == KernelFamily::S20 ? 5u : e->family == KernelFamily::S61 ? S61_KS : s16_ks(e);
   const size_t lds = sizeof(double) * e->R * ks * 64;
   const void * fn = nullptr;
@@ -2759,7 +2785,7 @@ int derivatives_impl(pll_partition_t * p, int parent_scaler_index, int child_sca
     return PLL_FAILURE;
   }
   if (!sync_model(p) || !ensure_invariant(p)) return PLL_FAILURE;
-  const unsigned nblocks = e->blocked ? scan_grid(e) : reduce_grid(e);
+  const unsigned nblocks = (e->blocked || e->family == KernelFamily::S4) ? scan_grid(e) : reduce_grid(e);
   const ModelView mv = model_view(e);
   const ParamIdx params = make_params(p, params_indices);
   // lengths per launch: the matrix-core kernel (20 / 61 states) takes four; the others are
@@ -2934,7 +2960,8 @@ int pllhip_newton_branch(pll_partition_t * p, int parent_scaler_index, int child
 {
   Engine * e = engine_of(p);
   static const int enabled = getenv("PLLHIP_DEVICE_NEWTON") ? atoi(getenv("PLLHIP_DEVICE_NEWTON")) : 1;
-  const bool family_ok = e->family == KernelFamily::S20 || e->family == KernelFamily::S16 || e->family == KernelFamily::S61;
+  const bool family_ok = e->family == KernelFamily::S20 || e->family == KernelFamily::S16 || e->family == KernelFamily::S61 ||
+                         (e->family == KernelFamily::S4 && !e->rate_scalers);
   if (!enabled || !e->shards.empty() || !family_ok || e->N > e->Nreal || !e->fused_finish || !max_newton)
   {
     set_error(PLLHIP_ERROR_NEWTON_UNSUPPORTED, "this partition does not run the Newton-Raphson loop on the device");
@@ -2998,7 +3025,15 @@ int pllhip_newton_branch(pll_partition_t * p, int parent_scaler_index, int child
                    (void *)&ro, nullptr, (void *)&ctl, (void *)&e->hd_newton, (void *)&host_flag, (void *)&seq};
   unsigned rs = e->rate_scalers ? 1u : 0u;
   args[12] = &rs;
-  PLLHIP_TRY(hipLaunchKernel(fn, dim3(nblocks), dim3(256), args, lds, e->stream));
+  if (e->family == KernelFamily::S4)
+  {
+    void * args4[] = {(void *)&mv, (void *)&params, (void *)&np, (void *)&d_sum, (void *)&ps, (void *)&cs,
+                      (void *)&e->d_weights, (void *)&e->d_invariant, (void *)&e->N, (void *)&e->R,
+                      (void *)&ro, (void *)&ctl, (void *)&e->hd_newton, (void *)&host_flag, (void *)&seq};
+    PLLHIP_TRY(hipLaunchKernel(fn, dim3(nblocks), dim3(256), args4, 0, e->stream));
+  }
+  else
+    PLLHIP_TRY(hipLaunchKernel(fn, dim3(nblocks), dim3(256), args, lds, e->stream));
   e->counters.derivative_calls++;
   const volatile unsigned long long * flag = reinterpret_cast<const volatile unsigned long long *>(e->h_newton + 112);
   if (!wait_sequence(e->stream, flag, seq)) return PLL_FAILURE;

@@ -430,7 +430,8 @@ def _host_newton(deriv, x, bl_min, bl_max, tol, max_newton):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("states,nsites,pinv", [(20, 5000, 0.0), (20, 333, 0.1), (61, 700, 0.0), (10, 2000, 0.0),
-                                                (24, 1500, 0.0), (62, 300, 0.0), (2, 4000, 0.0)])
+                                                (24, 1500, 0.0), (62, 300, 0.0), (2, 4000, 0.0),
+                                                (4, 5000, 0.0), (4, 777, 0.2), (4, 200_000, 0.0), (20, 120_000, 0.0)])
 def test_device_newton_makes_the_host_loop_s_iterates(product, states, nsites, pinv):
     """one launch runs the whole Newton-Raphson loop of a branch: every iterate is, bit for bit, the one the
     host loop reaches by calling pll_compute_likelihood_derivatives once per iterate"""
@@ -469,8 +470,8 @@ def test_device_newton_says_when_it_cannot(product):
         t = a.tree
         st = a.alloc_sumtable()
         a.update_sumtable(t.root_a, t.root_b, t.scaler_of(t.root_a), t.scaler_of(t.root_b), st)
-        with pytest.raises(RuntimeError, match="912"):
-            a.newton_branch(t.scaler_of(t.root_a), t.scaler_of(t.root_b), st, 0.1, 1e-4, 10.0, 1e-5, 32)
+        with pytest.raises(RuntimeError, match="912"):       # no iterations allowed: nothing for the loop to do
+            a.newton_branch(t.scaler_of(t.root_a), t.scaler_of(t.root_b), st, 0.1, 1e-4, 10.0, 1e-5, 0)
         a.free_sumtable(st)
     with pc.build_instance(product, states=20, rate_cats=4, ntips=6, nsites=500, coded=True) as a:
         pc.full_traversal(a)
@@ -483,7 +484,7 @@ def test_device_newton_says_when_it_cannot(product):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("states", [20, 61, 10])
+@pytest.mark.parametrize("states", [20, 61, 10, 4])
 def test_driver_with_device_newton_equals_driver_with_host_loop(product, states):
     """pllhip_eval_optimize_branches on one partition: the device loop and the host loop give the same tree,
     the same lnL and the same number of Newton iterations"""
