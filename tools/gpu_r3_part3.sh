@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, part 3: secondary workloads
 mkdir -p gpurun_out
-timeout -k 10 500 python tools/gpu_workloads.py blo blo_c2 spr alphabets32 > gpurun_out/wl_r3.json 2> gpurun_out/wl_r3.err; echo "wl rc=$?"
+timeout -k 10 700 python tools/gpu_workloads.py w2 w3 blo blo_c2 spr alphabets32 > gpurun_out/wl_r3.json 2> gpurun_out/wl_r3.err; echo "wl rc=$?"
 PLLHIP_EVAL_DEVICE_NEWTON=0 timeout -k 10 200 python tools/gpu_workloads.py blo125 > gpurun_out/wl_r3_hostnewton.json 2>> gpurun_out/wl_r3.err; echo "wl host newton rc=$?"
 : > gpurun_out/manypart_r3.jsonl
 for spec in "20 32 10000" "20 1 320000" "20 8 40000" "4 64 10000" "4 1 640000" "4 16 60000"; do
