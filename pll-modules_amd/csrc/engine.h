@@ -181,7 +181,7 @@ struct Engine
     unsigned ncodes = 0;              // size of the tip code table the class map was made under
     unsigned nclasses = 0;
     double * table = nullptr;         // blocked pseudo-CLV over the classes
-    unsigned short * pair = nullptr;  // [Nalloc] class per site
+    unsigned * pair = nullptr;        // [Nalloc] class per site
     uint8_t * flags = nullptr;        // [classes] scaled?
     unsigned cap_classes = 0;         // what table / flags were allocated for
     unsigned * rep = nullptr;         // [2 * classes] the children's classes of each class (null: a cherry, class = code1 * ncodes + code2)

@@ -8,7 +8,7 @@
 // the same structure at the end of this file, the 4-state family) therefore
 //   * computes a cherry's vector per code pair (k_cherry_build: the arithmetic of the tip x tip operation on a
 //     "pseudo alignment" whose sites are the pairs; a few hundred KiB that stay in the caches) and writes per site
-//     only the 16-bit class code and the scaler count (k_cherry_sites: 6 B instead of 640 B per site);
+//     only the class code and the scaler count (k_cherry_sites: 8 B instead of 640 B per site);
 //   * hands the cherry to the operation above it as a "wide tip": a child read through a lookup table with one row
 //     per class, [rate][class][20] = P . vector(class), built per traversal on the matrix cores with the very MFMA
 //     sequence an inner child takes (k_pair_lut) -- so the operation's result is, bit for bit, what it computes
@@ -42,7 +42,7 @@ struct CherryJob
   unsigned nclasses;
   double * table;                    // blocked pseudo-CLV [class block][rate][unit] (4 states: [class][rate][4])
   uint8_t * flags;                   // per class: the vector was scaled
-  const unsigned short * pair;       // per site: class
+  const unsigned * pair;             // per site: class
   unsigned * parent_scaler;          // per site, or null
   const unsigned * scaler1, * scaler2;   // per-site counts of the children (class nodes), or null
 };
@@ -136,11 +136,11 @@ __global__ __launch_bounds__(256) void k_cherry_sites(const CherryJob * jobs, un
 // ---------------------------------------------------------------------------
 // class maps (once per topology and orientation of a node; cached on the host side)
 // ---------------------------------------------------------------------------
-// classes of the two children per site: a tip's codes (bytes) or a class node's classes (16 bit)
+// classes of the two children per site: a tip's codes (bytes) or a class node's classes (32 bit)
 struct ClassMapArgs
 {
   const uint8_t * codes1, * codes2;          // tip children
-  const unsigned short * cls1, * cls2;       // class-node children
+  const unsigned * cls1, * cls2;             // class-node children
   unsigned n1, n2;                           // classes of the children
 };
 
@@ -153,10 +153,10 @@ __device__ inline unsigned class_key(const ClassMapArgs & a, unsigned s)
 }
 
 // a cherry: every code pair is a class.  grid = chunks, block = 256
-__global__ __launch_bounds__(256) void k_class_cherry(ClassMapArgs a, unsigned nalloc, unsigned short * pair)
+__global__ __launch_bounds__(256) void k_class_cherry(ClassMapArgs a, unsigned nalloc, unsigned * pair)
 {
   for (unsigned s = blockIdx.x * 256u + threadIdx.x; s < nalloc; s += gridDim.x * 256u)
-    pair[s] = (unsigned short)class_key(a, s);            // (padding sites carry code 0)
+    pair[s] = class_key(a, s);                            // (padding sites carry code 0)
 }
 
 // which pairs occur.  grid = chunks, block = 256; `seen` zeroed [n1 * n2]
@@ -196,9 +196,62 @@ __global__ __launch_bounds__(1024) void k_class_scan_top(unsigned * tile_sum, un
   if (threadIdx.x == 1023) *total = buf[1023];
 }
 
-// seen[k] becomes the class number of pair k (for pairs that occur); the children's classes of every class
+// More pairs of child classes than a table can hold: the pairs that occur go through a hash table (open addressing,
+// `slots` a power of two >= 2 N; key = pair + 1, 0 = empty).  Which slot a pair lands in depends on the order of the
+// inserts, so the numbering of the classes differs from run to run -- the classes themselves, and everything computed
+// from them, do not.  grid = chunks, block = 256
+__device__ inline unsigned class_hash(unsigned long long key, unsigned mask)
+{
+  key ^= key >> 33; key *= 0xff51afd7ed558ccdULL; key ^= key >> 33; key *= 0xc4ceb9fe1a85ec53ULL; key ^= key >> 33;
+  return (unsigned)key & mask;
+}
+
+__device__ inline unsigned long long class_key64(const ClassMapArgs & a, unsigned s)
+{
+  unsigned k1 = a.codes1 ? a.codes1[s] : a.cls1[s], k2 = a.codes2 ? a.codes2[s] : a.cls2[s];
+  if (k1 >= a.n1) k1 = 0;
+  if (k2 >= a.n2) k2 = 0;
+  return (unsigned long long)k1 * a.n2 + k2 + 1ULL;
+}
+
+__global__ __launch_bounds__(256) void k_class_hash_insert(ClassMapArgs a, unsigned N, unsigned long long * keys, unsigned * seen,
+                                                           unsigned mask)
+{
+  for (unsigned s = blockIdx.x * 256u + threadIdx.x; s < N; s += gridDim.x * 256u)
+  {
+    const unsigned long long key = class_key64(a, s);
+    for (unsigned h = class_hash(key, mask); ; h = (h + 1) & mask)
+    {
+      const unsigned long long old = atomicCAS(keys + h, 0ULL, key);
+      if (old == 0ULL) { seen[h] = 1u; break; }
+      if (old == key) break;
+    }
+  }
+}
+
+// ... after the prefix sum over `seen` (which then holds the class number of every occupied slot)
+__global__ __launch_bounds__(256) void k_class_hash_assign(ClassMapArgs a, unsigned N, unsigned nalloc, const unsigned long long * keys,
+                                                           const unsigned * ids, unsigned mask, unsigned * pair)
+{
+  for (unsigned s = blockIdx.x * 256u + threadIdx.x; s < nalloc; s += gridDim.x * 256u)
+  {
+    unsigned id = 0;
+    if (s < N)
+    {
+      const unsigned long long key = class_key64(a, s);
+      unsigned h = class_hash(key, mask);
+      while (keys[h] != key) h = (h + 1) & mask;
+      id = ids[h];
+    }
+    pair[s] = id;
+  }
+}
+
+// seen[k] becomes the class number of pair k (for pairs that occur); the children's classes of every class.
+// keys == nullptr: k IS the pair (table of possible pairs); else keys[k] - 1 is (hash table)
 __global__ __launch_bounds__(1024) void k_class_scan_apply(unsigned * seen, unsigned n, const unsigned * tile_sum,
-                                                           unsigned n2, unsigned * rep, unsigned rep_cap)
+                                                           unsigned n2, unsigned * rep, unsigned rep_cap,
+                                                           const unsigned long long * keys)
 {
   __shared__ unsigned part[16];
   const unsigned base = blockIdx.x * 4096u + threadIdx.x * 4u;
@@ -216,17 +269,22 @@ __global__ __launch_bounds__(1024) void k_class_scan_apply(unsigned * seen, unsi
     if (base + u < n)
     {
       seen[base + u] = id;
-      if (f[u] && id < rep_cap) { rep[2 * id] = (base + u) / n2; rep[2 * id + 1] = (base + u) % n2; }
+      if (f[u] && id < rep_cap)
+      {
+        const unsigned long long pr = keys ? keys[base + u] - 1ULL : (unsigned long long)(base + u);
+        rep[2 * id] = (unsigned)(pr / n2);
+        rep[2 * id + 1] = (unsigned)(pr % n2);
+      }
       id += f[u];
     }
 }
 
 // the class of every site.  grid = chunks, block = 256
 __global__ __launch_bounds__(256) void k_class_assign(ClassMapArgs a, unsigned N, unsigned nalloc, const unsigned * ids,
-                                                      unsigned short * pair)
+                                                      unsigned * pair)
 {
   for (unsigned s = blockIdx.x * 256u + threadIdx.x; s < nalloc; s += gridDim.x * 256u)
-    pair[s] = s < N ? (unsigned short)ids[class_key(a, s)] : (unsigned short)0;
+    pair[s] = s < N ? ids[class_key(a, s)] : 0u;
 }
 
 // lookup tables of the wide tips of a traversal.  grid = (pair blocks / 4, jobs), block = 256,
@@ -264,7 +322,7 @@ __global__ __launch_bounds__(256) void k_pair_lut(const PairLutJob * jobs)
 }
 
 // the site-indexed vector of a cherry, for a reader that needs it.  grid = site blocks / 4, block = 256
-__global__ __launch_bounds__(256) void k_cherry_expand(const double * table, const unsigned short * pair,
+__global__ __launch_bounds__(256) void k_cherry_expand(const double * table, const unsigned * pair,
                                                        unsigned nblk, unsigned R, double * clv)
 {
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -338,7 +396,7 @@ __global__ __launch_bounds__(256) void k_pair_lut_s4(const PairLutJob * jobs, un
 }
 
 // the site-indexed vector of a cherry: grid-stride over (site, rate) columns
-__global__ __launch_bounds__(256) void k_cherry_expand_s4(const double * table, const unsigned short * pair,
+__global__ __launch_bounds__(256) void k_cherry_expand_s4(const double * table, const unsigned * pair,
                                                           unsigned N, unsigned R, double * clv)
 {
   const unsigned long long total = (unsigned long long)N * R;

@@ -436,9 +436,9 @@ __device__ inline void s20_child_inner_c(const double * unit, const double * cfr
   s20_child_regs_c(b, cfrag_r, lane, t);
 }
 
-__device__ inline const unsigned short * s20_wide_codes(const double * clv, const uint8_t * codes, const double * pfrag)
+__device__ inline const unsigned * s20_wide_codes(const double * clv, const uint8_t * codes, const double * pfrag)
 {
-  return (!clv && !codes) ? reinterpret_cast<const unsigned short *>(pfrag) : nullptr;
+  return (!clv && !codes) ? reinterpret_cast<const unsigned *>(pfrag) : nullptr;
 }
 
 // one operation for one site block; X holds the handed-over operand on entry (when
@@ -457,9 +457,9 @@ __device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2
   const size_t site0 = (size_t)blk * S20_BS + 2 * n;
   unsigned c1e = 0, c1o = 0, c2e = 0, c2o = 0;
   // a "wide tip" (kernels_repeats.hpp: a cherry known per class of sites): neither vector nor byte codes; the
-  // pfrag field holds its 16-bit class codes, lut its table, childN_index the rows of that table
-  const unsigned short * w1 = s20_wide_codes(op.clv1, op.codes1, op.pfrag1);
-  const unsigned short * w2 = s20_wide_codes(op.clv2, op.codes2, op.pfrag2);
+  // pfrag field holds its class codes (32 bits each), lut its table, childN_index the rows of that table
+  const unsigned * w1 = s20_wide_codes(op.clv1, op.codes1, op.pfrag1);
+  const unsigned * w2 = s20_wide_codes(op.clv2, op.codes2, op.pfrag2);
   if (op.codes1) { c1e = op.codes1[site0]; c1o = op.codes1[site0 + 1]; }
   else if (w1) { c1e = w1[site0]; c1o = w1[site0 + 1]; }
   if (op.codes2) { c2e = op.codes2[site0]; c2o = op.codes2[site0 + 1]; }

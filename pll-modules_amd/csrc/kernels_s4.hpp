@@ -271,8 +271,8 @@ __device__ inline void s4_chain_step(const OpDesc & op, unsigned carried, const 
   constexpr unsigned T2 = R * S4_LUT_RS, M1 = 2 * R * S4_LUT_RS, M2 = 2 * R * S4_LUT_RS + R * 16;
   // a "wide tip" (kernels_repeats.hpp: a cherry known per class of sites): neither vector nor byte codes; pfrag
   // holds its 16-bit class codes, lut its table [rate][class][4], childN_index the classes
-  const unsigned short * w1 = (!op.clv1 && !op.codes1) ? reinterpret_cast<const unsigned short *>(op.pfrag1) : nullptr;
-  const unsigned short * w2 = (!op.clv2 && !op.codes2) ? reinterpret_cast<const unsigned short *>(op.pfrag2) : nullptr;
+  const unsigned * w1 = (!op.clv1 && !op.codes1) ? reinterpret_cast<const unsigned *>(op.pfrag1) : nullptr;
+  const unsigned * w2 = (!op.clv2 && !op.codes2) ? reinterpret_cast<const unsigned *>(op.pfrag2) : nullptr;
   const bool tip1 = op.codes1 || w1, tip2 = op.codes2 || w2;
   HalfP p1 = {}, p2 = {};
   if (!tip1) p1 = s4_load_half_p(base + M1, r, h);

@@ -1104,12 +1104,15 @@ struct RepeatPlan
   unsigned ncodes = 0;
 };
 
-// limits of the class numbering: pairs of child classes (libpll's PLL_REPEATS_LOOKUP_SIZE plays this role in
-// pll_update_repeats), classes of a node (16-bit class codes per site), and how much smaller than the alignment a
-// class table has to be for the node to be worth it
+// limits of the class numbering: pairs of child classes that go through a table of all possible pairs (libpll's
+// PLL_REPEATS_LOOKUP_SIZE plays this role in pll_update_repeats; more pairs: a hash table of the pairs that occur, as
+// long as its slots fit the prefix sum), and how much smaller than the alignment a class table has to be for the
+// node to be worth it (the class pipeline writes and gathers rows per class child: no gain from about a third)
+// (measured on one box, ms per traversal at ratio 16 / 8 / 4 / 3: C3 random 22.98 / 23.09 / 22.14 / 22.65, simulated
+// 20.92 / 20.68 / 18.75 / 18.71; C2 random 1.976 / 1.973 / 1.990 / 2.115, simulated 1.864 / 1.857 / 2.019 / 2.191:
+// the 128-byte vectors of 4 states leave less to win per site than the codes and counts of a class node cost)
 constexpr unsigned long long CLASS_MAX_PAIRS = 1024ULL * 4096ULL;
-constexpr unsigned CLASS_MAX = 65536u;
-constexpr unsigned CLASS_MIN_RATIO = 4u;
+constexpr unsigned CLASS_MIN_RATIO_S20 = 4u, CLASS_MIN_RATIO_S4 = 8u;
 
 static bool cherry_storage(Engine * e, unsigned node, unsigned nclasses)
 {
@@ -1162,7 +1165,7 @@ static bool class_map(Engine * e, unsigned node, unsigned c1, unsigned c2, unsig
   c.child_version[0] = class_child_version(e, c1); c.child_version[1] = class_child_version(e, c2);
   c.version = ++e->class_clock;
   e->plan.key.clear();
-  if (!pairs || pairs > CLASS_MAX_PAIRS) return false;
+  if (!pairs) return false;
   failed = true;
   if (!c.pair && !dev_alloc(&c.pair, (size_t)e->Nalloc, "class codes")) return false;
   ClassMapArgs a;
@@ -1175,7 +1178,6 @@ static bool class_map(Engine * e, unsigned node, unsigned c1, unsigned c2, unsig
   if (c1 < e->tips && c2 < e->tips)
   {
     // a cherry: every code pair is a class
-    if (pairs > CLASS_MAX) { failed = false; return false; }
     hipLaunchKernelGGL(k_class_cherry, gs, dim3(256), 0, e->stream, a, e->Nalloc, c.pair);
     if (hipGetLastError() != hipSuccess) { set_error(PLL_ERROR_HIP_RUNTIME, "class map launch failed"); return false; }
     c.nclasses = (unsigned)pairs;
@@ -1184,8 +1186,21 @@ static bool class_map(Engine * e, unsigned node, unsigned c1, unsigned c2, unsig
     failed = false;
     return true;
   }
-  // scratch: seen[pairs] | tile sums [1024] | total
-  const size_t words = (size_t)pairs + 1024 + 1;
+  // the pairs that occur are numbered through a table of all pairs, or through a hash table of 2 N .. 4 N slots
+  static const unsigned env_ratio = getenv("PLLHIP_CLASS_MIN_RATIO") ? (unsigned)std::max(1, atoi(getenv("PLLHIP_CLASS_MIN_RATIO"))) : 0u;
+  const unsigned ratio = env_ratio ? env_ratio : (e->family == KernelFamily::S4 ? CLASS_MIN_RATIO_S4 : CLASS_MIN_RATIO_S20);
+  const unsigned max_classes = (unsigned)std::min<unsigned long long>(pairs, e->N / ratio);
+  const bool hashed = pairs > CLASS_MAX_PAIRS;
+  unsigned long long slots = pairs;
+  if (hashed)
+  {
+    slots = 1024;
+    while (slots < 2ULL * e->N) slots <<= 1;
+    if (slots > CLASS_MAX_PAIRS) { failed = false; return false; }       // (alignments beyond 2 M sites: not numbered)
+  }
+  if (!max_classes) { failed = false; return false; }
+  // scratch: seen[slots] | tile sums [1024] | total | (hashed) keys[slots], 8-byte aligned
+  const size_t words = (size_t)slots + 1024 + 4 + (hashed ? 2 * (size_t)slots : 0);
   if (e->class_seen_cap < words)
   {
     if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
@@ -1195,28 +1210,36 @@ static bool class_map(Engine * e, unsigned node, unsigned c1, unsigned c2, unsig
   }
   if (!e->h_class_total && !hip_ok(hipHostMalloc(reinterpret_cast<void **>(&e->h_class_total), sizeof(unsigned), hipHostMallocDefault), "hipHostMalloc"))
     return false;
-  const unsigned rep_cap = (unsigned)std::min<unsigned long long>(pairs, CLASS_MAX);
-  if (c.rep_cap < rep_cap)
+  if (c.rep_cap < max_classes)
   {
     if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
     (void)hipFree(c.rep); c.rep = nullptr; c.rep_cap = 0;
-    if (!dev_alloc(&c.rep, 2 * (size_t)rep_cap, "class children")) return false;
-    c.rep_cap = rep_cap;
+    if (!dev_alloc(&c.rep, 2 * (size_t)max_classes, "class children")) return false;
+    c.rep_cap = max_classes;
   }
-  unsigned * seen = e->d_class_seen, * tiles = seen + pairs, * total = tiles + 1024;
-  const unsigned ntiles = (unsigned)((pairs + 4095) / 4096);
-  if (!hip_ok(hipMemsetAsync(seen, 0, (size_t)pairs * sizeof(unsigned), e->stream), "memset class scratch")) return false;
-  hipLaunchKernelGGL(k_class_mark, gs, dim3(256), 0, e->stream, a, e->N, seen);
-  hipLaunchKernelGGL(k_class_scan_tiles, dim3(ntiles), dim3(1024), 0, e->stream, seen, (unsigned)pairs, tiles);
+  unsigned * seen = e->d_class_seen, * tiles = seen + slots, * total = tiles + 1024;
+  unsigned long long * keys = hashed ? reinterpret_cast<unsigned long long *>(seen + ((slots + 1024 + 2 + 1) & ~(size_t)1)) : nullptr;
+  const unsigned ntiles = (unsigned)((slots + 4095) / 4096), mask = (unsigned)(slots - 1);
+  if (!hip_ok(hipMemsetAsync(seen, 0, (size_t)slots * sizeof(unsigned), e->stream), "memset class scratch")) return false;
+  if (hashed)
+  {
+    if (!hip_ok(hipMemsetAsync(keys, 0, (size_t)slots * sizeof(unsigned long long), e->stream), "memset class scratch")) return false;
+    hipLaunchKernelGGL(k_class_hash_insert, gs, dim3(256), 0, e->stream, a, e->N, keys, seen, mask);
+  }
+  else hipLaunchKernelGGL(k_class_mark, gs, dim3(256), 0, e->stream, a, e->N, seen);
+  hipLaunchKernelGGL(k_class_scan_tiles, dim3(ntiles), dim3(1024), 0, e->stream, seen, (unsigned)slots, tiles);
   hipLaunchKernelGGL(k_class_scan_top, dim3(1), dim3(1024), 0, e->stream, tiles, ntiles, total);
-  hipLaunchKernelGGL(k_class_scan_apply, dim3(ntiles), dim3(1024), 0, e->stream, seen, (unsigned)pairs, tiles, n2, c.rep, c.rep_cap);
+  hipLaunchKernelGGL(k_class_scan_apply, dim3(ntiles), dim3(1024), 0, e->stream, seen, (unsigned)slots, tiles, n2, c.rep, c.rep_cap,
+                     (const unsigned long long *)keys);
   if (hipGetLastError() != hipSuccess) { set_error(PLL_ERROR_HIP_RUNTIME, "class map launch failed"); return false; }
   if (!hip_ok(hipMemcpyAsync(e->h_class_total, total, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream), "class count") ||
       !hip_ok(hipStreamSynchronize(e->stream), "class count")) return false;
   failed = false;
   c.nclasses = *e->h_class_total;
-  if (!c.nclasses || c.nclasses > CLASS_MAX || (unsigned long long)c.nclasses * CLASS_MIN_RATIO > e->N) return false;
-  hipLaunchKernelGGL(k_class_assign, gs, dim3(256), 0, e->stream, a, e->N, e->Nalloc, (const unsigned *)seen, c.pair);
+  if (!c.nclasses || c.nclasses > max_classes) return false;
+  if (hashed) hipLaunchKernelGGL(k_class_hash_assign, gs, dim3(256), 0, e->stream, a, e->N, e->Nalloc, (const unsigned long long *)keys,
+                                 (const unsigned *)seen, mask, c.pair);
+  else hipLaunchKernelGGL(k_class_assign, gs, dim3(256), 0, e->stream, a, e->N, e->Nalloc, (const unsigned *)seen, c.pair);
   if (hipGetLastError() != hipSuccess) { set_error(PLL_ERROR_HIP_RUNTIME, "class map launch failed"); failed = true; return false; }
   c.trackable = true;
   return true;
@@ -1466,7 +1489,7 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
           // wide tip: no vector, no byte codes; pfrag = class codes, lut = its table, childN_index = table rows
           if (x) { po.d.clv2 = nullptr; po.d.codes2 = nullptr; po.d.pfrag2 = reinterpret_cast<const double *>(c.pair); po.d.lut2 = job.out; po.d.child2_index = c.nclasses; }
           else   { po.d.clv1 = nullptr; po.d.codes1 = nullptr; po.d.pfrag1 = reinterpret_cast<const double *>(c.pair); po.d.lut1 = job.out; po.d.child1_index = c.nclasses; }
-          wide_saved += (double)e->N * e->R * 8.0 * e->S - 2.0 * e->N;      // class codes instead of the vector
+          wide_saved += (double)e->N * e->R * 8.0 * e->S - 4.0 * e->N;      // class codes instead of the vector
         }
         // the handed-over child stays in registers: neither its vector nor its scaler counts are read
         dp.min_bytes += dp.algo_bytes - before - wide_saved;
@@ -1556,7 +1579,7 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
           double ab = 0.0;
           fill_desc(e, o, dummy, ab, dp.algo_flops);
           dp.algo_bytes += ab;
-          dp.min_bytes += 2.0 * e->N + 2.0 * e->N + (j.parent_scaler ? 4.0 * e->N * (1 + (j.scaler1 ? 1 : 0) + (j.scaler2 ? 1 : 0)) : 0.0);
+          dp.min_bytes += 2.0 * e->N + 4.0 * e->N + (j.parent_scaler ? 4.0 * e->N * (1 + (j.scaler1 ? 1 : 0) + (j.scaler2 ? 1 : 0)) : 0.0);
           ++nops_virtual;
         }
         L.job_end = (unsigned)cherry_jobs.size();
