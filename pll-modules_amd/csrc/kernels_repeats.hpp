@@ -21,8 +21,8 @@
 // Second step: classes of whole subtrees.  A node both of whose children are known per class (tips, cherries, or
 // nodes of this kind) is known per class itself: the class of a site is the pair (class below child 1, class below
 // child 2).  The pairs that occur are numbered densely on the device once per topology (k_class_mark, a prefix sum,
-// k_class_assign: what libpll's pll_update_repeats does with its lookup table, and like there only while the table
-// of possible pairs stays small), and the node's table is rows1[class of child 1] * rows2[class of child 2], where
+// k_class_assign: what libpll's pll_update_repeats does with its lookup table; when the table of possible pairs would
+// be too large, a hash table of the pairs that occur: k_class_hash_insert / _assign), and the node's table is rows1[class of child 1] * rows2[class of child 2], where
 // the rows of a tip are its lookup table and the rows of a class node are P . its table (k_pair_lut again).  The
 // frontier -- the first operation above that is computed per site -- reads its class children as wide tips.
 #pragma once
