@@ -1190,7 +1190,9 @@ static bool class_map(Engine * e, unsigned node, unsigned c1, unsigned c2, unsig
   static const unsigned env_ratio = getenv("PLLHIP_CLASS_MIN_RATIO") ? (unsigned)std::max(1, atoi(getenv("PLLHIP_CLASS_MIN_RATIO"))) : 0u;
   const unsigned ratio = env_ratio ? env_ratio : (e->family == KernelFamily::S4 ? CLASS_MIN_RATIO_S4 : CLASS_MIN_RATIO_S20);
   const unsigned max_classes = (unsigned)std::min<unsigned long long>(pairs, e->N / ratio);
-  const bool hashed = pairs > CLASS_MAX_PAIRS;
+  // (PLLHIP_CLASS_TABLE_PAIRS: the largest table of possible pairs, for tests of the hash numbering on small inputs)
+  static const unsigned long long env_pairs = getenv("PLLHIP_CLASS_TABLE_PAIRS") ? strtoull(getenv("PLLHIP_CLASS_TABLE_PAIRS"), nullptr, 10) : 0ULL;
+  const bool hashed = pairs > (env_pairs ? std::min(env_pairs, CLASS_MAX_PAIRS) : CLASS_MAX_PAIRS);
   unsigned long long slots = pairs;
   if (hashed)
   {

@@ -1,4 +1,7 @@
-"""PLL_ATTRIB_SITE_REPEATS, first step (pll-modules_amd/csrc/kernels_repeats.hpp): cherries are kept per class of
+"""(PLLHIP_CLASS_TABLE_PAIRS=64 in the environment sends every class numbering of this file through the hash table
+instead of the table of possible pairs; PLLHIP_SITE_REPEATS=2 runs the whole -m gpu suite under the attribute.)
+
+PLL_ATTRIB_SITE_REPEATS, first step (pll-modules_amd/csrc/kernels_repeats.hpp): cherries are kept per class of
 sites (pair of tip codes).  Everything a caller can observe must be identical -- bit for bit -- to the attribute
 being off: the reference's own tests run every program with and without it and compare the text
 (test/src/common.c:31, test/runtest.py:45-51)."""
