@@ -68,8 +68,9 @@ def parse_args():
                          "them (src/tree/treeinfo.c:845-865); batched = one call with count = 2n-3")
     ap.add_argument("--site-repeats", action="store_true",
                     help="PLL_ATTRIB_SITE_REPEATS (first step: cherries are computed per class of sites, not per site)")
-    ap.add_argument("--data", default="random", choices=["random", "simulated"],
-                    help="random: iid uniform tip states (seed 44); simulated: states evolved along the tree (SURVEY.md 8d, seed 45)")
+    ap.add_argument("--data", default="random", choices=["random", "simulated", "tiled"],
+                    help="random: iid uniform tip states (seed 44); simulated: states evolved along the tree (SURVEY.md 8d, seed 45); "
+                         "tiled: copies of one random 1000-site tile (the extreme of site repeats: no node has more than 1000 classes)")
     ap.add_argument("--rate-scalers", action="store_true",
                     help="PLL_ATTRIB_RATE_SCALERS: one scaling count per (site, rate) instead of per site")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
@@ -447,6 +448,11 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
             if world > 1:
                 raise SystemExit("bench.py: --data simulated is a one-GPU data set")
             codes = pc.simulated_codes(tree, p_[1], p_[0], seed=45 + k)
+        elif args.data == "tiled":
+            if world > 1:
+                raise SystemExit("bench.py: --data tiled is a one-GPU data set")
+            tile = pc.random_codes(tree.ntips, 1000, p_[0], 44 + 101 * k)
+            codes = np.tile(tile, (1, (p_[1] + 999) // 1000))[:, :p_[1]].copy()
         else:
             codes = pc.random_codes(tree.ntips, p_[1], p_[0], 44 + 101 * k, first_site=first_sites[k])
         insts.append(ev.add_partition(k, p_[0], p_[1], rate_cats, codes, subst, freqs, alpha, coded=True,

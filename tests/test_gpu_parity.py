@@ -712,6 +712,26 @@ def test_baseline_sizes_through_tiling(product, oracle, cfg, tile):
         big.tree = t2
         l_rerooted = pc.full_traversal(big)
         assert abs(l_rerooted - l_full) <= 1e-9 * abs(l_full)
+    if S == 61:
+        return
+    # ... and with PLL_ATTRIB_SITE_REPEATS: K copies of a tile are the extreme of repeats -- no node has more classes
+    # than the tile has sites, so every operation that has a consumer is computed per class, level above level up to
+    # the root edge.  Same likelihood, per-site values and scaler counts, bit for bit.
+    with pc.Instance(product, ntips, S, tile * K, R, attributes=pc.PLL_ATTRIB_PATTERN_TIP | pc.PLL_ATTRIB_SITE_REPEATS) as rep:
+        rep.set_model(subst, freqs, product.gamma_cats(alpha, R))
+        cmap = pc.state_charmap(S)
+        for k in range(ntips):
+            rep.set_tip_states(k, cmap, (np.tile(tile_codes[k], K) + 48).tobytes())
+        rep.tree = t
+        assert pc.full_traversal(rep) == l_full
+        _, persite_rep = rep.edge_lnl(t.root_a, t.scaler_of(t.root_a), t.root_b, t.scaler_of(t.root_b),
+                                      t.root_matrix, persite=True)
+        assert np.array_equal(persite_rep, persite)
+        assert np.array_equal(rep.get_scaler(t.scaler_of(t.root_a)), sc)
+        st = rep.repeat_stats()
+        assert st.cherries >= ntips - 4 and st.classes * 100 < st.sites
+        rep.tree = t2
+        assert pc.full_traversal(rep) == l_rerooted
 
 
 @pytest.mark.parametrize("states,coded", [(20, True), (4, False), (61, True), (10, False), (2, True)])
