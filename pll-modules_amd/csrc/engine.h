@@ -183,6 +183,8 @@ struct Engine
     double * table = nullptr;         // blocked pseudo-CLV over the classes
     unsigned * pair = nullptr;        // [Nalloc] class per site
     uint8_t * flags = nullptr;        // [classes] scaled?
+    unsigned * counts = nullptr;      // [classes] scaler count of the class: own decision + the counts of the children's classes
+    int scaler_index = -1;            // the scale buffer the class operation was given (PLL_SCALE_BUFFER_NONE = -1)
     unsigned cap_classes = 0;         // what table / flags were allocated for
     unsigned * rep = nullptr;         // [2 * classes] the children's classes of each class (null: a cherry, class = code1 * ncodes + code2)
     unsigned rep_cap = 0;
@@ -195,6 +197,9 @@ struct Engine
     unsigned long long version = 0;   // changes with the map
   };
   std::vector<Cherry> cherries;       // by CLV index (empty unless site_repeats)
+  // scale buffers whose per-site counts exist per class only: scaler_lazy[buffer] = the class node whose `counts`
+  // stand for it (-1: the buffer holds its counts per site); need_scaler() writes them out for a reader
+  std::vector<int> scaler_lazy;
   std::vector<unsigned long long> tip_version;    // changes with a tip's codes
   unsigned long long class_clock = 0;
   unsigned * d_class_seen = nullptr;  // [pairs of child classes] scratch of the class numbering, + tile sums + total

@@ -42,9 +42,8 @@ struct CherryJob
   unsigned nclasses;
   double * table;                    // blocked pseudo-CLV [class block][rate][unit] (4 states: [class][rate][4])
   uint8_t * flags;                   // per class: the vector was scaled
-  const unsigned * pair;             // per site: class
-  unsigned * parent_scaler;          // per site, or null
-  const unsigned * scaler1, * scaler2;   // per-site counts of the children (class nodes), or null
+  unsigned * counts;                 // per class: scaler count (own decision + the children's counts), or null: the operation has no scale buffer
+  const unsigned * cnt1, * cnt2;     // per-class counts of the children (class nodes with a scale buffer), or null
 };
 
 // one row table of a traversal: the table of a class node seen through the P-matrix of the branch above it
@@ -94,7 +93,7 @@ __global__ __launch_bounds__(256) void k_cherry_build(const CherryJob * jobs, un
     }
   }
   double fe = 1.0, fo = 1.0;
-  if (job.parent_scaler)
+  if (job.counts)
   {
     small_e = s20_and_q(small_e);
     small_o = s20_and_q(small_o);
@@ -102,8 +101,11 @@ __global__ __launch_bounds__(256) void k_cherry_build(const CherryJob * jobs, un
     fo = small_o ? SCALE_FACTOR : 1.0;
     if (q == 0)
     {
-      if (pe < npairs) flags[pe] = (uint8_t)small_e;
-      if (po < npairs) flags[po] = (uint8_t)small_o;
+      // the scaler count of the class: its own decision plus the counts of the children's classes
+      const unsigned * cnt1 = as_global(job.cnt1), * cnt2 = as_global(job.cnt2);
+      unsigned * counts = as_global(job.counts);
+      if (pe < npairs) { flags[pe] = (uint8_t)small_e; counts[pe] = (unsigned)small_e + (cnt1 ? cnt1[ae] : 0u) + (cnt2 ? cnt2[be] : 0u); }
+      if (po < npairs) { flags[po] = (uint8_t)small_o; counts[po] = (unsigned)small_o + (cnt1 ? cnt1[ao] : 0u) + (cnt2 ? cnt2[bo] : 0u); }
     }
   }
 #pragma unroll
@@ -115,22 +117,12 @@ __global__ __launch_bounds__(256) void k_cherry_build(const CherryJob * jobs, un
   }
 }
 
-// scaler counts per site: the class's own decision plus the counts below.  The jobs are in post-order and a thread
-// walks them for its sites, so the counts of a class child are there when its parent adds them.
-// grid = chunks, block = 256
-__global__ __launch_bounds__(256) void k_cherry_sites(const CherryJob * jobs, unsigned njobs, unsigned nalloc)
+// the per-site scaler counts of a class node, for a reader that needs them (the counts live per class, like the
+// vector: k_cherry_build).  grid = chunks, block = 256
+__global__ __launch_bounds__(256) void k_class_scaler_expand(const unsigned * counts, const unsigned * pair, unsigned nalloc,
+                                                             unsigned * ps)
 {
-  for (unsigned s = blockIdx.x * 256u + threadIdx.x; s < nalloc; s += gridDim.x * 256u)
-    for (unsigned j = 0; j < njobs; ++j)
-    {
-      const CherryJob & job = jobs[j];
-      unsigned * ps = job.parent_scaler;
-      if (!ps) continue;
-      unsigned cnt = job.flags[job.pair[s]];
-      if (job.scaler1) cnt += job.scaler1[s];
-      if (job.scaler2) cnt += job.scaler2[s];
-      ps[s] = cnt;
-    }
+  for (unsigned s = blockIdx.x * 256u + threadIdx.x; s < nalloc; s += gridDim.x * 256u) ps[s] = counts[pair[s]];
 }
 
 // ---------------------------------------------------------------------------
@@ -366,9 +358,11 @@ __global__ __launch_bounds__(256) void k_cherry_build_s4(const CherryJob * jobs,
       table[((size_t)p * R + r) * 4 + i] = v;
       small = small && (v < SCALE_THRESHOLD);
     }
-  if (job.parent_scaler)
+  if (job.counts)
   {
+    const unsigned * cnt1 = as_global(job.cnt1), * cnt2 = as_global(job.cnt2);
     as_global(job.flags)[p] = small ? 1 : 0;
+    as_global(job.counts)[p] = (small ? 1u : 0u) + (cnt1 ? cnt1[a] : 0u) + (cnt2 ? cnt2[b] : 0u);
     if (small)
       for (unsigned e = 0; e < R * 4; ++e) table[(size_t)p * R * 4 + e] *= SCALE_FACTOR;
   }

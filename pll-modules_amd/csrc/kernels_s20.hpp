@@ -557,14 +557,17 @@ __device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2
   {
     ce = small_e ? 1u : 0u;
     co = small_o ? 1u : 0u;
+    // (a wide tip's counts are kept per class, like its vector: indexed by the class codes)
     if (op.scaler1)
     {
       if (carried == 1) { ce += xe[0]; co += xo[0]; }
+      else if (w1) { ce += op.scaler1[c1e]; co += op.scaler1[c1o]; }
       else { ce += op.scaler1[site0]; co += op.scaler1[site0 + 1]; }
     }
     if (op.scaler2)
     {
       if (carried == 2) { ce += xe[0]; co += xo[0]; }
+      else if (w2) { ce += op.scaler2[c2e]; co += op.scaler2[c2o]; }
       else { ce += op.scaler2[site0]; co += op.scaler2[site0 + 1]; }
     }
     op.parent_scaler[site0] = ce;

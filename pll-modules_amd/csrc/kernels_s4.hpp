@@ -280,8 +280,9 @@ __device__ inline void s4_chain_step(const OpDesc & op, unsigned carried, const 
   unsigned child_cnt = 0;
   if (op.parent_scaler && nsc < N)
   {
-    if (op.scaler1) child_cnt += (carried == 1) ? xcnt : op.scaler1[nsc];
-    if (op.scaler2) child_cnt += (carried == 2) ? xcnt : op.scaler2[nsc];
+    // (a wide tip's counts are kept per class, like its vector: indexed by the class code of the site)
+    if (op.scaler1) child_cnt += (carried == 1) ? xcnt : w1 ? op.scaler1[w1[nsc]] : op.scaler1[nsc];
+    if (op.scaler2) child_cnt += (carried == 2) ? xcnt : w2 ? op.scaler2[w2[nsc]] : op.scaler2[nsc];
   }
   unsigned scaled_mask = 0;
   // the tip codes of the chunk's 64 sites: one coalesced byte load per child (lane l holds

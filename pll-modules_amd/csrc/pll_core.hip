@@ -299,6 +299,7 @@ Engine * engine_create(pll_partition_t * p)
   {
     e->cherries.assign(e->nodes, Engine::Cherry());
     e->tip_version.assign(e->tips, 0);
+    e->scaler_lazy.assign(e->nscalers, -1);
   }
   else e->site_repeats = false;                 // (first step: the 20- and the 4-state family)
   e->pmat_brlen.assign(e->nmat, std::numeric_limits<double>::quiet_NaN());
@@ -360,7 +361,7 @@ void engine_destroy(Engine * e)
   (void)hipFree(e->d_model);
   (void)hipFree(e->d_partials);
   (void)hipFree(e->d_persite);
-  for (auto & c : e->cherries) { (void)hipFree(c.table); (void)hipFree(c.pair); (void)hipFree(c.flags); (void)hipFree(c.rep); }
+  for (auto & c : e->cherries) { (void)hipFree(c.table); (void)hipFree(c.pair); (void)hipFree(c.flags); (void)hipFree(c.rep); (void)hipFree(c.counts); }
   (void)hipFree(e->d_class_seen);
   if (e->h_class_total) (void)hipHostFree(e->h_class_total);
   (void)hipFree(e->d_pairlut);
@@ -1076,11 +1077,27 @@ static int upload_plan(DevicePlan & dp, hipStream_t stream, PlanView & view)
 // ---------------------------------------------------------------------------
 // site repeats (kernels_repeats.hpp): host side
 // ---------------------------------------------------------------------------
-// a reader needs the site-indexed vector of `idx`: expand it if the node is a cherry kept per class
+// a reader needs the per-site counts of scale buffer `sidx`: written out if they exist per class only
+static int need_scaler(Engine * e, int sidx)
+{
+  if (sidx < 0 || (size_t)sidx >= e->scaler_lazy.size() || e->scaler_lazy[sidx] < 0) return PLL_SUCCESS;
+  const Engine::Cherry & c = e->cherries[e->scaler_lazy[sidx]];
+  hipLaunchKernelGGL(k_class_scaler_expand, dim3(std::max(1u, std::min((e->Nalloc + 255u) / 256u, 4u * e->cu_count))), dim3(256), 0,
+                     e->stream, (const unsigned *)c.counts, (const unsigned *)c.pair, e->Nalloc,
+                     e->d_scalers + (size_t)sidx * e->sc_len);
+  PLLHIP_TRY(hipGetLastError());
+  e->scaler_lazy[sidx] = -1;
+  return PLL_SUCCESS;
+}
+
+// a reader needs the site-indexed vector of `idx` (and the per-site counts that go with it): expand them if the node
+// is kept per class
 static int need_clv(Engine * e, unsigned idx)
 {
   if (e->cherries.empty() || idx >= e->cherries.size()) return PLL_SUCCESS;
   Engine::Cherry & c = e->cherries[idx];
+  if (c.valid && c.scaler_index >= 0 && (size_t)c.scaler_index < e->scaler_lazy.size() && e->scaler_lazy[c.scaler_index] == (int)idx &&
+      !need_scaler(e, c.scaler_index)) return PLL_FAILURE;
   if (!c.valid || c.materialized) return PLL_SUCCESS;
   if (e->family == KernelFamily::S4)
     hipLaunchKernelGGL(k_cherry_expand_s4, dim3(std::max(1u, std::min((e->N * e->R + 255u) / 256u, e->cu_count * 8u))), dim3(256), 0,
@@ -1123,11 +1140,12 @@ static bool cherry_storage(Engine * e, unsigned node, unsigned nclasses)
   if (c.cap_classes < nclasses)
   {
     if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
-    (void)hipFree(c.table); (void)hipFree(c.flags);
-    c.table = nullptr; c.flags = nullptr; c.cap_classes = 0;
+    (void)hipFree(c.table); (void)hipFree(c.flags); (void)hipFree(c.counts);
+    c.table = nullptr; c.flags = nullptr; c.counts = nullptr; c.cap_classes = 0;
     e->plan.key.clear();                          // cached schedules point at the old tables
     if (!dev_alloc(&c.table, table_doubles, "class table") ||
         !dev_alloc(&c.flags, (size_t)npblk * S20_BS, "class flags") ||
+        !dev_alloc(&c.counts, (size_t)npblk * S20_BS, "class scaler counts") ||
         !hip_ok(hipMemsetAsync(c.flags, 0, (size_t)npblk * S20_BS, e->stream), "memset flags"))
       return false;
     c.cap_classes = nclasses;
@@ -1310,12 +1328,18 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
     for (unsigned k = 0; k < count; ++k)
     {
       const unsigned child[2] = {ops[k].child1_clv_index, ops[k].child2_clv_index};
+      const int child_scaler[2] = {ops[k].child1_scaler_index, ops[k].child2_scaler_index};
       for (int x = 0; x < 2; ++x)
       {
+        // (counts of a buffer that another class node stands for: written out first)
+        if (child_scaler[x] >= 0 && e->scaler_lazy[child_scaler[x]] >= 0 && e->scaler_lazy[child_scaler[x]] != (int)child[x] &&
+            !need_scaler(e, child_scaler[x])) return false;
         if (child[x] < e->tips || made[child[x]] || !e->cherries[child[x]].valid) continue;
         // (a cherry built under another code table -- a tip has taken a new ambiguity code since -- is read
-        // through its expanded vector: its classes are not the ones this schedule indexes)
-        if (e->cherries[child[x]].ncodes == lut_used) { wide[2 * k + x] = 1; ++nwide; }
+        // through its expanded vector: its classes are not the ones this schedule indexes; so is a class node whose
+        // counts are asked for under another scale buffer than the one its operation wrote)
+        const Engine::Cherry & cc = e->cherries[child[x]];
+        if (cc.ncodes == lut_used && (child_scaler[x] == cc.scaler_index)) { wide[2 * k + x] = 1; ++nwide; }
         else if (!need_clv(e, child[x])) return false;
       }
       made[ops[k].parent_clv_index] = 1;
@@ -1489,8 +1513,11 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
           pairlut_used += (size_t)e->R * c.nclasses * e->S;
           pair_jobs.push_back(job);
           // wide tip: no vector, no byte codes; pfrag = class codes, lut = its table, childN_index = table rows
-          if (x) { po.d.clv2 = nullptr; po.d.codes2 = nullptr; po.d.pfrag2 = reinterpret_cast<const double *>(c.pair); po.d.lut2 = job.out; po.d.child2_index = c.nclasses; }
-          else   { po.d.clv1 = nullptr; po.d.codes1 = nullptr; po.d.pfrag1 = reinterpret_cast<const double *>(c.pair); po.d.lut1 = job.out; po.d.child1_index = c.nclasses; }
+          // (... and its scaler counts per class)
+          if (x) { po.d.clv2 = nullptr; po.d.codes2 = nullptr; po.d.pfrag2 = reinterpret_cast<const double *>(c.pair); po.d.lut2 = job.out; po.d.child2_index = c.nclasses;
+                   if (po.d.scaler2) po.d.scaler2 = c.counts; }
+          else   { po.d.clv1 = nullptr; po.d.codes1 = nullptr; po.d.pfrag1 = reinterpret_cast<const double *>(c.pair); po.d.lut1 = job.out; po.d.child1_index = c.nclasses;
+                   if (po.d.scaler1) po.d.scaler1 = c.counts; }
           wide_saved += (double)e->N * e->R * 8.0 * e->S - 4.0 * e->N;      // class codes instead of the vector
         }
         // the handed-over child stays in registers: neither its vector nor its scaler counts are read
@@ -1566,13 +1593,14 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
               L.max_rows = std::max(L.max_rows, cc.nclasses);
               rows = pj.out; nrows = cc.nclasses;
             }
-            if (x) { j.lut2 = rows; j.rows2 = nrows; j.scaler2 = scaler_ptr(e, child_scaler[x]); }
-            else   { j.lut1 = rows; j.rows1 = nrows; j.scaler1 = scaler_ptr(e, child_scaler[x]); }
+            const unsigned * cnt = (child[x] >= e->tips && child_scaler[x] >= 0) ? e->cherries[child[x]].counts : nullptr;
+            if (x) { j.lut2 = rows; j.rows2 = nrows; j.cnt2 = cnt; }
+            else   { j.lut1 = rows; j.rows1 = nrows; j.cnt1 = cnt; }
           }
           j.rep = c.rep;
           j.nclasses = c.nclasses;
-          j.table = c.table; j.flags = c.flags; j.pair = c.pair;
-          j.parent_scaler = const_cast<unsigned *>(scaler_ptr(e, o.parent_scaler_index));
+          j.table = c.table; j.flags = c.flags;
+          j.counts = o.parent_scaler_index >= 0 ? c.counts : nullptr;
           cherry_jobs.push_back(j);
           L.max_classes = std::max(L.max_classes, c.nclasses);
           dp.repeat_classes += c.nclasses;
@@ -1581,7 +1609,7 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
           double ab = 0.0;
           fill_desc(e, o, dummy, ab, dp.algo_flops);
           dp.algo_bytes += ab;
-          dp.min_bytes += 2.0 * e->N + 4.0 * e->N + (j.parent_scaler ? 4.0 * e->N * (1 + (j.scaler1 ? 1 : 0) + (j.scaler2 ? 1 : 0)) : 0.0);
+          dp.min_bytes += 2.0 * e->N + 4.0 * e->N;            // (tip codes in once per topology; a class code per site for the consumer)
           ++nops_virtual;
         }
         L.job_end = (unsigned)cherry_jobs.size();
@@ -1698,13 +1726,26 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
   {
     // every vector this list writes stops being the cherry it may have been; one that the list reads first
     // (and that exists per class only) is expanded before it goes
-    std::vector<char> read(e->nodes, 0);
+    // ... and the same for scale buffers whose counts exist per class only
+    std::vector<char> read(e->nodes, 0), sread(e->nscalers, 0);
     for (unsigned k = 0; k < count; ++k)
     {
       read[ops[k].child1_clv_index] = read[ops[k].child2_clv_index] = 1;
+      if (ops[k].child1_scaler_index >= 0) sread[ops[k].child1_scaler_index] = 1;
+      if (ops[k].child2_scaler_index >= 0) sread[ops[k].child2_scaler_index] = 1;
       Engine::Cherry & c = e->cherries[ops[k].parent_clv_index];
       if (c.valid && read[ops[k].parent_clv_index] && !need_clv(e, ops[k].parent_clv_index)) return PLL_FAILURE;
+      // the node stops being a class node: counts it stands for under a buffer this operation does not rewrite
+      // are written out while its table still describes them
+      if (c.valid && c.scaler_index >= 0 && e->scaler_lazy[c.scaler_index] == (int)ops[k].parent_clv_index &&
+          c.scaler_index != ops[k].parent_scaler_index && !need_scaler(e, c.scaler_index)) return PLL_FAILURE;
       c.valid = false;
+      const int sp = ops[k].parent_scaler_index;
+      if (sp >= 0 && e->scaler_lazy[sp] >= 0)
+      {
+        if (sread[sp] && !need_scaler(e, sp)) return PLL_FAILURE;
+        e->scaler_lazy[sp] = -1;
+      }
     }
   }
   for (unsigned k = 0; k < count; ++k)
@@ -1758,6 +1799,16 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
     e->prof_min_bytes += (min_bytes >= 0.0) ? min_bytes : bytes;
     e->prof_flops += flops;
     e->prof_ops += nops;
+    return PLL_SUCCESS;
+  };
+
+  // the paths that read child scaler counts per site (everything but the resident schedules, whose wide tips read
+  // them per class): counts that exist per class only are written out first
+  auto plain_scalers = [&]() -> int
+  {
+    if (e->scaler_lazy.empty()) return PLL_SUCCESS;
+    for (unsigned k = 0; k < count; ++k)
+      if (!need_scaler(e, ops[k].child1_scaler_index) || !need_scaler(e, ops[k].child2_scaler_index)) return PLL_FAILURE;
     return PLL_SUCCESS;
   };
 
@@ -1832,7 +1883,8 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
             else
             {
               const Engine::Cherry & cc = e->cherries[child[x]];
-              ok = (now[child[x]] || cc.valid) && cc.map_valid && cc.trackable && cc.ncodes == lut_used;
+              ok = (now[child[x]] || cc.valid) && cc.map_valid && cc.trackable && cc.ncodes == lut_used &&
+                   child_scaler[x] == cc.scaler_index;          // (its counts per class are the ones asked for)
             }
           }
           if (ok)
@@ -1847,6 +1899,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
             if (!cherry_storage(e, o.parent_clv_index, c.nclasses)) return PLL_FAILURE;
             c.valid = true;
             c.materialized = false;
+            c.scaler_index = o.parent_scaler_index;
             now[o.parent_clv_index] = 1;
             rp.cherry_ops.push_back(k);
           }
@@ -1870,19 +1923,13 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
         if (!upload_plan(e->plan, e->stream, view)) return PLL_FAILURE;
         if (dp.ncherry_jobs || dp.npair_jobs)
         {
-          // level by level: the row tables of the class children of a level, then the tables of the level; the last
-          // entry holds the row tables of the wide tips of the chains.  The scaler counts follow the tables.
+          // level by level: the row tables of the class children of a level, then the tables of the level (with the
+          // scaler counts per class); the last entry holds the row tables of the wide tips of the chains
           const CherryJob * cj = reinterpret_cast<const CherryJob *>(dp.d_buf + dp.off_cherry_jobs);
           const PairLutJob * pj = reinterpret_cast<const PairLutJob *>(dp.d_buf + dp.off_pair_jobs);
           for (size_t lv = 0; lv < dp.repeat_levels.size(); ++lv)
           {
             const DevicePlan::RepeatLevel & L = dp.repeat_levels[lv];
-            if (lv + 1 == dp.repeat_levels.size() && dp.ncherry_jobs)
-            {
-              hipLaunchKernelGGL(k_cherry_sites, dim3(std::max(1u, std::min((e->Nalloc + 255u) / 256u, 4u * e->cu_count))), dim3(256), 0,
-                                 e->stream, cj, dp.ncherry_jobs, e->Nalloc);
-              PLLHIP_TRY(hipGetLastError());
-            }
             if (L.pair_end > L.pair_begin)
             {
               const unsigned njobs = L.pair_end - L.pair_begin, npblk = (L.max_rows + S20_BS - 1) / S20_BS;
@@ -1907,6 +1954,10 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
               PLLHIP_TRY(hipGetLastError());
             }
           }
+          // the scale buffers of the class operations hold their counts per class from now on (need_scaler)
+          if (rp.active)
+            for (unsigned k : rp.cherry_ops)
+              if (ops[k].parent_scaler_index >= 0) e->scaler_lazy[ops[k].parent_scaler_index] = (int)ops[k].parent_clv_index;
           e->repeat_stats.cherries += dp.ncherry_jobs;
           e->repeat_stats.classes += dp.repeat_classes;
           e->repeat_stats.sites += (unsigned long long)dp.ncherry_jobs * e->N;
@@ -1929,6 +1980,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
       }
       plan = ChainPlan();
     }
+    if (!plain_scalers()) return PLL_FAILURE;
     if (!chains16 && plan_chains(e, ops, count, chain_max, chain_lds, lut_used, plan))
     {
       for (int round = 0; round < plan.rounds; ++round)
@@ -2002,6 +2054,8 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
       return PLL_SUCCESS;
     }
   }
+
+  if (!plain_scalers()) return PLL_FAILURE;
 
   // 61 states.  (1) Cherries -- tip x tip operations, bound by HBM writes while the matrix cores
   // idle -- are folded into the operation that consumes them (kernels_s61.hpp, k_partials_s61v4).
@@ -2592,6 +2646,7 @@ double loglikelihood_impl(pll_partition_t * p, unsigned pc, int psc, unsigned cc
   }
   if (!sync_model(p) || !flush_pmatrices(p) || !ensure_luts(p) || !ensure_invariant(p)) return fail;
   if (!need_clv(e, pc) || (matrix_index >= 0 && !need_clv(e, cc))) return fail;
+  if (!need_scaler(e, psc) || (matrix_index >= 0 && !need_scaler(e, csc))) return fail;
   // ascertainment-bias correction: the kernel runs over alignment + constant patterns (the
   // latter weigh 0 on the device), the per-site values of the constant patterns come back
   // through the mapped result buffer and the host adds the closed-form correction
@@ -2810,6 +2865,7 @@ int derivatives_impl(pll_partition_t * p, int parent_scaler_index, int child_sca
     return PLL_FAILURE;
   }
   if (!sync_model(p) || !ensure_invariant(p)) return PLL_FAILURE;
+  if (!need_scaler(e, parent_scaler_index) || !need_scaler(e, child_scaler_index)) return PLL_FAILURE;
   const unsigned nblocks = (e->blocked || e->family == KernelFamily::S4) ? scan_grid(e) : reduce_grid(e);
   const ModelView mv = model_view(e);
   const ParamIdx params = make_params(p, params_indices);
@@ -3001,6 +3057,7 @@ int pllhip_newton_branch(pll_partition_t * p, int parent_scaler_index, int child
     return PLL_FAILURE;
   }
   if (!sync_model(p) || !ensure_invariant(p)) return PLL_FAILURE;
+  if (!need_scaler(e, parent_scaler_index) || !need_scaler(e, child_scaler_index)) return PLL_FAILURE;
   // the scan's own grid (derivatives_impl): the block totals, and with them every bit of the sums, are the same
   const unsigned nblocks = scan_grid(e);
   const void * fn = nullptr;
@@ -3332,6 +3389,7 @@ int pllhip_get_scaler(pll_partition_t * p, unsigned int idx, unsigned int * out)
   PLLHIP_TRY(hipSetDevice(e->device));
   if (idx >= e->nscalers) { set_error(PLL_ERROR_PARAM_INVALID, "scaler index out of range"); return PLL_FAILURE; }
   if (!e->N) return PLL_SUCCESS;
+  if (!need_scaler(e, (int)idx)) return PLL_FAILURE;
   PLLHIP_TRY(hipMemcpyAsync(out, e->d_scalers + (size_t)idx * e->sc_len,
                             sizeof(unsigned) * e->N * (e->rate_scalers ? e->R : 1),
                             hipMemcpyDeviceToHost, e->stream));
@@ -3352,6 +3410,7 @@ int pllhip_set_scaler(pll_partition_t * p, unsigned int idx, const unsigned int 
   PLLHIP_TRY(hipSetDevice(e->device));
   if (idx >= e->nscalers) { set_error(PLL_ERROR_PARAM_INVALID, "scaler index out of range"); return PLL_FAILURE; }
   if (!e->N) return PLL_SUCCESS;
+  if (idx < e->scaler_lazy.size()) e->scaler_lazy[idx] = -1;         // the caller's counts replace whatever stood for the buffer
   PLLHIP_TRY(hipMemcpyAsync(e->d_scalers + (size_t)idx * e->sc_len, in,
                             sizeof(unsigned) * e->N * (e->rate_scalers ? e->R : 1),
                             hipMemcpyHostToDevice, e->stream));
