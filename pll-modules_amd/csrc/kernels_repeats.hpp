@@ -8,7 +8,8 @@
 // the same structure at the end of this file, the 4-state family) therefore
 //   * computes a cherry's vector per code pair (k_cherry_build: the arithmetic of the tip x tip operation on a
 //     "pseudo alignment" whose sites are the pairs; a few hundred KiB that stay in the caches) and writes per site
-//     only the class code and the scaler count (k_cherry_sites: 8 B instead of 640 B per site);
+//     only the class code (4 B instead of 640 B; the scaler counts live per class as well and are written out per
+//     site, k_class_scaler_expand, only for a reader that needs them);
 //   * hands the cherry to the operation above it as a "wide tip": a child read through a lookup table with one row
 //     per class, [rate][class][20] = P . vector(class), built per traversal on the matrix cores with the very MFMA
 //     sequence an inner child takes (k_pair_lut) -- so the operation's result is, bit for bit, what it computes
