@@ -2806,6 +2806,24 @@ static int newton_capacity(Engine * e, const void ** fn_out, size_t * lds_out)
                             : reinterpret_cast<const void *>(k_newton_mfma_resident<S61_KS, 0, 1, 1>);
         nb = 1;
       }
+      else if (e->family == KernelFamily::S16)
+      {
+        // 2 .. 32 states: as many blocks in registers as ~240 of them hold (16 KS per block), one more in LDS
+#define PLLHIP_RES(KK, NBR) do { rfn = reinterpret_cast<const void *>(k_newton_mfma_resident<KK, 0, NBR + 1, NBR>); nb = NBR + 1; \
+                                 res_lds = lds + sizeof(double2) * 4 * 4 * KK * 64; } while (0)
+        switch (ks)
+        {
+          case 1: PLLHIP_RES(1, 7); break;
+          case 2: PLLHIP_RES(2, 7); break;
+          case 3: PLLHIP_RES(3, 5); break;
+          case 4: PLLHIP_RES(4, 3); break;
+          case 5: PLLHIP_RES(5, 3); break;
+          case 6: PLLHIP_RES(6, 2); break;
+          case 7: PLLHIP_RES(7, 2); break;
+          default: PLLHIP_RES(8, 1); break;
+        }
+#undef PLLHIP_RES
+      }
     }
     if (rfn)
     {

@@ -431,7 +431,7 @@ def _host_newton(deriv, x, bl_min, bl_max, tol, max_newton):
 @pytest.mark.gpu
 @pytest.mark.parametrize("states,nsites,pinv", [(20, 5000, 0.0), (20, 333, 0.1), (61, 700, 0.0), (10, 2000, 0.0),
                                                 (24, 1500, 0.0), (62, 300, 0.0), (2, 4000, 0.0),
-                                                (4, 5000, 0.0), (4, 777, 0.2), (4, 200_000, 0.0), (20, 120_000, 0.0)])
+                                                (4, 5000, 0.0), (4, 777, 0.2), (4, 200_000, 0.0), (20, 120_000, 0.0), (10, 150_000, 0.0)])
 def test_device_newton_makes_the_host_loop_s_iterates(product, states, nsites, pinv):
     """one launch runs the whole Newton-Raphson loop of a branch: every iterate is, bit for bit, the one the
     host loop reaches by calling pll_compute_likelihood_derivatives once per iterate"""
