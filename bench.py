@@ -77,6 +77,9 @@ def parse_args():
                     help="N > 1: rccl = the library's own RCCL communicator, lnL reduced on the device (default); "
                          "torch = the reduce callback through torch.distributed (a rehearsal path: with "
                          "PLLHIP_BENCH_DIST_BACKEND=gloo and PLLHIP_ALLOW_DEVICE_WRAP=1 all ranks can share one GPU)")
+    ap.add_argument("--transient", action="store_true",
+                    help="evaluate-only traversals (pllhip_eval_set_transient): the vectors inside operation chains stay in "
+                         "registers; what a model-parameter optimiser's full evaluations need")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tree", default="random", choices=["random", "ladder", "balanced"],
                     help="tree shape: random stepwise addition (seed 42, the benchmark's), a caterpillar, a complete binary tree")
@@ -461,6 +464,8 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
     if not insts:
         raise SystemExit("bench.py: a rank without work")
     inst = max(insts, key=lambda i: i.N * i.S)        # the partition that dominates the traffic
+    if getattr(args, "transient", False):
+        ev.set_transient(1)
 
     comm_mode = ctx.comm_mode
     reduce_cb = None
@@ -553,7 +558,7 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
     traffic_source = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and world == 1 and not sites and not taxa and not args.rate_scalers and not args.site_repeats \
-            and args.data == "random" and args.tree == "random":
+            and args.data == "random" and args.tree == "random" and not getattr(args, "transient", False):
         try:
             tj = json.load(open(tpath))
             per_step = tj.get(f"{config}:{kernel}:per_step")
@@ -646,6 +651,7 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
             "scalers": ("per (site, rate)" if args.rate_scalers else "per-site") + ", one buffer per inner node",
             "pmatrix_calls": args.pmatrix_calls, "alignment": args.data, "tree": args.tree,
             "site_repeats": repeats,
+            "transient": bool(getattr(args, "transient", False)),
             "pmatrix_launches_per_step": pmatrix_launches // evals,
             "partial_launches_per_step": partial_launches // evals,
             "parallelism": (f"one process, every partition spread over {args.gpus} devices inside the engine, "

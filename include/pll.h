@@ -180,9 +180,13 @@ extern "C" {
 typedef unsigned long long pll_state_t;
 typedef int pll_bool_t;
 
-/* site-repeats bookkeeping (only the fields src/binary touches; this engine
-   does not implement site repeats: the attribute is accepted, results are
-   identical, `repeats` stays NULL) */
+/* site-repeats bookkeeping: the fields pll-modules touches (src/binary/binary_io_operations.c:231-236,
+   265-282, 329-390; src/binary/pll_binary.c:388-406, 655, 747, 841-851; src/msa/pll_msa.c:108-112).
+   A partition created with PLL_ATTRIB_SITE_REPEATS carries a table that says "no node is compressed"
+   (pernode_ids[i] = 0, perscale_ids[i] = 0, pernode_allocated_clvs[i] = pll_get_sites_number(), per-node
+   index arrays NULL; csrc/host/pll_repeats.c): the engine computes per class of sites on the device
+   (4- and 20-state families, coded tips, per-site scalers; other partitions ignore the attribute), but every
+   vector a caller can see -- host mirrors, pllhip_get_clv, a checkpoint -- is site-indexed. */
 struct pll_partition;
 typedef struct pll_repeats
 {

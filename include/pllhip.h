@@ -163,6 +163,34 @@ typedef struct pllhip_repeat_stats
 PLL_EXPORT int pllhip_repeat_stats(const pll_partition_t * partition, pllhip_repeat_stats_t * out);
 PLL_EXPORT int pllhip_profile_read(pll_partition_t * partition, pllhip_profile_t * out);
 
+/* Evaluate-only traversals.  The model-parameter optimisers of pll-modules evaluate the whole tree after every
+   parameter poke (src/algorithm/algo_callback.c:338, 465, 568, 678: pllmod_treeinfo_compute_loglh(treeinfo, 0);
+   src/optimize/opt_algorithms.c:734-773: nmax + 1 of them per L-BFGS-B iteration): every vector is recomputed by
+   the next evaluation and never read in between, yet two thirds of what such an evaluation moves are stores.
+   While the mode is on, an operation list with the shape of a tree traversal (pll_update_partials /
+   pllhip_update_partials_batch, resident schedules of the 4-, 2..32- and 20-state families) hands the vectors
+   inside its operation chains on in registers WITHOUT storing them; the last vector of every chain and all scaler
+   counts are stored as always.  Nothing observable changes: a vector that was not stored stays recomputable (the
+   engine keeps its operation) and is stored
+     - for the first reader that needs it (a later operation list, an edge / root log-likelihood, a sumtable,
+       pllhip_get_clv, pllhip_sync_to_host, ...), and
+     - before one of its inputs changes (a P-matrix it was computed with, a tip, a child vector or scaler buffer
+       that a later list overwrites),
+   with the very operations that made it, so every later result is bit-identical to the mode being off.
+   pllhip_discard_transient declares the vectors that were not stored dead (a caller that is about to change the
+   model and evaluate the whole tree again: nothing is recomputed for the P-matrix updates that follow);
+   reading one of them afterwards without recomputing it is the caller's error, as after any invalidation.
+   PLLHIP_TRANSIENT=1 in the environment switches the mode on for every partition (the test suite under it). */
+typedef struct pllhip_transient_stats
+{
+  unsigned long long skipped;          /* vectors a traversal did not store */
+  unsigned long long materialized;     /* ... that were recomputed and stored for a reader or before a change */
+  unsigned long long discarded;        /* ... that were declared dead or overwritten before anybody asked */
+} pllhip_transient_stats_t;
+PLL_EXPORT int pllhip_set_transient(pll_partition_t * partition, int enable);
+PLL_EXPORT int pllhip_discard_transient(pll_partition_t * partition);
+PLL_EXPORT int pllhip_transient_stats(const pll_partition_t * partition, pllhip_transient_stats_t * out);
+
 /* kernel family actually used for pll_update_partials on this partition:
    "s4-valu", "s20-mfma", "generic" ... (for tests that must prove the
    specialised path ran) */
@@ -223,10 +251,16 @@ PLL_EXPORT unsigned int pllhip_free_trial_lengths(const pll_partition_t * partit
    PLLHIP_ERROR_NEWTON_LIMIT (more than max_newton iterations) / PLLHIP_ERROR_NEWTON_DERIVATIVES (a non-finite
    derivative) -- the reference's two failure modes -- or PLLHIP_ERROR_NEWTON_UNSUPPORTED: this partition cannot
    run the loop on the device (4-state / generic kernel family, ascertainment-bias correction, a partition spread
-   over devices, a scan grid larger than the chip holds at once); the caller then iterates itself. */
+   over devices, a scan grid larger than the chip holds at once); the caller then iterates itself.
+   PLLHIP_ERROR_NEWTON_STUCK: the workgroups of the loop wait for one another inside the launch, so all of them
+   have to be on the chip at once; the grid is sized for a device this partition has to itself, and other work on
+   the device (another process, another stream) can keep a workgroup out.  Every wait is bounded: the launch then
+   ends with this code after the bound (about a second), the engine's reduction state is reset, nothing was
+   changed -- the caller iterates itself (pllhip_eval does, and stops asking for the device loop). */
 #define PLLHIP_ERROR_NEWTON_LIMIT        910
 #define PLLHIP_ERROR_NEWTON_DERIVATIVES  911
 #define PLLHIP_ERROR_NEWTON_UNSUPPORTED  912
+#define PLLHIP_ERROR_NEWTON_STUCK        913
 PLL_EXPORT int pllhip_newton_branch(pll_partition_t * partition,
                                     int parent_scaler_index, int child_scaler_index,
                                     const unsigned int * params_indices, const double * sumtable,

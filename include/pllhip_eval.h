@@ -136,6 +136,22 @@ PLL_EXPORT void pllhip_eval_invalidate_clv(pllhip_eval_t * ev, const pll_unode_t
    invalid P-matrices and CLVs.  NaN on error (pll_errno set). */
 PLL_EXPORT double pllhip_eval_loglh(pllhip_eval_t * ev, int incremental);
 
+/* Evaluate-only traversals (include/pllhip.h, pllhip_set_transient) for FULL evaluations -- the call the
+   reference's model-parameter optimisers make after every parameter change
+   (pllmod_treeinfo_compute_loglh(treeinfo, 0): src/algorithm/algo_callback.c:338, 465, 568, 678;
+   nmax + 1 of them per L-BFGS-B iteration: src/optimize/opt_algorithms.c:734-773).  A full evaluation declares
+   every vector invalid first, so what an earlier one did not store is given up (pllhip_discard_transient), and
+   the vectors inside the operation chains of this one stay in registers.  Whatever reads a vector later
+   (an incremental evaluation from another root, a branch-length optimisation, an SPR round) gets it recomputed on
+   demand: results are bit-identical in every mode.
+     OFF   never (default: pll_update_partials stores every vector, like the reference)
+     ON    every full evaluation
+     AUTO  a full evaluation that directly follows a full evaluation (the optimiser pattern) */
+#define PLLHIP_EVAL_TRANSIENT_OFF  0
+#define PLLHIP_EVAL_TRANSIENT_ON   1
+#define PLLHIP_EVAL_TRANSIENT_AUTO 2
+PLL_EXPORT void pllhip_eval_set_transient(pllhip_eval_t * ev, int mode);
+
 /* change a branch length and invalidate what depends on it */
 PLL_EXPORT void pllhip_eval_set_branch_length(pllhip_eval_t * ev, pll_unode_t * edge, double length);
 

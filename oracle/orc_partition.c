@@ -12,6 +12,7 @@
  *   error convention               src/pllmod_common.c:42-50
  */
 #include "orc_internal.h"
+#include "../pll-modules_amd/csrc/host/pll_repeats.h"
 #include <stdarg.h>
 
 __thread int pll_errno = 0;
@@ -36,10 +37,12 @@ void * pll_aligned_alloc(size_t size, size_t alignment)
 
 void pll_aligned_free(void * ptr) { free(ptr); }
 
+/* libpll-2: the sites a node's vector is allocated for (its classes when it has repeats; no node of this
+   library has: ../pll-modules_amd/csrc/host/pll_repeats.c), plus the ascertainment-bias columns */
 unsigned int pll_get_sites_number(const pll_partition_t * p, unsigned int clv_index)
 {
-  (void)clv_index;
-  return p->sites;
+  unsigned int n = (p->repeats && clv_index < p->nodes) ? p->repeats->pernode_ids[clv_index] : 0u;
+  return orc_salloc(p) - p->sites + (n ? n : p->sites);
 }
 
 unsigned int pll_get_clv_size(const pll_partition_t * p, unsigned int clv_index)
@@ -169,6 +172,8 @@ pll_partition_t * pll_partition_create(unsigned int tips,
       p->maxstates = 16;
     }
   }
+  /* the reference dereferences partition->repeats whenever the attribute is set */
+  if ((attributes & PLL_ATTRIB_SITE_REPEATS) && !pll_repeats_attach(p)) goto nomem;
   return p;
 
 nomem:
@@ -206,6 +211,7 @@ void pll_partition_destroy(pll_partition_t * p)
   free(p->charmap);
   free(p->tipmap);
   pll_aligned_free(p->ttlookup);
+  pll_repeats_release(p);
   free(p);
 }
 

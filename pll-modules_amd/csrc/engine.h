@@ -99,7 +99,8 @@ struct PlanOp
   OpDesc d;
   unsigned carried;      // 0 = both children from memory, 1 / 2 = child 1 / 2 is the previous op's parent
   unsigned slot1, slot2; // 20 states: LDS offsets (doubles) of the two children's tables
-  unsigned pad;
+  unsigned flags;        // bit 0: the parent vector is not stored (an evaluate-only traversal hands it to the next
+                         // operation of its chain in registers; pllhip_set_transient)
 };
 // operations [first, first + len) of PlanOp[], and what the kernels need to know about the partition
 // the chain belongs to (a batched schedule -- pllhip_update_partials_batch -- holds chains of several
@@ -208,6 +209,17 @@ struct Engine
   double * d_pairlut = nullptr;       // lookup tables of the wide tips of the resident schedule
   size_t pairlut_cap = 0;
   pllhip_repeat_stats_t repeat_stats = {};
+  // Evaluate-only traversals (pllhip_set_transient): a resident schedule may hand the vectors inside its chains on
+  // in registers without storing them.  Such a vector stays recomputable -- the operation that made it is kept --
+  // and is stored for the first reader that needs it, or before one of its inputs changes.
+  pll_partition_t * owner = nullptr;
+  bool transient_mode = false;
+  bool transient_busy = false;                  // a materialisation is running (its lists are exempt from the checks)
+  unsigned ntransient = 0;                      // vectors that exist as their operation only
+  std::vector<char> transient_live;             // [nodes]
+  std::vector<pll_operation_t> transient_op;    // [nodes] what recomputes the vector
+  std::vector<unsigned> transient_mat_users;    // [nmat] live operations that read the matrix
+  pllhip_transient_stats_t transient_stats = {};
   size_t sc_len = 0;                  // entries per scale buffer on the device
   KernelFamily family = KernelFamily::Generic;
   unsigned cu_count = 256;

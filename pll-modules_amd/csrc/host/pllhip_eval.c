@@ -8,6 +8,8 @@
 #include "pllhip.h"
 #pragma weak pllhip_eval_attach_comm   /* HIP engine only (pllhip_comm.hip) */
 #pragma weak pllhip_newton_branch      /* HIP engine only (pll_core.hip) */
+#pragma weak pllhip_set_transient      /* HIP engine only: the CPU oracle stores every vector */
+#pragma weak pllhip_discard_transient
 #include <stdarg.h>
 
 static __thread pllhip_eval_t * cb_self;   /* pll_utree_traverse callbacks carry no user pointer */
@@ -81,6 +83,8 @@ pllhip_eval_t * pllhip_eval_create(pll_utree_t * tree, unsigned int partition_co
   {
     const char * env = getenv("PLLHIP_EVAL_DEVICE_NEWTON");
     ev->device_newton = (pllhip_newton_branch && (!env || atoi(env))) ? 1 : 0;
+    env = getenv("PLLHIP_EVAL_TRANSIENT");          /* 0 / 1 / 2: pllhip_eval_set_transient for every evaluator */
+    if (env) ev->transient = atoi(env);
   }
   /* Several partitions: leave every partition's lnL / derivative totals on the device and wait ONCE per
      evaluation / Newton round (include/pllhip.h, pllhip_results_*) instead of once per partition -- the
@@ -424,12 +428,37 @@ static int injected_fault(void)
   return 0;
 }
 
+void pllhip_eval_set_transient(pllhip_eval_t * ev, int mode)
+{
+  ev->transient = mode;
+  ev->last_was_full = 0;
+}
+
+/* mode of the partitions' engines for the operation list that follows */
+static void partitions_transient(pllhip_eval_t * ev, int on, int discard)
+{
+  unsigned int p;
+  if (!pllhip_set_transient || !pllhip_discard_transient) return;
+  for (p = 0; p < ev->nparts; ++p)
+  {
+    if (!ev->parts[p]) continue;
+    if (discard) (void)pllhip_discard_transient(ev->parts[p]);
+    (void)pllhip_set_transient(ev->parts[p], on);
+  }
+}
+
 double pllhip_eval_loglh(pllhip_eval_t * ev, int incremental)
 {
   unsigned int n = 0, nops = 0, i;
   int failed = 0;
+  /* a full evaluation recomputes every vector: what the last one kept in registers only is given up BEFORE the
+     P-matrices change (nothing is recomputed for them), and this one may keep its own in registers */
+  const int transient = !incremental && (ev->transient == PLLHIP_EVAL_TRANSIENT_ON ||
+                                         (ev->transient == PLLHIP_EVAL_TRANSIENT_AUTO && ev->last_was_full));
+  ev->last_was_full = !incremental;
   if (!incremental) pllhip_eval_invalidate_all(ev);
   pll_errno = 0;
+  if (!incremental && ev->transient != PLLHIP_EVAL_TRANSIENT_OFF) partitions_transient(ev, transient, 1);
   failed = injected_fault() || !update_pmatrices(ev);
 
   cb_self = ev;
@@ -448,6 +477,7 @@ double pllhip_eval_loglh(pllhip_eval_t * ev, int incremental)
       ev->n_ops += nops;
     }
   }
+  if (transient) partitions_transient(ev, 0, 0);
   return edge_loglh(ev, ev->root, failed);
 }
 
@@ -672,9 +702,11 @@ static int newton(const blo_t * b, const pll_unode_t * e, double * x)
       pllhip_eval_error(PLLHIP_EVAL_ERROR_NEWTON_DERIV, "Wrong likelihood derivatives");
       return PLL_FAILURE;
     }
-    if (pll_errno != PLLHIP_ERROR_NEWTON_UNSUPPORTED) return PLL_FAILURE;
+    /* UNSUPPORTED: this partition cannot; STUCK: the device is shared and the loop's workgroups did not all get
+       onto it (nothing was changed): either way this branch -- and the ones after it -- iterate on the host */
+    if (pll_errno != PLLHIP_ERROR_NEWTON_UNSUPPORTED && pll_errno != PLLHIP_ERROR_NEWTON_STUCK) return PLL_FAILURE;
     pll_errno = 0;
-    ev->device_newton = 0;                     /* this partition iterates on the host */
+    ev->device_newton = 0;
   }
   *x = PLL_MAX(PLL_MIN(*x, b->bl_max), b->bl_min);
   for (;;)

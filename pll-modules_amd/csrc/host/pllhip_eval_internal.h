@@ -36,6 +36,8 @@ struct pllhip_eval
   double ** part_brlens;          /* [nparts][edges] by pmatrix_index, UNLINKED only (else NULL) */
   double * nr_x, * nr_xl, * nr_xh, * nr_f, * nr_df, * nr_orig;   /* [nparts] Newton-Raphson state, UNLINKED */
   int * nr_converged;
+  int transient;                  /* PLLHIP_EVAL_TRANSIENT_*: which full evaluations run evaluate-only */
+  int last_was_full;              /* the previous call into the driver was a full evaluation */
 };
 
 #define PLLHIP_EVAL_MAX_TRIALS 8

@@ -430,13 +430,15 @@ static bool sum_prep_needed(Engine * e, const ParamIdx & params, bool want_lut)
   return true;
 }
 
-static unsigned round_grid(const Engine * e, unsigned gx, unsigned rows, unsigned per_cu_default = 4u)
+// keep: workgroups a row keeps whatever the other rows take (the ones it needs to share a LARGE partition out
+// finely enough -- few long-lived workgroups per row leave a tail at the end of every round)
+static unsigned round_grid(const Engine * e, unsigned gx, unsigned rows, unsigned per_cu_default = 4u, unsigned keep = 0u)
 {
   static const int env = getenv("PLLHIP_ROUND_WGS") ? atoi(getenv("PLLHIP_ROUND_WGS")) : -1;
   const unsigned per_cu = (env >= 0 && per_cu_default >= 4u) ? (unsigned)env : per_cu_default;
   if (rows <= 1 || per_cu == 0) return gx;
   const unsigned share = (e->cu_count * per_cu + rows - 1) / rows;
-  return std::max(1u, std::min(gx, share));
+  return std::max(1u, std::min(gx, std::max(share, keep)));
 }
 
 } // namespace pllhip

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void k_newton_s4(ModelView mv, ParamIdx params
   unsigned c_wgt[NC][4];
 
   double x = np.x0;
+  if (blockIdx.x == np.stall_block) return;             // (fault injection: a workgroup that never arrives)
   for (unsigned it = 0; ; ++it)
   {
     double e0[4], e1[4], e2[4];
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(256) void k_newton_s4(ModelView mv, ParamIdx params
       d4 sv[4];
       double inv4[4];
       unsigned wgt[4];
-      const bool fetch = NT == 0 || it == 0;
+      // (a trip beyond the NT the registers hold -- a grid smaller than the one the host sized NT for -- is streamed)
+      const bool fetch = NT == 0 || it == 0 || trip >= NT;
       if (fetch)
       {
         bool live[4];

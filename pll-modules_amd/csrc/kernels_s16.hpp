@@ -266,7 +266,8 @@ template <unsigned KS, unsigned RT, bool RS>
 __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2 X[RT][KS],
                                     const double * s1, const double * s2, unsigned S, unsigned lut_codes,
                                     bool lut_lds, unsigned blk, unsigned lane,
-                                    unsigned (&xe)[RS ? RT : 1], unsigned (&xo)[RS ? RT : 1], bool nt, bool ntl = false)
+                                    unsigned (&xe)[RS ? RT : 1], unsigned (&xo)[RS ? RT : 1], bool nt, bool ntl = false,
+                                    bool store = true)   // store: false = handed on in registers only (PlanOp::flags bit 0)
 {
   constexpr unsigned UNIT = 4 * KS * S20_BS;
   const unsigned q = lane >> 4, n = lane & 15;
@@ -329,7 +330,8 @@ __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2
         op.parent_scaler[io] = co;
       }
     }
-    if (nt) s16_store_d_nt<KS>(op.parent + ubase, lane, X[r]); else s16_store_d<KS>(op.parent + ubase, lane, X[r]);
+    if (!store) { }
+    else if (nt) s16_store_d_nt<KS>(op.parent + ubase, lane, X[r]); else s16_store_d<KS>(op.parent + ubase, lane, X[r]);
     xe[RS ? r : 0] = ce;
     xo[RS ? r : 0] = co;
   }
@@ -347,6 +349,7 @@ __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2
   {
 #pragma unroll
     for (unsigned v = 0; v < KS; ++v) { X[r][v].x *= fe; X[r][v].y *= fo; }
+    if (!store) continue;
     if (nt) s16_store_d_nt<KS>(op.parent + ((size_t)blk * RT + r) * UNIT, lane, X[r]);
     else s16_store_d<KS>(op.parent + ((size_t)blk * RT + r) * UNIT, lane, X[r]);
   }
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanVi
       {
         const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
         s16_chain_op<KS, RT, RS>(po.d, i ? po.carried : 0u, X, lds + po.slot1, lds + po.slot2, S, lut_codes,
-                                 lut_lds, blk, lane, xe, xo, nt, ntl);
+                                 lut_lds, blk, lane, xe, xo, nt, ntl, !(po.flags & 1u));
       }
     }
   }
@@ -655,7 +658,8 @@ static int launch_traverse_s16(Engine * e, const PlanView & plan, unsigned lds_d
 {
   const size_t lds = sizeof(double) * lds_doubles;
   const unsigned need = (extent + S16_CHAIN_WAVES - 1) / S16_CHAIN_WAVES;
-  const unsigned gx = round_grid(e, std::max(1u, std::min(need, e->cu_count)), rows, row_wgs_per_cu ? row_wgs_per_cu : 4u);
+  const unsigned gx = round_grid(e, std::max(1u, std::min(need, e->cu_count)), rows, row_wgs_per_cu ? row_wgs_per_cu : 4u,
+                                 (extent + 16u * S16_CHAIN_WAVES - 1) / (16u * S16_CHAIN_WAVES));
   static const int env_nt = getenv("PLLHIP_S16_NT") ? atoi(getenv("PLLHIP_S16_NT")) : 2;   // stores and loads past the caches: 3 - 15 % faster
   const unsigned nt_flags = (env_nt ? 2u : 0u) | (env_nt == 2 ? 4u : 0u);
   static bool attr_set_dev[64] = {false};

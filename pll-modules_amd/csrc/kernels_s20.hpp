@@ -446,20 +446,24 @@ __device__ inline const unsigned * s20_wide_codes(const double * clv, const uint
 // xe / xo: the scaler counts that go with X (per rate with RS = PLL_ATTRIB_RATE_SCALERS, where
 // the vote covers one (site, rate) unit and the counts live at scaler[site * R + rate];
 // otherwise one count per site, held in element 0).
-template <unsigned RT, bool RS>
+// WIDE: the schedule may hold wide tips (site repeats); without them the instantiation carries none of their
+// pointers and branches (the attribute-off kernel is the round-2 one: 13 instead of 19 spilled registers).
+// store: false = the result is handed to the next operation of the chain in registers only (an evaluate-only
+// traversal, PlanOp::flags bit 0); its scaler counts are written either way.
+template <unsigned RT, bool RS, bool WIDE>
 __device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2 X[RT][5],
                                     const double * s1, const double * s2,
                                     unsigned lut_codes, unsigned lut_used, bool lut_lds,
                                     unsigned blk, unsigned lane, bool nt_ld, bool nt_st,
-                                    unsigned (&xe)[RS ? RT : 1], unsigned (&xo)[RS ? RT : 1])
+                                    unsigned (&xe)[RS ? RT : 1], unsigned (&xo)[RS ? RT : 1], bool store = true)
 {
   const unsigned q = lane >> 4, n = lane & 15;
   const size_t site0 = (size_t)blk * S20_BS + 2 * n;
   unsigned c1e = 0, c1o = 0, c2e = 0, c2o = 0;
   // a "wide tip" (kernels_repeats.hpp: a cherry known per class of sites): neither vector nor byte codes; the
   // pfrag field holds its class codes (32 bits each), lut its table, childN_index the rows of that table
-  const unsigned * w1 = s20_wide_codes(op.clv1, op.codes1, op.pfrag1);
-  const unsigned * w2 = s20_wide_codes(op.clv2, op.codes2, op.pfrag2);
+  const unsigned * w1 = WIDE ? s20_wide_codes(op.clv1, op.codes1, op.pfrag1) : nullptr;
+  const unsigned * w2 = WIDE ? s20_wide_codes(op.clv2, op.codes2, op.pfrag2) : nullptr;
   if (op.codes1) { c1e = op.codes1[site0]; c1o = op.codes1[site0 + 1]; }
   else if (w1) { c1e = w1[site0]; c1o = w1[site0 + 1]; }
   if (op.codes2) { c2e = op.codes2[site0]; c2o = op.codes2[site0 + 1]; }
@@ -528,7 +532,7 @@ __device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2
         op.parent_scaler[io] = co;
       }
     }
-    s20_store_d(op.parent + ubase, lane, X[r], nt_st);
+    if (store) s20_store_d(op.parent + ubase, lane, X[r], nt_st);
     xe[RS ? r : 0] = ce;
     xo[RS ? r : 0] = co;
   }
@@ -550,7 +554,7 @@ __device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2
       X[r][k].x *= fe;
       X[r][k].y *= fo;
     }
-    s20_store_d(op.parent + ((size_t)blk * RT + r) * S20_UNIT, lane, X[r], nt_st);
+    if (store) s20_store_d(op.parent + ((size_t)blk * RT + r) * S20_UNIT, lane, X[r], nt_st);
   }
   unsigned ce = 0, co = 0;
   if (scaling && q == 0)
@@ -647,7 +651,7 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_chain_s20(ChainBatc
     unsigned xe[RS ? RT : 1] = {}, xo[RS ? RT : 1] = {};
 #pragma unroll 1
     for (unsigned i = 0; i < len; ++i)
-      s20_chain_op<RT, RS>(batch.op[first + i], i ? batch.carried[first + i] : 0u, X,
+      s20_chain_op<RT, RS, false>(batch.op[first + i], i ? batch.carried[first + i] : 0u, X,
                        lds + batch.slot1[first + i], lds + batch.slot2[first + i],
                        lut_codes, lut_used, lut_lds, blk, lane, nt_ld, nt_st, xe, xo);
   }
@@ -658,7 +662,9 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_chain_s20(ChainBatc
 // reads from an earlier chain it has written itself -- there is nothing to wait for but the
 // workgroup's own barrier around the re-staging of the LDS tables.
 // grid = gx, block = 512, dynamic LDS = the largest chain area of the schedule.
-template <unsigned RT, bool RS>
+// TRANS: an evaluate-only traversal -- operations whose PlanOp::flags bit 0 is set hand their result on in registers only
+// (a compile-time switch: as a run-time flag in front of every store it cost the storing traversal 3.5 %)
+template <unsigned RT, bool RS, bool WIDE, bool TRANS>
 __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanView plan, unsigned chain_begin,
                                                                            unsigned chain_end, unsigned nblk,
                                                                            unsigned slab, unsigned flags)
@@ -685,9 +691,9 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanVi
       for (unsigned i = 0; i < ch.len; ++i)
       {
         const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
-        if (po.d.clv1 || po.d.codes1)       // (a wide tip has no table in LDS)
+        if (!WIDE || po.d.clv1 || po.d.codes1)       // (a wide tip has no table in LDS)
           s20_fill_slot(lds + po.slot1, po.d.pmat1, po.d.pfrag1, po.d.codes1 ? po.d.lut1 : nullptr, RT, lut_codes, lut_used, lut_lds);
-        if (po.d.clv2 || po.d.codes2)
+        if (!WIDE || po.d.clv2 || po.d.codes2)
           s20_fill_slot(lds + po.slot2, po.d.pmat2, po.d.pfrag2, po.d.codes2 ? po.d.lut2 : nullptr, RT, lut_codes, lut_used, lut_lds);
       }
       __syncthreads();
@@ -700,8 +706,8 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanVi
         for (unsigned i = 0; i < ch.len; ++i)
         {
           const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
-          s20_chain_op<RT, RS>(po.d, i ? po.carried : 0u, X, lds + po.slot1, lds + po.slot2,
-                           lut_codes, lut_used, lut_lds, blk, lane, nt_ld, nt_st, xe, xo);
+          s20_chain_op<RT, RS, WIDE>(po.d, i ? po.carried : 0u, X, lds + po.slot1, lds + po.slot2,
+                                     lut_codes, lut_used, lut_lds, blk, lane, nt_ld, nt_st, xe, xo, TRANS ? !(po.flags & 1u) : true);
         }
       }
     }
@@ -1214,7 +1220,9 @@ struct NewtonControl          // device memory, one per engine
   double trail[96];           // the iterates (NEWTON_TRAIL_MAX), copied to the host when the loop ends
 };
 
-struct NewtonParams { double x0, bl_min, bl_max, tolerance, dxmax; unsigned max_newton; };
+// spin_limit: polls a workgroup waits for the next iterate before it gives up (NEWTON_SPIN_LIMIT; tests lower it);
+// stall_block: fault injection -- that workgroup leaves at once, as if it had never been given a CU (~0u: none)
+struct NewtonParams { double x0, bl_min, bl_max, tolerance, dxmax; unsigned max_newton, spin_limit, stall_block; };
 
 // mapped host memory: [0] final length, [1] iterations, [2] status, [3] last f, [4] last df, [8 ...] the trail
 constexpr unsigned NEWTON_RUNNING = 0, NEWTON_CONVERGED = 1, NEWTON_LIMIT = 2, NEWTON_NONFINITE = 3, NEWTON_STUCK = 4;
@@ -1293,16 +1301,23 @@ __device__ inline unsigned newton_step_and_wait(unsigned it, bool last, double &
     // several hundred times per microsecond)
     while (__hip_atomic_load(&ctl->iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != it + 1)
     {
-      if (++spins > NEWTON_SPIN_LIMIT)
+      if (++spins > np.spin_limit)
       {
+        // a workgroup is missing (not resident: the device is shared): the run has failed, and the host is told --
+        // every block that gives up writes the same words
         __hip_atomic_store(&ctl->status, NEWTON_STUCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        host_out[0] = x;
+        host_out[1] = (double)it;
+        host_out[2] = (double)NEWTON_STUCK;
+        __threadfence_system();
+        __hip_atomic_store(host_flag, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
       __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    *s_status = (spins > NEWTON_SPIN_LIMIT) ? NEWTON_STUCK
-                                           : __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_status = (spins > np.spin_limit) ? NEWTON_STUCK
+                                        : __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *s_x = __hip_atomic_load(&ctl->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
@@ -1327,6 +1342,7 @@ __device__ inline void newton_loop(const ModelView & mv, const ParamIdx & params
   __shared__ double s_x;
   __shared__ unsigned s_status;
   double x = np.x0;                                     // (clamped by the host, as newton() does first)
+  if (blockIdx.x == np.stall_block) return;             // (fault injection: a workgroup that never arrives)
   DerivResident<KS, NB ? NB : 1, NB ? NBR : 1, NB ? 4 : 1> res;
   for (unsigned it = 0; ; ++it)
   {
@@ -1502,7 +1518,8 @@ static int launch_chains_s20(Engine * e, const ChainBatch & batch, unsigned ncha
 
 // `extent`: site blocks of the largest partition the chains [chain_begin, chain_end) belong to
 static int launch_traverse_s20(Engine * e, const PlanView & plan, unsigned lds_doubles, unsigned extent,
-                               unsigned chain_begin, unsigned chain_end, unsigned rows, unsigned row_wgs_per_cu = 0)
+                               unsigned chain_begin, unsigned chain_end, unsigned rows, unsigned row_wgs_per_cu = 0,
+                               bool wide = false, bool transient = false)
 {
   const size_t lds = sizeof(double) * lds_doubles;
   const unsigned flags = []() { const char * v = getenv("PLLHIP_S20_NT"); return v ? (unsigned)atoi(v) & 3u : 0u; }();
@@ -1510,14 +1527,19 @@ static int launch_traverse_s20(Engine * e, const PlanView & plan, unsigned lds_d
   bool & attr_set = attr_set_dev[e->device & 63];
   if (!attr_set)
   {
-    if (!s20_allow_full_lds(k_traverse_s20<4, false>) || !s20_allow_full_lds(k_traverse_s20<2, false>) ||
-        !s20_allow_full_lds(k_traverse_s20<1, false>) || !s20_allow_full_lds(k_traverse_s20<4, true>) ||
-        !s20_allow_full_lds(k_traverse_s20<2, true>) || !s20_allow_full_lds(k_traverse_s20<1, true>))
+#define PLLHIP_ALLOW(RS_, W_, T_) (s20_allow_full_lds(k_traverse_s20<4, RS_, W_, T_>) && s20_allow_full_lds(k_traverse_s20<2, RS_, W_, T_>) && \
+                                   s20_allow_full_lds(k_traverse_s20<1, RS_, W_, T_>))
+    if (!PLLHIP_ALLOW(false, false, false) || !PLLHIP_ALLOW(true, false, false) || !PLLHIP_ALLOW(false, true, false) ||
+        !PLLHIP_ALLOW(false, false, true) || !PLLHIP_ALLOW(true, false, true))
       return PLL_FAILURE;
+#undef PLLHIP_ALLOW
     attr_set = true;
   }
   const unsigned need = (extent + S20_CHAIN_WAVES - 1) / S20_CHAIN_WAVES;
-  const unsigned gx = round_grid(e, std::max(1u, std::min(need, e->cu_count)), rows, row_wgs_per_cu ? row_wgs_per_cu : 4u);
+  // (a row keeps at least the workgroups that leave a wave 16 site blocks: large partitions are shared out finely --
+  // 256 instead of 26 workgroups per row in the first round of C3, 32.9 against 33.7 ms on one box)
+  const unsigned gx = round_grid(e, std::max(1u, std::min(need, e->cu_count)), rows, row_wgs_per_cu ? row_wgs_per_cu : 4u,
+                                 (extent + 16u * S20_CHAIN_WAVES - 1) / (16u * S20_CHAIN_WAVES));
   // slab: site blocks that go through the whole schedule together (default: all of them; smaller
   // slabs were measured and lose to the per-chain re-staging)
   static const int env_slab = getenv("PLLHIP_S20_SLAB") ? atoi(getenv("PLLHIP_S20_SLAB")) : 0;
@@ -1526,7 +1548,17 @@ static int launch_traverse_s20(Engine * e, const PlanView & plan, unsigned lds_d
   slab = std::max(per_pass, (slab + per_pass - 1) / per_pass * per_pass);   // whole passes of the grid
   const dim3 grid(gx, std::max(1u, rows)), block(64 * S20_CHAIN_WAVES);
 #define PLLHIP_CALL(K) hipLaunchKernelGGL(K, grid, block, lds, e->stream, plan, chain_begin, chain_end, extent, slab, flags)
-  PLLHIP_S20_CHAIN_DISPATCH(k_traverse_s20, PLLHIP_CALL);
+#define PLLHIP_BY_RATES(RS_, W_, T_)                                              \
+  do {                                                                           \
+    if (e->R == 4) { PLLHIP_CALL((k_traverse_s20<4, RS_, W_, T_>)); }             \
+    else if (e->R == 2) { PLLHIP_CALL((k_traverse_s20<2, RS_, W_, T_>)); }        \
+    else { PLLHIP_CALL((k_traverse_s20<1, RS_, W_, T_>)); }                       \
+  } while (0)
+  // (wide tips -- site repeats -- exist with per-site scaling only, and without evaluate-only traversals)
+  if (wide && !e->rate_scalers) PLLHIP_BY_RATES(false, true, false);
+  else if (e->rate_scalers) { if (transient) PLLHIP_BY_RATES(true, false, true); else PLLHIP_BY_RATES(true, false, false); }
+  else { if (transient) PLLHIP_BY_RATES(false, false, true); else PLLHIP_BY_RATES(false, false, false); }
+#undef PLLHIP_BY_RATES
 #undef PLLHIP_CALL
   PLLHIP_TRY(hipGetLastError());
   return PLL_SUCCESS;

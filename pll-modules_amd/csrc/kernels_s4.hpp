@@ -265,8 +265,9 @@ template <unsigned U, unsigned R, int NT = 0>
 __device__ inline void s4_chain_step(const OpDesc & op, unsigned carried, const double * base,
                                      double2 (&X)[2 * R], unsigned & xcnt,
                                      unsigned long long hc0, unsigned long long nsc, unsigned long long total,
-                                     unsigned N, unsigned lane, unsigned r, unsigned h)
+                                     unsigned N, unsigned lane, unsigned r, unsigned h, bool store = true)
 {
+  // store: false = the result is handed to the next operation of the chain in registers only (PlanOp::flags bit 0)
   constexpr unsigned group = 2 * R, spi = 64 / group;
   constexpr unsigned T2 = R * S4_LUT_RS, M1 = 2 * R * S4_LUT_RS, M2 = 2 * R * S4_LUT_RS + R * 16;
   // a "wide tip" (kernels_repeats.hpp: a cherry known per class of sites): neither vector nor byte codes; pfrag
@@ -338,7 +339,7 @@ __device__ inline void s4_chain_step(const OpDesc & op, unsigned carried, const 
         }
       }
       X[k] = v;
-      if (live[u])
+      if (live[u] && store)
       {
         if (NT != 0)
         {
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256) void k_traverse_s4(PlanView plan, unsigned cha
       {
         const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
         s4_chain_step<U, R, NT>(po.d, i ? po.carried : 0u, lds + i * S4_CHAIN_OP_LDS,
-                            X, xcnt, hc0, nsc, total, N, lane, r, h);
+                            X, xcnt, hc0, nsc, total, N, lane, r, h, !(po.flags & 1u));
       }
     }
   }

@@ -59,6 +59,9 @@ static int current_device()
 
 int flush_pmatrices(pll_partition_t * p);
 static int ensure_luts(pll_partition_t * p);
+static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops, unsigned count);
+static int transient_materialize(Engine * e, const std::vector<unsigned> & want);
+static int transient_flush_all(Engine * e);
 static void batch_free(BatchPlan * b);
 static void batch_free_hook(BatchPlan * b) { batch_free(b); }
 
@@ -304,6 +307,11 @@ Engine * engine_create(pll_partition_t * p)
   else e->site_repeats = false;                 // (first step: the 20- and the 4-state family)
   e->pmat_brlen.assign(e->nmat, std::numeric_limits<double>::quiet_NaN());
   e->pmat_params.assign(e->nmat, std::vector<unsigned>());
+  e->owner = p;
+  e->transient_live.assign(e->nodes, 0);
+  e->transient_op.assign(e->nodes, pll_operation_t());
+  e->transient_mat_users.assign(e->nmat, 0);
+  e->transient_mode = getenv("PLLHIP_TRANSIENT") && atoi(getenv("PLLHIP_TRANSIENT")) != 0;
 
   // model block layout
   size_t off = 0;
@@ -460,6 +468,7 @@ int upload_tip_codes(pll_partition_t * p, unsigned tip)
     return PLL_SUCCESS;
   }
   PLLHIP_TRY(hipSetDevice(e->device));
+  if (!transient_flush_all(e)) return PLL_FAILURE;           // vectors that exist as their operation only read the old codes
   if (e->N)
     PLLHIP_TRY(hipMemcpyAsync(e->d_codes[tip], p->tipchars[tip], (size_t)e->N,
                               hipMemcpyHostToDevice, e->stream));
@@ -526,6 +535,7 @@ int upload_tip_clv(pll_partition_t * p, unsigned tip, const double * host_clv)
     return PLL_SUCCESS;
   }
   PLLHIP_TRY(hipSetDevice(e->device));
+  if (!transient_flush_all(e)) return PLL_FAILURE;
   return store_clv(e, e->d_clv[tip], host_clv);
 }
 
@@ -1094,6 +1104,9 @@ static int need_scaler(Engine * e, int sidx)
 // is kept per class
 static int need_clv(Engine * e, unsigned idx)
 {
+  // (an evaluate-only traversal kept it in registers: recomputed and stored now)
+  if (e->ntransient && !e->transient_busy && idx < e->transient_live.size() && e->transient_live[idx] &&
+      !transient_materialize(e, std::vector<unsigned>(1, idx))) return PLL_FAILURE;
   if (e->cherries.empty() || idx >= e->cherries.size()) return PLL_SUCCESS;
   Engine::Cherry & c = e->cherries[idx];
   if (c.valid && c.scaler_index >= 0 && (size_t)c.scaler_index < e->scaler_lazy.size() && e->scaler_lazy[c.scaler_index] == (int)idx &&
@@ -1265,6 +1278,128 @@ static bool class_map(Engine * e, unsigned node, unsigned c1, unsigned c2, unsig
   return true;
 }
 
+// ---------------------------------------------------------------------------
+// evaluate-only traversals (include/pllhip.h, pllhip_set_transient): host side
+// ---------------------------------------------------------------------------
+// the vector of `node` stops being "its operation only": it is being stored (dead = false) or replaced / given up
+static void transient_drop(Engine * e, unsigned node, bool dead)
+{
+  if (!e->ntransient || !e->transient_live[node]) return;
+  const pll_operation_t & o = e->transient_op[node];
+  e->transient_live[node] = 0;
+  --e->transient_mat_users[o.child1_matrix_index];
+  --e->transient_mat_users[o.child2_matrix_index];
+  --e->ntransient;
+  if (dead) e->transient_stats.discarded++;
+}
+
+static void transient_mark(Engine * e, const pll_operation_t & o)
+{
+  transient_drop(e, o.parent_clv_index, true);
+  e->transient_live[o.parent_clv_index] = 1;
+  e->transient_op[o.parent_clv_index] = o;
+  ++e->transient_mat_users[o.child1_matrix_index];
+  ++e->transient_mat_users[o.child2_matrix_index];
+  ++e->ntransient;
+  e->transient_stats.skipped++;
+}
+
+// store the vectors of `want` that exist as their operation only: the operations that made them run again (and,
+// below them, the ones of the children that were not stored either), as an ordinary list -- the same kernels on the
+// same inputs, so what is stored is what the traversal would have stored
+static int transient_materialize(Engine * e, const std::vector<unsigned> & want)
+{
+  if (!e->ntransient) return PLL_SUCCESS;
+  std::vector<pll_operation_t> list;
+  std::vector<char> seen(e->nodes, 0);
+  std::vector<std::pair<unsigned, unsigned>> stack;   // (node, children looked at)
+  for (unsigned w : want)
+  {
+    if (w >= e->nodes || !e->transient_live[w] || seen[w]) continue;
+    seen[w] = 1;
+    stack.emplace_back(w, 0u);
+    while (!stack.empty())
+    {
+      const unsigned node = stack.back().first;
+      const pll_operation_t & o = e->transient_op[node];
+      if (stack.back().second < 2)
+      {
+        const unsigned c = stack.back().second++ ? o.child2_clv_index : o.child1_clv_index;
+        if (e->transient_live[c] && !seen[c]) { seen[c] = 1; stack.emplace_back(c, 0u); }
+      }
+      else { list.push_back(o); stack.pop_back(); }
+    }
+  }
+  if (list.empty()) return PLL_SUCCESS;
+  const bool mode = e->transient_mode;
+  e->transient_busy = true;
+  e->transient_mode = false;
+  const int rc = update_partials_impl(e->owner, list.data(), (unsigned)list.size());
+  e->transient_mode = mode;
+  e->transient_busy = false;
+  if (rc) e->transient_stats.materialized += list.size();
+  return rc;
+}
+
+static int transient_flush_all(Engine * e)
+{
+  if (!e->ntransient || e->transient_busy) return PLL_SUCCESS;
+  std::vector<unsigned> all;
+  for (unsigned n = 0; n < e->nodes; ++n) if (e->transient_live[n]) all.push_back(n);
+  return transient_materialize(e, all);
+}
+
+// before an operation list runs: vectors it reads that were not stored, and vectors that were not stored whose
+// inputs (children, scaler buffers) the list overwrites, are stored first; what the list itself overwrites is given up
+static int transient_before_list(Engine * e, const pll_operation_t * ops, unsigned count)
+{
+  if (!e->ntransient) return PLL_SUCCESS;
+  if (!e->transient_busy)
+  {
+    std::vector<char> written(e->nodes, 0), swritten(e->nscalers, 0);
+    std::vector<unsigned> want;
+    for (unsigned k = 0; k < count; ++k)
+    {
+      const unsigned child[2] = {ops[k].child1_clv_index, ops[k].child2_clv_index};
+      for (int x = 0; x < 2; ++x)
+        if (e->transient_live[child[x]] && !written[child[x]]) want.push_back(child[x]);
+      written[ops[k].parent_clv_index] = 1;
+      if (ops[k].parent_scaler_index >= 0) swritten[ops[k].parent_scaler_index] = 1;
+    }
+    for (unsigned t = 0; t < e->nodes; ++t)
+    {
+      if (!e->transient_live[t] || written[t]) continue;
+      const pll_operation_t & o = e->transient_op[t];
+      if (written[o.child1_clv_index] || written[o.child2_clv_index] ||
+          (o.child1_scaler_index >= 0 && swritten[o.child1_scaler_index]) ||
+          (o.child2_scaler_index >= 0 && swritten[o.child2_scaler_index]) ||
+          (o.parent_scaler_index >= 0 && swritten[o.parent_scaler_index]))
+        want.push_back(t);
+    }
+    if (!want.empty() && !transient_materialize(e, want)) return PLL_FAILURE;
+  }
+  for (unsigned k = 0; k < count && e->ntransient; ++k) transient_drop(e, ops[k].parent_clv_index, !e->transient_busy);
+  return PLL_SUCCESS;
+}
+
+// after the launches of a resident schedule: the operations whose vectors stayed in registers
+static void transient_after_list(Engine * e, const pll_operation_t * ops, unsigned count, const DevicePlan & dp)
+{
+  const PlanOp * pops = reinterpret_cast<const PlanOp *>(dp.bytes.data());
+  std::vector<int> by_parent;
+  for (unsigned i = 0; i < dp.nops; ++i)
+  {
+    if (!(pops[i].flags & 1u)) continue;
+    if (by_parent.empty())
+    {
+      by_parent.assign(e->nodes, -1);
+      for (unsigned k = 0; k < count; ++k) by_parent[ops[k].parent_clv_index] = (int)k;
+    }
+    const int k = by_parent[pops[i].d.parent_index];
+    if (k >= 0) transient_mark(e, ops[k]);
+  }
+}
+
 // resolve one operation to device pointers and add its algorithmic bytes
 // (child vectors in -- 8*S per (site, rate), a coded tip is 1 byte
 // per site --, parent vector out, scalers, the two P-matrices or lookup tables
@@ -1309,7 +1444,7 @@ static std::atomic<unsigned long long> plan_generation{0};
 
 static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_operation_t * ops, unsigned count,
                              unsigned mode, const RepeatPlan * rp = nullptr,
-                             const pll_operation_t * all_ops = nullptr, unsigned all_count = 0)
+                             const pll_operation_t * all_ops = nullptr, unsigned all_count = 0, bool transient = false)
 {
   const bool chains20 = e->family == KernelFamily::S20, chains16 = e->family == KernelFamily::S16;
   const bool chains4 = e->family == KernelFamily::S4;
@@ -1354,7 +1489,8 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
   std::vector<unsigned char> key(3 * sizeof(unsigned) + (size_t)key_count * sizeof(pll_operation_t) + wide.size() + tracked.size());
   memcpy(key.data(), &key_count, sizeof(unsigned));
   memcpy(key.data() + sizeof(unsigned), &lut_used, sizeof(unsigned));
-  memcpy(key.data() + 2 * sizeof(unsigned), &mode, sizeof(unsigned));
+  const unsigned mode_key = mode | (transient ? 0x100u : 0u);
+  memcpy(key.data() + 2 * sizeof(unsigned), &mode_key, sizeof(unsigned));
   memcpy(key.data() + 3 * sizeof(unsigned), key_ops, (size_t)key_count * sizeof(pll_operation_t));
   if (!wide.empty()) memcpy(key.data() + 3 * sizeof(unsigned) + (size_t)key_count * sizeof(pll_operation_t), wide.data(), wide.size());
   if (!tracked.empty()) memcpy(key.data() + key.size() - tracked.size(), tracked.data(), tracked.size());
@@ -1498,7 +1634,9 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
         const double before = dp.algo_bytes;
         fill_desc(e, o, po.d, dp.algo_bytes, dp.algo_flops);
         po.carried = i ? plan.carried[ch[i]] : 0;
-        double wide_saved = 0.0;
+        // an evaluate-only traversal: the vectors inside a chain are handed on in registers only
+        po.flags = (transient && i + 1 < ch.size()) ? 1u : 0u;
+        double wide_saved = (po.flags & 1u) ? (double)e->N * e->R * 8.0 * e->S : 0.0;
         for (int x = 0; x < 2 && !wide.empty(); ++x)
         {
           if (!wide[2 * ch[i] + x]) continue;
@@ -1722,6 +1860,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
   std::vector<int> clv_level(e->nodes, -1), sc_level(e->nscalers, -1), level(count, 0);
   int max_level = 0;
   if (!validate_ops(e, ops, count)) return PLL_FAILURE;
+  if (!transient_before_list(e, ops, count)) return PLL_FAILURE;
   if (!e->cherries.empty())
   {
     // every vector this list writes stops being the cherry it may have been; one that the list reads first
@@ -1913,8 +2052,10 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
         else
           for (unsigned k : rp.cherry_ops) e->cherries[ops[k].parent_clv_index].valid = false;
       }
+      // (evaluate-only traversals: not together with site repeats, whose class operations leave the list)
+      const bool transient = e->transient_mode && !e->site_repeats;
       const bool have = rp.active ? prepare_schedule(e, p, rp.ops.data(), (unsigned)rp.ops.size(), mode, &rp, ops, count)
-                                  : prepare_schedule(e, p, ops, count, mode);
+                                  : prepare_schedule(e, p, ops, count, mode, nullptr, nullptr, 0, transient);
       if (!have && rp.active)
         for (unsigned k : rp.cherry_ops) e->cherries[ops[k].parent_clv_index].valid = false;     // the plain paths below compute them
       if (have)
@@ -1967,13 +2108,14 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
           const unsigned rows = l.rows;
           hipEvent_t ev1;
           if (!prof_begin(ev1)) return PLL_FAILURE;
-          if (chains20 ? !launch_traverse_s20(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows)
+          if (chains20 ? !launch_traverse_s20(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows, 0, !e->cherries.empty(), transient)
                        : chains16 ? !launch_traverse_s16(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows)
                                   : !launch_traverse_s4(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows))
             return PLL_FAILURE;
           if (!prof_end(ev1, l.bytes, l.flops, l.ops, l.min_bytes)) return PLL_FAILURE;
           e->counters.partial_launches++;
         }
+        if (transient) transient_after_list(e, ops, count, dp);
         e->counters.partial_ops += count;
         e->counters.site_updates += (unsigned long long)count * e->N * e->R;
         return PLL_SUCCESS;
@@ -2274,7 +2416,8 @@ static int update_partials_group(const std::vector<pll_partition_t *> & g, const
   {
     Engine * e = engine_of(p);
     if (!validate_ops(e, ops, count)) return -1;
-    if (!prepare_schedule(e, p, ops, count, mode)) return 0;
+    if (e->ntransient && (hipSetDevice(e->device) != hipSuccess || !transient_before_list(e, ops, count))) return -1;
+    if (!prepare_schedule(e, p, ops, count, mode, nullptr, nullptr, 0, e->transient_mode && !e->site_repeats)) return 0;
   }
   // launches can be shared when every member's schedule has the same shape (same list, same family: always,
   // unless the tables of one member fill the LDS earlier and cut its chains elsewhere)
@@ -2392,7 +2535,9 @@ static int update_partials_group(const std::vector<pll_partition_t *> & g, const
     // of it, so exactly the workgroups that are resident at once (one per CU; three at 4 states)
     static const int env_walk = getenv("PLLHIP_BATCH_WGS") ? atoi(getenv("PLLHIP_BATCH_WGS")) : 0;
     const unsigned wgs = mode ? (env_walk > 0 ? (unsigned)env_walk : lead->family == KernelFamily::S4 ? 3u : 1u) : 0u;
-    const int ok = lead->family == KernelFamily::S20 ? launch_traverse_s20(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs)
+    bool any_transient = false;
+    for (pll_partition_t * p : g) any_transient = any_transient || (engine_of(p)->transient_mode && !engine_of(p)->site_repeats);
+    const int ok = lead->family == KernelFamily::S20 ? launch_traverse_s20(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs, false, any_transient)
                  : lead->family == KernelFamily::S16 ? launch_traverse_s16(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs)
                                                      : launch_traverse_s4(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs);
     if (!ok) return -1;
@@ -2413,6 +2558,7 @@ static int update_partials_group(const std::vector<pll_partition_t *> & g, const
   for (pll_partition_t * p : g)
   {
     Engine * e = engine_of(p);
+    if (e->transient_mode && !e->site_repeats) transient_after_list(e, ops, count, e->plan);
     e->counters.partial_ops += count;
     e->counters.site_updates += (unsigned long long)count * e->N * e->R;
   }
@@ -2584,6 +2730,16 @@ int pll_update_prob_matrices(pll_partition_t * p,
                 matrix_indices[m], branch_lengths[m]);
       return PLL_FAILURE;
     }
+  // a vector that an evaluate-only traversal did not store is recomputed with the matrices it was made with:
+  // stored now, before one of them changes (pllhip_discard_transient: the caller gave those vectors up)
+  if (e->ntransient)
+    for (unsigned m = 0; m < count; ++m)
+      if (e->transient_mat_users[matrix_indices[m]])
+      {
+        PLLHIP_TRY(hipSetDevice(e->device));
+        if (!transient_flush_all(e)) return PLL_FAILURE;
+        break;
+      }
   // queue; a request for a matrix that is already queued replaces it
   const ParamIdx params = make_params(p, params_indices);
   if (!e->pend_midx.empty() && memcmp(&params, &e->pend_params, sizeof(params)) != 0)
@@ -2748,7 +2904,9 @@ static int newton_capacity(Engine * e, const void ** fn_out, size_t * lds_out)
         return -1;
       const unsigned cap2 = (unsigned)std::max(0, cu2) * e->cu_count;
       const unsigned long long limit = ((unsigned long long)e->N * e->R + 63ULL) & ~63ULL;
-      const unsigned g2 = std::min(reduce_grid(e), cap2);
+      // (the grid the loop is launched on: scan_grid() = the reduction grid, at most four workgroups per CU and at
+      // most what the chip holds at once)
+      const unsigned g2 = std::min({reduce_grid(e), 4u * e->cu_count, cap2});
       const bool resident = env_res && g2 && (limit + 1024ULL * g2 - 1) / (1024ULL * g2) <= 2;
       e->newton_resident = resident ? 2 : 0;
       e->newton_fn = fn2;
@@ -3101,6 +3259,14 @@ int pllhip_newton_branch(pll_partition_t * p, int parent_scaler_index, int child
   np.dxmax = bl_max / max_newton;
   np.max_newton = max_newton;
   np.x0 = std::max(std::min(start, bl_max), bl_min);
+  // PLLHIP_NEWTON_SPIN_LIMIT: polls before a waiting workgroup gives up; PLLHIP_FAULT=newton_stall: workgroup 0 of
+  // the next PLLHIP_FAULT_COUNT (default 1) launches never arrives (tests of the PLLHIP_ERROR_NEWTON_STUCK path)
+  static const unsigned env_spin = getenv("PLLHIP_NEWTON_SPIN_LIMIT") ? (unsigned)strtoul(getenv("PLLHIP_NEWTON_SPIN_LIMIT"), nullptr, 10) : 0u;
+  static int stall_left = (getenv("PLLHIP_FAULT") && !strcmp(getenv("PLLHIP_FAULT"), "newton_stall"))
+                              ? (getenv("PLLHIP_FAULT_COUNT") ? atoi(getenv("PLLHIP_FAULT_COUNT")) : 1) : 0;
+  np.spin_limit = env_spin ? env_spin : NEWTON_SPIN_LIMIT;
+  np.stall_block = ~0u;
+  if (stall_left > 0 && nblocks > 1) { --stall_left; np.stall_block = 0u; }
   NewtonControl init;
   memset(&init, 0, sizeof(init));
   init.x = np.x0; init.xl = bl_min; init.xh = bl_max; init.iter = 0; init.status = NEWTON_RUNNING;
@@ -3138,6 +3304,17 @@ int pllhip_newton_branch(pll_partition_t * p, int parent_scaler_index, int child
   const volatile unsigned long long * flag = reinterpret_cast<const volatile unsigned long long *>(e->h_newton + 112);
   if (!wait_sequence(e->stream, flag, seq)) return PLL_FAILURE;
   const unsigned its = (unsigned)e->h_newton[1], status = (unsigned)e->h_newton[2];
+  if (status == NEWTON_STUCK)
+  {
+    // the grid drains by itself (every wait is bounded); the tickets of the unfinished reduction go back to zero
+    // before anything else uses them
+    PLLHIP_TRY(hipStreamSynchronize(e->stream));
+    PLLHIP_TRY(hipMemsetAsync(e->d_counter, 0, REDUCE_COUNTER_WORDS * sizeof(unsigned), e->stream));
+    PLLHIP_TRY(hipStreamSynchronize(e->stream));
+    set_error(PLLHIP_ERROR_NEWTON_STUCK, "the device-resident Newton-Raphson loop did not get all its workgroups onto the "
+              "chip at once (the device is shared with other work)");
+    return PLL_FAILURE;
+  }
   e->counters.derivative_points += its;
   if (length) *length = e->h_newton[0];
   if (iterations) *iterations = its;
@@ -3384,8 +3561,31 @@ int pllhip_set_clv(pll_partition_t * p, unsigned int clv_index, const double * c
     set_error(PLL_ERROR_PARAM_INVALID, "CLV %u is a coded tip", clv_index);
     return PLL_FAILURE;
   }
+  if (!transient_flush_all(e)) return PLL_FAILURE;            // (vectors that were not stored may read this one)
   if (!e->cherries.empty()) e->cherries[clv_index].valid = false;
   return store_clv(e, e->d_clv[clv_index], clv);
+}
+
+int pllhip_set_transient(pll_partition_t * p, int enable)
+{
+  Engine * e = engine_of(p);
+  for (pll_partition_t * c : e->shards) (void)pllhip_set_transient(c, enable);
+  e->transient_mode = enable != 0;
+  return PLL_SUCCESS;
+}
+
+int pllhip_discard_transient(pll_partition_t * p)
+{
+  Engine * e = engine_of(p);
+  for (pll_partition_t * c : e->shards) (void)pllhip_discard_transient(c);
+  for (unsigned n = 0; n < e->nodes && e->ntransient; ++n) transient_drop(e, n, true);
+  return PLL_SUCCESS;
+}
+
+int pllhip_transient_stats(const pll_partition_t * p, pllhip_transient_stats_t * out)
+{
+  *out = exec_engine(p)->transient_stats;
+  return PLL_SUCCESS;
 }
 
 int pllhip_repeat_stats(const pll_partition_t * p, pllhip_repeat_stats_t * out)
@@ -3428,6 +3628,7 @@ int pllhip_set_scaler(pll_partition_t * p, unsigned int idx, const unsigned int 
   PLLHIP_TRY(hipSetDevice(e->device));
   if (idx >= e->nscalers) { set_error(PLL_ERROR_PARAM_INVALID, "scaler index out of range"); return PLL_FAILURE; }
   if (!e->N) return PLL_SUCCESS;
+  if (!transient_flush_all(e)) return PLL_FAILURE;
   if (idx < e->scaler_lazy.size()) e->scaler_lazy[idx] = -1;         // the caller's counts replace whatever stood for the buffer
   PLLHIP_TRY(hipMemcpyAsync(e->d_scalers + (size_t)idx * e->sc_len, in,
                             sizeof(unsigned) * e->N * (e->rate_scalers ? e->R : 1),
@@ -3512,6 +3713,7 @@ int pllhip_sync_to_device(pll_partition_t * p, unsigned int what)
   if (!e->shards.empty())
     for (pll_partition_t * c : e->shards) push_model(p, c);     // a loader filled the parent's model arrays
   if (e->shards.empty()) PLLHIP_TRY(hipSetDevice(e->device));
+  if (e->shards.empty() && !transient_flush_all(e)) return PLL_FAILURE;
   e->eigen_touched = true;                                  // a loader may have filled the model arrays
   e->pmatrix_burst = false;
   if (what & PLLHIP_SYNC_TIPS)

@@ -14,6 +14,7 @@
 // tables partition->clv / scale_buffer exist (pll-modules indexes them) but
 // hold NULL until pllhip_sync_to_host() materialises them.
 #include "engine.h"
+#include "host/pll_repeats.h"
 
 #include <cstdarg>
 #include <cstdlib>
@@ -76,9 +77,13 @@ void * pll_aligned_alloc(size_t size, size_t alignment)
 
 void pll_aligned_free(void * ptr) { free(ptr); }
 
-unsigned int pll_get_sites_number(const pll_partition_t * p, unsigned int)
+// libpll-2: the sites a node's vector is allocated for -- its classes when it has repeats, else every site (+ the
+// ascertainment-bias columns).  No node of this library has repeats in the reference's sense (host/pll_repeats.c).
+unsigned int pll_get_sites_number(const pll_partition_t * p, unsigned int clv_index)
 {
-  return p->sites;
+  unsigned int n = (p->repeats && clv_index < p->nodes) ? p->repeats->pernode_ids[clv_index] : 0u;
+  if (!n) n = p->sites;
+  return n + (p->asc_bias_alloc ? (unsigned)p->asc_additional_sites : 0u);
 }
 
 unsigned int pll_get_clv_size(const pll_partition_t * p, unsigned int)
@@ -190,6 +195,12 @@ pll_partition_t * pll_partition_create(unsigned int tips,
     return nullptr;
   }
 
+  if ((attributes & PLL_ATTRIB_SITE_REPEATS) && !pll_repeats_attach(p))
+  {
+    set_error(PLL_ERROR_MEM_ALLOC, "Unable to allocate the site-repeats tables.");
+    pll_partition_destroy(p);
+    return nullptr;
+  }
   p->engine = engine_create(p);   // sets pll_errno on failure
   if (!p->engine)
   {
@@ -240,6 +251,7 @@ void pll_partition_destroy(pll_partition_t * p)
   free(p->charmap);
   free(p->tipmap);
   pll_aligned_free(p->ttlookup);
+  pll_repeats_release(p);
   free(p);
 }
 

@@ -35,6 +35,13 @@ c_double_p = C.POINTER(C.c_double)
 c_uint_p = C.POINTER(C.c_uint)
 
 
+class Repeats(C.Structure):
+    """pll_repeats_t (include/pll.h): what pll-modules dereferences under PLL_ATTRIB_SITE_REPEATS"""
+    _fields_ = [("pernode_site_id", C.POINTER(c_uint_p)), ("pernode_id_site", C.POINTER(c_uint_p)),
+                ("pernode_ids", c_uint_p), ("perscale_ids", c_uint_p), ("pernode_allocated_clvs", c_uint_p),
+                ("enable_repeats", C.c_void_p), ("reallocate_repeats", C.c_void_p)]
+
+
 class Partition(C.Structure):
     _fields_ = [
         ("tips", C.c_uint), ("clv_buffers", C.c_uint), ("nodes", C.c_uint),
@@ -56,7 +63,7 @@ class Partition(C.Structure):
         ("charmap", C.POINTER(C.c_ubyte)), ("ttlookup", c_double_p),
         ("tipmap", C.POINTER(C.c_ulonglong)),
         ("asc_bias_alloc", C.c_int), ("asc_additional_sites", C.c_int),
-        ("repeats", C.c_void_p), ("engine", C.c_void_p),
+        ("repeats", C.POINTER(Repeats)), ("engine", C.c_void_p),
     ]
 
 
@@ -99,6 +106,10 @@ class RepeatStats(C.Structure):
     _fields_ = [(n, C.c_ulonglong) for n in ("cherries", "classes", "sites", "expansions")]
 
 
+class TransientStats(C.Structure):
+    _fields_ = [(n, C.c_ulonglong) for n in ("skipped", "materialized", "discarded")]
+
+
 class Profile(C.Structure):
     _fields_ = [("launches", C.c_ulonglong), ("ops", C.c_ulonglong),
                 ("kernel_ms", C.c_double), ("algorithmic_bytes", C.c_double),
@@ -132,7 +143,7 @@ pllhip_eval_set_branch_length pllhip_eval_optimize_branches pllhip_eval_ops
 pllhip_eval_pmatrix_updates pllhip_eval_derivative_calls pllhip_eval_spr_round
 pllhip_eval_set_fused pllhip_eval_newton_iterations pllhip_eval_set_brlen_linkage
 pllhip_eval_set_brlen_scaler pllhip_eval_get_brlen_scaler pllhip_eval_get_partition_branch_length
-pllhip_eval_set_partition_branch_length""".split()
+pllhip_eval_set_partition_branch_length pllhip_eval_set_transient""".split()
 
 PLLHIP_H_FUNCTIONS = """pllhip_device_count pllhip_set_device pllhip_get_device
 pllhip_device_arch pllhip_eigen_decompose pllhip_sync_to_host pllhip_sync_to_device pllhip_get_clv
@@ -143,7 +154,8 @@ pllhip_profile_partials pllhip_profile_read pllhip_comm_rank pllhip_comm_size
 pllhip_compute_likelihood_derivatives_multi pllhip_free_trial_lengths pllhip_set_sharding
 pllhip_shard_count pllhip_results_create pllhip_results_destroy
 pllhip_results_edge_loglikelihood pllhip_results_derivatives pllhip_results_fetch
-pllhip_eval_attach_comm pllhip_update_partials_batch pllhip_results_poison pllhip_newton_branch pllhip_repeat_stats""".split()
+pllhip_eval_attach_comm pllhip_update_partials_batch pllhip_results_poison pllhip_newton_branch pllhip_repeat_stats
+pllhip_set_transient pllhip_discard_transient pllhip_transient_stats""".split()
 
 
 def _u32(a):
@@ -168,6 +180,10 @@ class PllLib:
         L.pll_partition_create.restype = pp
         L.pll_partition_create.argtypes = [C.c_uint] * 9
         L.pll_partition_destroy.argtypes = [pp]
+        L.pll_get_sites_number.argtypes = [pp, C.c_uint]
+        L.pll_get_sites_number.restype = C.c_uint
+        L.pll_get_clv_size.argtypes = [pp, C.c_uint]
+        L.pll_get_clv_size.restype = C.c_uint
         L.pll_set_tip_states.argtypes = [pp, C.c_uint, C.POINTER(C.c_ulonglong), C.c_char_p]
         L.pll_set_tip_clv.argtypes = [pp, C.c_uint, c_double_p, C.c_int]
         L.pll_set_pattern_weights.argtypes = [pp, c_uint_p]
@@ -230,6 +246,8 @@ class PllLib:
             L.pllhip_eval_loglh.restype = C.c_double
             L.pllhip_eval_loglh.argtypes = [C.c_void_p, C.c_int]
             L.pllhip_eval_set_branch_length.argtypes = [C.c_void_p, up, C.c_double]
+            L.pllhip_eval_set_transient.argtypes = [C.c_void_p, C.c_int]
+            L.pllhip_eval_set_transient.restype = None
             L.pllhip_eval_optimize_branches.restype = C.c_double
             L.pllhip_eval_optimize_branches.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double,
                                                         C.c_int, C.c_int]
@@ -270,6 +288,9 @@ class PllLib:
             L.pllhip_profile_partials.argtypes = [pp, C.c_int]
             L.pllhip_profile_read.argtypes = [pp, C.POINTER(Profile)]
             L.pllhip_repeat_stats.argtypes = [pp, C.POINTER(RepeatStats)]
+            L.pllhip_set_transient.argtypes = [pp, C.c_int]
+            L.pllhip_discard_transient.argtypes = [pp]
+            L.pllhip_transient_stats.argtypes = [pp, C.POINTER(TransientStats)]
             L.pllhip_comm_get_unique_id.argtypes = [C.c_char_p]
             L.pllhip_comm_create.restype = C.c_void_p
             L.pllhip_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
@@ -544,6 +565,18 @@ class Instance:
     def repeat_stats(self):
         st = RepeatStats()
         self.L.pllhip_repeat_stats(self.p, C.byref(st))
+        return st
+
+    # evaluate-only traversals (include/pllhip.h, pllhip_set_transient)
+    def set_transient(self, on=True):
+        self.L.pllhip_set_transient(self.p, 1 if on else 0)
+
+    def discard_transient(self):
+        self.L.pllhip_discard_transient(self.p)
+
+    def transient_stats(self):
+        st = TransientStats()
+        self.L.pllhip_transient_stats(self.p, C.byref(st))
         return st
 
 
@@ -882,6 +915,10 @@ class Evaluation:
         """per-site lnL of partition `index` at the root edge (CLVs must be valid: call loglh first)"""
         pc_, psc, cc, csc, m = self.root_edge()
         return self.parts[index].edge_lnl(pc_, psc, cc, csc, m, persite=True)
+
+    def set_transient(self, mode):
+        """0 off, 1 every full evaluation, 2 a full evaluation that directly follows one (include/pllhip_eval.h)"""
+        self.L.pllhip_eval_set_transient(self.ev, int(mode))
 
     def loglh(self, incremental=False):
         v = self.L.pllhip_eval_loglh(self.ev, 1 if incremental else 0)

@@ -13,6 +13,12 @@ import pllhip_ctypes as pc
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 NONE = pc.PLL_SCALE_BUFFER_NONE
+# tests/test_00_forced_modes.py runs the whole -m gpu suite with every partition treated as if it had
+# PLL_ATTRIB_SITE_REPEATS (PLLHIP_SITE_REPEATS=2) and with evaluate-only traversals everywhere (PLLHIP_TRANSIENT=1):
+# every NUMBER must stay what it is; asserts about how many launches / class operations a call took are void there
+FORCED_REPEATS = os.environ.get("PLLHIP_SITE_REPEATS") == "2"
+FORCED_TRANSIENT = os.environ.get("PLLHIP_TRANSIENT", "0") not in ("", "0")
+FORCED = FORCED_REPEATS or FORCED_TRANSIENT
 
 
 def fixtures():

@@ -4,10 +4,15 @@
  * library: dump a partition with its CLVs, scalers and P-matrices, load it into a new
  * partition, and evaluate the edge log-likelihood WITHOUT recomputing anything
  * (the reference's own criterion, test/src/binary/binary-sequential.c:344-354).
- * usage: binary_driver <file> tv|clv
+ * usage: binary_driver <file> tv|clv|tv-repeats|clv-repeats
+ * "-repeats": the partition is created with PLL_ATTRIB_SITE_REPEATS; the reference then dereferences
+ * partition->repeats in its dump / load walk (src/binary/binary_io_operations.c:231-236, 265-282;
+ * src/binary/pll_binary.c:388-406) and in pllmod_msa_empirical_frequencies (src/msa/pll_msa.c:108-112),
+ * which is called here on every partition (the reference's own src/msa/pll_msa.c, compiled unchanged).
  */
 #include "pllmod_common.h"
 #include "pll_binary.h"
+#include "pll_msa.h"
 #include <stdio.h>
 
 #define TAXA 9
@@ -25,7 +30,8 @@ static int cb_all(pll_unode_t * n) { (void)n; return 1; }
 int main(int argc, char ** argv)
 {
   if (argc < 3) return 2;
-  const unsigned int attrs = !strcmp(argv[2], "tv") ? PLL_ATTRIB_PATTERN_TIP : 0;
+  const unsigned int attrs = (!strncmp(argv[2], "tv", 2) ? PLL_ATTRIB_PATTERN_TIP : 0) |
+                             (strstr(argv[2], "-repeats") ? PLL_ATTRIB_SITE_REPEATS : 0);
   const unsigned int states = 20, sites = 333, cats = 4;
   const char * nwk = "((t0:0.11,t1:0.07):0.05,(t2:0.13,(t3:0.06,t4:0.09):0.04):0.03,"
                      "((t5:0.10,t6:0.05):0.02,(t7:0.08,t8:0.07):0.05):0.06);";
@@ -71,6 +77,14 @@ int main(int argc, char ** argv)
   const int ps = root->scaler_index, cs = root->back->scaler_index;
   const double before = pll_compute_edge_loglikelihood(p, pc, ps, cc, cs, pm, params, NULL);
   printf("lnL before: %.10f\n", before);
+  {
+    double * ef = pllmod_msa_empirical_frequencies(p);
+    if (!ef) { fprintf(stderr, "empirical frequencies: %s\n", pll_errmsg); return 1; }
+    printf("freqs:");
+    for (i = 0; i < states; ++i) printf(" %.12f", ef[i]);
+    printf("\n");
+    free(ef);
+  }
 
   pll_binary_header_t header;
   FILE * f = pllmod_binary_create(argv[1], &header, PLLMOD_BIN_ACCESS_SEQUENTIAL, 0);
@@ -90,6 +104,8 @@ int main(int argc, char ** argv)
   const double after = pll_compute_edge_loglikelihood(p, pc, ps, cc, cs, pm, params, NULL);
   printf("lnL after:  %.10f\n", after);
   printf("weights: %u\n", p->pattern_weight_sum);
+  printf("attributes restored: %s\n", ((p->attributes ^ attrs) & (PLL_ATTRIB_SITE_REPEATS | PLL_ATTRIB_PATTERN_TIP)) ? "no" : "yes");
+  if ((attrs & PLL_ATTRIB_SITE_REPEATS) && !p->repeats) { fprintf(stderr, "loaded partition without repeats table\n"); return 1; }
   /* the restored partition keeps working: same result after recomputing everything */
   if (!pll_update_prob_matrices(p, params, midx, brlens, nm)) return 1;
   pll_update_partials(p, ops, no);

@@ -1,0 +1,35 @@
+"""The whole `-m gpu` suite once more under two engine-wide switches, each in a child process of its own (started
+before this process has touched the GPU: the file sorts first):
+
+  PLLHIP_SITE_REPEATS=2  every partition is treated as if it had been created with PLL_ATTRIB_SITE_REPEATS -- the
+                         reference's test harness runs every program with and without the attribute and compares the
+                         text (test/runtest.py:45-51, test/src/common.c:31);
+  PLLHIP_TRANSIENT=1     every resident schedule runs evaluate-only (include/pllhip.h, pllhip_set_transient): vectors
+                         inside operation chains are not stored and come back on demand.
+
+Every oracle comparison, golden value and bit-for-bit check of the suite has to hold unchanged; the few asserts that
+count launches or class operations are switched off through tests/common.py (FORCED_*)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,env", [("site_repeats", {"PLLHIP_SITE_REPEATS": "2"}), ("transient", {"PLLHIP_TRANSIENT": "1"})])
+def test_gpu_suite_under(name, env):
+    if os.environ.get("PLLHIP_FORCED_CHILD"):
+        pytest.skip("already inside a forced-mode run")
+    cmd = [sys.executable, "-m", "pytest", "tests", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+           "--ignore=tests/test_00_forced_modes.py"]
+    r = subprocess.run(cmd, cwd=ROOT, env={**os.environ, **env, "PLLHIP_FORCED_CHILD": "1"}, capture_output=True,
+                       text=True, timeout=1500)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, f"forced_{name}.log"), "w") as f:
+            f.write(r.stdout + "\n" + r.stderr)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
+    assert " passed" in r.stdout

@@ -239,7 +239,7 @@ def test_own_spr_round_makes_the_reference_s_moves(spr_driver, tmp_path, mode, n
 # ---------------------------------------------------------------------------
 # binary checkpoint module (src/binary): dump a partition with CLVs, load it, evaluate
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("mode", ["tv", "clv"])
+@pytest.mark.parametrize("mode", ["tv", "clv", "tv-repeats", "clv-repeats"])
 def test_reference_binary_module_round_trip(oracle, tmp_path, mode):
     """the reference's checkpoint code walks the partition's arrays
     directly (src/binary/binary_io_operations.c:161-314); compiled unchanged against
@@ -249,12 +249,14 @@ def test_reference_binary_module_round_trip(oracle, tmp_path, mode):
     if not os.path.isdir(REF):
         pytest.skip("reference tree not present on this box")
     exe = tmp_path / "binary_driver"
-    src = [os.path.join(ROOT, "tests", "dropin", "binary_driver.c"), f"{REF}/src/pllmod_common.c"]
+    src = [os.path.join(ROOT, "tests", "dropin", "binary_driver.c"), f"{REF}/src/pllmod_common.c", f"{REF}/src/msa/pll_msa.c"]
     src += sorted(glob.glob(f"{REF}/src/binary/*.c"))
-    inc = sum((["-I", d] for d in [f"{ROOT}/include", f"{REF}/src", f"{REF}/src/binary", f"{REF}/src/tree"]), [])
+    inc = sum((["-I", d] for d in [f"{ROOT}/include", f"{REF}/src", f"{REF}/src/binary", f"{REF}/src/tree",
+                                   f"{REF}/src/msa"]), [])
     libdir = os.path.dirname(ORACLE_LIB)
-    subprocess.run(["gcc", "-std=gnu99", "-D_GNU_SOURCE", "-O2", "-w", *inc, "-o", str(exe), *src,
-                    "-L", libdir, "-lpll_oracle", "-lm", f"-Wl,-rpath,{libdir}"], check=True)
+    # (pll_msa.c's statistics function calls into src/util, which is not on this path: unused sections are dropped)
+    subprocess.run(["gcc", "-std=gnu99", "-D_GNU_SOURCE", "-O2", "-w", "-ffunction-sections", *inc, "-o", str(exe), *src,
+                    "-L", libdir, "-lpll_oracle", "-lm", f"-Wl,-rpath,{libdir}", "-Wl,--gc-sections"], check=True)
     out = subprocess.run([str(exe), str(tmp_path / "ckpt.bin"), mode], check=True, capture_output=True,
                          text=True, timeout=120).stdout
     v = {k.strip(): float(x) for k, x in re.findall(r"^(lnL \w+):\s+(-?[0-9.]+)$", out, re.M)}
@@ -262,3 +264,13 @@ def test_reference_binary_module_round_trip(oracle, tmp_path, mode):
     assert v["lnL before"] < -1000
     assert abs(v["lnL after"] - v["lnL before"]) < 1e-7
     assert abs(v["lnL redo"] - v["lnL before"]) < 1e-7
+    assert "attributes restored: yes" in out
+    # "-repeats": with PLL_ATTRIB_SITE_REPEATS the reference's dump / load and its empirical frequencies go through
+    # partition->repeats (src/binary/binary_io_operations.c:231-282, src/msa/pll_msa.c:108-112): same numbers as without
+    freqs = [float(x) for x in re.search(r"^freqs:(.*)$", out, re.M).group(1).split()]
+    assert len(freqs) == 20 and abs(sum(freqs) - 1.0) < 1e-9
+    seen = test_reference_binary_module_round_trip.__dict__.setdefault("seen", {})
+    seen[mode] = (v["lnL before"], freqs)
+    base = mode.split("-")[0]
+    if base in seen and mode in seen and base != mode:
+        assert seen[base] == seen[mode]

@@ -244,6 +244,27 @@ def test_communicator_failure_paths(tmp_path, mode):
         assert r["errno"][2] == 904 and r["errno"][3] == 904                # PLL_ERROR_HIP_COMM_ABORTED
 
 
+@pytest.mark.parametrize("states", [20, 4, 61])
+def test_device_newton_that_cannot_get_its_workgroups(states):
+    """The device-resident Newton-Raphson loop sizes its grid for a device the partition has to itself; a workgroup
+    that never arrives (tests/_newton_stall_worker.py) ends the launch with PLLHIP_ERROR_NEWTON_STUCK after the bounded
+    wait instead of failing the optimisation: the engine's reductions keep working, the driver redoes the branch on
+    the host loop and stays there -- same likelihoods, same tree, same iterate count as without the fault."""
+    import json
+    import subprocess
+    import sys
+    got = {}
+    for stall in (1, 0):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_newton_stall_worker.py"), str(states), str(stall)],
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        got[stall] = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got[1]["direct_errno"] == 913 and got[0]["direct_errno"] == 0          # PLLHIP_ERROR_NEWTON_STUCK
+    assert got[1]["deriv_unchanged"] and got[0]["deriv_unchanged"]
+    for k in ("lnl_after", "lnl0", "lnl1", "newick", "iterations"):
+        assert got[1][k] == got[0][k], k
+
+
 @pytest.mark.parametrize("states,nshards", [(20, 3), (4, 2), (61, 2), (10, 4)])
 def test_partition_spread_over_devices(product, states, nshards):
     """engine-internal sharding (include/pllhip.h: pllhip_set_sharding; SURVEY.md 8e topology i): ONE

@@ -4,14 +4,48 @@ instead of the table of possible pairs; PLLHIP_SITE_REPEATS=2 runs the whole -m 
 PLL_ATTRIB_SITE_REPEATS, first step (pll-modules_amd/csrc/kernels_repeats.hpp): cherries are kept per class of
 sites (pair of tip codes).  Everything a caller can observe must be identical -- bit for bit -- to the attribute
 being off: the reference's own tests run every program with and without it and compare the text
-(test/src/common.c:31, test/runtest.py:45-51)."""
+(test/src/common.c:31, test/runtest.py:45-51).
+
+Two checks per case: the engine with the attribute against the engine without it (bit for bit), AND the engine with
+the attribute against the CPU oracle on the same inputs (likelihoods, every vector, exact scaler counts, per-site
+likelihoods, derivatives) -- an error shared by both device paths would pass the first one only."""
+import os
+
 import numpy as np
 import pytest
 
+import common
 import pllhip_ctypes as pc
+from test_gpu_parity import lnl_close, site_err, REL_CLV
 
 pytestmark = pytest.mark.gpu
 NONE = pc.PLL_SCALE_BUFFER_NONE
+# PLLHIP_SITE_REPEATS=2: every partition is treated as if it had the attribute (tests/test_forced_modes.py runs the
+# whole suite that way); "the attribute off" then computes per class as well, and asserts about its statistics are void
+FORCED = common.FORCED_REPEATS
+
+
+def _close_to_oracle(got, ref, nsites, states):
+    """`got`: _everything() of the engine, `ref`: of the oracle"""
+    assert got.keys() == ref.keys()
+    for k in got:
+        a, b = got[k], ref[k]
+        if k.endswith("scaler"):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), k                      # integers: exact
+        elif k.endswith("clv"):
+            for x, y in zip(a if isinstance(a, list) else [a], b if isinstance(b, list) else [b]):
+                assert site_err(np.asarray(x), np.asarray(y)) <= REL_CLV, k
+        elif k == "persite":
+            fin = np.isfinite(b)
+            assert np.array_equal(fin, np.isfinite(a))
+            assert np.all(np.abs(a[fin] - b[fin]) <= 1e-10 * np.abs(b[fin]) + 1e-11), k
+        elif k == "deriv":
+            assert np.allclose(np.asarray(a), np.asarray(b), rtol=1e-9, atol=1e-9 * nsites), k
+        elif np.isfinite(b):
+            assert lnl_close(a, b, nsites, states), (k, a, b)
+        else:
+            assert a == b, k
 
 
 def _build(product, tree, nsites, repeats, seed=44, gaps=False, states=20, ambiguity=False):
@@ -72,19 +106,21 @@ def _same(a, b):
 @pytest.mark.parametrize("states", [20, 4])
 @pytest.mark.parametrize("ntips,nsites,gaps,ambiguity", [(14, 1031, False, False), (40, 5000, True, False),
                                                          (9, 257, True, True), (100, 3333, False, False)])
-def test_site_repeats_change_nothing_a_caller_can_see(product, ntips, nsites, gaps, ambiguity, states):
+def test_site_repeats_change_nothing_a_caller_can_see(product, oracle, ntips, nsites, gaps, ambiguity, states):
     tree = pc.Tree(ntips, 42, 43)
     with _build(product, tree, nsites, True, gaps=gaps, ambiguity=ambiguity, states=states) as on, \
-            _build(product, tree, nsites, False, gaps=gaps, ambiguity=ambiguity, states=states) as off:
+            _build(product, tree, nsites, False, gaps=gaps, ambiguity=ambiguity, states=states) as off, \
+            _build(oracle, tree, nsites, False, gaps=gaps, ambiguity=ambiguity, states=states) as ref:
         a, b = _everything(on), _everything(off)
         _same(a, b)
+        _close_to_oracle(a, _everything(ref), nsites, states)
         st = on.repeat_stats()
         assert st.cherries > 0 and st.classes < st.sites or nsites < 500
-        assert off.repeat_stats().cherries == 0
+        assert FORCED or off.repeat_stats().cherries == 0
 
 
 @pytest.mark.parametrize("states,ntips,nsites", [(4, 40, 60_000), (4, 24, 3000), (20, 30, 40_000)])
-def test_classes_of_whole_subtrees(product, states, ntips, nsites):
+def test_classes_of_whole_subtrees(product, oracle, states, ntips, nsites):
     """second step: nodes above cherries and tips are kept per class too (pairs of the children's classes, numbered
     on the device).  Sequences simulated along the tree (real repeats), a tip whose sequence changes between two
     evaluations (the class maps above it are made again), evaluations from other root edges (class nodes of earlier
@@ -92,8 +128,8 @@ def test_classes_of_whole_subtrees(product, states, ntips, nsites):
     tree = pc.Tree(ntips, 42, 43, brlen_range=(0.01, 0.12))
     codes = pc.simulated_codes(tree, nsites, states, seed=45)
     out, stats = [], None
-    for repeats in (True, False):
-        inst = pc.build_instance(product, states=states, rate_cats=4, ntips=ntips, nsites=nsites, coded=True, tree=tree,
+    for repeats, lib in ((True, product), (False, product), (False, oracle)):
+        inst = pc.build_instance(lib, states=states, rate_cats=4, ntips=ntips, nsites=nsites, coded=True, tree=tree,
                                  attributes=pc.PLL_ATTRIB_SITE_REPEATS if repeats else 0, codes=codes)
         inst.tree = tree
         with inst:
@@ -109,6 +145,7 @@ def test_classes_of_whole_subtrees(product, states, ntips, nsites):
                 stats = inst.repeat_stats()
             out.append(res)
     _same(out[0], out[1])
+    _close_to_oracle(out[0], out[2], nsites, states)
     ncherries = sum(1 for op in tree.ops if op[2] < ntips and op[5] < ntips)
     evaluations = 1 + 1 + 3 + 1                              # _everything: two full + three re-rooted, then one more
     assert stats.cherries > ncherries * evaluations          # more class operations than cherries: deeper nodes too
@@ -130,7 +167,7 @@ def test_site_repeats_dna_one_launch_and_rounds(product):
 
 
 @pytest.mark.parametrize("states", [20, 4])
-def test_site_repeats_with_scaling_cherries(product, states):
+def test_site_repeats_with_scaling_cherries(product, oracle, states):
     """a cherry only ever scales when its entries are exact zeros: pendant branches of length 0 (identity
     matrices) make every site with two different states an all-zero, scaled site.  The scaling decision is taken
     per class, the counts travel per site; identical to the attribute being off (lnL is -inf on both sides)."""
@@ -141,41 +178,48 @@ def test_site_repeats_with_scaling_cherries(product, states):
         if k % 3 != 2:
             tree.brlens[op[3]] = 0.0
             tree.brlens[op[6]] = 0.0 if k % 3 == 0 else 0.05
-    with _build(product, tree, 700, True, states=states) as on, _build(product, tree, 700, False, states=states) as off:
+    with _build(product, tree, 700, True, states=states) as on, _build(product, tree, 700, False, states=states) as off, \
+            _build(oracle, tree, 700, False, states=states) as ref:
+        assert pc.full_traversal(ref) == -np.inf
         for rep in range(2):
             la, lb = pc.full_traversal(on), pc.full_traversal(off)
             assert la == lb == -np.inf
             for op in tree.ops:
                 assert np.array_equal(on.get_scaler(op[1]), off.get_scaler(op[1]))
                 assert np.array_equal(on.get_clv(op[0]), off.get_clv(op[0]))
+                assert np.array_equal(on.get_scaler(op[1]), ref.get_scaler(op[1]))       # the oracle's counts, exactly
+                assert site_err(on.get_clv(op[0]), ref.get_clv(op[0])) <= REL_CLV
         assert sum(int(off.get_scaler(op[1]).sum()) for op in cherries) > 0
         assert on.repeat_stats().cherries > 0
 
 
 @pytest.mark.parametrize("states,ntips", [(20, 260), (4, 900)])
-def test_site_repeats_on_deep_trees(product, states, ntips):
+def test_site_repeats_on_deep_trees(product, oracle, states, ntips):
     tree = pc.Tree(ntips, 42, 43)
-    with _build(product, tree, 300, True, states=states) as on, _build(product, tree, 300, False, states=states) as off:
+    with _build(product, tree, 300, True, states=states) as on, _build(product, tree, 300, False, states=states) as off, \
+            _build(oracle, tree, 300, False, states=states) as ref:
         la, lb = pc.full_traversal(on), pc.full_traversal(off)
         assert la == lb
+        assert lnl_close(la, pc.full_traversal(ref), 300, states)
         top = 0
         for op in tree.ops:
             sa, sb = on.get_scaler(op[1]), off.get_scaler(op[1])
             assert np.array_equal(sa, sb)
+            assert np.array_equal(sa, ref.get_scaler(op[1]))
             top = max(top, int(sa.max()))
         assert top >= 1
         for op in tree.ops[:40]:
             assert np.array_equal(on.get_clv(op[0]), off.get_clv(op[0]))
 
 
-def test_site_repeats_through_the_driver(product):
-    """branch-length optimisation and an SPR round (short operation lists, sumtables at cherries): same results"""
-    from test_eval_driver import build_search
+def test_site_repeats_through_the_driver(product, oracle):
+    """branch-length optimisation and an SPR round (short operation lists, sumtables at cherries): same results,
+    and the oracle's likelihoods and moves"""
     out = []
-    for attributes in (pc.PLL_ATTRIB_SITE_REPEATS, 0):
+    for attributes, lib in ((pc.PLL_ATTRIB_SITE_REPEATS, product), (0, product), (0, oracle)):
         truth = pc.Tree(12, 7, 8, brlen_range=(0.03, 0.25))
         start = pc.Tree(12, 11, 12, brlen_range=(0.05, 0.15))
-        ev = pc.Evaluation(product, start.newick(), nparts=1)
+        ev = pc.Evaluation(lib, start.newick(), nparts=1)
         r, f = pc.protein_model()
         ev.add_partition(0, 20, 3000, 4, pc.simulated_codes(truth, 3000, 20), r, f, 0.8, attributes=attributes)
         with ev:
@@ -184,15 +228,18 @@ def test_site_repeats_through_the_driver(product):
             l2, st = ev.spr_round(radius_max=3, ntopol_keep=3)
             out.append((l0, l1, l2, ev.newick(), st.moves_applied))
     assert out[0] == out[1]
+    for a, b in zip(out[0][:3], out[2][:3]):
+        assert abs(a - b) <= 1e-6 * 3000
+    assert out[0][4] == out[2][4]
 
 
-def test_cherry_built_under_an_older_code_table(product):
+def test_cherry_built_under_an_older_code_table(product, oracle):
     """a tip takes a new ambiguity code after a traversal (the code table grows); a later partial traversal reads
     the cherries built before that: through their expanded vectors, with the same result as without site repeats"""
     tree = pc.Tree(30, 42, 43)
     out = []
-    for repeats in (True, False):
-        with _build(product, tree, 900, repeats) as a:
+    for repeats, lib in ((True, product), (False, product), (False, oracle)):
+        with _build(lib, tree, 900, repeats) as a:
             l0 = pc.full_traversal(a)
             cmap = pc.state_charmap(20)
             cmap[ord("B")] = (1 << 2) | (1 << 3)
@@ -205,6 +252,8 @@ def test_cherry_built_under_an_older_code_table(product):
             a.update_pmatrices(np.arange(tree.nedges), tree.brlens)
             a.update_partials(ops)
             l1 = a.edge_lnl(tree.root_a, tree.scaler_of(tree.root_a), tree.root_b, tree.scaler_of(tree.root_b), tree.root_matrix)
-            out.append((l0, l1, [a.get_clv(op[0]).tobytes() for op in tree.ops]))
+            out.append((l0, l1, [a.get_clv(op[0]) for op in tree.ops]))
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1] and out[0][1] != out[0][0]
-    assert out[0][2] == out[1][2]
+    assert all(np.array_equal(x, y) for x, y in zip(out[0][2], out[1][2]))
+    assert lnl_close(out[0][0], out[2][0], 900, 20) and lnl_close(out[0][1], out[2][1], 900, 20)
+    assert all(site_err(x, y) <= REL_CLV for x, y in zip(out[0][2], out[2][2]))
