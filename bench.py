@@ -81,6 +81,9 @@ def parse_args():
                     help="evaluate-only traversals (pllhip_eval_set_transient): the vectors inside operation chains stay in "
                          "registers; what a model-parameter optimiser's full evaluations need")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "on", "off"],
+                    help="roofline.traffic from two rocprofv3 --pmc child passes of this very command (FETCH_SIZE, WRITE_SIZE), "
+                         "started before this process touches the GPU; auto: for the default line only")
     ap.add_argument("--tree", default="random", choices=["random", "ladder", "balanced"],
                     help="tree shape: random stepwise addition (seed 42, the benchmark's), a caterpillar, a complete binary tree")
     ap.add_argument("--as-rank", default="",
@@ -397,6 +400,88 @@ def assign_partitions(job_plan, rate_cats, rank, world):
     return out
 
 
+# ---------------------------------------------------------------------------
+# roofline.traffic, measured in the run that reports it: HBM bytes of the partials kernels from the PMC counters,
+# collected and corrected as /opt/skills/guides/MI355X_MICROARCH.md (section HBM) prescribes -- FETCH_SIZE and WRITE_SIZE
+# in separate `rocprofv3 --pmc` passes (they do not fit one), no trace domains next to them, the program directly
+# after `--`; the counters are in KiB, FETCH_SIZE reports half of the bytes of a wide coalesced streaming read on
+# gfx950 (doubled here), WRITE_SIZE is exact for 16-B-per-lane streaming stores.  The two passes are CHILD processes
+# of a parent that has not touched the GPU yet, each running this command for two evaluations (one warm-up, one step).
+# ---------------------------------------------------------------------------
+PARTIALS_KERNELS = ("k_traverse", "k_chain", "k_partials", "k_s61_scale_fixup", "k_s61_cherry_scale", "k_cherry_build",
+                    "k_pair_lut", "k_class_")
+
+
+def _pmc_pass(counter, child_args, outdir):
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", outdir, "--", sys.executable,
+           os.path.abspath(__file__)] + child_args
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+    except (OSError, subprocess.TimeoutExpired) as exc:
+        return None, f"{type(exc).__name__}: {exc}"
+    files = glob.glob(os.path.join(outdir, "**", "*_counter_collection.csv"), recursive=True)
+    if r.returncode != 0 or not files:
+        return None, f"rc {r.returncode}: {r.stderr[-300:]}"
+    per_kernel, steps = {}, 0
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != counter:
+                continue
+            name = row["Kernel_Name"].split("(")[0]
+            a = per_kernel.setdefault(name, [0, 0.0])
+            a[0] += 1
+            a[1] += float(row["Counter_Value"])
+    steps = sum(v[0] for k, v in per_kernel.items() if "k_edge_lnl" in k)
+    return {"per_kernel": per_kernel, "evaluations": steps}, None
+
+
+def measure_traffic(args):
+    """HBM bytes the partials kernels of ONE evaluation move (dict), or a dict with only `error`"""
+    import shutil
+    import tempfile
+    child = ["--config", args.config, "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-also", "--pmc", "off",
+             "--pmatrix-calls", args.pmatrix_calls, "--data", args.data, "--tree", args.tree]
+    if args.sites:
+        child += ["--sites", str(args.sites)]
+    if args.taxa:
+        child += ["--taxa", str(args.taxa)]
+    for flag in ("site_repeats", "rate_scalers", "transient"):
+        if getattr(args, flag, False):
+            child.append("--" + flag.replace("_", "-"))
+    out = {}
+    t0 = time.perf_counter()
+    for counter, factor in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
+        d = tempfile.mkdtemp(prefix="pllhip_pmc_", dir="/tmp")
+        try:
+            res, err = _pmc_pass(counter, child, d)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+        if err:
+            return {"error": f"{counter}: {err}"}
+        evals = max(1, res["evaluations"])
+        tot = sum(v[1] for k, v in res["per_kernel"].items() if any(x in k for x in PARTIALS_KERNELS))
+        n = sum(v[0] for k, v in res["per_kernel"].items() if any(x in k for x in ("k_traverse", "k_chain", "k_partials")))
+        out[counter] = {"bytes_per_evaluation": tot * factor / evals, "raw_kib_per_evaluation": tot / evals,
+                        "partials_launches_per_evaluation": n / evals, "evaluations": evals,
+                        "kernels": {k: v[0] for k, v in res["per_kernel"].items() if any(x in k for x in PARTIALS_KERNELS)}}
+    out["read_bytes_per_evaluation"] = out["FETCH_SIZE"]["bytes_per_evaluation"]
+    out["write_bytes_per_evaluation"] = out["WRITE_SIZE"]["bytes_per_evaluation"]
+    out["bytes_per_evaluation"] = out["read_bytes_per_evaluation"] + out["write_bytes_per_evaluation"]
+    out["wall_s"] = round(time.perf_counter() - t0, 1)
+    out["source"] = ("measured in this run: two `rocprofv3 --pmc` child passes of this command (FETCH_SIZE, WRITE_SIZE; "
+                     "one warm-up + one step each), started before this process touched the GPU; KiB -> bytes, "
+                     "FETCH_SIZE doubled (gfx950: MI355X_MICROARCH.md, HBM)")
+    return out
+
+
 class Ctx:
     """what every leg of a run shares"""
     def __init__(self, **kw):
@@ -512,12 +597,16 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
     barrier()
     elapsed = time.perf_counter() - t0
     prof = pc.Profile()           # summed over the partitions of the evaluation
+    families = {}                 # kernel family -> its launches (partitions of a family share theirs: one stream's events)
     for i in insts:
         one = pc.Profile()
         product.lib.pllhip_profile_read(i.p, C.byref(one))
         product.lib.pllhip_profile_partials(i.p, 0)
         for f, _ in pc.Profile._fields_:
             setattr(prof, f, getattr(prof, f) + getattr(one, f))
+        fam = families.setdefault(product.lib.pllhip_partials_kernel_name(i.p).decode(), pc.Profile())
+        for f, _ in pc.Profile._fields_:
+            setattr(fam, f, getattr(fam, f) + getattr(one, f))
     counters = [i.counters() for i in insts]
     repeats = None
     if args.site_repeats:
@@ -548,16 +637,34 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
     kernel_s = prof.kernel_ms * 1e-3
     achieved = prof.algorithmic_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
     minimum = prof.minimum_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    per_family = None
     if several:
         # partitions of different families run on their own streams and overlap on the device: the summed
         # event times exceed the wall time, so the kernels are priced against the
-        # whole step instead (a lower bound of what they achieve)
+        # whole step instead (a lower bound of what they achieve) ...
         achieved = prof.algorithmic_bytes / elapsed / 1e9
         minimum = prof.minimum_bytes / elapsed / 1e9
+        # ... and per family against the HIP events of its own launches (the partitions of a family share one
+        # launch per round on one stream; while it runs the other family's launches share the chip with it)
+        per_family = []
+        for name, fp in sorted(families.items()):
+            if not fp.launches or fp.kernel_ms <= 0:
+                continue
+            fs = fp.kernel_ms * 1e-3
+            per_family.append({"kernel": name, "launches": int(fp.launches), "ops": int(fp.ops),
+                               "avg_launch_ms": round(fp.kernel_ms / fp.launches, 4),
+                               "algorithmic_GBps": round(fp.algorithmic_bytes / fs / 1e9, 1),
+                               "frac": round(fp.algorithmic_bytes / fs / 1e9 / HBM_PEAK_GBS, 4),
+                               "frac_minimum": round(fp.minimum_bytes / fs / 1e9 / HBM_PEAK_GBS, 4),
+                               "kernel_share_of_step": round(fs / elapsed, 4)})
     traffic = None
     traffic_source = None
+    measured = getattr(ctx, "traffic", None) if config == args.config and not sites and not taxa else None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and world == 1 and not sites and not taxa and not args.rate_scalers and not args.site_repeats \
+    if measured and "bytes_per_evaluation" in measured and prof.launches:
+        traffic = round(measured["bytes_per_evaluation"] * steps / prof.launches)       # per launch, like `achieved`
+        traffic_source = measured["source"]
+    elif os.path.exists(tpath) and world == 1 and not sites and not taxa and not args.rate_scalers and not args.site_repeats \
             and args.data == "random" and args.tree == "random" and not getattr(args, "transient", False):
         try:
             tj = json.load(open(tpath))
@@ -584,6 +691,10 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
         "unit": "TFLOP/s" if mfma_bound else "GB/s",
         "frac": round(tflops / FP64_MFMA_PEAK_TFLOPS, 4) if mfma_bound else round(achieved / HBM_PEAK_GBS, 4),
         "traffic": traffic, "traffic_source": traffic_source,
+        "traffic_measured": ({k: measured[k] for k in ("read_bytes_per_evaluation", "write_bytes_per_evaluation",
+                                                       "bytes_per_evaluation", "wall_s")} | {"passes": {c: measured[c] for c in ("FETCH_SIZE", "WRITE_SIZE")}}
+                             if measured and "bytes_per_evaluation" in measured else
+                             ({"error": measured["error"]} if measured else None)),
         "algorithmic_GBps": round(achieved, 1), "algorithmic_TFLOPs": round(tflops, 2),
         # `frac` prices SURVEY.md 8d's algorithmic bytes (every child vector one read).  Operation chains hand
         # the carried child over in registers, so the schedule has to move less than that:
@@ -601,7 +712,9 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
         "avg_launch_ms": round(prof.kernel_ms / launches, 4),
         "algorithmic_bytes_per_launch": round(prof.algorithmic_bytes / launches),
         "minimum_bytes_per_launch": round(prof.minimum_bytes / launches),
-        "kernel_share_of_step": round(kernel_s / elapsed, 4),
+        # (several families: the share of the family whose launches take longest -- they overlap on their streams)
+        "kernel_share_of_step": round((max(f_["kernel_share_of_step"] for f_ in per_family) if per_family else kernel_s / elapsed), 4),
+        "families": per_family,
         # tools/micro/mfma_f64.hip: v_mfma_f64_16x16x4_f64 back to back on every SIMD sustains
         # 47.5 TFLOP/s on this chip (29.9 ns per MFMA per SIMD with <= 128 CUs busy, 44.1 ns with
         # all 256: clocks drop under a full-chip FP64 matrix load), not the 78.6 TFLOP/s data-sheet peak
@@ -681,7 +794,7 @@ def also_legs(ctx):
             "workload": d["config"]["workload"], "value": d["value"], "ms_per_step": d["ms_per_step"], "steps": steps,
             "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_minimum",
                                            "frac_physical", "frac_of_sustained", "traffic_over_algorithmic",
-                                           "avg_launch_ms", "launches", "kernel_share_of_step")},
+                                           "avg_launch_ms", "launches", "kernel_share_of_step", "families")},
             "traffic_over_algorithmic": r["traffic_over_algorithmic"],
             "dlnl_per_site": d["dlnl_per_site"], "max_persite_dlnl": d["max_persite_dlnl"],
             "parity_sample_sites": d["parity"]["sample_sites"] if d["parity"] else None,
@@ -705,6 +818,25 @@ def also_legs(ctx):
         }
     finally:
         ATTRIBUTES, ctx.args.site_repeats = saved
+    # the headline configuration as a model-parameter optimiser evaluates it: full evaluations whose vectors nobody
+    # reads before the next one recomputes them (src/algorithm/algo_callback.c:338, 465, 568, 678) -- evaluate-only
+    # traversals (include/pllhip.h, pllhip_set_transient): same lnL to the last bit, the vectors inside the operation
+    # chains are not stored
+    ctx.args.transient = True
+    try:
+        t0 = time.perf_counter()
+        d = run_leg(ctx, "c3", steps=steps, warmup=2, cpu="parity")
+        r = d["roofline"]
+        also["c3_transient"] = {
+            "workload": d["config"]["workload"] + "; evaluate-only", "value": d["value"], "ms_per_step": d["ms_per_step"],
+            "steps": steps, "lnl": d["lnl"],
+            "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_minimum", "minimum_GBps",
+                                           "minimum_bytes_per_launch", "avg_launch_ms", "launches", "kernel_share_of_step")},
+            "dlnl_per_site": d["dlnl_per_site"], "max_persite_dlnl": d["max_persite_dlnl"],
+            "leg_wall_s": round(time.perf_counter() - t0, 2),
+        }
+    finally:
+        ctx.args.transient = False
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gpu_workloads as gw
     out = {}
@@ -715,6 +847,15 @@ def also_legs(ctx):
     also["blo_c3_125k"] = {k: b[k] for k in ("s_per_smoothing_pass", "newton_iterations", "sumtable_scans",
                                              "single_op_updates", "pmatrix_updates", "branches", "lnl_before", "lnl_after")}
     also["blo_c3_125k"]["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+    # ... and over C4's four partitions (linked branch lengths) at the per-GPU slice of an 8-way split: the partitions'
+    # derivative sums meet between two iterates -- on the device (include/pllhip.h, pllhip_newton_branch_multi)
+    t0 = time.perf_counter()
+    gw.blo_c4(ctx.product, out, nsites=125_000)
+    b = out["BLO_c4_125000"]
+    also["blo_c4_125k_us_per_iterate"] = b["us_per_derivative_call_incl_everything"]
+    also["blo_c4_125k"] = {k: b[k] for k in ("s_per_smoothing_pass", "newton_iterations", "single_op_updates", "pmatrix_updates",
+                                             "branches", "partitions", "lnl_before", "lnl_after")}
+    also["blo_c4_125k"]["leg_wall_s"] = round(time.perf_counter() - t0, 2)
     t0 = time.perf_counter()
     gw.spr(ctx.product, out, nsites=25_000)
     sp = out["SPR_c5_50x25000_fast"]
@@ -757,6 +898,12 @@ def main():
     # kernel arguments in device memory (3 - 5 us per short launch, pll_core.hip): decided HERE, before any
     # library that initialises the HIP runtime is loaded, so that N = 1 and N > 1 run under the same setting
     os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+    default_shape = (world == 1 and not internal and args.config == "c3" and not args.sites and not args.taxa and
+                     not args.rate_scalers and not args.no_also and not args.no_cpu_baseline and not args.site_repeats and
+                     args.data == "random" and args.tree == "random" and not args.transient)
+    traffic_measured = None
+    if world == 1 and not internal and not args.as_rank and (args.pmc == "on" or (args.pmc == "auto" and default_shape)):
+        traffic_measured = measure_traffic(args)      # child processes; nothing here has touched the GPU yet
     if world > 1:
         # torch brings its own HIP and RCCL runtimes (same SONAMEs as /opt/rocm's): whichever is
         # loaded first serves the whole process, and torch does not find the GPU on the system's.
@@ -815,14 +962,14 @@ def main():
             comm_mode = "torch"
 
     ctx = Ctx(pc=pc, product=product, args=args, rank=rank, world=world, dist=dist, comm=comm,
-              comm_mode=comm_mode, internal=internal)
+              comm_mode=comm_mode, internal=internal, traffic=traffic_measured)
     out = run_leg(ctx, args.config, sites=args.sites, taxa=args.taxa, steps=args.steps, warmup=args.warmup,
                   cpu=None if args.no_cpu_baseline else "full")
     out["runtime"] = {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG"),
                       "torch_loaded_before_engine": world > 1}
     default_run = (world == 1 and not internal and args.config == "c3" and not args.sites and not args.taxa and
                    not args.rate_scalers and not args.no_also and not args.no_cpu_baseline and not args.site_repeats and
-                   args.data == "random" and args.tree == "random")
+                   args.data == "random" and args.tree == "random" and not args.transient)
     if default_run:
         t0 = time.perf_counter()
         out["also"] = also_legs(ctx)

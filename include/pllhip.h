@@ -268,6 +268,22 @@ PLL_EXPORT int pllhip_newton_branch(pll_partition_t * partition,
                                     unsigned int max_newton,
                                     double * length, unsigned int * iterations, double * trail);
 
+/* The same loop for SEVERAL partitions that share the branch length -- linked lengths, or scaled ones (partition p
+   sees length_scalers[p] * x; NULL: all 1) --: the reference's multi-partition derivative function
+   (src/optimize/pll_optimize.c:1223-1287: f = sum s_p f_p, f' = sum s_p^2 f'_p, added in partition order) inside
+   the loop.  Every partition runs its own instance of the loop on its own stream (its family's kernel, its own scan
+   grid: its totals are those of its blocking derivative call); the instances meet on the device after every scan.
+   All partitions live on ONE device and none is remote (a sum over workers needs the host loop); at most 8.
+   Same results and error codes as pllhip_newton_branch; PLLHIP_ERROR_NEWTON_UNSUPPORTED also when the partitions'
+   scan grids do not fit the chip together. */
+PLL_EXPORT int pllhip_newton_branch_multi(pll_partition_t * const * partitions, unsigned int count,
+                                          int parent_scaler_index, int child_scaler_index,
+                                          const unsigned int * const * params_indices,
+                                          const double * const * sumtables, const double * length_scalers,
+                                          double start, double bl_min, double bl_max, double tolerance,
+                                          unsigned int max_newton,
+                                          double * length, unsigned int * iterations, double * trail);
+
 /* pll_update_partials for several partitions that are evaluated on ONE tree: the result is what
    pll_update_partials(partitions[i], operations, count) stores for every non-NULL partitions[i], bit for
    bit.  pll-modules walks the partitions of an analysis one after the other

@@ -305,6 +305,11 @@ struct Engine
   int newton_resident = 0;            // blocks per wave that k_newton_mfma_resident keeps in registers (0: the streaming loop)
   const void * newton_fn = nullptr;
   size_t newton_lds = 0;
+  // ... and the streaming form of the same loop (several partitions under one branch length share the chip)
+  const void * newton_stream_fn = nullptr;
+  size_t newton_stream_lds = 0;
+  int newton_stream_capacity = 0;
+  hipEvent_t newton_ready = nullptr;  // the control block of a multi-partition loop is initialised
 
   // caller-keyed device sumtables (pointer value is the key)
   std::list<std::pair<const void *, double *>> sumtables;

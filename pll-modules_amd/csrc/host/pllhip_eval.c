@@ -8,6 +8,7 @@
 #include "pllhip.h"
 #pragma weak pllhip_eval_attach_comm   /* HIP engine only (pllhip_comm.hip) */
 #pragma weak pllhip_newton_branch      /* HIP engine only (pll_core.hip) */
+#pragma weak pllhip_newton_branch_multi
 #pragma weak pllhip_set_transient      /* HIP engine only: the CPU oracle stores every vector */
 #pragma weak pllhip_discard_transient
 #include <stdarg.h>
@@ -675,17 +676,30 @@ static int newton(const blo_t * b, const pll_unode_t * e, double * x)
   double xl = b->bl_min, xh = b->bl_max, f, df, dx;
   double t[PLLHIP_EVAL_MAX_TRIALS], tf[PLLHIP_EVAL_MAX_TRIALS], tdf[PLLHIP_EVAL_MAX_TRIALS];
   unsigned int nt = 0, k, iter = 0;
-  /* One partition, one worker, the tree's own lengths: the whole loop runs on the device (include/pllhip.h,
-     pllhip_newton_branch: the same iterates, one launch and one wait per branch instead of one per iterate).
-     With several partitions or workers the sums of their derivatives have to meet between two iterates:
-     the loop below. */
-  if (ev->device_newton && ev->nparts == 1 && ev->parts[0] && !ev->reduce_cb && !ev->part_brlens &&
-      ev->brlen_scalers[0] == 1.0)
+  /* Every partition on this worker, one length per branch (linked, or scaled by a per-partition factor): the whole
+     loop runs on the device (include/pllhip.h, pllhip_newton_branch / _multi: the same iterates, one wait per branch
+     instead of one per iterate).  With other workers the sums of the derivatives have to meet on the host between
+     two iterates: the loop below. */
+  /* (a result group with a communicator installs the reduce callback too: pllhip_eval_attach_comm) */
+  /* (PLLHIP_EVAL_ALWAYS_SPECULATE asks for the host loop's trial lengths: tests) */
+  if (ev->device_newton && !ev->reduce_cb && !ev->part_brlens && !(ev->flags & PLLHIP_EVAL_ALWAYS_SPECULATE) &&
+      (ev->nparts == 1 ? (ev->parts[0] && ev->brlen_scalers[0] == 1.0)
+                       : (pllhip_newton_branch_multi != NULL && ev->nparts <= 8)))
   {
-    unsigned int its = 0;
+    unsigned int its = 0, p;
     double len = *x;
-    if (pllhip_newton_branch(ev->parts[0], e->scaler_index, e->back->scaler_index, ev->params[0], ev->sumtables[0],
-                             *x, b->bl_min, b->bl_max, b->tolerance, b->max_newton, &len, &its, NULL))
+    int ok, local = 1;
+    for (p = 0; p < ev->nparts; ++p) if (!ev->parts[p]) local = 0;
+    if (!local) ok = 0, pll_errno = PLLHIP_ERROR_NEWTON_UNSUPPORTED;
+    else if (ev->nparts == 1)
+      ok = pllhip_newton_branch(ev->parts[0], e->scaler_index, e->back->scaler_index, ev->params[0], ev->sumtables[0],
+                                *x, b->bl_min, b->bl_max, b->tolerance, b->max_newton, &len, &its, NULL);
+    else
+      ok = pllhip_newton_branch_multi(ev->parts, ev->nparts, e->scaler_index, e->back->scaler_index,
+                                      (const unsigned int * const *)ev->params, (const double * const *)ev->sumtables,
+                                      ev->brlen_scalers, *x, b->bl_min, b->bl_max, b->tolerance, b->max_newton,
+                                      &len, &its, NULL);
+    if (ok)
     {
       *x = len;
       ev->n_newton += its;
@@ -694,11 +708,16 @@ static int newton(const blo_t * b, const pll_unode_t * e, double * x)
     }
     if (pll_errno == PLLHIP_ERROR_NEWTON_LIMIT)
     {
+      /* (counted like the loop below: it gives up BEFORE the evaluation that would exceed the limit, the device
+         loop after it) */
+      if (its) { ev->n_newton += its - 1; ev->n_deriv += its - 1; }
       pllhip_eval_error(PLLHIP_EVAL_ERROR_NEWTON_LIMIT, "Exceeded maximum number of iterations");
       return PLL_FAILURE;
     }
     if (pll_errno == PLLHIP_ERROR_NEWTON_DERIVATIVES)
     {
+      ev->n_newton += its;
+      ev->n_deriv += its;
       pllhip_eval_error(PLLHIP_EVAL_ERROR_NEWTON_DERIV, "Wrong likelihood derivatives");
       return PLL_FAILURE;
     }

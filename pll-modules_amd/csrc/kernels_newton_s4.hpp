@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_newton_s4(ModelView mv, ParamIdx params
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
-      const double lam = ev[k] * rho, ex = exp(lam * x);
+      const double lam = ev[k] * rho, ex = exp(lam * (np.xscale * x));
       e0[k] = wr * ex;
       e1[k] = wr * ex * lam;
       e2[k] = wr * ex * lam * lam;

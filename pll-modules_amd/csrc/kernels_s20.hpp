@@ -68,6 +68,20 @@ __device__ inline v4d mfma_f64(double a, double b, v4d c)
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// Rows 16 .. 19 of a 20-state product.  A second 16-row M tile would carry 12 rows of padding (and did until round 4:
+// half of the matrix time of a unit).  v_mfma_f64_4x4x4_4b_f64 computes four independent 4 x 4 x 4 products, block
+// b = (lane >> 2) & 3, with the k index in the lane's upper two bits -- exactly where this family keeps it: with
+// lane = 16 q + n the instruction reads A_b[i][k] from lane (k = q, i = n & 3), B_b[k][j] from lane (k = q, column
+// n = 4 b + j) and leaves D_b[i][j] in lane (i = q, column n).  So the B operand is the register the 16 x 16 x 4
+// sequence uses (state row 4 ks + q, sites 2n / 2n + 1), the A operand is M[16 + (n & 3)][4 ks + q] for every block,
+// and the result lands where the D layout wants it: row 16 + q, column n -- one double instead of a v4d of which one
+// element was used.  A quarter of the matrix-pipe time of the padded tile; bit-identical results (the same four-term
+// inner sum per k-step: tools/micro/mfma_4x4x4.hip compares the two instructions on random data).
+__device__ inline double mfma_f64_tail(double a, double b, double c)
+{
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
 // row (state) held by D slot k of lane group q: k = 0..3 -> first M-tile
 // registers, k = 4 -> register 0 of the second M-tile (states 16..19)
 __device__ inline unsigned s20_row(unsigned k, unsigned q) { return (k < 4) ? q + 4 * k : 16 + q; }
@@ -95,22 +109,25 @@ __device__ inline void s20_child_inner(const double * unit, const double * frag_
 #pragma unroll
   for (int ks = 0; ks < 5; ++ks)
     b[ks] = s20_ld(unit + ks * 128 + off, nt);
-  v4d a0e = {0, 0, 0, 0}, a0o = {0, 0, 0, 0}, a1e = {0, 0, 0, 0}, a1o = {0, 0, 0, 0};
+  v4d a0e = {0, 0, 0, 0}, a0o = {0, 0, 0, 0};
+  double a1e = 0.0, a1o = 0.0;
+  // (rows 16 .. 19: the fragment of lane 16 q + (n & 3), see mfma_f64_tail)
+  const double * tail_r = frag_r + 5 * 64 + (lane & ~12u);
 #pragma unroll
   for (int ks = 0; ks < 5; ++ks)
   {
     const double f0 = frag_r[ks * 64 + lane];
-    const double f1 = frag_r[(5 + ks) * 64 + lane];
+    const double f1 = tail_r[ks * 64];
     a0e = mfma_f64(f0, b[ks].x, a0e);
     a0o = mfma_f64(f0, b[ks].y, a0o);
-    a1e = mfma_f64(f1, b[ks].x, a1e);
-    a1o = mfma_f64(f1, b[ks].y, a1o);
+    a1e = mfma_f64_tail(f1, b[ks].x, a1e);
+    a1o = mfma_f64_tail(f1, b[ks].y, a1o);
   }
   t[0] = make_double2(a0e[0], a0o[0]);
   t[1] = make_double2(a0e[1], a0o[1]);
   t[2] = make_double2(a0e[2], a0o[2]);
   t[3] = make_double2(a0e[3], a0o[3]);
-  t[4] = make_double2(a1e[0], a1o[0]);
+  t[4] = make_double2(a1e, a1o);
 }
 
 // row stride of a lookup table staged in LDS: 21 doubles -- with 20, codes that differ by a
@@ -405,25 +422,25 @@ __device__ inline void s20_child_regs_c(const double2 b[5], const double * cfrag
                                         double2 t[5])
 {
   const unsigned q = lane >> 4, n = lane & 15;
-  const bool tail = n < 4;
-  const double * tail_r = cfrag_r + 320 + q * 4 + (tail ? n : 0);
-  v4d a0e = {0, 0, 0, 0}, a0o = {0, 0, 0, 0}, a1e = {0, 0, 0, 0}, a1o = {0, 0, 0, 0};
+  // (rows 16 .. 19: M[16 + (n & 3)][4 ks + q] for every lane, see mfma_f64_tail)
+  const double * tail_r = cfrag_r + 320 + q * 4 + (n & 3u);
+  v4d a0e = {0, 0, 0, 0}, a0o = {0, 0, 0, 0};
+  double a1e = 0.0, a1o = 0.0;
 #pragma unroll
   for (int ks = 0; ks < 5; ++ks)
   {
     const double f0 = cfrag_r[ks * 64 + lane];
-    const double f1r = tail_r[ks * 16];
-    const double f1 = tail ? f1r : 0.0;
+    const double f1 = tail_r[ks * 16];
     a0e = mfma_f64(f0, b[ks].x, a0e);
     a0o = mfma_f64(f0, b[ks].y, a0o);
-    a1e = mfma_f64(f1, b[ks].x, a1e);
-    a1o = mfma_f64(f1, b[ks].y, a1o);
+    a1e = mfma_f64_tail(f1, b[ks].x, a1e);
+    a1o = mfma_f64_tail(f1, b[ks].y, a1o);
   }
   t[0] = make_double2(a0e[0], a0o[0]);
   t[1] = make_double2(a0e[1], a0o[1]);
   t[2] = make_double2(a0e[2], a0o[2]);
   t[3] = make_double2(a0e[3], a0o[3]);
-  t[4] = make_double2(a1e[0], a1o[0]);
+  t[4] = make_double2(a1e, a1o);
 }
 
 __device__ inline void s20_child_inner_c(const double * unit, const double * cfrag_r, unsigned lane,
@@ -1210,6 +1227,7 @@ __global__ __launch_bounds__(256) void k_derivatives_mfma(ModelView mv, ParamIdx
 // Every wait is bounded (NEWTON_SPIN_LIMIT polls): a workgroup that gives up marks the run as failed, so the
 // grid always drains.
 // ---------------------------------------------------------------------------
+constexpr unsigned NEWTON_MAX_PARTS = 8;
 struct NewtonControl          // device memory, one per engine
 {
   double x;                   // the iterate the next scan evaluates
@@ -1218,11 +1236,19 @@ struct NewtonControl          // device memory, one per engine
   unsigned status;            // NEWTON_RUNNING, or how the loop ended
   double tot[8];              // totals of the scan (grid reduction sink)
   double trail[96];           // the iterates (NEWTON_TRAIL_MAX), copied to the host when the loop ends
+  // several partitions under one branch length (pllhip_newton_branch_multi): every partition runs its own launch
+  // of the loop; they meet in the FIRST partition's control block
+  unsigned arrived;           // partitions whose totals of the current scan are complete
+  unsigned pad;
+  double ptot[NEWTON_MAX_PARTS][2];   // {f, f'} of partition p at its own length s_p x
+  double pscale[NEWTON_MAX_PARTS];    // s_p: the partition's branch-length scaler (1 with linked lengths)
 };
 
 // spin_limit: polls a workgroup waits for the next iterate before it gives up (NEWTON_SPIN_LIMIT; tests lower it);
 // stall_block: fault injection -- that workgroup leaves at once, as if it had never been given a CU (~0u: none)
-struct NewtonParams { double x0, bl_min, bl_max, tolerance, dxmax; unsigned max_newton, spin_limit, stall_block; };
+// part / nparts / xscale: this launch is partition `part` of `nparts` that share the branch (nparts = 1: alone); it scans
+// its sumtable at xscale * x and leaves its totals in ro.dst, a scratch of its own
+struct NewtonParams { double x0, bl_min, bl_max, tolerance, dxmax; unsigned max_newton, spin_limit, stall_block, part, nparts; double xscale; };
 
 // mapped host memory: [0] final length, [1] iterations, [2] status, [3] last f, [4] last df, [8 ...] the trail
 constexpr unsigned NEWTON_RUNNING = 0, NEWTON_CONVERGED = 1, NEWTON_LIMIT = 2, NEWTON_NONFINITE = 3, NEWTON_STUCK = 4;
@@ -1239,10 +1265,38 @@ __device__ inline unsigned newton_step_and_wait(unsigned it, bool last, double &
                                                 NewtonControl * ctl, double * host_out, unsigned long long * host_flag,
                                                 unsigned long long host_seq, double * s_x, unsigned * s_status)
 {
-  if (last && threadIdx.x == 0)
+  bool apply = last && threadIdx.x == 0;
+  double f = 0.0, df = 0.0;
+  if (apply && np.nparts > 1)
+  {
+    // Several partitions share the branch: this partition's totals are complete.  They go to the shared control
+    // block with the hand-over of the in-launch reductions (write-through stores, waited for, then the arrival
+    // ticket; kernels_common.hpp); the partition that arrives last adds all of them in partition order with the
+    // chain rule of the scalers -- f = sum s_p f_p, f' = sum s_p^2 f'_p: the host loop's derivatives()
+    // (csrc/host/pllhip_eval.c; src/optimize/pll_optimize.c:1258-1267) -- and applies the step rule.
+    __hip_atomic_store(&ctl->ptot[np.part][0], ro.dst[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ctl->ptot[np.part][1], ro.dst[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned k = 0; k <= REDUCE_SHARDS; ++k)                          // this partition's tickets back to zero
+      __hip_atomic_store(ro.counter + k * REDUCE_SHARD_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned a = __hip_atomic_fetch_add(&ctl->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    apply = (a + 1 == np.nparts);
+    if (apply)
+    {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      for (unsigned p = 0; p < np.nparts; ++p)
+      {
+        const double sc = ctl->pscale[p];
+        f += sc * __hip_atomic_load(&ctl->ptot[p][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        df += sc * sc * __hip_atomic_load(&ctl->ptot[p][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_store(&ctl->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  else if (apply) { f = ro.dst[0]; df = ro.dst[1]; }
+  if (apply)
   {
     // the step rule of newton() (csrc/host/pllhip_eval.c), expression by expression
-    const double f = ro.dst[0], df = ro.dst[1];
     double xl = ctl->xl, xh = ctl->xh, dx;
     unsigned status = NEWTON_RUNNING;
     if (it > np.max_newton) status = NEWTON_LIMIT;                  // (the host loop counts the same way)
@@ -1279,8 +1333,9 @@ __device__ inline unsigned newton_step_and_wait(unsigned it, bool last, double &
     ctl->xh = xh;
     ctl->x = x;
     ctl->status = status;
-    for (unsigned k = 0; k <= REDUCE_SHARDS; ++k)                          // tickets back to zero for the next scan
-      __hip_atomic_store(ro.counter + k * REDUCE_SHARD_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (np.nparts <= 1)
+      for (unsigned k = 0; k <= REDUCE_SHARDS; ++k)                        // tickets back to zero for the next scan
+        __hip_atomic_store(ro.counter + k * REDUCE_SHARD_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (status != NEWTON_RUNNING)
     {
       for (unsigned k = 0; k <= it && k < NEWTON_TRAIL_MAX; ++k) host_out[NEWTON_TRAIL_SLOT + k] = ctl->trail[k];
@@ -1348,12 +1403,12 @@ __device__ inline void newton_loop(const ModelView & mv, const ParamIdx & params
   {
     double mine;
     if constexpr (NB > 0)
-      mine = deriv_block_totals_resident<KS, SREAL, NB, NBR, 4>(mv, params, x, sumtable, ps, cs, weights, invariant, N, nblk, frag, res, it == 0);
+      mine = deriv_block_totals_resident<KS, SREAL, NB, NBR, 4>(mv, params, np.xscale * x, sumtable, ps, cs, weights, invariant, N, nblk, frag, res, it == 0);
     else
     {
       TrialLengths tl;
 #pragma unroll
-      for (unsigned i = 0; i < MAX_TRIAL_LENGTHS; ++i) tl.t[i] = x;
+      for (unsigned i = 0; i < MAX_TRIAL_LENGTHS; ++i) tl.t[i] = np.xscale * x;
       mine = deriv_block_totals<KS, SREAL>(mv, params, tl, 1u, sumtable, ps, cs, weights, invariant,
                                            N, nblk, R, rate_scalers, frag);
     }

@@ -410,8 +410,12 @@ __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
 // range of chunks through every chain of the schedule, re-staging the tables between two chains.
 // More workgroups than fit the chip: each finishes its range and makes room for the next, so the
 // ranges in flight at any time are a slab of the alignment that moves through the whole tree.
-template <unsigned U, unsigned R, int NT = 0>
-__global__ __launch_bounds__(256) void k_traverse_s4(PlanView plan, unsigned chain_begin, unsigned chain_end)
+// TRANS: an evaluate-only traversal (PlanOp::flags bit 0 = the result is handed on in registers only).  A template
+// flag: as a run-time test in front of the stores it cost one VGPR, 169 instead of 168 -- and with that the third
+// wave per SIMD (C2: 5.2 instead of 3.4 ms)
+// (three waves per SIMD: 168 VGPRs)
+template <unsigned U, unsigned R, int NT = 0, bool TRANS = false>
+__global__ __launch_bounds__(256, 3) void k_traverse_s4(PlanView plan, unsigned chain_begin, unsigned chain_end)
 {
   constexpr unsigned group = 2 * R;
   constexpr unsigned S4_CHAIN_OP_LDS = s4_chain_op_lds(R);
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(256) void k_traverse_s4(PlanView plan, unsigned cha
       {
         const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
         s4_chain_step<U, R, NT>(po.d, i ? po.carried : 0u, lds + i * S4_CHAIN_OP_LDS,
-                            X, xcnt, hc0, nsc, total, N, lane, r, h, !(po.flags & 1u));
+                            X, xcnt, hc0, nsc, total, N, lane, r, h, TRANS ? !(po.flags & 1u) : true);
       }
     }
   }
@@ -706,43 +710,34 @@ static int launch_chains_s4(Engine * e, const ChainBatch & batch, unsigned nchai
 
 // `extent`: sites of the largest partition the chains [chain_begin, chain_end) belong to
 static int launch_traverse_s4(Engine * e, const PlanView & plan, unsigned longest, unsigned extent, unsigned chain_begin,
-                              unsigned chain_end, unsigned rows, unsigned row_wgs_per_cu = 0)
+                              unsigned chain_end, unsigned rows, unsigned row_wgs_per_cu = 0, bool transient = false)
 {
   const unsigned nchunks = (extent + 63) / 64;
   const size_t lds = sizeof(double) * longest * s4_chain_op_lds(e->R);
-  // exactly the workgroups that are resident at once (measured on C2, workgroups per CU:
-  // 2: 4.06 ms, 3 = resident: 3.58, 4: 4.12, 6: 3.68, 8: 3.82; one launch per round of chains: 3.85)
+  // vectors are written once and read (if at all) once, by a later chain: stores and loads that do not
+  // allocate in the caches are 5 % (1 M sites) to 17 % (100 k - 250 k sites) faster.  PLLHIP_S4_NT=0: plain.
+  static const int env_nt = getenv("PLLHIP_S4_NT") ? atoi(getenv("PLLHIP_S4_NT")) : 1;
+  const void * fn = nullptr;
+#define PLLHIP_PICK(NT_, T_) fn = e->R == 4 ? reinterpret_cast<const void *>(k_traverse_s4<4, 4, NT_, T_>)   \
+                                : e->R == 2 ? reinterpret_cast<const void *>(k_traverse_s4<4, 2, NT_, T_>) \
+                                            : reinterpret_cast<const void *>(k_traverse_s4<2, 1, NT_, T_>)
+  if (env_nt) { if (transient) PLLHIP_PICK(2, true); else PLLHIP_PICK(2, false); }
+  else { if (transient) PLLHIP_PICK(0, true); else PLLHIP_PICK(0, false); }
+#undef PLLHIP_PICK
+  // exactly the workgroups that are resident at once -- of the instantiation that is launched -- (measured on C2,
+  // workgroups per CU: 2: 4.06 ms, 3 = resident: 3.58, 4: 4.12, 6: 3.68, 8: 3.82; one launch per round of chains: 3.85)
   static const int env_bpc = getenv("PLLHIP_S4_TRAVERSE_BPC") ? atoi(getenv("PLLHIP_S4_TRAVERSE_BPC")) : 0;
   int per_cu = env_bpc;
   if (per_cu <= 0)
   {
-    const void * fn = e->R == 4 ? reinterpret_cast<const void *>(k_traverse_s4<4, 4>)
-                    : e->R == 2 ? reinterpret_cast<const void *>(k_traverse_s4<4, 2>)
-                                : reinterpret_cast<const void *>(k_traverse_s4<2, 1>);
     PLLHIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
     per_cu = std::max(1, per_cu);
   }
   // a round of chains (rows > 1): the chains share the chip, eight workgroups per CU and chain as in k_chain_s4
   const unsigned gx = round_grid(e, std::max(1u, std::min((nchunks + 3) / 4, e->cu_count * (rows > 1 ? 8u : (unsigned)per_cu))), rows, row_wgs_per_cu ? row_wgs_per_cu : 8u);
   const dim3 grid(gx, std::max(1u, rows));
-  // vectors are written once and read (if at all) once, by a later chain: stores and loads that do not
-  // allocate in the caches are 5 % (1 M sites) to 17 % (100 k - 250 k sites) faster.  PLLHIP_S4_NT=0: plain.
-  static const int env_nt = getenv("PLLHIP_S4_NT") ? atoi(getenv("PLLHIP_S4_NT")) : 1;
-#define PLLHIP_CALL(K) hipLaunchKernelGGL(K, grid, dim3(256), lds, e->stream, plan, chain_begin, chain_end)
-  if (env_nt)
-  {
-    if (e->R == 4) PLLHIP_CALL((k_traverse_s4<4, 4, 2>));
-    else if (e->R == 2) PLLHIP_CALL((k_traverse_s4<4, 2, 2>));
-    else PLLHIP_CALL((k_traverse_s4<2, 1, 2>));
-  }
-  else
-  {
-    if (e->R == 4) PLLHIP_CALL((k_traverse_s4<4, 4, 0>));
-    else if (e->R == 2) PLLHIP_CALL((k_traverse_s4<4, 2, 0>));
-    else PLLHIP_CALL((k_traverse_s4<2, 1, 0>));
-  }
-#undef PLLHIP_CALL
-  PLLHIP_TRY(hipGetLastError());
+  void * args[] = {(void *)&plan, (void *)&chain_begin, (void *)&chain_end};
+  PLLHIP_TRY(hipLaunchKernel(fn, grid, dim3(256), args, lds, e->stream));
   return PLL_SUCCESS;
 }
 

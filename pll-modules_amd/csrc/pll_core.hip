@@ -374,6 +374,7 @@ void engine_destroy(Engine * e)
   if (e->h_class_total) (void)hipHostFree(e->h_class_total);
   (void)hipFree(e->d_pairlut);
   (void)hipFree(e->d_newton);
+  if (e->newton_ready) (void)hipEventDestroy(e->newton_ready);
   if (e->h_newton) (void)hipHostFree(e->h_newton);
   (void)hipFree(e->d_sum_scratch);
   if (e->h_result) (void)hipHostFree(e->h_result);
@@ -612,6 +613,15 @@ int flush_pmatrices(pll_partition_t * p)
   Engine * e = engine_of(p);
   if (e->pend_midx.empty()) return PLL_SUCCESS;
   PLLHIP_TRY(hipSetDevice(e->device));
+  // a vector that an evaluate-only traversal did not store is recomputed with the matrices it was made with: stored
+  // now, before one of them changes (an operation list gives the vectors it overwrites up BEFORE it comes here)
+  if (e->ntransient && !e->transient_busy)
+    for (unsigned m : e->pend_midx)
+      if (e->transient_mat_users[m])
+      {
+        if (!transient_flush_all(e)) return PLL_FAILURE;
+        break;
+      }
   if (e->coded_tips)
   {
     // LUT storage must exist so that the kernel can fill it in the same pass
@@ -1853,14 +1863,17 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
 {
   Engine * e = engine_of(p);
   PLLHIP_TRY(hipSetDevice(e->device));
-  if (!flush_pmatrices(p) || !ensure_luts(p)) return PLL_FAILURE;
+  if (!validate_ops(e, ops, count)) return PLL_FAILURE;
+  // (before the queued P-matrices are launched: vectors that were not stored and that this list overwrites are given
+  // up, the ones it reads are stored with the matrices they were made with; a list that stores such vectors -- 
+  // transient_busy -- runs on the matrices the device holds)
+  if (!transient_before_list(e, ops, count)) return PLL_FAILURE;
+  if ((!e->transient_busy && !flush_pmatrices(p)) || !ensure_luts(p)) return PLL_FAILURE;
 
   // dependency levels: an op runs after the producers of its children and
   // after every earlier op that touched its output buffers
   std::vector<int> clv_level(e->nodes, -1), sc_level(e->nscalers, -1), level(count, 0);
   int max_level = 0;
-  if (!validate_ops(e, ops, count)) return PLL_FAILURE;
-  if (!transient_before_list(e, ops, count)) return PLL_FAILURE;
   if (!e->cherries.empty())
   {
     // every vector this list writes stops being the cherry it may have been; one that the list reads first
@@ -2110,7 +2123,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
           if (!prof_begin(ev1)) return PLL_FAILURE;
           if (chains20 ? !launch_traverse_s20(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows, 0, !e->cherries.empty(), transient)
                        : chains16 ? !launch_traverse_s16(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows)
-                                  : !launch_traverse_s4(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows))
+                                  : !launch_traverse_s4(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows, 0, transient))
             return PLL_FAILURE;
           if (!prof_end(ev1, l.bytes, l.flops, l.ops, l.min_bytes)) return PLL_FAILURE;
           e->counters.partial_launches++;
@@ -2539,7 +2552,7 @@ static int update_partials_group(const std::vector<pll_partition_t *> & g, const
     for (pll_partition_t * p : g) any_transient = any_transient || (engine_of(p)->transient_mode && !engine_of(p)->site_repeats);
     const int ok = lead->family == KernelFamily::S20 ? launch_traverse_s20(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs, false, any_transient)
                  : lead->family == KernelFamily::S16 ? launch_traverse_s16(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs)
-                                                     : launch_traverse_s4(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs);
+                                                     : launch_traverse_s4(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs, any_transient);
     if (!ok) return -1;
     if (lead->profiling)
     {
@@ -2579,7 +2592,10 @@ extern "C" int pllhip_update_partials_batch(pll_partition_t * const * partitions
   for (unsigned i = 0; i < partition_count; ++i)
     if (partitions[i] && !is_router(partitions[i]))
     {
-      PLLHIP_TRY(hipSetDevice(engine_of(partitions[i])->device));
+      Engine * e = engine_of(partitions[i]);
+      PLLHIP_TRY(hipSetDevice(e->device));
+      // (vectors an evaluate-only traversal did not store: settled before the queued P-matrices are launched)
+      if (e->ntransient && (!validate_ops(e, ops, count) || !transient_before_list(e, ops, count))) return PLL_FAILURE;
       if (!flush_pmatrices(partitions[i]) || !ensure_luts(partitions[i])) return PLL_FAILURE;
     }
   for (unsigned i = 0; i < partition_count; ++i)
@@ -2730,16 +2746,6 @@ int pll_update_prob_matrices(pll_partition_t * p,
                 matrix_indices[m], branch_lengths[m]);
       return PLL_FAILURE;
     }
-  // a vector that an evaluate-only traversal did not store is recomputed with the matrices it was made with:
-  // stored now, before one of them changes (pllhip_discard_transient: the caller gave those vectors up)
-  if (e->ntransient)
-    for (unsigned m = 0; m < count; ++m)
-      if (e->transient_mat_users[matrix_indices[m]])
-      {
-        PLLHIP_TRY(hipSetDevice(e->device));
-        if (!transient_flush_all(e)) return PLL_FAILURE;
-        break;
-      }
   // queue; a request for a matrix that is already queued replaces it
   const ParamIdx params = make_params(p, params_indices);
   if (!e->pend_midx.empty() && memcmp(&params, &e->pend_params, sizeof(params)) != 0)
@@ -2763,7 +2769,9 @@ int pll_update_prob_matrices(pll_partition_t * p,
   // every matrix of the partition is queued: no later request can join this launch (a repeated one replaces its
   // entry), so it goes now -- with several partitions the kernel of this one runs while the host issues the
   // per-branch calls of the next (src/tree/treeinfo.c:845-865 loops the partitions inside every branch)
-  if (e->pend_midx.size() >= 4 * MAX_PMAT_PER_LAUNCH || e->pend_midx.size() == e->nmat) return flush_pmatrices(p);
+  // (not while vectors exist as their operation only: the launch waits for the consumer -- if that is the next
+  // traversal, it gives those vectors up before the matrices they were made with change; flush_pmatrices)
+  if (!e->ntransient && (e->pend_midx.size() >= 4 * MAX_PMAT_PER_LAUNCH || e->pend_midx.size() == e->nmat)) return flush_pmatrices(p);
   return PLL_SUCCESS;
 }
 
@@ -2946,6 +2954,9 @@ static int newton_capacity(Engine * e, const void ** fn_out, size_t * lds_out)
     if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor"))
       return -1;
     e->newton_capacity = std::max(0, per_cu) * (int)e->cu_count;
+    e->newton_stream_fn = fn;
+    e->newton_stream_lds = lds;
+    e->newton_stream_capacity = e->newton_capacity;
     // Does the sumtable fit the registers of the waves of ONE co-resident grid (k_newton_mfma_resident)?  Then that
     // grid is the scan grid of this partition -- for the single scans of derivatives_impl as well, so that both
     // add the same block totals in the same order.
@@ -3210,24 +3221,44 @@ int pll_compute_likelihood_derivatives(pll_partition_t * p,
                           sumtable, nullptr, d_f, dd_f);
 }
 
-int pllhip_newton_branch(pll_partition_t * p, int parent_scaler_index, int child_scaler_index,
-                         const unsigned int * params_indices, const double * sumtable,
-                         double start, double bl_min, double bl_max, double tolerance, unsigned int max_newton,
-                         double * length, unsigned int * iterations, double * trail)
+} // extern "C"
+
+namespace pllhip {
+
+// one partition's launch of the Newton-Raphson loop, everything resolved
+struct NewtonLaunch
+{
+  Engine * e = nullptr;
+  const void * fn = nullptr;
+  size_t lds = 0;
+  unsigned nblocks = 0;
+  double share = 0.0;             // fraction of the chip its workgroups take while they are all resident
+  double * d_sum = nullptr;
+  const unsigned * ps = nullptr, * cs = nullptr;
+  ModelView mv;
+  ParamIdx params;
+};
+
+// checks and kernel choice of pllhip_newton_branch for one partition.  resident: the loop may keep the sumtable in the
+// registers of one-workgroup-per-CU launches (a partition that has the device to itself); otherwise the streaming loop,
+// whose workgroups leave room for the other partitions' launches.  Same grid either way: same block totals.
+static int newton_prepare(pll_partition_t * p, int parent_scaler_index, int child_scaler_index,
+                          const unsigned * params_indices, const double * sumtable, bool resident, NewtonLaunch & L)
 {
   Engine * e = engine_of(p);
   static const int enabled = getenv("PLLHIP_DEVICE_NEWTON") ? atoi(getenv("PLLHIP_DEVICE_NEWTON")) : 1;
   const bool family_ok = e->family == KernelFamily::S20 || e->family == KernelFamily::S16 || e->family == KernelFamily::S61 ||
                          (e->family == KernelFamily::S4 && !e->rate_scalers);
-  if (!enabled || !e->shards.empty() || !family_ok || e->N > e->Nreal || !e->fused_finish || !max_newton)
+  if (!enabled || !e->shards.empty() || !family_ok || e->N > e->Nreal || !e->fused_finish)
   {
     set_error(PLLHIP_ERROR_NEWTON_UNSUPPORTED, "this partition does not run the Newton-Raphson loop on the device");
     return PLL_FAILURE;
   }
   PLLHIP_TRY(hipSetDevice(e->device));
   if (!check_scaler_index(e, parent_scaler_index) || !check_scaler_index(e, child_scaler_index)) return PLL_FAILURE;
-  double * d_sum = sumtable_device(e, sumtable, false);
-  if (!d_sum)
+  L.e = e;
+  L.d_sum = sumtable_device(e, sumtable, false);
+  if (!L.d_sum)
   {
     set_error(PLL_ERROR_PARAM_INVALID, "pllhip_newton_branch: no sumtable was computed for this buffer");
     return PLL_FAILURE;
@@ -3235,18 +3266,23 @@ int pllhip_newton_branch(pll_partition_t * p, int parent_scaler_index, int child
   if (!sync_model(p) || !ensure_invariant(p)) return PLL_FAILURE;
   if (!need_scaler(e, parent_scaler_index) || !need_scaler(e, child_scaler_index)) return PLL_FAILURE;
   // the scan's own grid (derivatives_impl): the block totals, and with them every bit of the sums, are the same
-  const unsigned nblocks = scan_grid(e);
-  const void * fn = nullptr;
-  size_t lds = 0;
-  const int capacity = newton_capacity(e, &fn, &lds);
+  L.nblocks = scan_grid(e);
+  int capacity = newton_capacity(e, &L.fn, &L.lds);
   if (capacity < 0) return PLL_FAILURE;
+  if (!resident && e->newton_resident && e->family != KernelFamily::S4)
+  {
+    L.fn = e->newton_stream_fn;
+    L.lds = e->newton_stream_lds;
+    capacity = e->newton_stream_capacity;
+  }
   // every workgroup waits for the others inside the launch: all of them have to be on the chip at once
-  if ((int)nblocks > capacity || capacity == 0)
+  if ((int)L.nblocks > capacity || capacity == 0)
   {
     set_error(PLLHIP_ERROR_NEWTON_UNSUPPORTED, "the scan grid (%u workgroups) does not fit the chip at once (%d)",
-              nblocks, e->newton_capacity);
+              L.nblocks, capacity);
     return PLL_FAILURE;
   }
+  L.share = (double)L.nblocks / (double)capacity;
   if (!e->d_newton)
   {
     if (!dev_alloc(reinterpret_cast<NewtonControl **>(&e->d_newton), 1, "Newton-Raphson control block")) return PLL_FAILURE;
@@ -3254,6 +3290,50 @@ int pllhip_newton_branch(pll_partition_t * p, int parent_scaler_index, int child
     memset(e->h_newton, 0, 128 * sizeof(double));
     PLLHIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->hd_newton), e->h_newton, 0));
   }
+  L.mv = model_view(e);
+  L.params = make_params(p, params_indices);
+  L.ps = scaler_ptr(e, parent_scaler_index);
+  L.cs = scaler_ptr(e, child_scaler_index);
+  return PLL_SUCCESS;
+}
+
+// the launch: totals of the partition's scans go to its OWN control block's `tot`, everything else (iterate, bracket,
+// status, trail, the partitions' meeting point) lives in `ctl`, results in host_out / host_flag
+static int newton_launch(const NewtonLaunch & L, const NewtonParams & np_, NewtonControl * ctl, double * host_out,
+                         unsigned long long * host_flag, unsigned long long seq)
+{
+  Engine * e = L.e;
+  NewtonParams np = np_;
+  ReduceOut ro;
+  ro.block_out = e->d_partials;
+  ro.counter = e->d_counter;
+  ro.dst = static_cast<NewtonControl *>(e->d_newton)->tot;
+  ro.flag = nullptr;
+  ro.seq = 0;
+  ro.fused = 1;
+  ro.nq = 2;
+  unsigned rs = e->rate_scalers ? 1u : 0u;
+  if (e->family == KernelFamily::S4)
+  {
+    void * args4[] = {(void *)&L.mv, (void *)&L.params, (void *)&np, (void *)&L.d_sum, (void *)&L.ps, (void *)&L.cs,
+                      (void *)&e->d_weights, (void *)&e->d_invariant, (void *)&e->N, (void *)&e->R,
+                      (void *)&ro, (void *)&ctl, (void *)&host_out, (void *)&host_flag, (void *)&seq};
+    PLLHIP_TRY(hipLaunchKernel(L.fn, dim3(L.nblocks), dim3(256), args4, 0, e->stream));
+  }
+  else
+  {
+    void * args[] = {(void *)&L.mv, (void *)&L.params, (void *)&np, (void *)&L.d_sum, (void *)&L.ps, (void *)&L.cs,
+                     (void *)&e->d_weights, (void *)&e->d_invariant, (void *)&e->N, (void *)&e->nblk, (void *)&e->R,
+                     (void *)&ro, (void *)&rs, (void *)&ctl, (void *)&host_out, (void *)&host_flag, (void *)&seq};
+    PLLHIP_TRY(hipLaunchKernel(L.fn, dim3(L.nblocks), dim3(256), args, L.lds, e->stream));
+  }
+  e->counters.derivative_calls++;
+  return PLL_SUCCESS;
+}
+
+static NewtonParams newton_params(double start, double bl_min, double bl_max, double tolerance, unsigned max_newton,
+                                  unsigned nblocks_first)
+{
   NewtonParams np;
   np.bl_min = bl_min; np.bl_max = bl_max; np.tolerance = tolerance;
   np.dxmax = bl_max / max_newton;
@@ -3266,59 +3346,39 @@ int pllhip_newton_branch(pll_partition_t * p, int parent_scaler_index, int child
                               ? (getenv("PLLHIP_FAULT_COUNT") ? atoi(getenv("PLLHIP_FAULT_COUNT")) : 1) : 0;
   np.spin_limit = env_spin ? env_spin : NEWTON_SPIN_LIMIT;
   np.stall_block = ~0u;
-  if (stall_left > 0 && nblocks > 1) { --stall_left; np.stall_block = 0u; }
-  NewtonControl init;
-  memset(&init, 0, sizeof(init));
-  init.x = np.x0; init.xl = bl_min; init.xh = bl_max; init.iter = 0; init.status = NEWTON_RUNNING;
-  NewtonControl * ctl = static_cast<NewtonControl *>(e->d_newton);
-  // (pageable source: staged by the runtime before the call returns)
-  PLLHIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, e->stream));
-  ReduceOut ro;
-  ro.block_out = e->d_partials;
-  ro.counter = e->d_counter;
-  ro.dst = ctl->tot;
-  ro.flag = nullptr;
-  ro.seq = 0;
-  ro.fused = 1;
-  ro.nq = 2;
-  const unsigned long long seq = ++e->newton_seq;
-  unsigned long long * host_flag = reinterpret_cast<unsigned long long *>(e->hd_newton + 112);
-  const ModelView mv = model_view(e);
-  const ParamIdx params = make_params(p, params_indices);
-  const unsigned * ps = scaler_ptr(e, parent_scaler_index), * cs = scaler_ptr(e, child_scaler_index);
-  void * args[] = {(void *)&mv, (void *)&params, (void *)&np, (void *)&d_sum, (void *)&ps, (void *)&cs,
-                   (void *)&e->d_weights, (void *)&e->d_invariant, (void *)&e->N, (void *)&e->nblk, (void *)&e->R,
-                   (void *)&ro, nullptr, (void *)&ctl, (void *)&e->hd_newton, (void *)&host_flag, (void *)&seq};
-  unsigned rs = e->rate_scalers ? 1u : 0u;
-  args[12] = &rs;
-  if (e->family == KernelFamily::S4)
-  {
-    void * args4[] = {(void *)&mv, (void *)&params, (void *)&np, (void *)&d_sum, (void *)&ps, (void *)&cs,
-                      (void *)&e->d_weights, (void *)&e->d_invariant, (void *)&e->N, (void *)&e->R,
-                      (void *)&ro, (void *)&ctl, (void *)&e->hd_newton, (void *)&host_flag, (void *)&seq};
-    PLLHIP_TRY(hipLaunchKernel(fn, dim3(nblocks), dim3(256), args4, 0, e->stream));
-  }
-  else
-    PLLHIP_TRY(hipLaunchKernel(fn, dim3(nblocks), dim3(256), args, lds, e->stream));
-  e->counters.derivative_calls++;
-  const volatile unsigned long long * flag = reinterpret_cast<const volatile unsigned long long *>(e->h_newton + 112);
-  if (!wait_sequence(e->stream, flag, seq)) return PLL_FAILURE;
-  const unsigned its = (unsigned)e->h_newton[1], status = (unsigned)e->h_newton[2];
+  if (stall_left > 0 && nblocks_first > 1) { --stall_left; np.stall_block = 0u; }
+  np.part = 0;
+  np.nparts = 1;
+  np.xscale = 1.0;
+  return np;
+}
+
+// wait for the loop that `lead` hosts and translate how it ended; `all`: every engine that took part
+static int newton_finish(Engine * lead, const std::vector<Engine *> & all, unsigned long long seq,
+                         double * length, unsigned int * iterations, double * trail)
+{
+  const volatile unsigned long long * flag = reinterpret_cast<const volatile unsigned long long *>(lead->h_newton + 112);
+  if (!wait_sequence(lead->stream, flag, seq)) return PLL_FAILURE;
+  const unsigned its = (unsigned)lead->h_newton[1], status = (unsigned)lead->h_newton[2];
   if (status == NEWTON_STUCK)
   {
-    // the grid drains by itself (every wait is bounded); the tickets of the unfinished reduction go back to zero
-    // before anything else uses them
-    PLLHIP_TRY(hipStreamSynchronize(e->stream));
-    PLLHIP_TRY(hipMemsetAsync(e->d_counter, 0, REDUCE_COUNTER_WORDS * sizeof(unsigned), e->stream));
-    PLLHIP_TRY(hipStreamSynchronize(e->stream));
+    // the grids drain by themselves (every wait is bounded); the tickets of the unfinished reductions go back to
+    // zero before anything else uses them
+    for (Engine * e : all)
+    {
+      PLLHIP_TRY(hipSetDevice(e->device));
+      PLLHIP_TRY(hipStreamSynchronize(e->stream));
+      PLLHIP_TRY(hipMemsetAsync(e->d_counter, 0, REDUCE_COUNTER_WORDS * sizeof(unsigned), e->stream));
+      PLLHIP_TRY(hipStreamSynchronize(e->stream));
+    }
     set_error(PLLHIP_ERROR_NEWTON_STUCK, "the device-resident Newton-Raphson loop did not get all its workgroups onto the "
               "chip at once (the device is shared with other work)");
     return PLL_FAILURE;
   }
-  e->counters.derivative_points += its;
-  if (length) *length = e->h_newton[0];
+  for (Engine * e : all) e->counters.derivative_points += its;
+  if (length) *length = lead->h_newton[0];
   if (iterations) *iterations = its;
-  if (trail) for (unsigned i = 0; i < its && i < NEWTON_TRAIL_MAX; ++i) trail[i] = e->h_newton[NEWTON_TRAIL_SLOT + i];
+  if (trail) for (unsigned i = 0; i < its && i < NEWTON_TRAIL_MAX; ++i) trail[i] = lead->h_newton[NEWTON_TRAIL_SLOT + i];
   switch (status)
   {
     case NEWTON_CONVERGED: return PLL_SUCCESS;
@@ -3327,6 +3387,116 @@ int pllhip_newton_branch(pll_partition_t * p, int parent_scaler_index, int child
     default: set_error(PLL_ERROR_HIP_RUNTIME, "the device-resident Newton-Raphson loop did not complete (status %u)", status);
              return PLL_FAILURE;
   }
+}
+
+} // namespace pllhip
+
+extern "C" {
+
+int pllhip_newton_branch(pll_partition_t * p, int parent_scaler_index, int child_scaler_index,
+                         const unsigned int * params_indices, const double * sumtable,
+                         double start, double bl_min, double bl_max, double tolerance, unsigned int max_newton,
+                         double * length, unsigned int * iterations, double * trail)
+{
+  if (!max_newton)
+  {
+    set_error(PLLHIP_ERROR_NEWTON_UNSUPPORTED, "this partition does not run the Newton-Raphson loop on the device");
+    return PLL_FAILURE;
+  }
+  NewtonLaunch L;
+  if (!newton_prepare(p, parent_scaler_index, child_scaler_index, params_indices, sumtable, true, L)) return PLL_FAILURE;
+  Engine * e = L.e;
+  const NewtonParams np = newton_params(start, bl_min, bl_max, tolerance, max_newton, L.nblocks);
+  NewtonControl init;
+  memset(&init, 0, sizeof(init));
+  init.x = np.x0; init.xl = bl_min; init.xh = bl_max; init.iter = 0; init.status = NEWTON_RUNNING;
+  NewtonControl * ctl = static_cast<NewtonControl *>(e->d_newton);
+  // (pageable source: staged by the runtime before the call returns)
+  PLLHIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, e->stream));
+  const unsigned long long seq = ++e->newton_seq;
+  if (!newton_launch(L, np, ctl, e->hd_newton, reinterpret_cast<unsigned long long *>(e->hd_newton + 112), seq)) return PLL_FAILURE;
+  return newton_finish(e, std::vector<Engine *>(1, e), seq, length, iterations, trail);
+}
+
+// Several partitions under ONE branch length (linked lengths, or scaled ones: partition p sees s_p x): the loop of
+// pllhip_newton_branch with the sum over the partitions inside it.  Every partition launches its own instance of the
+// loop on its own stream -- its family's kernel on its own scan grid, so its totals are the ones its blocking derivative
+// call returns, bit for bit --; the instances meet in the first partition's control block after every scan (the
+// partition that arrives last adds the totals in partition order and applies the step rule) and all wait there for the
+// next iterate.  All launches have to be resident together: their shares of the chip must add up to less than one
+// (with the register-resident form where that fits, else the streaming form), otherwise PLLHIP_ERROR_NEWTON_UNSUPPORTED.
+int pllhip_newton_branch_multi(pll_partition_t * const * partitions, unsigned int count,
+                               int parent_scaler_index, int child_scaler_index,
+                               const unsigned int * const * params_indices, const double * const * sumtables,
+                               const double * length_scalers,
+                               double start, double bl_min, double bl_max, double tolerance, unsigned int max_newton,
+                               double * length, unsigned int * iterations, double * trail)
+{
+  if (count == 1 && (!length_scalers || length_scalers[0] == 1.0))
+    return pllhip_newton_branch(partitions[0], parent_scaler_index, child_scaler_index, params_indices[0], sumtables[0],
+                                start, bl_min, bl_max, tolerance, max_newton, length, iterations, trail);
+  if (!count || count > NEWTON_MAX_PARTS || !max_newton)
+  {
+    set_error(PLLHIP_ERROR_NEWTON_UNSUPPORTED, "1 to %u partitions per device-resident Newton-Raphson loop", NEWTON_MAX_PARTS);
+    return PLL_FAILURE;
+  }
+  for (unsigned k = 0; k < count; ++k)
+    if (!partitions[k] || engine_of(partitions[k])->device != engine_of(partitions[0])->device)
+    {
+      set_error(PLLHIP_ERROR_NEWTON_UNSUPPORTED, "the partitions of a device-resident Newton-Raphson loop live on one device");
+      return PLL_FAILURE;
+    }
+  static const double max_share = getenv("PLLHIP_NEWTON_MAX_SHARE") ? atof(getenv("PLLHIP_NEWTON_MAX_SHARE")) : 0.8;
+  std::vector<NewtonLaunch> L(count);
+  bool fits = false;
+  for (int resident = 1; resident >= 0 && !fits; --resident)
+  {
+    double share = 0.0;
+    for (unsigned k = 0; k < count; ++k)
+    {
+      L[k] = NewtonLaunch();
+      if (!newton_prepare(partitions[k], parent_scaler_index, child_scaler_index, params_indices[k], sumtables[k],
+                          resident != 0, L[k]))
+        return PLL_FAILURE;
+      share += L[k].share;
+    }
+    fits = share <= max_share;
+  }
+  if (!fits)
+  {
+    set_error(PLLHIP_ERROR_NEWTON_UNSUPPORTED, "the scan grids of the %u partitions do not fit the chip together", count);
+    return PLL_FAILURE;
+  }
+  Engine * lead = L[0].e;
+  NewtonParams np = newton_params(start, bl_min, bl_max, tolerance, max_newton, L[0].nblocks);
+  NewtonControl init;
+  memset(&init, 0, sizeof(init));
+  init.x = np.x0; init.xl = bl_min; init.xh = bl_max; init.iter = 0; init.status = NEWTON_RUNNING;
+  for (unsigned k = 0; k < count; ++k) init.pscale[k] = length_scalers ? length_scalers[k] : 1.0;
+  NewtonControl * ctl = static_cast<NewtonControl *>(lead->d_newton);
+  PLLHIP_TRY(hipSetDevice(lead->device));
+  PLLHIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, lead->stream));
+  // the other partitions' launches read the control block: after its initialisation
+  if (!lead->newton_ready) PLLHIP_TRY(hipEventCreateWithFlags(&lead->newton_ready, hipEventDisableTiming));
+  PLLHIP_TRY(hipEventRecord(lead->newton_ready, lead->stream));
+  const unsigned long long seq = ++lead->newton_seq;
+  unsigned long long * host_flag = reinterpret_cast<unsigned long long *>(lead->hd_newton + 112);
+  std::vector<Engine *> all;
+  np.nparts = count;
+  for (unsigned k = 0; k < count; ++k)
+  {
+    np.part = k;
+    np.xscale = init.pscale[k];
+    if (k) { np.stall_block = ~0u; PLLHIP_TRY(hipStreamWaitEvent(L[k].e->stream, lead->newton_ready, 0)); }
+    all.push_back(L[k].e);
+    if (!newton_launch(L[k], np, ctl, lead->hd_newton, host_flag, seq))
+    {
+      // (the instances already launched give up after their bounded wait)
+      (void)newton_finish(lead, all, seq, nullptr, nullptr, nullptr);
+      return PLL_FAILURE;
+    }
+  }
+  return newton_finish(lead, all, seq, length, iterations, trail);
 }
 
 unsigned int pllhip_free_trial_lengths(const pll_partition_t * p)

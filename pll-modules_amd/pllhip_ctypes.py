@@ -155,7 +155,7 @@ pllhip_compute_likelihood_derivatives_multi pllhip_free_trial_lengths pllhip_set
 pllhip_shard_count pllhip_results_create pllhip_results_destroy
 pllhip_results_edge_loglikelihood pllhip_results_derivatives pllhip_results_fetch
 pllhip_eval_attach_comm pllhip_update_partials_batch pllhip_results_poison pllhip_newton_branch pllhip_repeat_stats
-pllhip_set_transient pllhip_discard_transient pllhip_transient_stats""".split()
+pllhip_set_transient pllhip_discard_transient pllhip_transient_stats pllhip_newton_branch_multi""".split()
 
 
 def _u32(a):
@@ -318,6 +318,10 @@ class PllLib:
         if hasattr(L, "pllhip_newton_branch"):
             L.pllhip_newton_branch.argtypes = [pp, C.c_int, C.c_int, c_uint_p, c_double_p, C.c_double, C.c_double,
                                                C.c_double, C.c_double, C.c_uint, c_double_p, c_uint_p, c_double_p]
+        if hasattr(L, "pllhip_newton_branch_multi"):
+            L.pllhip_newton_branch_multi.argtypes = [C.POINTER(pp), C.c_uint, C.c_int, C.c_int, C.POINTER(c_uint_p),
+                                                     C.POINTER(c_double_p), c_double_p, C.c_double, C.c_double, C.c_double,
+                                                     C.c_double, C.c_uint, c_double_p, c_uint_p, c_double_p]
         if hasattr(L, "pllhip_update_partials_batch"):
             L.pllhip_update_partials_batch.argtypes = [C.POINTER(pp), C.c_uint, C.POINTER(Operation), C.c_uint]
         if hasattr(L, "pllhip_compute_likelihood_derivatives_multi"):
@@ -1046,6 +1050,25 @@ def build_instance(lib, states, rate_cats, ntips, nsites, coded=True, scalers=Tr
     inst.tree = tree
     inst.codes = codes
     return inst
+
+
+def newton_branch_multi(lib, insts, psc, csc, sumtables, scalers, start, bl_min, bl_max, tolerance, max_newton):
+    """pllhip_newton_branch_multi over `insts` (their own sumtables, optional branch-length scalers):
+    (length, iterations, trail) or raises with the library's message"""
+    n = len(insts)
+    parts = (C.POINTER(Partition) * n)(*[i.p for i in insts])
+    params = (c_uint_p * n)(*[i.params_p for i in insts])
+    sts = (c_double_p * n)(*[C.cast(s_, c_double_p) for s_ in sumtables])
+    sc = _f64(scalers) if scalers is not None else None
+    length, its = C.c_double(), C.c_uint()
+    trail = np.zeros(96)
+    lib.errno = 0
+    ok = lib.lib.pllhip_newton_branch_multi(parts, n, psc, csc, params, sts, sc.ctypes.data_as(c_double_p) if sc is not None else None,
+                                            start, bl_min, bl_max, tolerance, max_newton, C.byref(length), C.byref(its),
+                                            trail.ctypes.data_as(c_double_p))
+    if not ok:
+        raise RuntimeError(f"[{lib.errno}] {lib.errmsg}")
+    return length.value, its.value, trail[:its.value]
 
 
 def update_partials_batch(lib, insts, ops, count=None):

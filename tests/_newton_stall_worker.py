@@ -22,7 +22,7 @@ def main():
     lib = pc.PllLib(pc.PRODUCT_LIB)
     out = {}
     # (1) the entry point itself
-    with pc.build_instance(lib, states=states, rate_cats=4, ntips=10, nsites=5000, coded=True) as a:
+    with pc.build_instance(lib, states=states, rate_cats=4, ntips=10, nsites=5000 if states <= 20 else 800, coded=True) as a:
         pc.full_traversal(a)
         t = a.tree
         sa, sb = t.scaler_of(t.root_a), t.scaler_of(t.root_b)
@@ -40,9 +40,10 @@ def main():
         a.free_sumtable(st)
     # (2) through the driver: the first branch meets the second injected stall, falls back, and stays on the host loop
     tree = pc.Tree(12, 42, 43)
-    subst, freqs = (pc.protein_model() if states == 20 else (pc.DNA_GTR_RATES, pc.DNA_FREQS))
+    subst, freqs = (pc.protein_model() if states == 20 else pc.codon_model() if states == 61 else (pc.DNA_GTR_RATES, pc.DNA_FREQS))
     with pc.Evaluation(lib, tree.newick()) as ev:
-        ev.add_partition(0, states, 4000, 4, pc.simulated_codes(tree, 4000, states, 45), subst, freqs, 0.7)
+        nsites = 4000 if states <= 20 else 600
+        ev.add_partition(0, states, nsites, 4, pc.simulated_codes(tree, nsites, states, 45), subst, freqs, 0.7)
         out["lnl0"] = ev.loglh()
         out["lnl1"] = ev.optimize_branches(iters=2)
         out["newick"] = ev.newick()

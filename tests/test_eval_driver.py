@@ -464,6 +464,91 @@ def test_device_newton_makes_the_host_loop_s_iterates(product, states, nsites, p
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("spec,scalers", [
+    ([(20, 3000), (20, 1700)], None),
+    ([(4, 6000), (4, 2500), (20, 1500), (20, 900)], None),                 # C4's mix: two kernel families in one loop
+    ([(4, 6000), (4, 2500), (20, 1500), (20, 900)], [1.0, 0.7, 1.9, 1.2]),   # scaled branch lengths: chain rule s, s^2
+    ([(61, 300), (20, 800), (10, 1200), (4, 50_000)], [0.8, 1.0, 1.3, 1.1]),
+    ([(20, 60_000), (20, 50_000)], None),                                   # register-resident instances side by side
+])
+def test_device_newton_over_several_partitions(product, spec, scalers):
+    """pllhip_newton_branch_multi: partitions that share a branch length run ONE loop on the device; every iterate is
+    the host loop's -- f = sum s_p f_p(s_p x), f' = sum s_p^2 f'_p(s_p x) added in partition order
+    (src/optimize/pll_optimize.c:1223-1287) -- bit for bit"""
+    tree = pc.Tree(9, 42, 43)
+    insts = [pc.build_instance(product, states=s_, rate_cats=4, ntips=9, nsites=n_, coded=True, tree=tree, seed_shift=k)
+             for k, (s_, n_) in enumerate(spec)]
+    sc = scalers or [1.0] * len(insts)
+    try:
+        sts = []
+        for a in insts:
+            a.tree = tree
+            pc.full_traversal(a)
+            sts.append(a.alloc_sumtable())
+        for root_edge in (tree.root_matrix, 2):
+            t2 = pc.Tree(9, 42, 43)
+            t2.set_root_edge(root_edge)
+            if t2.root_b < t2.ntips and t2.root_a < t2.ntips:
+                continue
+            sa, sb = t2.scaler_of(t2.root_a), t2.scaler_of(t2.root_b)
+            for a, st in zip(insts, sts):
+                a.tree = t2
+                pc.full_traversal(a)
+                a.update_sumtable(t2.root_a, t2.root_b, sa, sb, st)
+
+            def deriv(x):
+                f = df = 0.0
+                for a, st, s_ in zip(insts, sts, sc):
+                    fp, dfp = a.derivatives(sa, sb, s_ * x, st)
+                    f += s_ * fp
+                    df += s_ * s_ * dfp
+                return f, df
+            for start in (float(t2.brlens[root_edge]), 1e-4, 3.0):
+                try:
+                    want_x, want_trail = _host_newton(deriv, start, 1e-4, 10.0, 1e-5, 32)
+                except OverflowError:
+                    with pytest.raises(RuntimeError, match="910"):
+                        pc.newton_branch_multi(product, insts, sa, sb, sts, scalers, start, 1e-4, 10.0, 1e-5, 32)
+                    continue
+                got_x, its, trail = pc.newton_branch_multi(product, insts, sa, sb, sts, scalers, start, 1e-4, 10.0, 1e-5, 32)
+                assert its == len(want_trail), (root_edge, start, its, len(want_trail))
+                assert list(trail) == want_trail
+                assert got_x == want_x
+        for a, st in zip(insts, sts):
+            a.free_sumtable(st)
+    finally:
+        for a in insts:
+            a.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("linkage", [0, 1])
+def test_driver_with_device_newton_over_partitions(product, linkage):
+    """pllhip_eval_optimize_branches over C4's mix of partitions (linked, and scaled branch lengths): the device loop
+    and the host loop give the same tree, the same lnL and the same number of Newton iterations"""
+    import os
+    tree = pc.Tree(12, 42, 43)
+    out, launches = [], []
+    for flag in ("0", "1"):
+        os.environ["PLLHIP_EVAL_DEVICE_NEWTON"] = flag
+        try:
+            with pc.Evaluation(product, tree.newick(), nparts=4) as ev:
+                for k, (s_, n_) in enumerate([(4, 3000), (4, 2000), (20, 900), (20, 700)]):
+                    subst, freqs = (pc.protein_model() if s_ == 20 else (pc.DNA_GTR_RATES, pc.DNA_FREQS))
+                    ev.add_partition(k, s_, n_, 4, pc.simulated_codes(tree, n_, s_, 45 + k), subst, freqs, 0.7)
+                if linkage:
+                    ev.set_linkage(1, [1.0, 0.8, 1.5, 1.1])
+                l0 = ev.loglh()
+                l1 = ev.optimize_branches(1e-4, 10.0, 0.01, 3, -1)
+                out.append((l0, l1, ev.newick(), ev.newton_iterations()))
+                launches.append(sum(p_.counters().derivative_calls for p_ in ev.parts))
+        finally:
+            del os.environ["PLLHIP_EVAL_DEVICE_NEWTON"]
+    assert out[0] == out[1]
+    assert launches[1] < launches[0] // 2        # one launch per partition and branch instead of one per iterate
+
+
+@pytest.mark.gpu
 def test_device_newton_says_when_it_cannot(product):
     with pc.build_instance(product, states=4, rate_cats=4, ntips=6, nsites=500, coded=True) as a:
         pc.full_traversal(a)

@@ -274,7 +274,8 @@ with pc.build_instance(lib, states=%d, rate_cats=4, ntips=tree.ntips, nsites=153
             runs.append(subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True,
                                        text=True, timeout=300).stdout.splitlines())
         assert runs[0][:4] == runs[1][:4] and len(runs[0]) == 5
-        assert int(runs[0][4]) == 4 and int(runs[1][4]) > 8        # one launch per traversal / several
+        if not common.FORCED_TRANSIENT:       # (vectors that were not stored are recomputed for the hashes: more launches)
+            assert int(runs[0][4]) == 4 and int(runs[1][4]) > 8        # one launch per traversal / several
 
 
 @pytest.mark.parametrize("shape", ["random", "ladder", "balanced"])

@@ -221,7 +221,7 @@ def test_site_repeats_through_the_driver(product, oracle):
         start = pc.Tree(12, 11, 12, brlen_range=(0.05, 0.15))
         ev = pc.Evaluation(lib, start.newick(), nparts=1)
         r, f = pc.protein_model()
-        ev.add_partition(0, 20, 3000, 4, pc.simulated_codes(truth, 3000, 20), r, f, 0.8, attributes=attributes)
+        ev.add_partition(0, 20, 900, 4, pc.simulated_codes(truth, 900, 20), r, f, 0.8, attributes=attributes)
         with ev:
             l0 = ev.loglh()
             l1 = ev.optimize_branches(1e-4, 10.0, 0.01, 2, -1)
@@ -229,7 +229,7 @@ def test_site_repeats_through_the_driver(product, oracle):
             out.append((l0, l1, l2, ev.newick(), st.moves_applied))
     assert out[0] == out[1]
     for a, b in zip(out[0][:3], out[2][:3]):
-        assert abs(a - b) <= 1e-6 * 3000
+        assert abs(a - b) <= 1e-6 * 900
     assert out[0][4] == out[2][4]
 
 

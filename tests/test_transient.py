@@ -7,11 +7,13 @@ recomputed for its first reader, or before one of its inputs changes -- and must
 import numpy as np
 import pytest
 
+import common
 import pllhip_ctypes as pc
 from test_gpu_parity import lnl_close, site_err, REL_CLV, CLV_SITE_61
 from test_site_repeats import _everything, _same
 
-pytestmark = pytest.mark.gpu
+# (with every partition forced to compute per class of sites the evaluate-only mode is off: kernels_repeats.hpp)
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(common.FORCED_REPEATS, reason="evaluate-only traversals are off under site repeats")]
 NONE = pc.PLL_SCALE_BUFFER_NONE
 
 FAMILIES = [(20, 4), (4, 4), (10, 4), (2, 4), (24, 4), (4, 2), (20, 2)]
@@ -65,7 +67,19 @@ def test_a_vector_that_was_not_stored_is_stored_before_its_inputs_change(product
         # (1) new lengths for every branch: the vectors are the old ones
         for inst in (on, off):
             inst.update_pmatrices(np.arange(tree.nedges), tree.brlens * 1.7)
+        for i in inner:
+            assert np.array_equal(on.get_clv(i), off.get_clv(i)), i
         assert on.transient_stats().materialized == on.transient_stats().skipped
+        # ... and an evaluation right after new lengths gives the old vectors up without recomputing them
+        m0 = on.transient_stats().materialized
+        for inst in (on, off):
+            pc.full_traversal(inst)
+            inst.update_pmatrices(np.arange(tree.nedges), tree.brlens * 0.6, one_by_one=True)
+            pc.full_traversal(inst)
+        assert on.transient_stats().materialized == m0
+        sa, sb = tree.scaler_of(tree.root_a), tree.scaler_of(tree.root_b)
+        # (the edge likelihood first: it launches the queued matrices of the last update)
+        assert on.edge_lnl(tree.root_a, sa, tree.root_b, sb, tree.root_matrix) == off.edge_lnl(tree.root_a, sa, tree.root_b, sb, tree.root_matrix)
         for i in inner:
             assert np.array_equal(on.get_clv(i), off.get_clv(i)), i
         # (2) a tip changes after the next evaluation

@@ -171,6 +171,43 @@ def blo(lib, cfg, out, nsites=None):
                                          "sumtable once per iterate); scans evaluate up to 4 trial lengths"}
 
 
+def blo_c4(lib, out, nsites=None):
+    """the same smoothing pass over C4's four partitions under linked branch lengths (2 DNA + 2 protein partitions,
+    BASELINE.json configs[3]; nsites: the configured total, e.g. 125 000 = the per-GPU slice of an 8-way split):
+    the sums of the partitions' derivatives meet between two Newton iterates (src/optimize/pll_optimize.c:1223-1287)"""
+    S, R, ntips, N = pc.CONFIGS["c4"]
+    N = nsites or N
+    t = pc.Tree(ntips, 42, 43)
+    parts = [(4, 0.25), (4, 0.25), (20, 0.125), (20, 0.125)]
+    ev = pc.Evaluation(lib, t.newick(), nparts=len(parts))
+    insts = []
+    for k, (s_, share) in enumerate(parts):
+        n_ = max(1, int(round(N * share)))
+        if s_ == 4:
+            subst, freqs, alpha = pc.DNA_GTR_RATES, pc.DNA_FREQS, 0.841
+        else:
+            (subst, freqs), alpha = pc.protein_model(), 0.5
+        insts.append(ev.add_partition(k, s_, n_, R, pc.random_codes(ntips, n_, s_, 44 + 101 * k), subst, freqs, alpha))
+    with ev:
+        l0 = ev.loglh()
+        for i in insts:
+            lib.lib.pllhip_synchronize(i.p)
+        ops0, pm0, d0 = ev.counters()
+        n0 = ev.newton_iterations()
+        t0 = time.perf_counter()
+        l1 = ev.optimize_branches(1e-4, 10.0, 0.01, 1, -1)
+        dt = time.perf_counter() - t0
+        ops1, pm1, d1 = ev.counters()
+        n1 = ev.newton_iterations()
+        out[f"BLO_c4_{N}"] = {"s_per_smoothing_pass": dt, "lnl_before": l0, "lnl_after": l1,
+                              "newton_iterations": n1 - n0, "single_op_updates": ops1 - ops0,
+                              "pmatrix_updates": pm1 - pm0, "branches": t.nedges, "partitions": len(parts),
+                              "us_per_derivative_call_incl_everything": dt / max(1, n1 - n0) * 1e6,
+                              "device_newton": os.environ.get("PLLHIP_EVAL_DEVICE_NEWTON", "1") != "0",
+                              "what": "pllhip_eval_optimize_branches(iters=1, radius=ALL) over four partitions with linked "
+                                      "branch lengths; a derivative call = one Newton-Raphson iterate of all partitions"}
+
+
 def spr(lib, out, nsites=None, ntips=None, radius_max=5, thorough=False):
     """BASELINE config 5: codon GY94-like + G4, 50 taxa, one SPR round from a scrambled start"""
     S, R, taxa, N = pc.CONFIGS["c5"]
@@ -266,6 +303,9 @@ def main():
         blo(lib, "c3", out)
         blo(lib, "c2", out)
         blo(lib, "c3", out, nsites=125_000)
+    if "blo_c4" in which:
+        blo_c4(lib, out, nsites=125_000)
+        blo_c4(lib, out)
     if "w2" in which:
         w2(lib, "c3", out)
         w2(lib, "c2", out)
