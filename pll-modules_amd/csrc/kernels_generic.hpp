@@ -162,9 +162,9 @@ __global__ __launch_bounds__(256) void k_pmatrix(ModelView mv, ParamIdx params, 
     double * F = pfrag + ((size_t)m * R + r) * 400;
     for (unsigned x = threadIdx.x; x < 400; x += blockDim.x)
     {
-      unsigned i, j;
-      if (x < 320) { i = x & 15; j = 4 * (x >> 6) + ((x & 63) >> 4); }
-      else { const unsigned y = x - 320; i = 16 + (y & 3); j = 4 * (y >> 4) + ((y >> 2) & 3); }
+      // (kernels_s20.hpp, s20_cfrag_index: [k-step][row group][q][row in group])
+      const unsigned t = x >> 4, ks = t / 5, g = t - 5 * ks;
+      const unsigned i = 4 * g + (x & 3u), j = 4 * ks + ((x >> 2) & 3u);
       F[x] = Pl[i * PS + j];
     }
   }

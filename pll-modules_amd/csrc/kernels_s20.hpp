@@ -403,16 +403,24 @@ constexpr unsigned S20_CHAIN_LDS = 20480;             // doubles: the whole LDS 
 constexpr unsigned S20_CHAIN_MAX = 8;                 // operations per chain (the LDS usually ends it earlier)
 constexpr unsigned S20_CHAIN_WAVES = 8;
 
-// cfrag[r*400 + ks*64 + lane]                  = M[r][lane & 15][4 ks + (lane >> 4)]
-// cfrag[r*400 + 320 + ks*16 + q*4 + n] (n < 4) = M[r][16 + n][4 ks + q]
+// Compact fragments for the 4 x 4 x 4 matrix instruction (mfma_f64_tail above): row group g = rows 4 g .. 4 g + 3,
+// five groups for 20 states, no padding at all.  Lane (q, n) reads the A operand of (k-step ks, group g) at
+//   cfrag[r*400 + (ks*5 + g)*16 + q*4 + (n & 3)] = M[r][4 g + (n & 3)][4 ks + q]
+// (sixteen consecutive doubles per wave read: no bank conflicts, the four lanes of a (q, i) share an address).
+__device__ inline void s20_cfrag_index(unsigned x, unsigned & row, unsigned & col)
+{
+  const unsigned t = x >> 4, ks = t / 5, g = t - 5 * ks;
+  row = 4 * g + (x & 3u);
+  col = 4 * ks + ((x >> 2) & 3u);
+}
+
 __device__ inline void s20_fill_cfrags(double * cfrag, const double * mats, unsigned R)
 {
   staged_loop<8>(R * S20_CFRAGS, [=](unsigned e)
   {
     const unsigned r = e / S20_CFRAGS, x = e % S20_CFRAGS;
     unsigned i, j;
-    if (x < 320) { i = x & 15; j = 4 * (x >> 6) + ((x & 63) >> 4); }
-    else { const unsigned y = x - 320; i = 16 + (y & 3); j = 4 * (y >> 4) + ((y >> 2) & 3); }
+    s20_cfrag_index(x, i, j);
     return mats[((size_t)r * 20 + i) * 20 + j];
   }, [=](unsigned e, double x) { cfrag[e] = x; });
 }
@@ -421,16 +429,20 @@ __device__ inline void s20_fill_cfrags(double * cfrag, const double * mats, unsi
 __device__ inline void s20_child_regs_c(const double2 b[5], const double * cfrag_r, unsigned lane,
                                         double2 t[5])
 {
+  // rows 0 .. 15: one 16 x 16 x 4 tile (its A operand M[n][4 ks + q] sits at group n >> 2, row n & 3 of the compact
+  // fragments); rows 16 .. 19: the 4 x 4 x 4 instruction (mfma_f64_tail).  All five groups on the short instruction
+  // were measured too: the same at 1 M sites (29.8 against 30.0 ms), 3.5 % slower at the 125 k-site slice (25 instead
+  // of 10 LDS operand reads per unit).
   const unsigned q = lane >> 4, n = lane & 15;
-  // (rows 16 .. 19: M[16 + (n & 3)][4 ks + q] for every lane, see mfma_f64_tail)
-  const double * tail_r = cfrag_r + 320 + q * 4 + (n & 3u);
+  const double * head_r = cfrag_r + (n >> 2) * 16 + q * 4 + (n & 3u);
+  const double * tail_r = cfrag_r + 4 * 16 + q * 4 + (n & 3u);
   v4d a0e = {0, 0, 0, 0}, a0o = {0, 0, 0, 0};
   double a1e = 0.0, a1o = 0.0;
 #pragma unroll
   for (int ks = 0; ks < 5; ++ks)
   {
-    const double f0 = cfrag_r[ks * 64 + lane];
-    const double f1 = tail_r[ks * 16];
+    const double f0 = head_r[ks * 80];
+    const double f1 = tail_r[ks * 80];
     a0e = mfma_f64(f0, b[ks].x, a0e);
     a0o = mfma_f64(f0, b[ks].y, a0o);
     a1e = mfma_f64_tail(f1, b[ks].x, a1e);
@@ -952,7 +964,7 @@ __device__ inline double deriv_block_totals(const ModelView & mv, const ParamIdx
   // The wave walks its (site block, rate) units with two alternating operand buffers: the
   // loads of unit u + 1 are in flight while the MFMAs of unit u run (the very first unit was
   // requested before the tables above were built).
-  v4d acc_e = {0, 0, 0, 0}, acc_o = {0, 0, 0, 0};
+  double acc_e[3] = {0.0, 0.0, 0.0}, acc_o[3] = {0.0, 0.0, 0.0};       // {A, B, C} of trial length q
   double inv_e = 0, inv_o = 0;
   SiteSide sd = {0u, 0u, 0u, 0u};
   unsigned r = 0;
@@ -979,12 +991,19 @@ __device__ inline double deriv_block_totals(const ModelView & mv, const ParamIdx
       const double fo = rate_factor(ps, cs, site0 + 1, R, r, sd.cnt_o);                               \
       _Pragma("unroll") for (unsigned ks = 0; ks < KS; ++ks) { CUR[ks].x *= fe; CUR[ks].y *= fo; }    \
     }                                                                                                 \
-    const double * fr = frag + (size_t)r * KS * 64 + lane;                                            \
+    /* rows j, 4 + j, 8 + j of the left operand (e0, e1, e2 of trial length j) as three row groups of the  */ \
+    /* 4 x 4 x 4 instruction (mfma_f64_tail): lane (q, n) reads row 4 g + (n & 3), k = 4 ks + q, and gets */ \
+    /* quantity g of trial length q -- six independent short chains instead of two long ones            */ \
+    const double * fr = frag + (size_t)r * KS * 64 + (lane >> 4) * 16 + (lane & 3u);                  \
     _Pragma("unroll") for (unsigned ks = 0; ks < KS; ++ks)                                            \
     {                                                                                                 \
-      const double f = fr[ks * 64];                                                                   \
-      acc_e = mfma_f64(f, CUR[ks].x, acc_e);                                                          \
-      acc_o = mfma_f64(f, CUR[ks].y, acc_o);                                                          \
+      const double f0 = fr[ks * 64], f1 = fr[ks * 64 + 4], f2 = fr[ks * 64 + 8];                      \
+      acc_e[0] = mfma_f64_tail(f0, CUR[ks].x, acc_e[0]);                                              \
+      acc_o[0] = mfma_f64_tail(f0, CUR[ks].y, acc_o[0]);                                              \
+      acc_e[1] = mfma_f64_tail(f1, CUR[ks].x, acc_e[1]);                                              \
+      acc_o[1] = mfma_f64_tail(f1, CUR[ks].y, acc_o[1]);                                              \
+      acc_e[2] = mfma_f64_tail(f2, CUR[ks].x, acc_e[2]);                                              \
+      acc_o[2] = mfma_f64_tail(f2, CUR[ks].y, acc_o[2]);                                              \
     }                                                                                                 \
     if (invariant)                                                                                    \
     {                                                                                                 \
@@ -1015,8 +1034,8 @@ __device__ inline double deriv_block_totals(const ModelView & mv, const ParamIdx
         df -= w * ba;                                                                                 \
         ddf += w * (ba * ba - ca);                                                                    \
       }                                                                                               \
-      acc_e = v4d{0, 0, 0, 0};                                                                        \
-      acc_o = v4d{0, 0, 0, 0};                                                                        \
+      acc_e[0] = acc_e[1] = acc_e[2] = 0.0;                                                           \
+      acc_o[0] = acc_o[1] = acc_o[2] = 0.0;                                                           \
       inv_e = inv_o = 0.0;                                                                            \
     }                                                                                                 \
     blk = nb;                                                                                         \
@@ -1147,19 +1166,23 @@ __device__ inline double deriv_block_totals_resident(const ModelView & mv, const
     const unsigned blk = blk0 + b * wstride;
     if (blk >= nblk) break;
     const size_t site0 = (size_t)blk * S20_BS + 2 * n;
-    v4d acc_e = {0, 0, 0, 0}, acc_o = {0, 0, 0, 0};
+    double acc_e[3] = {0.0, 0.0, 0.0}, acc_o[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (unsigned r = 0; r < RT; ++r)
     {
-      const double * fr = frag + (size_t)r * KS * 64 + lane;
+      const double * fr = frag + (size_t)r * KS * 64 + (lane >> 4) * 16 + (lane & 3u);     // (as in deriv_block_totals)
 #pragma unroll
       for (unsigned ks = 0; ks < KS; ++ks)
       {
-        const double f = fr[ks * 64];
+        const double f0 = fr[ks * 64], f1 = fr[ks * 64 + 4], f2 = fr[ks * 64 + 8];
         const double2 u = b < NBR ? res.unit[b < NBR ? b : 0][r][ks]
                                   : lds_units[((((b - NBR) * 4 + wave) * RT + r) * KS + ks) * 64 + lane];
-        acc_e = mfma_f64(f, u.x, acc_e);
-        acc_o = mfma_f64(f, u.y, acc_o);
+        acc_e[0] = mfma_f64_tail(f0, u.x, acc_e[0]);
+        acc_o[0] = mfma_f64_tail(f0, u.y, acc_o[0]);
+        acc_e[1] = mfma_f64_tail(f1, u.x, acc_e[1]);
+        acc_o[1] = mfma_f64_tail(f1, u.y, acc_o[1]);
+        acc_e[2] = mfma_f64_tail(f2, u.x, acc_e[2]);
+        acc_o[2] = mfma_f64_tail(f2, u.y, acc_o[2]);
       }
     }
     const SiteSide sd = res.sd[b];

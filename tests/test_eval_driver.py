@@ -342,6 +342,18 @@ def test_speculative_newton_on_oracle(oracle):
     check_speculative_newton(oracle)
 
 
+def test_transient_mode_is_harmless_without_an_engine_that_has_it(oracle):
+    """pllhip_eval_set_transient on the CPU oracle (which stores every vector and exports no pllhip_set_transient:
+    the driver binds those symbols weakly): the same numbers in every mode"""
+    out = []
+    for mode in (0, 1, 2):
+        with build(oracle) as ev:
+            ev.set_transient(mode)
+            seq = [ev.loglh(), ev.loglh(), ev.optimize_branches(1e-4, 10.0, 0.01, 2, -1), ev.loglh(incremental=True), ev.loglh()]
+            out.append(seq)
+    assert out[0] == out[1] == out[2]
+
+
 def test_multi_length_derivatives_on_oracle(oracle):
     inst = pc.build_instance(oracle, states=20, rate_cats=4, ntips=8, nsites=200, coded=True)
     with inst:

@@ -526,7 +526,8 @@ def test_one_by_one_pmatrix_calls_and_single_op_calls(product):
         got = a.edge_lnl(t.root_a, t.scaler_of(t.root_a), t.root_b, t.scaler_of(t.root_b), t.root_matrix)
         assert got == ref
         c = a.counters()
-        assert c.partial_ops == 2 * len(t.ops)
+        # (under PLLHIP_TRANSIENT=1 vectors the first traversal kept in registers are recomputed for the single operations)
+        assert c.partial_ops == 2 * len(t.ops) or common.FORCED_TRANSIENT
 
 
 @pytest.mark.parametrize("states,ladder,rate_cats", [(4, False, 4), (4, True, 4), (20, True, 4), (4, False, 1),

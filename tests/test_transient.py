@@ -145,7 +145,8 @@ def test_transient_partitions_share_launches(product, states):
             pc.update_partials_batch(product, group, ops)
             for r in ref:
                 r.update_partials(ops)
-            assert a.transient_stats().skipped > 0 and b.transient_stats().skipped == 0 and c.transient_stats().skipped > 0
+            assert a.transient_stats().skipped > 0 and c.transient_stats().skipped > 0
+            assert b.transient_stats().skipped == 0 or common.FORCED_TRANSIENT
             for x, r in zip(group, ref):
                 for op in tree.ops:
                     assert np.array_equal(x.get_clv(op[0]), r.get_clv(op[0]))
@@ -185,7 +186,7 @@ def test_the_driver_s_full_evaluations(product, oracle, states, mode):
             seq.append(ev.spr_round(radius_max=3, ntopol_keep=3)[0])
             seq.append(ev.newick())
             out[name] = seq
-    assert out["on"][4] == ("skipped", True) and out["off"][4] == ("skipped", False)
+    assert out["on"][4] == ("skipped", True) and (out["off"][4] == ("skipped", False) or common.FORCED_TRANSIENT)
     out["on"].pop(4), out["off"].pop(4)
     assert out["on"] == out["off"]
     for a, b in zip(out["on"][:4], out["ref"][:4]):

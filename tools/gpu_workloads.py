@@ -303,6 +303,8 @@ def main():
         blo(lib, "c3", out)
         blo(lib, "c2", out)
         blo(lib, "c3", out, nsites=125_000)
+    if "blo_c4_125" in which:
+        blo_c4(lib, out, nsites=125_000)
     if "blo_c4" in which:
         blo_c4(lib, out, nsites=125_000)
         blo_c4(lib, out)
