@@ -898,6 +898,7 @@ def main():
     # kernel arguments in device memory (3 - 5 us per short launch, pll_core.hip): decided HERE, before any
     # library that initialises the HIP runtime is loaded, so that N = 1 and N > 1 run under the same setting
     os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # (a queue per partition stream: pll_core.hip, pllhip_runtime_defaults)
     default_shape = (world == 1 and not internal and args.config == "c3" and not args.sites and not args.taxa and
                      not args.rate_scalers and not args.no_also and not args.no_cpu_baseline and not args.site_repeats and
                      args.data == "random" and args.tree == "random" and not args.transient)
@@ -966,6 +967,7 @@ def main():
     out = run_leg(ctx, args.config, sites=args.sites, taxa=args.taxa, steps=args.steps, warmup=args.warmup,
                   cpu=None if args.no_cpu_baseline else "full")
     out["runtime"] = {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG"),
+                      "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                       "torch_loaded_before_engine": world > 1}
     default_run = (world == 1 and not internal and args.config == "c3" and not args.sites and not args.taxa and
                    not args.rate_scalers and not args.no_also and not args.no_cpu_baseline and not args.site_repeats and

@@ -310,6 +310,7 @@ struct Engine
   size_t newton_stream_lds = 0;
   int newton_stream_capacity = 0;
   hipEvent_t newton_ready = nullptr;  // the control block of a multi-partition loop is initialised
+  hipEvent_t newton_done = nullptr;   // this partition's instance of the last multi-partition loop has left the device
 
   // caller-keyed device sumtables (pointer value is the key)
   std::list<std::pair<const void *, double *>> sumtables;

@@ -1265,13 +1265,14 @@ struct NewtonControl          // device memory, one per engine
   unsigned pad;
   double ptot[NEWTON_MAX_PARTS][2];   // {f, f'} of partition p at its own length s_p x
   double pscale[NEWTON_MAX_PARTS];    // s_p: the partition's branch-length scaler (1 with linked lengths)
+  unsigned dbg_enter[NEWTON_MAX_PARTS], dbg_leave[NEWTON_MAX_PARTS], dbg_arrive[NEWTON_MAX_PARTS];   // PLLHIP_NEWTON_DEBUG
 };
 
 // spin_limit: polls a workgroup waits for the next iterate before it gives up (NEWTON_SPIN_LIMIT; tests lower it);
 // stall_block: fault injection -- that workgroup leaves at once, as if it had never been given a CU (~0u: none)
 // part / nparts / xscale: this launch is partition `part` of `nparts` that share the branch (nparts = 1: alone); it scans
 // its sumtable at xscale * x and leaves its totals in ro.dst, a scratch of its own
-struct NewtonParams { double x0, bl_min, bl_max, tolerance, dxmax; unsigned max_newton, spin_limit, stall_block, part, nparts; double xscale; };
+struct NewtonParams { double x0, bl_min, bl_max, tolerance, dxmax; unsigned max_newton, spin_limit, stall_block, part, nparts; double xscale; unsigned debug; };
 
 // mapped host memory: [0] final length, [1] iterations, [2] status, [3] last f, [4] last df, [8 ...] the trail
 constexpr unsigned NEWTON_RUNNING = 0, NEWTON_CONVERGED = 1, NEWTON_LIMIT = 2, NEWTON_NONFINITE = 3, NEWTON_STUCK = 4;
@@ -1297,6 +1298,7 @@ __device__ inline unsigned newton_step_and_wait(unsigned it, bool last, double &
     // ticket; kernels_common.hpp); the partition that arrives last adds all of them in partition order with the
     // chain rule of the scalers -- f = sum s_p f_p, f' = sum s_p^2 f'_p: the host loop's derivatives()
     // (csrc/host/pllhip_eval.c; src/optimize/pll_optimize.c:1258-1267) -- and applies the step rule.
+    if (np.debug) __hip_atomic_store(&ctl->dbg_arrive[np.part], it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&ctl->ptot[np.part][0], ro.dst[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&ctl->ptot[np.part][1], ro.dst[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (unsigned k = 0; k <= REDUCE_SHARDS; ++k)                          // this partition's tickets back to zero
@@ -1375,6 +1377,7 @@ __device__ inline unsigned newton_step_and_wait(unsigned it, bool last, double &
   if (threadIdx.x == 0)
   {
     unsigned spins = 0;
+    if (np.debug) __hip_atomic_fetch_add(&ctl->dbg_enter[np.part], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // (relaxed polls, ONE acquire afterwards: an acquire per poll invalidates the caches of the whole chip
     // several hundred times per microsecond)
     while (__hip_atomic_load(&ctl->iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != it + 1)
@@ -1394,6 +1397,7 @@ __device__ inline unsigned newton_step_and_wait(unsigned it, bool last, double &
       __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (np.debug && spins <= np.spin_limit) __hip_atomic_fetch_add(&ctl->dbg_leave[np.part], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *s_status = (spins > np.spin_limit) ? NEWTON_STUCK
                                         : __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *s_x = __hip_atomic_load(&ctl->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

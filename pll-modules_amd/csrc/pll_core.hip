@@ -138,6 +138,13 @@ __attribute__((constructor)) static void pllhip_runtime_defaults()
   const char * opt = getenv("PLLHIP_SET_RUNTIME_DEFAULTS");
   if (opt && !atoi(opt)) return;
   if (!getenv("HIP_FORCE_DEV_KERNARG")) setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
+  // The runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), in order within a
+  // queue.  Every partition has a stream of its own, and the Newton-Raphson loop over several partitions
+  // (pllhip_newton_branch_multi) needs its instances -- one launch per partition -- on the device TOGETHER: with five
+  // streams (four partitions + a result group) two of them shared a queue, the second instance started when the first
+  // had given up, and the loop ended in PLLHIP_ERROR_NEWTON_STUCK (the callers then iterate on the host; found with
+  // PLLHIP_NEWTON_DEBUG=1).  Sixteen queues cover the eight partitions such a loop takes and the streams next to them.
+  if (!getenv("GPU_MAX_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "16", 0);
 }
 #endif
 
@@ -375,6 +382,7 @@ void engine_destroy(Engine * e)
   (void)hipFree(e->d_pairlut);
   (void)hipFree(e->d_newton);
   if (e->newton_ready) (void)hipEventDestroy(e->newton_ready);
+  if (e->newton_done) (void)hipEventDestroy(e->newton_done);
   if (e->h_newton) (void)hipHostFree(e->h_newton);
   (void)hipFree(e->d_sum_scratch);
   if (e->h_result) (void)hipHostFree(e->h_result);
@@ -3350,6 +3358,7 @@ static NewtonParams newton_params(double start, double bl_min, double bl_max, do
   np.part = 0;
   np.nparts = 1;
   np.xscale = 1.0;
+  np.debug = getenv("PLLHIP_NEWTON_DEBUG") ? 1u : 0u;
   return np;
 }
 
@@ -3368,6 +3377,21 @@ static int newton_finish(Engine * lead, const std::vector<Engine *> & all, unsig
     {
       PLLHIP_TRY(hipSetDevice(e->device));
       PLLHIP_TRY(hipStreamSynchronize(e->stream));
+      if (getenv("PLLHIP_NEWTON_DEBUG"))
+      {
+        // where the loop stood: the meeting point and every instance's tickets
+        NewtonControl c;
+        std::vector<unsigned> t(REDUCE_COUNTER_WORDS);
+        (void)hipMemcpy(&c, lead->d_newton, sizeof(c), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(t.data(), e->d_counter, t.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
+        fprintf(stderr, "newton stuck: instance %p iter %u status %u arrived %u x %g | tickets", (void *)e, c.iter, c.status, c.arrived, c.x);
+        for (unsigned k = 0; k <= REDUCE_SHARDS; ++k) fprintf(stderr, " %u", t[k * REDUCE_SHARD_STRIDE]);
+        fprintf(stderr, " | ptot");
+        for (unsigned k = 0; k < all.size(); ++k) fprintf(stderr, " (%g %g)", c.ptot[k][0], c.ptot[k][1]);
+        fprintf(stderr, " | waits entered / left / arrived-after-scan per instance:");
+        for (unsigned k = 0; k < all.size(); ++k) fprintf(stderr, " %u/%u/%u", c.dbg_enter[k], c.dbg_leave[k], c.dbg_arrive[k]);
+        fprintf(stderr, "\n");
+      }
       PLLHIP_TRY(hipMemsetAsync(e->d_counter, 0, REDUCE_COUNTER_WORDS * sizeof(unsigned), e->stream));
       PLLHIP_TRY(hipStreamSynchronize(e->stream));
     }
@@ -3446,7 +3470,10 @@ int pllhip_newton_branch_multi(pll_partition_t * const * partitions, unsigned in
       set_error(PLLHIP_ERROR_NEWTON_UNSUPPORTED, "the partitions of a device-resident Newton-Raphson loop live on one device");
       return PLL_FAILURE;
     }
-  static const double max_share = getenv("PLLHIP_NEWTON_MAX_SHARE") ? atof(getenv("PLLHIP_NEWTON_MAX_SHARE")) : 0.8;
+  // (a launch's share = its workgroups / the workgroups of its kernel the chip holds: an upper bound of the resources
+  // it takes, so shares that add up to one fit; the margin is for the order in which the dispatcher fills the CUs.
+  // A wrong guess costs one bounded wait: PLLHIP_ERROR_NEWTON_STUCK, and the caller's own loop from then on)
+  static const double max_share = getenv("PLLHIP_NEWTON_MAX_SHARE") ? atof(getenv("PLLHIP_NEWTON_MAX_SHARE")) : 0.9;
   std::vector<NewtonLaunch> L(count);
   bool fits = false;
   for (int resident = 1; resident >= 0 && !fits; --resident)
@@ -3460,7 +3487,7 @@ int pllhip_newton_branch_multi(pll_partition_t * const * partitions, unsigned in
         return PLL_FAILURE;
       share += L[k].share;
     }
-    fits = share <= max_share;
+    fits = share <= max_share + 1e-9;
   }
   if (!fits)
   {
@@ -3473,8 +3500,13 @@ int pllhip_newton_branch_multi(pll_partition_t * const * partitions, unsigned in
   memset(&init, 0, sizeof(init));
   init.x = np.x0; init.xl = bl_min; init.xh = bl_max; init.iter = 0; init.status = NEWTON_RUNNING;
   for (unsigned k = 0; k < count; ++k) init.pscale[k] = length_scalers ? length_scalers[k] : 1.0;
-  NewtonControl * ctl = static_cast<NewtonControl *>(lead->d_newton);
   PLLHIP_TRY(hipSetDevice(lead->device));
+  // (the instances are different kernels on different hardware queues -- pllhip_runtime_defaults asks the runtime for
+  // enough of them; they meet in the first partition's control block)
+  NewtonControl * ctl = static_cast<NewtonControl *>(lead->d_newton);
+  // (the instances of the previous loop of these partitions have left the device: they read the block to the end)
+  for (unsigned k = 1; k < count; ++k)
+    if (L[k].e->newton_done) PLLHIP_TRY(hipStreamWaitEvent(lead->stream, L[k].e->newton_done, 0));
   PLLHIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, lead->stream));
   // the other partitions' launches read the control block: after its initialisation
   if (!lead->newton_ready) PLLHIP_TRY(hipEventCreateWithFlags(&lead->newton_ready, hipEventDisableTiming));
@@ -3483,6 +3515,9 @@ int pllhip_newton_branch_multi(pll_partition_t * const * partitions, unsigned in
   unsigned long long * host_flag = reinterpret_cast<unsigned long long *>(lead->hd_newton + 112);
   std::vector<Engine *> all;
   np.nparts = count;
+  // (an instance that shares a hardware queue with another one never meets it: a shorter bound than the single loop's)
+  static const bool env_spin_set = getenv("PLLHIP_NEWTON_SPIN_LIMIT") != nullptr;
+  if (!env_spin_set) np.spin_limit = NEWTON_SPIN_LIMIT >> 4;
   for (unsigned k = 0; k < count; ++k)
   {
     np.part = k;
@@ -3494,6 +3529,11 @@ int pllhip_newton_branch_multi(pll_partition_t * const * partitions, unsigned in
       // (the instances already launched give up after their bounded wait)
       (void)newton_finish(lead, all, seq, nullptr, nullptr, nullptr);
       return PLL_FAILURE;
+    }
+    if (k)
+    {
+      if (!L[k].e->newton_done) PLLHIP_TRY(hipEventCreateWithFlags(&L[k].e->newton_done, hipEventDisableTiming));
+      PLLHIP_TRY(hipEventRecord(L[k].e->newton_done, L[k].e->stream));
     }
   }
   return newton_finish(lead, all, seq, length, iterations, trail);
