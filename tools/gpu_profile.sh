@@ -7,7 +7,7 @@ set -x
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 CFG=${1:-c3}
-python bench.py --config $CFG > gpurun_out/bench_$CFG.json 2> gpurun_out/bench_$CFG.err
+python bench.py --config $CFG --pmc on > gpurun_out/bench_$CFG.json 2> gpurun_out/bench_$CFG.err
 tail -c 2500 gpurun_out/bench_$CFG.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$CFG -- python3 $R/bench.py --config $CFG --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_$CFG.log 2>&1

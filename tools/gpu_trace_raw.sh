@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/gpu_trace_raw.sh <label> <program> [args...]: rocprofv3 --kernel-trace of one command; per kernel the
-# count / min / median / max duration and the median gap to the previous dispatch (us)
+# count / min / median / max duration and the median gap to the previous dispatch (us).  TRACE_WINDOW=first,count also
+# lists that run of dispatches one by one (start relative to the first of them, duration, queue) in traceraw_<label>_window.txt
 cd "$(dirname "$0")/.."
 ROOT="$PWD"
 label=$1; shift
@@ -9,10 +10,19 @@ d=$ROOT/gpurun_out/traceraw_$label
 rm -rf "$d"; mkdir -p "$d"
 (cd /tmp && rocprofv3 --kernel-trace -d "$d" -o t --output-format csv -- "$@" > "$d/stdout.txt" 2> "$d/stderr.txt") || { tail -5 "$d/stderr.txt"; exit 1; }
 f=$(find "$d" -name '*kernel_trace.csv' | head -1)
-python3 - "$f" > "$ROOT/gpurun_out/traceraw_${label}.txt" <<'PY'
-import csv, sys, statistics as st
+python3 - "$f" "$ROOT/gpurun_out/traceraw_${label}_window.txt" > "$ROOT/gpurun_out/traceraw_${label}.txt" <<'PY'
+import csv, os, sys, statistics as st
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+if os.environ.get("TRACE_WINDOW"):
+    a, n = (int(v) for v in os.environ["TRACE_WINDOW"].split(","))
+    a = a if a >= 0 else len(rows) + a
+    w = rows[a:a + n]
+    with open(sys.argv[2], "w") as out:
+        t0 = int(w[0]["Start_Timestamp"])
+        for r in w:
+            s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            out.write(f"{(s - t0) / 1e3:9.1f} +{(e - s) / 1e3:7.1f} us  q{r.get('Queue_Id', '?'):>3s}  grid {r.get('Grid_Size_X') or r.get('Grid_Size', '?'):>7s}  {r['Kernel_Name'].split('(')[0][-70:]}\n")
 by = {}
 prev_end = None
 for r in rows:
