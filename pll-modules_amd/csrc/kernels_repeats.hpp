@@ -30,6 +30,7 @@
 
 #include "kernels_common.hpp"
 #include "kernels_s20.hpp"
+#include "kernels_s16.hpp"
 #include "engine.h"
 
 namespace pllhip {
@@ -403,6 +404,131 @@ __global__ __launch_bounds__(256) void k_cherry_expand_s4(const double * table, 
     const double * src = table + ((size_t)pair[n] * R + r) * 4;
     double * dst = clv + c * 4;
     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// the same for the 2 .. 32-state family (kernels_s16.hpp; KS = ceil(S / 4) k-steps, units of 4 KS rows, tip tables
+// [rate][code][S]) -- the reference runs its 5-state branch-length test under the attribute (test/runtest.py:45-51,
+// test/src/common.c:31).  The rate count is a run-time value here: a class block is stored unscaled rate by rate and
+// brought up by 2^256 afterwards where the vote over all rates says so -- k_partials_s16's rule, hence its bits.
+// ---------------------------------------------------------------------------
+// grid = (class blocks of the largest job / 4, jobs), block = 256
+template <unsigned KS>
+__global__ __launch_bounds__(256) void k_cherry_build_s16(const CherryJob * jobs, unsigned ncodes, unsigned R, unsigned S)
+{
+  constexpr unsigned UNIT = 4 * KS * S20_BS;
+  const CherryJob job = plan_fetch(jobs + blockIdx.y);
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, n = lane & 15;
+  const unsigned npairs = job.nclasses, npblk = (npairs + S20_BS - 1) / S20_BS;
+  const unsigned blk = blockIdx.x * 4 + wave;
+  if (blk >= npblk) return;
+  const double * lut1 = as_global(job.lut1), * lut2 = as_global(job.lut2);
+  const unsigned * rep = as_global(job.rep);
+  double * table = as_global(job.table);
+  uint8_t * flags = as_global(job.flags);
+  const unsigned pe = blk * S20_BS + 2 * n, po = pe + 1;
+  const unsigned ce = pe < npairs ? pe : 0, co = po < npairs ? po : 0;
+  const unsigned ae = rep ? rep[2 * ce] : ce / ncodes, be = rep ? rep[2 * ce + 1] : ce % ncodes;
+  const unsigned ao = rep ? rep[2 * co] : co / ncodes, bo = rep ? rep[2 * co + 1] : co % ncodes;
+  int small_e = 1, small_o = 1;
+  for (unsigned r = 0; r < R; ++r)
+  {
+    double2 t1[KS], t2[KS];
+    s16_child_tip<KS>(lut1 + (size_t)r * job.rows1 * S, ae, ao, q, S, t1);
+    s16_child_tip<KS>(lut2 + (size_t)r * job.rows2 * S, be, bo, q, S, t2);
+#pragma unroll
+    for (unsigned v = 0; v < KS; ++v)
+    {
+      t1[v].x *= t2[v].x;
+      t1[v].y *= t2[v].y;
+      small_e &= (t1[v].x < SCALE_THRESHOLD);      // rows >= S are zero: they never veto
+      small_o &= (t1[v].y < SCALE_THRESHOLD);
+    }
+    s16_store_d<KS>(table + ((size_t)blk * R + r) * UNIT, lane, t1);
+  }
+  if (!job.counts) return;
+  small_e = s20_and_q(small_e);
+  small_o = s20_and_q(small_o);
+  if (__any(small_e | small_o))
+  {
+    const double fe = small_e ? SCALE_FACTOR : 1.0, fo = small_o ? SCALE_FACTOR : 1.0;
+    for (unsigned r = 0; r < R; ++r)
+    {
+      double * unit = table + ((size_t)blk * R + r) * UNIT;
+      double2 t[KS];
+      s16_load_d<KS>(unit, lane, t);
+#pragma unroll
+      for (unsigned v = 0; v < KS; ++v) { t[v].x *= fe; t[v].y *= fo; }
+      s16_store_d<KS>(unit, lane, t);
+    }
+  }
+  if (q == 0)
+  {
+    const unsigned * cnt1 = as_global(job.cnt1), * cnt2 = as_global(job.cnt2);
+    unsigned * counts = as_global(job.counts);
+    if (pe < npairs) { flags[pe] = (uint8_t)small_e; counts[pe] = (unsigned)small_e + (cnt1 ? cnt1[ae] : 0u) + (cnt2 ? cnt2[be] : 0u); }
+    if (po < npairs) { flags[po] = (uint8_t)small_o; counts[po] = (unsigned)small_o + (cnt1 ? cnt1[ao] : 0u) + (cnt2 ? cnt2[bo] : 0u); }
+  }
+}
+
+// row tables [rate][rows][S] = P . table(class), with the MFMA sequence an inner child takes (s16_child_inner).
+// job.pfrag: the branch's matrices [rate][S][Sp].  grid = (row blocks / 4, jobs), block = 256,
+// dynamic LDS = R * s16_fr(KS) doubles
+template <unsigned KS>
+__global__ __launch_bounds__(256) void k_pair_lut_s16(const PairLutJob * jobs, unsigned R, unsigned S, unsigned Sp)
+{
+  extern __shared__ double frag[];
+  constexpr unsigned UNIT = 4 * KS * S20_BS;
+  const PairLutJob job = plan_fetch(jobs + blockIdx.y);
+  const unsigned npairs = job.nrows;
+  s16_fill_frags<KS>(frag, as_global(job.pfrag), R, S, Sp);
+  __syncthreads();
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, n = lane & 15;
+  const unsigned npblk = (npairs + S20_BS - 1) / S20_BS;
+  const unsigned blk = blockIdx.x * 4 + wave;
+  if (blk >= npblk) return;
+  const double * table = as_global(job.table);
+  double * out = as_global(job.out);
+  const unsigned pe = blk * S20_BS + 2 * n, po = pe + 1;
+  for (unsigned r = 0; r < R; ++r)
+  {
+    double2 t[KS];
+    s16_child_inner<KS>(table + ((size_t)blk * R + r) * UNIT, frag + r * s16_fr(KS), lane, t);
+#pragma unroll
+    for (unsigned v = 0; v < KS; ++v)
+    {
+      const unsigned i = 4 * v + q;
+      if (i >= S) continue;
+      if (pe < npairs) out[((size_t)r * npairs + pe) * S + i] = t[v].x;
+      if (po < npairs) out[((size_t)r * npairs + po) * S + i] = t[v].y;
+    }
+  }
+}
+
+// the site-indexed vector of a class node.  grid = site blocks / 4, block = 256
+template <unsigned KS>
+__global__ __launch_bounds__(256) void k_cherry_expand_s16(const double * table, const unsigned * pair,
+                                                           unsigned nblk, unsigned R, double * clv)
+{
+  constexpr unsigned UNIT = 4 * KS * S20_BS;
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, n = lane & 15;
+  for (unsigned blk = blockIdx.x * 4 + wave; blk < nblk; blk += gridDim.x * 4)
+  {
+    const size_t site0 = (size_t)blk * S20_BS + 2 * n;
+    const unsigned pe = pair[site0], po = pair[site0 + 1];
+    for (unsigned r = 0; r < R; ++r)
+    {
+      const double * ue = table + ((size_t)(pe / S20_BS) * R + r) * UNIT + (q * 16 + (pe % S20_BS) / 2) * 2 + (pe & 1u);
+      const double * uo = table + ((size_t)(po / S20_BS) * R + r) * UNIT + (q * 16 + (po % S20_BS) / 2) * 2 + (po & 1u);
+      double2 t[KS];
+#pragma unroll
+      for (unsigned v = 0; v < KS; ++v) t[v] = make_double2(ue[v * 128], uo[v * 128]);
+      s16_store_d<KS>(clv + ((size_t)blk * R + r) * UNIT, lane, t);
+    }
   }
 }
 

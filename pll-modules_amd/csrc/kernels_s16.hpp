@@ -284,7 +284,10 @@ constexpr unsigned S16_CHAIN_LDS = 20480;             // doubles: the whole LDS 
 
 // one operation for one site block; X: the handed-over operand on entry (carried != 0), the result on
 // exit; xe / xo: the scaler counts that go with X (per rate with RS, else element 0)
-template <unsigned KS, unsigned RT, bool RS>
+// WIDE: a child may be a "wide tip" (kernels_repeats.hpp: a node known per class of sites) -- neither vector nor byte
+// codes; pfragN holds its 32-bit class codes, lutN its row table [rate][class][S], childN_index the rows, scalerN its
+// counts per class
+template <unsigned KS, unsigned RT, bool RS, bool WIDE = false>
 __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2 X[RT][KS],
                                     const double * s1, const double * s2, unsigned S, unsigned lut_codes,
                                     bool lut_lds, unsigned blk, unsigned lane,
@@ -295,10 +298,16 @@ __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2
   const unsigned q = lane >> 4, n = lane & 15;
   const size_t site0 = (size_t)blk * S20_BS + 2 * n;
   unsigned c1e = 0, c1o = 0, c2e = 0, c2o = 0;
+  const unsigned * w1 = (WIDE && !op.clv1 && !op.codes1) ? reinterpret_cast<const unsigned *>(op.pfrag1) : nullptr;
+  const unsigned * w2 = (WIDE && !op.clv2 && !op.codes2) ? reinterpret_cast<const unsigned *>(op.pfrag2) : nullptr;
   if (op.codes1) { c1e = op.codes1[site0]; c1o = op.codes1[site0 + 1]; }
+  else if (w1) { c1e = w1[site0]; c1o = w1[site0 + 1]; }
   if (op.codes2) { c2e = op.codes2[site0]; c2o = op.codes2[site0 + 1]; }
+  else if (w2) { c2e = w2[site0]; c2o = w2[site0 + 1]; }
   const bool scaling = op.parent_scaler != nullptr;
   const double * l1 = lut_lds ? s1 : op.lut1, * l2 = lut_lds ? s2 : op.lut2;
+  // where a child's scaler counts of the lane's two sites are: per site, or (wide tip) per class
+  const size_t k1e = w1 ? c1e : site0, k1o = w1 ? c1o : site0 + 1, k2e = w2 ? c2e : site0, k2o = w2 ? c2o : site0 + 1;
   int small_e = 1, small_o = 1;
 #pragma unroll
   for (unsigned r = 0; r < RT; ++r)
@@ -306,9 +315,11 @@ __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2
     const size_t ubase = ((size_t)blk * RT + r) * UNIT;
     double2 t1[KS], t2[KS];
     if (carried == 1) s16_child_regs<KS>(X[r], s1 + r * s16_fr(KS), lane, t1);
+    else if (w1) s16_child_tip<KS>(op.lut1 + (size_t)r * op.child1_index * S, c1e, c1o, q, S, t1);
     else if (!op.codes1) s16_child_inner<KS>(op.clv1 + ubase, s1 + r * s16_fr(KS), lane, t1, ntl);
     else s16_child_tip<KS>(l1 + (size_t)r * lut_codes * S, c1e, c1o, q, S, t1);
     if (carried == 2) s16_child_regs<KS>(X[r], s2 + r * s16_fr(KS), lane, t2);
+    else if (w2) s16_child_tip<KS>(op.lut2 + (size_t)r * op.child2_index * S, c2e, c2o, q, S, t2);
     else if (!op.codes2) s16_child_inner<KS>(op.clv2 + ubase, s2 + r * s16_fr(KS), lane, t2, ntl);
     else s16_child_tip<KS>(l2 + (size_t)r * lut_codes * S, c2e, c2o, q, S, t2);
     int re = 1, ro = 1;
@@ -383,12 +394,12 @@ __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2
     if (op.scaler1)
     {
       if (carried == 1) { ce += xe[0]; co += xo[0]; }
-      else { ce += op.scaler1[site0]; co += op.scaler1[site0 + 1]; }
+      else { ce += op.scaler1[k1e]; co += op.scaler1[k1o]; }
     }
     if (op.scaler2)
     {
       if (carried == 2) { ce += xe[0]; co += xo[0]; }
-      else { ce += op.scaler2[site0]; co += op.scaler2[site0 + 1]; }
+      else { ce += op.scaler2[k2e]; co += op.scaler2[k2o]; }
     }
     op.parent_scaler[site0] = ce;
     op.parent_scaler[site0 + 1] = co;
@@ -397,7 +408,7 @@ __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2
   xo[0] = co;
 }
 
-template <unsigned KS, unsigned RT, bool RS>
+template <unsigned KS, unsigned RT, bool RS, bool WIDE = false>
 __global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanView plan, unsigned chain_begin,
                                                                            unsigned chain_end, unsigned S,
                                                                            unsigned Sp, unsigned nt_flags)
@@ -418,10 +429,13 @@ __global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanVi
     for (unsigned i = 0; i < ch.len; ++i)
     {
       const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
-      if (!po.d.codes1) s16_fill_frags<KS>(lds + po.slot1, po.d.pmat1, RT, S, Sp);
+      // (a wide tip has no table in LDS: its rows are gathered from memory)
+      if (WIDE && !po.d.clv1 && !po.d.codes1) { }
+      else if (!po.d.codes1) s16_fill_frags<KS>(lds + po.slot1, po.d.pmat1, RT, S, Sp);
       else if (lut_lds)
         staged_copy<8>(lds + po.slot1, po.d.lut1, RT * lut_codes * S);
-      if (!po.d.codes2) s16_fill_frags<KS>(lds + po.slot2, po.d.pmat2, RT, S, Sp);
+      if (WIDE && !po.d.clv2 && !po.d.codes2) { }
+      else if (!po.d.codes2) s16_fill_frags<KS>(lds + po.slot2, po.d.pmat2, RT, S, Sp);
       else if (lut_lds)
         staged_copy<8>(lds + po.slot2, po.d.lut2, RT * lut_codes * S);
     }
@@ -434,7 +448,7 @@ __global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanVi
       for (unsigned i = 0; i < ch.len; ++i)
       {
         const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
-        s16_chain_op<KS, RT, RS>(po.d, i ? po.carried : 0u, X, lds + po.slot1, lds + po.slot2, S, lut_codes,
+        s16_chain_op<KS, RT, RS, WIDE>(po.d, i ? po.carried : 0u, X, lds + po.slot1, lds + po.slot2, S, lut_codes,
                                  lut_lds, blk, lane, xe, xo, nt, ntl, !(po.flags & 1u));
       }
     }
@@ -675,8 +689,9 @@ static unsigned s16_chain_slot(const Engine * e, bool tip)
   return s16_chain_lut_lds(e) ? ((e->R * e->lut_codes * e->S + 7u) & ~7u) : 0u;
 }
 
+// wide: the schedule may hold wide tips (site repeats; per-site scaling only)
 static int launch_traverse_s16(Engine * e, const PlanView & plan, unsigned lds_doubles, unsigned extent, unsigned chain_begin,
-                               unsigned chain_end, unsigned rows, unsigned row_wgs_per_cu = 0)
+                               unsigned chain_end, unsigned rows, unsigned row_wgs_per_cu = 0, bool wide = false)
 {
   const size_t lds = sizeof(double) * lds_doubles;
   const unsigned need = (extent + S16_CHAIN_WAVES - 1) / S16_CHAIN_WAVES;
@@ -691,6 +706,7 @@ static int launch_traverse_s16(Engine * e, const PlanView & plan, unsigned lds_d
   do { \
     PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_traverse_s16<KK, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
     PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_traverse_s16<KK, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
+    PLLHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_traverse_s16<KK, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
   } while (0)
   if (!attr_set)
   {
@@ -703,6 +719,9 @@ static int launch_traverse_s16(Engine * e, const PlanView & plan, unsigned lds_d
   do { \
     if (e->rate_scalers) \
       hipLaunchKernelGGL((k_traverse_s16<KK, 4, true>), dim3(gx, std::max(1u, rows)), dim3(64 * S16_CHAIN_WAVES), lds, e->stream, \
+                         plan, chain_begin, chain_end, e->S, e->Sp, nt_flags); \
+    else if (wide) \
+      hipLaunchKernelGGL((k_traverse_s16<KK, 4, false, true>), dim3(gx, std::max(1u, rows)), dim3(64 * S16_CHAIN_WAVES), lds, e->stream, \
                          plan, chain_begin, chain_end, e->S, e->Sp, nt_flags); \
     else \
       hipLaunchKernelGGL((k_traverse_s16<KK, 4, false>), dim3(gx, std::max(1u, rows)), dim3(64 * S16_CHAIN_WAVES), lds, e->stream, \

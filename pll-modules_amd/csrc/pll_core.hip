@@ -305,13 +305,15 @@ Engine * engine_create(pll_partition_t * p)
     if (ok) memset(e->h_asc, 0, bytes);
     ok = ok && hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->d_asc), e->h_asc, 0), "map asc");
   }
-  if (e->site_repeats && (e->family == KernelFamily::S20 || e->family == KernelFamily::S4))
+  // (the 2 .. 32-state family: where it runs operation chains -- four rate categories, per-site scaling)
+  if (e->site_repeats && (e->family == KernelFamily::S20 || e->family == KernelFamily::S4 ||
+                          (e->family == KernelFamily::S16 && chains_supported_s16(e))))
   {
     e->cherries.assign(e->nodes, Engine::Cherry());
     e->tip_version.assign(e->tips, 0);
     e->scaler_lazy.assign(e->nscalers, -1);
   }
-  else e->site_repeats = false;                 // (first step: the 20- and the 4-state family)
+  else e->site_repeats = false;                 // (the 61-state family, other rate counts of the 2 .. 32-state one: not yet)
   e->pmat_brlen.assign(e->nmat, std::numeric_limits<double>::quiet_NaN());
   e->pmat_params.assign(e->nmat, std::vector<unsigned>());
   e->owner = p;
@@ -1133,6 +1135,14 @@ static int need_clv(Engine * e, unsigned idx)
   if (e->family == KernelFamily::S4)
     hipLaunchKernelGGL(k_cherry_expand_s4, dim3(std::max(1u, std::min((e->N * e->R + 255u) / 256u, e->cu_count * 8u))), dim3(256), 0,
                        e->stream, c.table, c.pair, e->N, e->R, e->d_clv[idx]);
+  else if (e->family == KernelFamily::S16)
+  {
+#define PLLHIP_CALL(KK) \
+    hipLaunchKernelGGL(k_cherry_expand_s16<KK>, dim3(std::max(1u, std::min((e->nblk + 3) / 4, e->cu_count * 8u))), dim3(256), 0, \
+                       e->stream, c.table, c.pair, e->nblk, e->R, e->d_clv[idx])
+    PLLHIP_DISPATCH_KS(s16_ks(e), PLLHIP_CALL);
+#undef PLLHIP_CALL
+  }
   else
     hipLaunchKernelGGL(k_cherry_expand, dim3(std::max(1u, std::min((e->nblk + 3) / 4, e->cu_count * 8u))), dim3(256), 0,
                        e->stream, c.table, c.pair, e->nblk, e->R, e->d_clv[idx]);
@@ -1167,7 +1177,9 @@ static bool cherry_storage(Engine * e, unsigned node, unsigned nclasses)
   Engine::Cherry & c = e->cherries[node];
   const unsigned npblk = (nclasses + S20_BS - 1) / S20_BS;
   // (20 states: blocked like a vector over the classes; 4 states: [class][rate][4])
-  const size_t table_doubles = e->family == KernelFamily::S4 ? (size_t)nclasses * e->R * 4 : (size_t)npblk * e->R * S20_UNIT;
+  const size_t table_doubles = e->family == KernelFamily::S4 ? (size_t)nclasses * e->R * 4
+                             : e->family == KernelFamily::S16 ? (size_t)npblk * e->R * 4 * s16_ks(e) * S20_BS
+                                                               : (size_t)npblk * e->R * S20_UNIT;
   if (c.cap_classes < nclasses)
   {
     if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
@@ -1663,7 +1675,8 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
           const Engine::Cherry & c = e->cherries[cidx];
           PairLutJob job;
           job.table = c.table;
-          job.pfrag = chains4 ? e->d_pmat + (size_t)midx * e->R * 16 : e->d_pfrag + (size_t)midx * e->R * 400;
+          job.pfrag = chains4 ? e->d_pmat + (size_t)midx * e->R * 16
+                    : chains16 ? e->d_pmat + (size_t)midx * e->R * e->S * e->Sp : e->d_pfrag + (size_t)midx * e->R * 400;
           job.out = e->d_pairlut + pairlut_used;
           job.nrows = c.nclasses;
           pairlut_used += (size_t)e->R * c.nclasses * e->S;
@@ -1741,7 +1754,8 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
               const Engine::Cherry & cc = e->cherries[child[x]];
               PairLutJob pj;
               pj.table = cc.table;
-              pj.pfrag = chains4 ? e->d_pmat + (size_t)matrix[x] * e->R * 16 : e->d_pfrag + (size_t)matrix[x] * e->R * 400;
+              pj.pfrag = chains4 ? e->d_pmat + (size_t)matrix[x] * e->R * 16
+                       : chains16 ? e->d_pmat + (size_t)matrix[x] * e->R * e->S * e->Sp : e->d_pfrag + (size_t)matrix[x] * e->R * 400;
               pj.out = e->d_pairlut + pairlut_used;
               pj.nrows = cc.nclasses;
               pairlut_used += (size_t)e->R * cc.nclasses * e->S;
@@ -2023,7 +2037,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
       // site repeats: the cherries of the list that an operation of the list consumes are kept per class
       // (kernels_repeats.hpp) and leave the list; their consumers read them as wide tips
       RepeatPlan rp;
-      if (e->site_repeats && (chains20 || chains4) && lut_used <= 64)
+      if (e->site_repeats && (chains20 || chains4 || chains16) && lut_used <= 64)
       {
         // an operation is kept per class if an operation of the list consumes it and both children are known per
         // class: coded tips, class operations earlier in the list, or class nodes of earlier calls whose tables
@@ -2099,6 +2113,13 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
               const dim3 gp((npblk + 3) / 4, njobs);
               const size_t lds = sizeof(double) * e->R * S20_CFRAGS;
               if (chains4) hipLaunchKernelGGL(k_pair_lut_s4, dim3((L.max_rows * e->R + 255) / 256, njobs), dim3(256), 0, e->stream, jobs, e->R);
+              else if (chains16)
+              {
+#define PLLHIP_CALL(KK) \
+                hipLaunchKernelGGL(k_pair_lut_s16<KK>, gp, dim3(256), sizeof(double) * e->R * s16_fr(KK), e->stream, jobs, e->R, e->S, e->Sp)
+                PLLHIP_DISPATCH_KS(s16_ks(e), PLLHIP_CALL);
+#undef PLLHIP_CALL
+              }
               else if (e->R == 4) hipLaunchKernelGGL(k_pair_lut<4>, gp, dim3(256), lds, e->stream, jobs);
               else if (e->R == 2) hipLaunchKernelGGL(k_pair_lut<2>, gp, dim3(256), lds, e->stream, jobs);
               else hipLaunchKernelGGL(k_pair_lut<1>, gp, dim3(256), lds, e->stream, jobs);
@@ -2110,6 +2131,13 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
               const CherryJob * jobs = cj + L.job_begin;
               const dim3 gb((npblk + 3) / 4, njobs);
               if (chains4) hipLaunchKernelGGL(k_cherry_build_s4, dim3((L.max_classes + 255) / 256, njobs), dim3(256), 0, e->stream, jobs, e->R, dp.repeat_codes);
+              else if (chains16)
+              {
+#define PLLHIP_CALL(KK) \
+                hipLaunchKernelGGL(k_cherry_build_s16<KK>, gb, dim3(256), 0, e->stream, jobs, dp.repeat_codes, e->R, e->S)
+                PLLHIP_DISPATCH_KS(s16_ks(e), PLLHIP_CALL);
+#undef PLLHIP_CALL
+              }
               else if (e->R == 4) hipLaunchKernelGGL(k_cherry_build<4>, gb, dim3(256), 0, e->stream, jobs, dp.repeat_codes);
               else if (e->R == 2) hipLaunchKernelGGL(k_cherry_build<2>, gb, dim3(256), 0, e->stream, jobs, dp.repeat_codes);
               else hipLaunchKernelGGL(k_cherry_build<1>, gb, dim3(256), 0, e->stream, jobs, dp.repeat_codes);
@@ -2130,7 +2158,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
           hipEvent_t ev1;
           if (!prof_begin(ev1)) return PLL_FAILURE;
           if (chains20 ? !launch_traverse_s20(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows, 0, !e->cherries.empty(), transient)
-                       : chains16 ? !launch_traverse_s16(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows)
+                       : chains16 ? !launch_traverse_s16(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows, 0, !e->cherries.empty())
                                   : !launch_traverse_s4(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows, 0, transient))
             return PLL_FAILURE;
           if (!prof_end(ev1, l.bytes, l.flops, l.ops, l.min_bytes)) return PLL_FAILURE;

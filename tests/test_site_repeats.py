@@ -55,7 +55,7 @@ def _build(product, tree, nsites, repeats, seed=44, gaps=False, states=20, ambig
         cmap = pc.state_charmap(states)
         if ambiguity:
             cmap[ord("B")] = (1 << 2) | (1 << 3)
-            cmap[ord("Z")] = (1 << 5) | (1 << 6) if states > 4 else (1 << 1) | (1 << 2)
+            cmap[ord("Z")] = (1 << 5) | (1 << 6) if states > 6 else (1 << 1) | (1 << 2)
         codes = pc.random_codes(tree.ntips, nsites, states, seed)
         rnd = pc.splitmix64(seed + 5, tree.ntips * nsites).reshape(tree.ntips, nsites)
         for t in range(tree.ntips):
@@ -103,7 +103,9 @@ def _same(a, b):
             assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
 
 
-@pytest.mark.parametrize("states", [20, 4])
+# (5 and 24 states: the 2 .. 32-state family, one and two row tiles -- the reference's own 5-state test runs under the
+# attribute, test/runtest.py:45-51)
+@pytest.mark.parametrize("states", [20, 4, 5, 24])
 @pytest.mark.parametrize("ntips,nsites,gaps,ambiguity", [(14, 1031, False, False), (40, 5000, True, False),
                                                          (9, 257, True, True), (100, 3333, False, False)])
 def test_site_repeats_change_nothing_a_caller_can_see(product, oracle, ntips, nsites, gaps, ambiguity, states):
@@ -119,7 +121,8 @@ def test_site_repeats_change_nothing_a_caller_can_see(product, oracle, ntips, ns
         assert FORCED or off.repeat_stats().cherries == 0
 
 
-@pytest.mark.parametrize("states,ntips,nsites", [(4, 40, 60_000), (4, 24, 3000), (20, 30, 40_000)])
+@pytest.mark.parametrize("states,ntips,nsites", [(4, 40, 60_000), (4, 24, 3000), (20, 30, 40_000), (5, 24, 3000),
+                                                 (16, 30, 20_000), (3, 30, 40_000)])
 def test_classes_of_whole_subtrees(product, oracle, states, ntips, nsites):
     """second step: nodes above cherries and tips are kept per class too (pairs of the children's classes, numbered
     on the device).  Sequences simulated along the tree (real repeats), a tip whose sequence changes between two
@@ -166,7 +169,7 @@ def test_site_repeats_dna_one_launch_and_rounds(product):
         assert st.cherries > 0 and st.classes * 100 < st.sites
 
 
-@pytest.mark.parametrize("states", [20, 4])
+@pytest.mark.parametrize("states", [20, 4, 7])
 def test_site_repeats_with_scaling_cherries(product, oracle, states):
     """a cherry only ever scales when its entries are exact zeros: pendant branches of length 0 (identity
     matrices) make every site with two different states an all-zero, scaled site.  The scaling decision is taken
@@ -193,7 +196,7 @@ def test_site_repeats_with_scaling_cherries(product, oracle, states):
         assert on.repeat_stats().cherries > 0
 
 
-@pytest.mark.parametrize("states,ntips", [(20, 260), (4, 900)])
+@pytest.mark.parametrize("states,ntips", [(20, 260), (4, 900), (12, 300)])
 def test_site_repeats_on_deep_trees(product, oracle, states, ntips):
     tree = pc.Tree(ntips, 42, 43)
     with _build(product, tree, 300, True, states=states) as on, _build(product, tree, 300, False, states=states) as off, \

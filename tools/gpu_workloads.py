@@ -287,10 +287,42 @@ def alphabets32(lib, out):
                                               "algorithmic_GBps": nb / dt / 1e9}
 
 
+def alphabets_repeats(lib, out):
+    """PLL_ATTRIB_SITE_REPEATS in the 2 .. 32-state family: full traversals with and without the attribute, on iid
+    uniform states and on an alignment simulated along the tree (seed 45); identical lnL asked for"""
+    for S, N in ((2, 1_000_000), (5, 1_000_000), (10, 500_000), (16, 500_000), (24, 500_000)):
+        tree = pc.Tree(50, 42, 43, brlen_range=(0.01, 0.12))
+        for data in ("random", "simulated"):
+            codes = pc.simulated_codes(tree, N, S, seed=45) if data == "simulated" else None
+            res = {}
+            for attr in (0, pc.PLL_ATTRIB_SITE_REPEATS):
+                inst = pc.build_instance(lib, states=S, rate_cats=4, ntips=50, nsites=N, coded=True, tree=tree,
+                                         attributes=attr, codes=codes)
+                inst.tree = tree
+                with inst:
+                    pc.full_traversal(inst)
+                    pc.full_traversal(inst)
+                    lib.lib.pllhip_synchronize(inst.p)
+                    t0 = time.perf_counter()
+                    for _ in range(5):
+                        lnl = pc.full_traversal(inst)
+                    dt = (time.perf_counter() - t0) / 5
+                    st = inst.repeat_stats()
+                    res["on" if attr else "off"] = {"ms_per_traversal": dt * 1e3, "lnl": lnl,
+                                                    "class_operations_per_traversal": st.cherries // 7 if attr else 0}
+            assert res["on"]["lnl"] == res["off"]["lnl"], (S, data, res)
+            out[f"REPEATS_{S}states_{N}_{data}"] = {"ms_attribute_off": res["off"]["ms_per_traversal"],
+                                                    "ms_attribute_on": res["on"]["ms_per_traversal"],
+                                                    "class_operations_per_traversal": res["on"]["class_operations_per_traversal"],
+                                                    "operations": len(tree.ops), "lnl": res["on"]["lnl"]}
+
+
 def main():
     lib = pc.PllLib(pc.PRODUCT_LIB)
     out = {}
     which = sys.argv[1:] or ["w2", "w3", "c4", "blo"]
+    if "alphabets_repeats" in which:
+        alphabets_repeats(lib, out)
     if "alphabets" in which:
         alphabets(lib, out)
     if "alphabets32" in which:
