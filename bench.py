@@ -68,6 +68,9 @@ def parse_args():
                          "them (src/tree/treeinfo.c:845-865); batched = one call with count = 2n-3")
     ap.add_argument("--site-repeats", action="store_true",
                     help="PLL_ATTRIB_SITE_REPEATS (first step: cherries are computed per class of sites, not per site)")
+    ap.add_argument("--clv-tips", action="store_true",
+                    help="partitions WITHOUT PLL_ATTRIB_PATTERN_TIP (tips are vectors set through pll_set_tip_states): the form "
+                         "libpll combines with PLL_ATTRIB_SITE_REPEATS, and the one the reference's harness runs under 'sr'")
     ap.add_argument("--data", default="random", choices=["random", "simulated", "tiled"],
                     help="random: iid uniform tip states (seed 44); simulated: states evolved along the tree (SURVEY.md 8d, seed 45); "
                          "tiled: copies of one random 1000-site tile (the extreme of site repeats: no node has more than 1000 classes)")
@@ -118,6 +121,7 @@ def partition_plan(config, states, nsites):
 
 
 ATTRIBUTES = 0      # extra pll_partition_create attributes of every partition (--rate-scalers)
+CODED_TIPS = True   # PLL_ATTRIB_PATTERN_TIP (--clv-tips: without)
 
 
 def make_evaluation(pc, lib, tree, plan, rate_cats, seed, per_branch, first_sites=None):
@@ -129,7 +133,7 @@ def make_evaluation(pc, lib, tree, plan, rate_cats, seed, per_branch, first_site
         subst, freqs, alpha = model_of(pc, states)
         codes = pc.random_codes(tree.ntips, nsites, states, seed + 101 * k,
                                 first_site=first_sites[k] if first_sites else 0)
-        insts.append(ev.add_partition(k, states, nsites, rate_cats, codes, subst, freqs, alpha, coded=True,
+        insts.append(ev.add_partition(k, states, nsites, rate_cats, codes, subst, freqs, alpha, coded=CODED_TIPS,
                                       attributes=ATTRIBUTES))
     return ev, insts
 
@@ -453,7 +457,7 @@ def measure_traffic(args):
         child += ["--sites", str(args.sites)]
     if args.taxa:
         child += ["--taxa", str(args.taxa)]
-    for flag in ("site_repeats", "rate_scalers", "transient"):
+    for flag in ("site_repeats", "rate_scalers", "transient", "clv_tips"):
         if getattr(args, flag, False):
             child.append("--" + flag.replace("_", "-"))
     out = {}
@@ -543,7 +547,7 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
             codes = np.tile(tile, (1, (p_[1] + 999) // 1000))[:, :p_[1]].copy()
         else:
             codes = pc.random_codes(tree.ntips, p_[1], p_[0], 44 + 101 * k, first_site=first_sites[k])
-        insts.append(ev.add_partition(k, p_[0], p_[1], rate_cats, codes, subst, freqs, alpha, coded=True,
+        insts.append(ev.add_partition(k, p_[0], p_[1], rate_cats, codes, subst, freqs, alpha, coded=CODED_TIPS,
                                       attributes=ATTRIBUTES))
         del codes
     if not insts:
@@ -760,7 +764,7 @@ def run_leg(ctx, config, sites=0, taxa=0, steps=10, warmup=2, cpu="full"):
             "emulated_rank": (f"{emulate[0]}/{emulate[1]}" if emulate else None),
             "partition_assignment": ("cost-balanced: whole partitions / large slices per rank, NULL slots elsewhere"
                                      if balanced else "every rank holds a contiguous 1/N site range of every partition"),
-            "tips": "1-byte codes",
+            "tips": "1-byte codes" if CODED_TIPS else "vectors (no PLL_ATTRIB_PATTERN_TIP), set through pll_set_tip_states",
             "scalers": ("per (site, rate)" if args.rate_scalers else "per-site") + ", one buffer per inner node",
             "pmatrix_calls": args.pmatrix_calls, "alignment": args.data, "tree": args.tree,
             "site_repeats": repeats,
@@ -901,7 +905,7 @@ def main():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # (a queue per partition stream: pll_core.hip, pllhip_runtime_defaults)
     default_shape = (world == 1 and not internal and args.config == "c3" and not args.sites and not args.taxa and
                      not args.rate_scalers and not args.no_also and not args.no_cpu_baseline and not args.site_repeats and
-                     args.data == "random" and args.tree == "random" and not args.transient)
+                     args.data == "random" and args.tree == "random" and not args.transient and not args.clv_tips)
     traffic_measured = None
     if world == 1 and not internal and not args.as_rank and (args.pmc == "on" or (args.pmc == "auto" and default_shape)):
         traffic_measured = measure_traffic(args)      # child processes; nothing here has touched the GPU yet
@@ -911,7 +915,8 @@ def main():
         # Load torch first, so that the engine binds to the runtime torch.cuda uses.
         import torch  # noqa: F401
     import pllhip_ctypes as pc
-    global ATTRIBUTES
+    global ATTRIBUTES, CODED_TIPS
+    CODED_TIPS = not args.clv_tips
     if args.rate_scalers:
         ATTRIBUTES = pc.PLL_ATTRIB_RATE_SCALERS
     if args.site_repeats:

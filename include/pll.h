@@ -185,8 +185,8 @@ typedef int pll_bool_t;
    A partition created with PLL_ATTRIB_SITE_REPEATS carries a table that says "no node is compressed"
    (pernode_ids[i] = 0, perscale_ids[i] = 0, pernode_allocated_clvs[i] = pll_get_sites_number(), per-node
    index arrays NULL; csrc/host/pll_repeats.c): the engine computes per class of sites on the device
-   (4 and 20 states, 2 .. 28 states with four rate categories; coded tips, per-site scalers; other partitions
-   ignore the attribute), but every
+   (4 and 20 states, 2 .. 28 states with four rate categories; per-site scalers; with or without
+   PLL_ATTRIB_PATTERN_TIP; other partitions ignore the attribute), but every
    vector a caller can see -- host mirrors, pllhip_get_clv, a checkpoint -- is site-indexed. */
 struct pll_partition;
 typedef struct pll_repeats

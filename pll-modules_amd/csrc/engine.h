@@ -175,6 +175,7 @@ struct Engine
   // PLL_ATTRIB_SITE_REPEATS, first step (kernels_repeats.hpp): a cherry is kept per class of sites (pair of
   // tip codes) and expanded to the site-indexed vector only for a reader that needs it
   bool site_repeats = false;
+  bool tip_classes = false;           // tips that are vectors are kept per class of sites as well (upload_tip_classes)
   struct Cherry                       // a node known per class of sites (a cherry, or a node above class nodes / tips)
   {
     bool valid = false;               // the node's vector IS this table (nothing has overwritten it since)
@@ -363,6 +364,8 @@ void engine_destroy(Engine * e);
 int sync_model(pll_partition_t * p, bool light = false);              // host model arrays -> HBM if changed
 int upload_tip_codes(pll_partition_t * p, unsigned tip);
 int upload_tip_clv(pll_partition_t * p, unsigned tip, const double * host_clv);
+int upload_tip_classes(pll_partition_t * p, unsigned tip, const unsigned * site_class, const unsigned long long * masks,
+                       unsigned nclasses);
 int upload_weights(pll_partition_t * p);
 void invalidate_luts(pll_partition_t * p);
 

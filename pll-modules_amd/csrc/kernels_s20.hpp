@@ -1612,7 +1612,7 @@ static int launch_traverse_s20(Engine * e, const PlanView & plan, unsigned lds_d
 #define PLLHIP_ALLOW(RS_, W_, T_) (s20_allow_full_lds(k_traverse_s20<4, RS_, W_, T_>) && s20_allow_full_lds(k_traverse_s20<2, RS_, W_, T_>) && \
                                    s20_allow_full_lds(k_traverse_s20<1, RS_, W_, T_>))
     if (!PLLHIP_ALLOW(false, false, false) || !PLLHIP_ALLOW(true, false, false) || !PLLHIP_ALLOW(false, true, false) ||
-        !PLLHIP_ALLOW(false, false, true) || !PLLHIP_ALLOW(true, false, true))
+        !PLLHIP_ALLOW(false, false, true) || !PLLHIP_ALLOW(true, false, true) || !PLLHIP_ALLOW(false, true, true))
       return PLL_FAILURE;
 #undef PLLHIP_ALLOW
     attr_set = true;
@@ -1636,8 +1636,8 @@ static int launch_traverse_s20(Engine * e, const PlanView & plan, unsigned lds_d
     else if (e->R == 2) { PLLHIP_CALL((k_traverse_s20<2, RS_, W_, T_>)); }        \
     else { PLLHIP_CALL((k_traverse_s20<1, RS_, W_, T_>)); }                       \
   } while (0)
-  // (wide tips -- site repeats -- exist with per-site scaling only, and without evaluate-only traversals)
-  if (wide && !e->rate_scalers) PLLHIP_BY_RATES(false, true, false);
+  // (wide tips -- site repeats, tips kept per class -- exist with per-site scaling only)
+  if (wide && !e->rate_scalers) { if (transient) PLLHIP_BY_RATES(false, true, true); else PLLHIP_BY_RATES(false, true, false); }
   else if (e->rate_scalers) { if (transient) PLLHIP_BY_RATES(true, false, true); else PLLHIP_BY_RATES(true, false, false); }
   else { if (transient) PLLHIP_BY_RATES(false, false, true); else PLLHIP_BY_RATES(false, false, false); }
 #undef PLLHIP_BY_RATES

@@ -689,7 +689,11 @@ static int launch_partials_s4(Engine * e, const OpBatch & batch, unsigned nops)
   return PLL_SUCCESS;
 }
 
-static bool chains_supported_s4(const Engine * e) { return (e->R == 4 || e->R == 2 || e->R == 1) && e->lut_codes == 16; }
+// (coded tips: through the 16-row tables of the family; tips that are vectors are read like inner children)
+static bool chains_supported_s4(const Engine * e)
+{
+  return (e->R == 4 || e->R == 2 || e->R == 1) && (!e->coded_tips || e->lut_codes == 16);
+}
 
 static int launch_chains_s4(Engine * e, const ChainBatch & batch, unsigned nchains, unsigned longest)
 {

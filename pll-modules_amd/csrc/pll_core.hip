@@ -62,6 +62,7 @@ static int ensure_luts(pll_partition_t * p);
 static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops, unsigned count);
 static int transient_materialize(Engine * e, const std::vector<unsigned> & want);
 static int transient_flush_all(Engine * e);
+static bool cherry_storage(Engine * e, unsigned node, unsigned nclasses);
 static void batch_free(BatchPlan * b);
 static void batch_free_hook(BatchPlan * b) { batch_free(b); }
 
@@ -231,7 +232,9 @@ Engine * engine_create(pll_partition_t * p)
   e->rate_scalers = (p->attributes & PLL_ATTRIB_RATE_SCALERS) != 0;
   // PLLHIP_SITE_REPEATS=0: never; =2: as if every partition had the attribute (the whole test suite under site repeats)
   const int env_repeats = getenv("PLLHIP_SITE_REPEATS") ? atoi(getenv("PLLHIP_SITE_REPEATS")) : 1;
-  e->site_repeats = ((p->attributes & PLL_ATTRIB_SITE_REPEATS) != 0 || env_repeats == 2) && e->coded_tips && !e->rate_scalers &&
+  // (without PLL_ATTRIB_PATTERN_TIP -- libpll's own combination: the two attributes exclude one another there -- the
+  // tips given through pll_set_tip_states are class nodes from the start: upload_tip_classes)
+  e->site_repeats = ((p->attributes & PLL_ATTRIB_SITE_REPEATS) != 0 || env_repeats == 2) && !e->rate_scalers &&
                     !p->asc_bias_alloc && env_repeats != 0;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) e->cu_count = prop.multiProcessorCount;
@@ -306,14 +309,21 @@ Engine * engine_create(pll_partition_t * p)
     ok = ok && hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->d_asc), e->h_asc, 0), "map asc");
   }
   // (the 2 .. 32-state family: where it runs operation chains -- four rate categories, per-site scaling)
-  if (e->site_repeats && (e->family == KernelFamily::S20 || e->family == KernelFamily::S4 ||
-                          (e->family == KernelFamily::S16 && chains_supported_s16(e))))
+  const bool class_family = e->family == KernelFamily::S20 || e->family == KernelFamily::S4 ||
+                            (e->family == KernelFamily::S16 && chains_supported_s16(e));
+  // Tips that are vectors (no PLL_ATTRIB_PATTERN_TIP) but came through pll_set_tip_states are known per class of sites
+  // -- the state masks -- whether or not the partition asks for site repeats: the operations above them read them as
+  // wide tips (4 bytes per site and a row table per branch instead of R * S * 8 bytes per site; bit for bit the same
+  // values: upload_tip_classes).  PLLHIP_TIP_CLASSES=0: tips as vectors only.
+  static const int env_tip_classes = getenv("PLLHIP_TIP_CLASSES") ? atoi(getenv("PLLHIP_TIP_CLASSES")) : 1;
+  e->tip_classes = env_tip_classes != 0 && !e->coded_tips && !e->rate_scalers && !p->asc_bias_alloc && class_family;
+  if ((e->site_repeats || e->tip_classes) && class_family)
   {
     e->cherries.assign(e->nodes, Engine::Cherry());
     e->tip_version.assign(e->tips, 0);
     e->scaler_lazy.assign(e->nscalers, -1);
   }
-  else e->site_repeats = false;                 // (the 61-state family, other rate counts of the 2 .. 32-state one: not yet)
+  if (!class_family) e->site_repeats = false;   // (the 61-state family, other rate counts of the 2 .. 32-state one: not yet)
   e->pmat_brlen.assign(e->nmat, std::numeric_limits<double>::quiet_NaN());
   e->pmat_params.assign(e->nmat, std::vector<unsigned>());
   e->owner = p;
@@ -547,7 +557,68 @@ int upload_tip_clv(pll_partition_t * p, unsigned tip, const double * host_clv)
   }
   PLLHIP_TRY(hipSetDevice(e->device));
   if (!transient_flush_all(e)) return PLL_FAILURE;
+  if (!e->cherries.empty())
+  {
+    // whatever classes the tip had are not those of the new vector (pll_set_tip_states tells them afterwards)
+    e->cherries[tip].valid = false;
+    e->tip_version[tip] = ++e->class_clock;
+    e->plan.key.clear();
+  }
   return store_clv(e, e->d_clv[tip], host_clv);
+}
+
+// Site repeats without PLL_ATTRIB_PATTERN_TIP (the combination libpll itself allows; the reference's harness:
+// test/src/common.c:15-31, "tv" and "sr" are separate switches): a tip set through pll_set_tip_states is a vector
+// AND a class node -- the class of a site is its state mask, the table the masks' 0/1 vectors -- so that the
+// operations above it are computed per class exactly as above coded tips: class maps from its classes, its rows
+// through the P-matrix of its branch with the MFMA sequence of an inner child (bit for bit what the vector gives).
+// site_class[n] < nclasses, masks[class] = the state set.
+int upload_tip_classes(pll_partition_t * p, unsigned tip, const unsigned * site_class, const unsigned long long * masks,
+                       unsigned nclasses)
+{
+  Engine * e = engine_of(p);
+  if (!e->shards.empty())
+  {
+    for (size_t k = 0; k < e->shards.size(); ++k)
+      if (!upload_tip_classes(e->shards[k], tip, site_class + e->shard_first[k], masks, nclasses)) return PLL_FAILURE;
+    return PLL_SUCCESS;
+  }
+  if (e->coded_tips || e->cherries.empty() || !nclasses || !e->N) return PLL_SUCCESS;
+  PLLHIP_TRY(hipSetDevice(e->device));
+  Engine::Cherry & c = e->cherries[tip];
+  if (!cherry_storage(e, tip, nclasses)) return PLL_FAILURE;
+  if (!c.pair && !dev_alloc(&c.pair, (size_t)e->Nalloc, "class codes")) return PLL_FAILURE;
+  std::vector<unsigned> cls(e->Nalloc, 0u);                       // (padding sites: class 0)
+  for (unsigned n = 0; n < e->N; ++n) cls[n] = site_class[n] < nclasses ? site_class[n] : 0u;
+  PLLHIP_TRY(hipMemcpyAsync(c.pair, cls.data(), cls.size() * sizeof(unsigned), hipMemcpyHostToDevice, e->stream));
+  // the table: a pseudo alignment of the classes in the API layout, brought into the layout of the family's tables
+  const unsigned npblk = (nclasses + S20_BS - 1) / S20_BS;
+  std::vector<double> api((size_t)nclasses * e->R * e->Sp, 0.0);
+  for (unsigned k = 0; k < nclasses; ++k)
+    for (unsigned r = 0; r < e->R; ++r)
+      for (unsigned j = 0; j < e->S; ++j)
+        api[((size_t)k * e->R + r) * e->Sp + j] = (double)((masks[k] >> j) & 1ULL);
+  DevTmp tmp;
+  if (e->blocked)
+  {
+    if (!dev_alloc(&tmp.ptr, api.size(), "class table staging")) return PLL_FAILURE;
+    PLLHIP_TRY(hipMemcpyAsync(tmp.ptr, api.data(), api.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_s20_to_blocked, dim3(std::max(1u, std::min(npblk * e->R, e->cu_count * 8u))), dim3(256), 0, e->stream,
+                       tmp.ptr, c.table, nclasses, npblk, e->R, e->Sp, e->rows);
+    PLLHIP_TRY(hipGetLastError());
+  }
+  else
+    PLLHIP_TRY(hipMemcpyAsync(c.table, api.data(), api.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  PLLHIP_TRY(hipStreamSynchronize(e->stream));                    // (the sources are local)
+  (void)hipFree(c.rep); c.rep = nullptr; c.rep_cap = 0;
+  c.nclasses = nclasses;
+  c.ncodes = 0;
+  c.valid = c.materialized = c.map_valid = c.trackable = true;
+  c.scaler_index = PLL_SCALE_BUFFER_NONE;
+  c.child[0] = c.child[1] = ~0u;
+  c.version = e->tip_version[tip] = ++e->class_clock;
+  e->plan.key.clear();
+  return PLL_SUCCESS;
 }
 
 void invalidate_luts(pll_partition_t * p)
@@ -1201,10 +1272,20 @@ static unsigned long long class_child_version(const Engine * e, unsigned idx)
   return idx < e->tips ? e->tip_version[idx] : e->cherries[idx].version;
 }
 
+// a tip that is read through byte codes and the partition's lookup tables (PLL_ATTRIB_PATTERN_TIP); without the
+// attribute a tip is a vector -- and, when it came through pll_set_tip_states, a class node as well (upload_tip_classes)
+static bool coded_tip(const Engine * e, unsigned idx) { return e->coded_tips && idx < e->tips; }
+
+// the class table of a child was made under the code table in use (a tip's own classes do not depend on it)
+static bool class_codes_match(const Engine * e, unsigned idx, unsigned lut_used)
+{
+  return idx < e->tips || e->cherries[idx].ncodes == lut_used;
+}
+
 // classes below a child of a class operation: a coded tip's codes, or the classes of a class node
 static unsigned class_child_count(const Engine * e, unsigned idx, unsigned lut_used)
 {
-  return idx < e->tips ? lut_used : e->cherries[idx].nclasses;
+  return coded_tip(e, idx) ? lut_used : e->cherries[idx].nclasses;
 }
 
 // The class map of `node` as the parent of (c1, c2) -- both coded tips or class nodes with current maps -- :
@@ -1230,13 +1311,13 @@ static bool class_map(Engine * e, unsigned node, unsigned c1, unsigned c2, unsig
   failed = true;
   if (!c.pair && !dev_alloc(&c.pair, (size_t)e->Nalloc, "class codes")) return false;
   ClassMapArgs a;
-  a.codes1 = c1 < e->tips ? e->d_codes[c1] : nullptr;
-  a.codes2 = c2 < e->tips ? e->d_codes[c2] : nullptr;
-  a.cls1 = c1 < e->tips ? nullptr : e->cherries[c1].pair;
-  a.cls2 = c2 < e->tips ? nullptr : e->cherries[c2].pair;
+  a.codes1 = coded_tip(e, c1) ? e->d_codes[c1] : nullptr;
+  a.codes2 = coded_tip(e, c2) ? e->d_codes[c2] : nullptr;
+  a.cls1 = coded_tip(e, c1) ? nullptr : e->cherries[c1].pair;
+  a.cls2 = coded_tip(e, c2) ? nullptr : e->cherries[c2].pair;
   a.n1 = n1; a.n2 = n2;
   const dim3 gs(std::max(1u, std::min((e->Nalloc + 255u) / 256u, 8u * e->cu_count)));
-  if (c1 < e->tips && c2 < e->tips)
+  if (coded_tip(e, c1) && coded_tip(e, c2))
   {
     // a cherry: every code pair is a class
     hipLaunchKernelGGL(k_class_cherry, gs, dim3(256), 0, e->stream, a, e->Nalloc, c.pair);
@@ -1499,12 +1580,12 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
         // (counts of a buffer that another class node stands for: written out first)
         if (child_scaler[x] >= 0 && e->scaler_lazy[child_scaler[x]] >= 0 && e->scaler_lazy[child_scaler[x]] != (int)child[x] &&
             !need_scaler(e, child_scaler[x])) return false;
-        if (child[x] < e->tips || made[child[x]] || !e->cherries[child[x]].valid) continue;
+        if (coded_tip(e, child[x]) || made[child[x]] || !e->cherries[child[x]].valid) continue;
         // (a cherry built under another code table -- a tip has taken a new ambiguity code since -- is read
         // through its expanded vector: its classes are not the ones this schedule indexes; so is a class node whose
         // counts are asked for under another scale buffer than the one its operation wrote)
         const Engine::Cherry & cc = e->cherries[child[x]];
-        if (cc.ncodes == lut_used && (child_scaler[x] == cc.scaler_index)) { wide[2 * k + x] = 1; ++nwide; }
+        if (class_codes_match(e, child[x], lut_used) && (child_scaler[x] == cc.scaler_index)) { wide[2 * k + x] = 1; ++nwide; }
         else if (!need_clv(e, child[x])) return false;
       }
       made[ops[k].parent_clv_index] = 1;
@@ -1539,8 +1620,8 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
     if (rp && rp->active)
       for (unsigned k : rp->cherry_ops)
       {
-        if (all_ops[k].child1_clv_index >= e->tips) rows += e->cherries[all_ops[k].child1_clv_index].nclasses;
-        if (all_ops[k].child2_clv_index >= e->tips) rows += e->cherries[all_ops[k].child2_clv_index].nclasses;
+        if (!coded_tip(e, all_ops[k].child1_clv_index)) rows += e->cherries[all_ops[k].child1_clv_index].nclasses;
+        if (!coded_tip(e, all_ops[k].child2_clv_index)) rows += e->cherries[all_ops[k].child2_clv_index].nclasses;
       }
     const size_t need = rows * e->R * e->S;
     if (need > e->pairlut_cap)
@@ -1748,7 +1829,7 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
           {
             const double * rows;
             unsigned nrows;
-            if (child[x] < e->tips) { rows = e->d_lut + lut_stride * matrix[x]; nrows = e->lut_codes; }
+            if (coded_tip(e, child[x])) { rows = e->d_lut + lut_stride * matrix[x]; nrows = e->lut_codes; }
             else
             {
               const Engine::Cherry & cc = e->cherries[child[x]];
@@ -1852,6 +1933,59 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
     have = true;
   }
   return have;
+}
+
+// the class operations and row tables of a resident schedule (kernels_repeats.hpp), on the engine's stream; the
+// schedule's job arrays are on the device (upload_plan)
+static int launch_class_levels(Engine * e, const DevicePlan & dp)
+{
+  const bool chains4 = e->family == KernelFamily::S4, chains16 = e->family == KernelFamily::S16;
+  // level by level: the row tables of the class children of a level, then the tables of the level (with the
+  // scaler counts per class); the last entry holds the row tables of the wide tips of the chains
+  const CherryJob * cj = reinterpret_cast<const CherryJob *>(dp.d_buf + dp.off_cherry_jobs);
+  const PairLutJob * pj = reinterpret_cast<const PairLutJob *>(dp.d_buf + dp.off_pair_jobs);
+  for (size_t lv = 0; lv < dp.repeat_levels.size(); ++lv)
+  {
+    const DevicePlan::RepeatLevel & L = dp.repeat_levels[lv];
+    if (L.pair_end > L.pair_begin)
+    {
+      const unsigned njobs = L.pair_end - L.pair_begin, npblk = (L.max_rows + S20_BS - 1) / S20_BS;
+      const PairLutJob * jobs = pj + L.pair_begin;
+      const dim3 gp((npblk + 3) / 4, njobs);
+      const size_t lds = sizeof(double) * e->R * S20_CFRAGS;
+      if (chains4) hipLaunchKernelGGL(k_pair_lut_s4, dim3((L.max_rows * e->R + 255) / 256, njobs), dim3(256), 0, e->stream, jobs, e->R);
+      else if (chains16)
+      {
+#define PLLHIP_CALL(KK) \
+        hipLaunchKernelGGL(k_pair_lut_s16<KK>, gp, dim3(256), sizeof(double) * e->R * s16_fr(KK), e->stream, jobs, e->R, e->S, e->Sp)
+        PLLHIP_DISPATCH_KS(s16_ks(e), PLLHIP_CALL);
+#undef PLLHIP_CALL
+      }
+      else if (e->R == 4) hipLaunchKernelGGL(k_pair_lut<4>, gp, dim3(256), lds, e->stream, jobs);
+      else if (e->R == 2) hipLaunchKernelGGL(k_pair_lut<2>, gp, dim3(256), lds, e->stream, jobs);
+      else hipLaunchKernelGGL(k_pair_lut<1>, gp, dim3(256), lds, e->stream, jobs);
+      PLLHIP_TRY(hipGetLastError());
+    }
+    if (L.job_end > L.job_begin)
+    {
+      const unsigned njobs = L.job_end - L.job_begin, npblk = (L.max_classes + S20_BS - 1) / S20_BS;
+      const CherryJob * jobs = cj + L.job_begin;
+      const dim3 gb((npblk + 3) / 4, njobs);
+      if (chains4) hipLaunchKernelGGL(k_cherry_build_s4, dim3((L.max_classes + 255) / 256, njobs), dim3(256), 0, e->stream, jobs, e->R, dp.repeat_codes);
+      else if (chains16)
+      {
+#define PLLHIP_CALL(KK) \
+        hipLaunchKernelGGL(k_cherry_build_s16<KK>, gb, dim3(256), 0, e->stream, jobs, dp.repeat_codes, e->R, e->S)
+        PLLHIP_DISPATCH_KS(s16_ks(e), PLLHIP_CALL);
+#undef PLLHIP_CALL
+      }
+      else if (e->R == 4) hipLaunchKernelGGL(k_cherry_build<4>, gb, dim3(256), 0, e->stream, jobs, dp.repeat_codes);
+      else if (e->R == 2) hipLaunchKernelGGL(k_cherry_build<2>, gb, dim3(256), 0, e->stream, jobs, dp.repeat_codes);
+      else hipLaunchKernelGGL(k_cherry_build<1>, gb, dim3(256), 0, e->stream, jobs, dp.repeat_codes);
+      PLLHIP_TRY(hipGetLastError());
+    }
+  }
+  return PLL_SUCCESS;
 }
 
 // index checks of an operation list (the reference interface returns nothing: errors go to pll_errno)
@@ -2053,11 +2187,11 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
           bool ok = consumer[o.parent_clv_index] > (int)k && child[0] != child[1];
           for (int x = 0; x < 2 && ok; ++x)
           {
-            if (child[x] < e->tips) ok = child_scaler[x] == PLL_SCALE_BUFFER_NONE;
+            if (coded_tip(e, child[x])) ok = child_scaler[x] == PLL_SCALE_BUFFER_NONE;
             else
             {
               const Engine::Cherry & cc = e->cherries[child[x]];
-              ok = (now[child[x]] || cc.valid) && cc.map_valid && cc.trackable && cc.ncodes == lut_used &&
+              ok = (now[child[x]] || cc.valid) && cc.map_valid && cc.trackable && class_codes_match(e, child[x], lut_used) &&
                    child_scaler[x] == cc.scaler_index;          // (its counts per class are the ones asked for)
             }
           }
@@ -2099,51 +2233,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
         if (!upload_plan(e->plan, e->stream, view)) return PLL_FAILURE;
         if (dp.ncherry_jobs || dp.npair_jobs)
         {
-          // level by level: the row tables of the class children of a level, then the tables of the level (with the
-          // scaler counts per class); the last entry holds the row tables of the wide tips of the chains
-          const CherryJob * cj = reinterpret_cast<const CherryJob *>(dp.d_buf + dp.off_cherry_jobs);
-          const PairLutJob * pj = reinterpret_cast<const PairLutJob *>(dp.d_buf + dp.off_pair_jobs);
-          for (size_t lv = 0; lv < dp.repeat_levels.size(); ++lv)
-          {
-            const DevicePlan::RepeatLevel & L = dp.repeat_levels[lv];
-            if (L.pair_end > L.pair_begin)
-            {
-              const unsigned njobs = L.pair_end - L.pair_begin, npblk = (L.max_rows + S20_BS - 1) / S20_BS;
-              const PairLutJob * jobs = pj + L.pair_begin;
-              const dim3 gp((npblk + 3) / 4, njobs);
-              const size_t lds = sizeof(double) * e->R * S20_CFRAGS;
-              if (chains4) hipLaunchKernelGGL(k_pair_lut_s4, dim3((L.max_rows * e->R + 255) / 256, njobs), dim3(256), 0, e->stream, jobs, e->R);
-              else if (chains16)
-              {
-#define PLLHIP_CALL(KK) \
-                hipLaunchKernelGGL(k_pair_lut_s16<KK>, gp, dim3(256), sizeof(double) * e->R * s16_fr(KK), e->stream, jobs, e->R, e->S, e->Sp)
-                PLLHIP_DISPATCH_KS(s16_ks(e), PLLHIP_CALL);
-#undef PLLHIP_CALL
-              }
-              else if (e->R == 4) hipLaunchKernelGGL(k_pair_lut<4>, gp, dim3(256), lds, e->stream, jobs);
-              else if (e->R == 2) hipLaunchKernelGGL(k_pair_lut<2>, gp, dim3(256), lds, e->stream, jobs);
-              else hipLaunchKernelGGL(k_pair_lut<1>, gp, dim3(256), lds, e->stream, jobs);
-              PLLHIP_TRY(hipGetLastError());
-            }
-            if (L.job_end > L.job_begin)
-            {
-              const unsigned njobs = L.job_end - L.job_begin, npblk = (L.max_classes + S20_BS - 1) / S20_BS;
-              const CherryJob * jobs = cj + L.job_begin;
-              const dim3 gb((npblk + 3) / 4, njobs);
-              if (chains4) hipLaunchKernelGGL(k_cherry_build_s4, dim3((L.max_classes + 255) / 256, njobs), dim3(256), 0, e->stream, jobs, e->R, dp.repeat_codes);
-              else if (chains16)
-              {
-#define PLLHIP_CALL(KK) \
-                hipLaunchKernelGGL(k_cherry_build_s16<KK>, gb, dim3(256), 0, e->stream, jobs, dp.repeat_codes, e->R, e->S)
-                PLLHIP_DISPATCH_KS(s16_ks(e), PLLHIP_CALL);
-#undef PLLHIP_CALL
-              }
-              else if (e->R == 4) hipLaunchKernelGGL(k_cherry_build<4>, gb, dim3(256), 0, e->stream, jobs, dp.repeat_codes);
-              else if (e->R == 2) hipLaunchKernelGGL(k_cherry_build<2>, gb, dim3(256), 0, e->stream, jobs, dp.repeat_codes);
-              else hipLaunchKernelGGL(k_cherry_build<1>, gb, dim3(256), 0, e->stream, jobs, dp.repeat_codes);
-              PLLHIP_TRY(hipGetLastError());
-            }
-          }
+          if (!launch_class_levels(e, dp)) return PLL_FAILURE;
           // the scale buffers of the class operations hold their counts per class from now on (need_scaler)
           if (rp.active)
             for (unsigned k : rp.cherry_ops)
@@ -2466,6 +2556,10 @@ static int update_partials_group(const std::vector<pll_partition_t *> & g, const
     Engine * e = engine_of(p);
     if (!validate_ops(e, ops, count)) return -1;
     if (e->ntransient && (hipSetDevice(e->device) != hipSuccess || !transient_before_list(e, ops, count))) return -1;
+    // (tips kept per class are written off as class nodes by an operation that overwrote one: never -- tips are not
+    // parents; the vectors this list writes stop being whatever class node they were)
+    if (!e->cherries.empty())
+      for (unsigned k = 0; k < count; ++k) e->cherries[ops[k].parent_clv_index].valid = false;
     if (!prepare_schedule(e, p, ops, count, mode, nullptr, nullptr, 0, e->transient_mode && !e->site_repeats)) return 0;
   }
   // launches can be shared when every member's schedule has the same shape (same list, same family: always,
@@ -2558,6 +2652,16 @@ static int update_partials_group(const std::vector<pll_partition_t *> & g, const
   }
   if (!b.done && !hip_ok(hipEventCreateWithFlags(&b.done, hipEventDisableTiming), "hipEventCreate")) return -1;
 
+  // the row tables of the members' wide tips (tips kept per class of sites), each on its member's stream
+  bool any_wide = false;
+  for (pll_partition_t * p : g)
+  {
+    Engine * e = engine_of(p);
+    any_wide = any_wide || !e->cherries.empty();
+    if (!e->plan.npair_jobs) continue;
+    PlanView own;
+    if (hipSetDevice(e->device) != hipSuccess || !upload_plan(e->plan, e->stream, own) || !launch_class_levels(e, e->plan)) return -1;
+  }
   // the members' streams have issued what the traversal reads (P-matrices, tables, tip data)
   for (size_t m = 1; m < M; ++m)
     if (!hip_ok(hipEventRecord(b.ready[m], engine_of(g[m])->stream), "hipEventRecord") ||
@@ -2586,8 +2690,8 @@ static int update_partials_group(const std::vector<pll_partition_t *> & g, const
     const unsigned wgs = mode ? (env_walk > 0 ? (unsigned)env_walk : lead->family == KernelFamily::S4 ? 3u : 1u) : 0u;
     bool any_transient = false;
     for (pll_partition_t * p : g) any_transient = any_transient || (engine_of(p)->transient_mode && !engine_of(p)->site_repeats);
-    const int ok = lead->family == KernelFamily::S20 ? launch_traverse_s20(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs, false, any_transient)
-                 : lead->family == KernelFamily::S16 ? launch_traverse_s16(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs)
+    const int ok = lead->family == KernelFamily::S20 ? launch_traverse_s20(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs, any_wide, any_transient)
+                 : lead->family == KernelFamily::S16 ? launch_traverse_s16(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs, any_wide)
                                                      : launch_traverse_s4(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs, any_transient);
     if (!ok) return -1;
     if (lead->profiling)
@@ -3800,7 +3904,11 @@ int pllhip_set_clv(pll_partition_t * p, unsigned int clv_index, const double * c
     return PLL_FAILURE;
   }
   if (!transient_flush_all(e)) return PLL_FAILURE;            // (vectors that were not stored may read this one)
-  if (!e->cherries.empty()) e->cherries[clv_index].valid = false;
+  if (!e->cherries.empty())
+  {
+    e->cherries[clv_index].valid = false;
+    if (clv_index < e->tips) { e->tip_version[clv_index] = ++e->class_clock; e->plan.key.clear(); }
+  }
   return store_clv(e, e->d_clv[clv_index], clv);
 }
 

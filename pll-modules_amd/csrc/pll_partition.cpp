@@ -21,6 +21,8 @@
 #include <cstring>
 #include <cmath>
 #include <new>
+#include <unordered_map>
+#include <vector>
 
 extern "C" {
 __thread int pll_errno = 0;
@@ -366,6 +368,9 @@ int pll_set_tip_states(pll_partition_t * p, unsigned int tip,
     }
   }
   unsigned old_codes = p->maxstates;
+  std::vector<unsigned> site_class(coded ? 0 : salloc_of(p), 0u);
+  std::vector<unsigned long long> masks;
+  std::unordered_map<unsigned long long, unsigned> class_of;
   for (unsigned n = 0; n < salloc_of(p); ++n)
   {
     // behind the alignment: the ascertainment-bias column of state n - sites
@@ -407,6 +412,20 @@ int pll_set_tip_states(pll_partition_t * p, unsigned int tip,
       for (unsigned r = 0; r < R; ++r)
         for (unsigned j = 0; j < Sp; ++j)
           v[r * Sp + j] = (j < S) ? static_cast<double>((m >> j) & 1ULL) : 0.0;
+      // the class of the site: its state mask (site repeats without pattern tips, upload_tip_classes)
+      unsigned k = 0;
+      if (class_of.size() <= 64)
+      {
+        for (; k < masks.size(); ++k) if (masks[k] == m) break;
+        if (k == masks.size()) { masks.push_back(m); class_of[m] = k; }
+      }
+      else
+      {
+        auto it = class_of.find(m);
+        if (it == class_of.end()) { k = (unsigned)masks.size(); masks.push_back(m); class_of[m] = k; }
+        else k = it->second;
+      }
+      site_class[n] = k;
     }
   }
   int rc;
@@ -420,6 +439,7 @@ int pll_set_tip_states(pll_partition_t * p, unsigned int tip,
   {
     rc = upload_tip_clv(p, tip, tmp);
     free(tmp);
+    if (rc) rc = upload_tip_classes(p, tip, site_class.data(), masks.data(), (unsigned)masks.size());
   }
   return rc;
 }

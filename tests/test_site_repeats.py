@@ -48,8 +48,8 @@ def _close_to_oracle(got, ref, nsites, states):
             assert a == b, k
 
 
-def _build(product, tree, nsites, repeats, seed=44, gaps=False, states=20, ambiguity=False):
-    inst = pc.build_instance(product, states=states, rate_cats=4, ntips=tree.ntips, nsites=nsites, coded=True, tree=tree,
+def _build(product, tree, nsites, repeats, seed=44, gaps=False, states=20, ambiguity=False, coded=True):
+    inst = pc.build_instance(product, states=states, rate_cats=4, ntips=tree.ntips, nsites=nsites, coded=coded, tree=tree,
                              attributes=pc.PLL_ATTRIB_SITE_REPEATS if repeats else 0)
     if gaps or ambiguity:
         cmap = pc.state_charmap(states)
@@ -108,22 +108,29 @@ def _same(a, b):
 @pytest.mark.parametrize("states", [20, 4, 5, 24])
 @pytest.mark.parametrize("ntips,nsites,gaps,ambiguity", [(14, 1031, False, False), (40, 5000, True, False),
                                                          (9, 257, True, True), (100, 3333, False, False)])
-def test_site_repeats_change_nothing_a_caller_can_see(product, oracle, ntips, nsites, gaps, ambiguity, states):
+# coded False: the attribute WITHOUT PLL_ATTRIB_PATTERN_TIP, the combination libpll itself allows and the reference's
+# harness runs ("sr" without "tv", test/src/common.c:15-31): tips are vectors, and class nodes from the start
+@pytest.mark.parametrize("coded", [True, False])
+def test_site_repeats_change_nothing_a_caller_can_see(product, oracle, ntips, nsites, gaps, ambiguity, states, coded):
     tree = pc.Tree(ntips, 42, 43)
-    with _build(product, tree, nsites, True, gaps=gaps, ambiguity=ambiguity, states=states) as on, \
-            _build(product, tree, nsites, False, gaps=gaps, ambiguity=ambiguity, states=states) as off, \
-            _build(oracle, tree, nsites, False, gaps=gaps, ambiguity=ambiguity, states=states) as ref:
+    with _build(product, tree, nsites, True, gaps=gaps, ambiguity=ambiguity, states=states, coded=coded) as on, \
+            _build(product, tree, nsites, False, gaps=gaps, ambiguity=ambiguity, states=states, coded=coded) as off, \
+            _build(oracle, tree, nsites, False, gaps=gaps, ambiguity=ambiguity, states=states, coded=coded) as ref:
         a, b = _everything(on), _everything(off)
         _same(a, b)
         _close_to_oracle(a, _everything(ref), nsites, states)
         st = on.repeat_stats()
-        assert st.cherries > 0 and st.classes < st.sites or nsites < 500
+        # (without pattern tips a cherry is numbered like any other class node and kept only while its classes are at
+        # most a quarter -- 4 states: an eighth -- of the sites: not on 1 031 random sites of 20 states)
+        if coded or nsites >= 8 * (states + 3) ** 2:
+            assert st.cherries > 0 and st.classes < st.sites or nsites < 500
         assert FORCED or off.repeat_stats().cherries == 0
 
 
 @pytest.mark.parametrize("states,ntips,nsites", [(4, 40, 60_000), (4, 24, 3000), (20, 30, 40_000), (5, 24, 3000),
                                                  (16, 30, 20_000), (3, 30, 40_000)])
-def test_classes_of_whole_subtrees(product, oracle, states, ntips, nsites):
+@pytest.mark.parametrize("coded", [True, False])
+def test_classes_of_whole_subtrees(product, oracle, states, ntips, nsites, coded):
     """second step: nodes above cherries and tips are kept per class too (pairs of the children's classes, numbered
     on the device).  Sequences simulated along the tree (real repeats), a tip whose sequence changes between two
     evaluations (the class maps above it are made again), evaluations from other root edges (class nodes of earlier
@@ -132,7 +139,7 @@ def test_classes_of_whole_subtrees(product, oracle, states, ntips, nsites):
     codes = pc.simulated_codes(tree, nsites, states, seed=45)
     out, stats = [], None
     for repeats, lib in ((True, product), (False, product), (False, oracle)):
-        inst = pc.build_instance(lib, states=states, rate_cats=4, ntips=ntips, nsites=nsites, coded=True, tree=tree,
+        inst = pc.build_instance(lib, states=states, rate_cats=4, ntips=ntips, nsites=nsites, coded=coded, tree=tree,
                                  attributes=pc.PLL_ATTRIB_SITE_REPEATS if repeats else 0, codes=codes)
         inst.tree = tree
         with inst:
@@ -169,8 +176,9 @@ def test_site_repeats_dna_one_launch_and_rounds(product):
         assert st.cherries > 0 and st.classes * 100 < st.sites
 
 
+@pytest.mark.parametrize("coded", [True, False])
 @pytest.mark.parametrize("states", [20, 4, 7])
-def test_site_repeats_with_scaling_cherries(product, oracle, states):
+def test_site_repeats_with_scaling_cherries(product, oracle, states, coded):
     """a cherry only ever scales when its entries are exact zeros: pendant branches of length 0 (identity
     matrices) make every site with two different states an all-zero, scaled site.  The scaling decision is taken
     per class, the counts travel per site; identical to the attribute being off (lnL is -inf on both sides)."""
@@ -181,8 +189,11 @@ def test_site_repeats_with_scaling_cherries(product, oracle, states):
         if k % 3 != 2:
             tree.brlens[op[3]] = 0.0
             tree.brlens[op[6]] = 0.0 if k % 3 == 0 else 0.05
-    with _build(product, tree, 700, True, states=states) as on, _build(product, tree, 700, False, states=states) as off, \
-            _build(oracle, tree, 700, False, states=states) as ref:
+    # (without pattern tips a cherry needs four times as many sites as it has classes to be kept per class)
+    nsites = 700 if coded or states < 20 else 2400
+    with _build(product, tree, nsites, True, states=states, coded=coded) as on, \
+            _build(product, tree, nsites, False, states=states, coded=coded) as off, \
+            _build(oracle, tree, nsites, False, states=states, coded=coded) as ref:
         assert pc.full_traversal(ref) == -np.inf
         for rep in range(2):
             la, lb = pc.full_traversal(on), pc.full_traversal(off)
