@@ -234,8 +234,9 @@ Engine * engine_create(pll_partition_t * p)
   const int env_repeats = getenv("PLLHIP_SITE_REPEATS") ? atoi(getenv("PLLHIP_SITE_REPEATS")) : 1;
   // (without PLL_ATTRIB_PATTERN_TIP -- libpll's own combination: the two attributes exclude one another there -- the
   // tips given through pll_set_tip_states are class nodes from the start: upload_tip_classes)
+  // (ascertainment-bias columns are sites like any other for the class maps: weight 0, a class of their own each)
   e->site_repeats = ((p->attributes & PLL_ATTRIB_SITE_REPEATS) != 0 || env_repeats == 2) && !e->rate_scalers &&
-                    !p->asc_bias_alloc && env_repeats != 0;
+                    env_repeats != 0;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) e->cu_count = prop.multiProcessorCount;
 
@@ -316,7 +317,7 @@ Engine * engine_create(pll_partition_t * p)
   // wide tips (4 bytes per site and a row table per branch instead of R * S * 8 bytes per site; bit for bit the same
   // values: upload_tip_classes).  PLLHIP_TIP_CLASSES=0: tips as vectors only.
   static const int env_tip_classes = getenv("PLLHIP_TIP_CLASSES") ? atoi(getenv("PLLHIP_TIP_CLASSES")) : 1;
-  e->tip_classes = env_tip_classes != 0 && !e->coded_tips && !e->rate_scalers && !p->asc_bias_alloc && class_family;
+  e->tip_classes = env_tip_classes != 0 && !e->coded_tips && !e->rate_scalers && class_family;
   if ((e->site_repeats || e->tip_classes) && class_family)
   {
     e->cherries.assign(e->nodes, Engine::Cherry());

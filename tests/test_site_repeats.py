@@ -271,3 +271,30 @@ def test_cherry_built_under_an_older_code_table(product, oracle):
     assert all(np.array_equal(x, y) for x, y in zip(out[0][2], out[1][2]))
     assert lnl_close(out[0][0], out[2][0], 900, 20) and lnl_close(out[0][1], out[2][1], 900, 20)
     assert all(site_err(x, y) <= REL_CLV for x, y in zip(out[0][2], out[2][2]))
+
+
+@pytest.mark.parametrize("coded", [True, False])
+@pytest.mark.parametrize("states", [4, 20, 7])
+def test_site_repeats_with_ascertainment_bias(product, oracle, states, coded):
+    """the ascertainment-bias columns (one per state, behind the alignment, weight 0) are sites like any other for the
+    class maps: corrected lnL, per-site values, scaler counts and the corrected derivatives are those of the attribute
+    being off, and the oracle's"""
+    tree = pc.Tree(30, 42, 43)
+    nsites = 6000
+    out = []
+    for repeats, lib in ((True, product), (False, product), (False, oracle)):
+        inst = pc.build_instance(lib, states=states, rate_cats=4, ntips=30, nsites=nsites, coded=coded, tree=tree,
+                                 attributes=pc.PLL_ATTRIB_AB_FLAG | pc.PLL_ATTRIB_AB_LEWIS |
+                                 (pc.PLL_ATTRIB_SITE_REPEATS if repeats else 0))
+        inst.tree = tree
+        with inst:
+            rng = np.random.RandomState(3)
+            inst.set_pattern_weights(rng.randint(1, 5, size=nsites).astype(np.uint32))
+            inst.set_asc(pc.PLL_ATTRIB_AB_LEWIS, None)
+            res = _everything(inst)
+            if repeats:
+                st = inst.repeat_stats()
+                assert st.cherries > 0
+            out.append(res)
+    _same(out[0], out[1])
+    _close_to_oracle(out[0], out[2], nsites, states)
