@@ -292,7 +292,8 @@ __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2
                                     const double * s1, const double * s2, unsigned S, unsigned lut_codes,
                                     bool lut_lds, unsigned blk, unsigned lane,
                                     unsigned (&xe)[RS ? RT : 1], unsigned (&xo)[RS ? RT : 1], bool nt, bool ntl = false,
-                                    bool store = true)   // store: false = handed on in registers only (PlanOp::flags bit 0)
+                                    bool store = true,   // store: false = handed on in registers only (PlanOp::flags bit 0)
+                                    unsigned wide_lds = 0)   // PlanOp::flags bit 1 / 2: the rows of wide tip 1 / 2 are staged at s1 / s2
 {
   constexpr unsigned UNIT = 4 * KS * S20_BS;
   const unsigned q = lane >> 4, n = lane & 15;
@@ -315,11 +316,11 @@ __device__ inline void s16_chain_op(const OpDesc & op, unsigned carried, double2
     const size_t ubase = ((size_t)blk * RT + r) * UNIT;
     double2 t1[KS], t2[KS];
     if (carried == 1) s16_child_regs<KS>(X[r], s1 + r * s16_fr(KS), lane, t1);
-    else if (w1) s16_child_tip<KS>(op.lut1 + (size_t)r * op.child1_index * S, c1e, c1o, q, S, t1);
+    else if (w1) s16_child_tip<KS>(((wide_lds & 2u) ? s1 : op.lut1) + (size_t)r * op.child1_index * S, c1e, c1o, q, S, t1);
     else if (!op.codes1) s16_child_inner<KS>(op.clv1 + ubase, s1 + r * s16_fr(KS), lane, t1, ntl);
     else s16_child_tip<KS>(l1 + (size_t)r * lut_codes * S, c1e, c1o, q, S, t1);
     if (carried == 2) s16_child_regs<KS>(X[r], s2 + r * s16_fr(KS), lane, t2);
-    else if (w2) s16_child_tip<KS>(op.lut2 + (size_t)r * op.child2_index * S, c2e, c2o, q, S, t2);
+    else if (w2) s16_child_tip<KS>(((wide_lds & 4u) ? s2 : op.lut2) + (size_t)r * op.child2_index * S, c2e, c2o, q, S, t2);
     else if (!op.codes2) s16_child_inner<KS>(op.clv2 + ubase, s2 + r * s16_fr(KS), lane, t2, ntl);
     else s16_child_tip<KS>(l2 + (size_t)r * lut_codes * S, c2e, c2o, q, S, t2);
     int re = 1, ro = 1;
@@ -429,12 +430,12 @@ __global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanVi
     for (unsigned i = 0; i < ch.len; ++i)
     {
       const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
-      // (a wide tip has no table in LDS: its rows are gathered from memory)
-      if (WIDE && !po.d.clv1 && !po.d.codes1) { }
+      // (a wide tip has its rows in LDS when they are few -- PlanOp::flags bit 1 / 2 --, else they are gathered from memory)
+      if (WIDE && !po.d.clv1 && !po.d.codes1) { if (po.flags & 2u) staged_copy<8>(lds + po.slot1, po.d.lut1, RT * po.d.child1_index * S); }
       else if (!po.d.codes1) s16_fill_frags<KS>(lds + po.slot1, po.d.pmat1, RT, S, Sp);
       else if (lut_lds)
         staged_copy<8>(lds + po.slot1, po.d.lut1, RT * lut_codes * S);
-      if (WIDE && !po.d.clv2 && !po.d.codes2) { }
+      if (WIDE && !po.d.clv2 && !po.d.codes2) { if (po.flags & 4u) staged_copy<8>(lds + po.slot2, po.d.lut2, RT * po.d.child2_index * S); }
       else if (!po.d.codes2) s16_fill_frags<KS>(lds + po.slot2, po.d.pmat2, RT, S, Sp);
       else if (lut_lds)
         staged_copy<8>(lds + po.slot2, po.d.lut2, RT * lut_codes * S);
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanVi
       {
         const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
         s16_chain_op<KS, RT, RS, WIDE>(po.d, i ? po.carried : 0u, X, lds + po.slot1, lds + po.slot2, S, lut_codes,
-                                 lut_lds, blk, lane, xe, xo, nt, ntl, !(po.flags & 1u));
+                                 lut_lds, blk, lane, xe, xo, nt, ntl, !(po.flags & 1u), WIDE ? po.flags : 0u);
       }
     }
   }

@@ -484,8 +484,10 @@ __device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2
                                     const double * s1, const double * s2,
                                     unsigned lut_codes, unsigned lut_used, bool lut_lds,
                                     unsigned blk, unsigned lane, bool nt_ld, bool nt_st,
-                                    unsigned (&xe)[RS ? RT : 1], unsigned (&xo)[RS ? RT : 1], bool store = true)
+                                    unsigned (&xe)[RS ? RT : 1], unsigned (&xo)[RS ? RT : 1], bool store = true,
+                                    unsigned wide_lds = 0)
 {
+  // wide_lds: PlanOp::flags -- bit 1 / 2: the rows of wide tip 1 / 2 are staged in LDS (s1 / s2, rows of S20_LUT_RS)
   const unsigned q = lane >> 4, n = lane & 15;
   const size_t site0 = (size_t)blk * S20_BS + 2 * n;
   unsigned c1e = 0, c1o = 0, c2e = 0, c2o = 0;
@@ -505,11 +507,13 @@ __device__ inline void s20_chain_op(const OpDesc & op, unsigned carried, double2
     const size_t ubase = ((size_t)blk * RT + r) * S20_UNIT;
     double2 t1[5], t2[5];
     if (carried == 1) s20_child_regs_c(X[r], s1 + r * S20_CFRAGS, lane, t1);
+    else if (w1 && (wide_lds & 2u)) s20_child_tip(s1 + r * op.child1_index * S20_LUT_RS, c1e, c1o, q, t1, S20_LUT_RS);
     else if (w1) s20_child_tip(op.lut1 + (size_t)r * op.child1_index * 20, c1e, c1o, q, t1);
     else if (!op.codes1) s20_child_inner_c(op.clv1 + ubase, s1 + r * S20_CFRAGS, lane, t1, nt_ld);
     else if (lut_lds) s20_child_tip(s1 + r * lut_used * S20_LUT_RS, c1e, c1o, q, t1, S20_LUT_RS);
     else s20_child_tip(op.lut1 + (size_t)r * lut_codes * 20, c1e, c1o, q, t1);
     if (carried == 2) s20_child_regs_c(X[r], s2 + r * S20_CFRAGS, lane, t2);
+    else if (w2 && (wide_lds & 4u)) s20_child_tip(s2 + r * op.child2_index * S20_LUT_RS, c2e, c2o, q, t2, S20_LUT_RS);
     else if (w2) s20_child_tip(op.lut2 + (size_t)r * op.child2_index * 20, c2e, c2o, q, t2);
     else if (!op.codes2) s20_child_inner_c(op.clv2 + ubase, s2 + r * S20_CFRAGS, lane, t2, nt_ld);
     else if (lut_lds) s20_child_tip(s2 + r * lut_used * S20_LUT_RS, c2e, c2o, q, t2, S20_LUT_RS);
@@ -720,10 +724,15 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanVi
       for (unsigned i = 0; i < ch.len; ++i)
       {
         const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
-        if (!WIDE || po.d.clv1 || po.d.codes1)       // (a wide tip has no table in LDS)
+        // (a wide tip has its rows in LDS when they are few -- PlanOp::flags bit 1 / 2 --, else no table there)
+        if (!WIDE || po.d.clv1 || po.d.codes1)
           s20_fill_slot(lds + po.slot1, po.d.pmat1, po.d.pfrag1, po.d.codes1 ? po.d.lut1 : nullptr, RT, lut_codes, lut_used, lut_lds);
+        else if (po.flags & 2u)
+          s20_fill_slot(lds + po.slot1, nullptr, nullptr, po.d.lut1, RT, po.d.child1_index, po.d.child1_index, true);
         if (!WIDE || po.d.clv2 || po.d.codes2)
           s20_fill_slot(lds + po.slot2, po.d.pmat2, po.d.pfrag2, po.d.codes2 ? po.d.lut2 : nullptr, RT, lut_codes, lut_used, lut_lds);
+        else if (po.flags & 4u)
+          s20_fill_slot(lds + po.slot2, nullptr, nullptr, po.d.lut2, RT, po.d.child2_index, po.d.child2_index, true);
       }
       __syncthreads();
 
@@ -736,7 +745,8 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanVi
         {
           const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
           s20_chain_op<RT, RS, WIDE>(po.d, i ? po.carried : 0u, X, lds + po.slot1, lds + po.slot2,
-                                     lut_codes, lut_used, lut_lds, blk, lane, nt_ld, nt_st, xe, xo, TRANS ? !(po.flags & 1u) : true);
+                                     lut_codes, lut_used, lut_lds, blk, lane, nt_ld, nt_st, xe, xo, TRANS ? !(po.flags & 1u) : true,
+                                     WIDE ? po.flags : 0u);
         }
       }
     }

@@ -261,7 +261,9 @@ constexpr unsigned s4_chain_op_lds(unsigned R) { return 2 * R * S4_LUT_RS + 2 * 
 // one operation of a chain for one 64-site chunk: X holds the handed-over operand on entry (when
 // carried != 0) and the result on exit, xcnt the scaler count that goes with it.
 // base: the operation's LDS tables
-template <unsigned U, unsigned R, int NT = 0>
+// WIDE: the operation may have wide tips (site repeats, tips kept per class); without them the instantiation carries
+// none of their pointers and branches (one VGPR more and the traversal kernel loses its third wave per SIMD)
+template <unsigned U, unsigned R, int NT = 0, bool WIDE = false>
 __device__ inline void s4_chain_step(const OpDesc & op, unsigned carried, const double * base,
                                      double2 (&X)[2 * R], unsigned & xcnt,
                                      unsigned long long hc0, unsigned long long nsc, unsigned long long total,
@@ -272,9 +274,12 @@ __device__ inline void s4_chain_step(const OpDesc & op, unsigned carried, const 
   constexpr unsigned T2 = R * S4_LUT_RS, M1 = 2 * R * S4_LUT_RS, M2 = 2 * R * S4_LUT_RS + R * 16;
   // a "wide tip" (kernels_repeats.hpp: a cherry known per class of sites): neither vector nor byte codes; pfrag
   // holds its 16-bit class codes, lut its table [rate][class][4], childN_index the classes
-  const unsigned * w1 = (!op.clv1 && !op.codes1) ? reinterpret_cast<const unsigned *>(op.pfrag1) : nullptr;
-  const unsigned * w2 = (!op.clv2 && !op.codes2) ? reinterpret_cast<const unsigned *>(op.pfrag2) : nullptr;
+  const unsigned * w1 = (WIDE && !op.clv1 && !op.codes1) ? reinterpret_cast<const unsigned *>(op.pfrag1) : nullptr;
+  const unsigned * w2 = (WIDE && !op.clv2 && !op.codes2) ? reinterpret_cast<const unsigned *>(op.pfrag2) : nullptr;
   const bool tip1 = op.codes1 || w1, tip2 = op.codes2 || w2;
+  // (a wide tip of at most 16 classes -- every tip that is kept per class: 15 state masks -- has its rows in LDS, in
+  // the place and layout of a coded tip's table: s4_chain_stage)
+  const bool l1 = op.codes1 || (w1 && op.child1_index <= 16u), l2 = op.codes2 || (w2 && op.child2_index <= 16u);
   HalfP p1 = {}, p2 = {};
   if (!tip1) p1 = s4_load_half_p(base + M1, r, h);
   if (!tip2) p2 = s4_load_half_p(base + M2, r, h);
@@ -308,12 +313,12 @@ __device__ inline void s4_chain_step(const OpDesc & op, unsigned carried, const 
       const int code2 = tip2 ? __shfl(cb2, src, 64) : 0;
       if (live[u])
       {
-        if (op.codes1)
+        if (l1)
           in1[u] = *reinterpret_cast<const double2 *>(&base[r * S4_LUT_RS + code1 * 4 + 2 * h]);
         else if (w1)
           in1[u] = *reinterpret_cast<const double2 *>(&op.lut1[((size_t)r * op.child1_index + (unsigned)code1) * 4 + 2 * h]);
         else if (carried != 1) in1[u] = s4_ld2<NT == 2>(op.clv1 + gu * 2);
-        if (op.codes2)
+        if (l2)
           in2[u] = *reinterpret_cast<const double2 *>(&base[T2 + r * S4_LUT_RS + code2 * 4 + 2 * h]);
         else if (w2)
           in2[u] = *reinterpret_cast<const double2 *>(&op.lut2[((size_t)r * op.child2_index + (unsigned)code2) * 4 + 2 * h]);
@@ -362,14 +367,20 @@ __device__ inline void s4_chain_step(const OpDesc & op, unsigned carried, const 
 }
 
 // stage an operation's tables: [R][16][4] lookup tables (rate stride padded) / [R][16] matrices
-template <unsigned R>
+template <unsigned R, bool WIDE = false>
 __device__ inline void s4_chain_stage(const OpDesc & op, double * base)
 {
   constexpr unsigned T2 = R * S4_LUT_RS, M1 = 2 * R * S4_LUT_RS, M2 = 2 * R * S4_LUT_RS + R * 16;
   const unsigned trow = (threadIdx.x >> 6) * S4_LUT_RS + (threadIdx.x & 63);
+  // a wide tip (neither vector nor codes) of at most 16 classes: its row table [rate][classes][4] into the layout of a
+  // coded tip's table
+  const unsigned n1 = (WIDE && !op.clv1 && !op.codes1 && op.child1_index <= 16u) ? op.child1_index * 4u : 0u;
+  const unsigned n2 = (WIDE && !op.clv2 && !op.codes2 && op.child2_index <= 16u) ? op.child2_index * 4u : 0u;
   if (op.codes1) { if (threadIdx.x < R * 64) base[trow] = op.lut1[threadIdx.x]; }
+  else if (n1) { if (threadIdx.x < R * n1) base[(threadIdx.x / n1) * S4_LUT_RS + threadIdx.x % n1] = op.lut1[threadIdx.x]; }
   else if (threadIdx.x < R * 16) base[M1 + threadIdx.x] = op.pmat1[threadIdx.x];
   if (op.codes2) { if (threadIdx.x < R * 64) base[T2 + trow] = op.lut2[threadIdx.x]; }
+  else if (n2) { if (threadIdx.x < R * n2) base[T2 + (threadIdx.x / n2) * S4_LUT_RS + threadIdx.x % n2] = op.lut2[threadIdx.x]; }
   else if (threadIdx.x < R * 16) base[M2 + threadIdx.x] = op.pmat2[threadIdx.x];
 }
 
@@ -414,7 +425,7 @@ __global__ __launch_bounds__(256) void k_chain_s4(ChainBatch batch, unsigned N)
 // flag: as a run-time test in front of the stores it cost one VGPR, 169 instead of 168 -- and with that the third
 // wave per SIMD (C2: 5.2 instead of 3.4 ms)
 // (three waves per SIMD: 168 VGPRs)
-template <unsigned U, unsigned R, int NT = 0, bool TRANS = false>
+template <unsigned U, unsigned R, int NT = 0, bool TRANS = false, bool WIDE = false>
 __global__ __launch_bounds__(256, 3) void k_traverse_s4(PlanView plan, unsigned chain_begin, unsigned chain_end)
 {
   constexpr unsigned group = 2 * R;
@@ -437,7 +448,7 @@ __global__ __launch_bounds__(256, 3) void k_traverse_s4(PlanView plan, unsigned 
     for (unsigned i = 0; i < ch.len; ++i)
     {
       const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
-      s4_chain_stage<R>(po.d, lds + i * S4_CHAIN_OP_LDS);
+      s4_chain_stage<R, WIDE>(po.d, lds + i * S4_CHAIN_OP_LDS);
     }
     __syncthreads();
     for (unsigned chunk = cbeg + (threadIdx.x >> 6); chunk < cend; chunk += 4)
@@ -450,7 +461,7 @@ __global__ __launch_bounds__(256, 3) void k_traverse_s4(PlanView plan, unsigned 
       for (unsigned i = 0; i < ch.len; ++i)
       {
         const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
-        s4_chain_step<U, R, NT>(po.d, i ? po.carried : 0u, lds + i * S4_CHAIN_OP_LDS,
+        s4_chain_step<U, R, NT, WIDE>(po.d, i ? po.carried : 0u, lds + i * S4_CHAIN_OP_LDS,
                             X, xcnt, hc0, nsc, total, N, lane, r, h, TRANS ? !(po.flags & 1u) : true);
       }
     }
@@ -714,7 +725,8 @@ static int launch_chains_s4(Engine * e, const ChainBatch & batch, unsigned nchai
 
 // `extent`: sites of the largest partition the chains [chain_begin, chain_end) belong to
 static int launch_traverse_s4(Engine * e, const PlanView & plan, unsigned longest, unsigned extent, unsigned chain_begin,
-                              unsigned chain_end, unsigned rows, unsigned row_wgs_per_cu = 0, bool transient = false)
+                              unsigned chain_end, unsigned rows, unsigned row_wgs_per_cu = 0, bool transient = false,
+                              bool wide = false)
 {
   const unsigned nchunks = (extent + 63) / 64;
   const size_t lds = sizeof(double) * longest * s4_chain_op_lds(e->R);
@@ -722,12 +734,14 @@ static int launch_traverse_s4(Engine * e, const PlanView & plan, unsigned longes
   // allocate in the caches are 5 % (1 M sites) to 17 % (100 k - 250 k sites) faster.  PLLHIP_S4_NT=0: plain.
   static const int env_nt = getenv("PLLHIP_S4_NT") ? atoi(getenv("PLLHIP_S4_NT")) : 1;
   const void * fn = nullptr;
-#define PLLHIP_PICK(NT_, T_) fn = e->R == 4 ? reinterpret_cast<const void *>(k_traverse_s4<4, 4, NT_, T_>)   \
-                                : e->R == 2 ? reinterpret_cast<const void *>(k_traverse_s4<4, 2, NT_, T_>) \
-                                            : reinterpret_cast<const void *>(k_traverse_s4<2, 1, NT_, T_>)
+#define PLLHIP_PICK_W(NT_, T_, W_) fn = e->R == 4 ? reinterpret_cast<const void *>(k_traverse_s4<4, 4, NT_, T_, W_>)   \
+                                    : e->R == 2 ? reinterpret_cast<const void *>(k_traverse_s4<4, 2, NT_, T_, W_>) \
+                                                : reinterpret_cast<const void *>(k_traverse_s4<2, 1, NT_, T_, W_>)
+#define PLLHIP_PICK(NT_, T_) do { if (wide) PLLHIP_PICK_W(NT_, T_, true); else PLLHIP_PICK_W(NT_, T_, false); } while (0)
   if (env_nt) { if (transient) PLLHIP_PICK(2, true); else PLLHIP_PICK(2, false); }
   else { if (transient) PLLHIP_PICK(0, true); else PLLHIP_PICK(0, false); }
 #undef PLLHIP_PICK
+#undef PLLHIP_PICK_W
   // exactly the workgroups that are resident at once -- of the instantiation that is launched -- (measured on C2,
   // workgroups per CU: 2: 4.06 ms, 3 = resident: 3.58, 4: 4.12, 6: 3.68, 8: 3.82; one launch per round of chains: 3.85)
   static const int env_bpc = getenv("PLLHIP_S4_TRAVERSE_BPC") ? atoi(getenv("PLLHIP_S4_TRAVERSE_BPC")) : 0;

@@ -1056,18 +1056,33 @@ struct ChainPlan
   int rounds = 0;
 };
 
+// LDS doubles of the rows of a wide tip (a class node read through its row table, kernels_repeats.hpp) with `rows`
+// classes: staged when they take no more than a coded tip's table may, else gathered from memory (0)
+static unsigned wide_slot(const Engine * e, unsigned rows)
+{
+  if (e->family == KernelFamily::S20)
+    return e->R * rows * S20_LUT_RS <= 2560u ? ((e->R * rows * S20_LUT_RS + 7u) & ~7u) : 0u;
+  if (e->family == KernelFamily::S16)
+    return e->R * rows * e->S <= S16_LUT_LDS ? ((e->R * rows * e->S + 7u) & ~7u) : 0u;
+  return 0u;
+}
+
 // LDS doubles the tables of operation `op` take in a chain kernel (20 states; 0 otherwise)
-static unsigned chain_op_lds(const Engine * e, const pll_operation_t & op, unsigned lut_used)
+// wide1 / wide2: the child is read as a wide tip
+static unsigned chain_op_lds(const Engine * e, const pll_operation_t & op, unsigned lut_used, bool wide1 = false, bool wide2 = false)
 {
   const bool t1 = e->coded_tips && op.child1_clv_index < e->tips;
   const bool t2 = e->coded_tips && op.child2_clv_index < e->tips;
-  if (e->family == KernelFamily::S16) return s16_chain_slot(e, t1) + s16_chain_slot(e, t2);
-  if (e->family != KernelFamily::S20) return 0u;
-  return s20_chain_slot(e, t1, lut_used) + s20_chain_slot(e, t2, lut_used);
+  if (e->family != KernelFamily::S16 && e->family != KernelFamily::S20) return 0u;
+  const bool s16 = e->family == KernelFamily::S16;
+  const unsigned a = wide1 ? wide_slot(e, e->cherries[op.child1_clv_index].nclasses) : s16 ? s16_chain_slot(e, t1) : s20_chain_slot(e, t1, lut_used);
+  const unsigned b = wide2 ? wide_slot(e, e->cherries[op.child2_clv_index].nclasses) : s16 ? s16_chain_slot(e, t2) : s20_chain_slot(e, t2, lut_used);
+  return a + b;
 }
 
+// wide: [2 * count] which children are read as wide tips (null: none)
 static bool plan_chains(const Engine * e, const pll_operation_t * ops, unsigned count, unsigned max_len,
-                        unsigned lds_cap, unsigned lut_used, ChainPlan & plan)
+                        unsigned lds_cap, unsigned lut_used, ChainPlan & plan, const std::vector<unsigned char> * wide = nullptr)
 {
   std::vector<int> producer(e->nodes, -1), sc_writer(e->nscalers, -1), chain_of(count, -1);
   std::vector<char> read_ext(e->nodes, 0), sc_read_ext(e->nscalers, 0);
@@ -1110,7 +1125,7 @@ static bool plan_chains(const Engine * e, const pll_operation_t * ops, unsigned 
     int heavy = -1;                               // which child (0 / 1) continues a chain
     if (pr[0] >= 0 && (pr[1] < 0 || size[pr[0]] >= size[pr[1]])) heavy = 0;
     else if (pr[1] >= 0) heavy = 1;
-    const unsigned cost = chain_op_lds(e, op, lut_used);
+    const unsigned cost = chain_op_lds(e, op, lut_used, wide && !wide->empty() && (*wide)[2 * k], wide && !wide->empty() && (*wide)[2 * k + 1]);
     if (heavy >= 0 && (plan.chains[chain_of[pr[heavy]]].size() >= max_len ||
                        plan.lds[chain_of[pr[heavy]]] + cost > lds_cap)) heavy = -1;
     int round = 0;
@@ -1637,7 +1652,7 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
   }
   std::vector<PairLutJob> pair_jobs;             // row tables of the wide tips of the chains
   size_t pairlut_used = 0;
-  if (!have && plan_chains(e, ops, count, chain_max, chain_lds, lut_used, plan))
+  if (!have && plan_chains(e, ops, count, chain_max, chain_lds, lut_used, plan, &wide))
   {
     // Order of the chains: depth first, so that a vector is consumed soon after it was written
     // (the kernel walks slabs of sites through ALL chains: what a slab wrote a few chains ago
@@ -1765,6 +1780,8 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
           pair_jobs.push_back(job);
           // wide tip: no vector, no byte codes; pfrag = class codes, lut = its table, childN_index = table rows
           // (... and its scaler counts per class)
+          // (bit 1 / 2 of the flags: few rows, staged in LDS by the chain kernels of the 20- and 2 .. 32-state families)
+          if (wide_slot(e, c.nclasses)) po.flags |= 2u << x;
           if (x) { po.d.clv2 = nullptr; po.d.codes2 = nullptr; po.d.pfrag2 = reinterpret_cast<const double *>(c.pair); po.d.lut2 = job.out; po.d.child2_index = c.nclasses;
                    if (po.d.scaler2) po.d.scaler2 = c.counts; }
           else   { po.d.clv1 = nullptr; po.d.codes1 = nullptr; po.d.pfrag1 = reinterpret_cast<const double *>(c.pair); po.d.lut1 = job.out; po.d.child1_index = c.nclasses;
@@ -1782,9 +1799,9 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
         {
           const bool w1 = !wide.empty() && wide[2 * ch[i]], w2 = !wide.empty() && wide[2 * ch[i] + 1];
           po.slot1 = off;
-          if (!w1) off += chains20 ? s20_chain_slot(e, t1, lut_used) : s16_chain_slot(e, t1);
+          off += w1 ? wide_slot(e, e->cherries[o.child1_clv_index].nclasses) : chains20 ? s20_chain_slot(e, t1, lut_used) : s16_chain_slot(e, t1);
           po.slot2 = off;
-          if (!w2) off += chains20 ? s20_chain_slot(e, t2, lut_used) : s16_chain_slot(e, t2);
+          off += w2 ? wide_slot(e, e->cherries[o.child2_clv_index].nclasses) : chains20 ? s20_chain_slot(e, t2, lut_used) : s16_chain_slot(e, t2);
         }
       }
       lds_max = std::max(lds_max, chains4 ? (unsigned)ch.size() : off);   // 4 states: the longest chain
@@ -2250,7 +2267,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
           if (!prof_begin(ev1)) return PLL_FAILURE;
           if (chains20 ? !launch_traverse_s20(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows, 0, !e->cherries.empty(), transient)
                        : chains16 ? !launch_traverse_s16(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows, 0, !e->cherries.empty())
-                                  : !launch_traverse_s4(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows, 0, transient))
+                                  : !launch_traverse_s4(e, view, dp.lds_doubles, dp.max_extent, l.begin, l.end, rows, 0, transient, !e->cherries.empty()))
             return PLL_FAILURE;
           if (!prof_end(ev1, l.bytes, l.flops, l.ops, l.min_bytes)) return PLL_FAILURE;
           e->counters.partial_launches++;
@@ -2693,7 +2710,7 @@ static int update_partials_group(const std::vector<pll_partition_t *> & g, const
     for (pll_partition_t * p : g) any_transient = any_transient || (engine_of(p)->transient_mode && !engine_of(p)->site_repeats);
     const int ok = lead->family == KernelFamily::S20 ? launch_traverse_s20(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs, any_wide, any_transient)
                  : lead->family == KernelFamily::S16 ? launch_traverse_s16(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs, any_wide)
-                                                     : launch_traverse_s4(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs, any_transient);
+                                                     : launch_traverse_s4(lead, view, b.plan.lds_doubles, b.plan.max_extent, l.begin, l.end, l.rows, wgs, any_transient, any_wide);
     if (!ok) return -1;
     if (lead->profiling)
     {
