@@ -5,6 +5,7 @@ and compare with the oracle (same C code, different library underneath).
 tests/test_dropin_modules.py additionally checks it against the reference's own
 treeinfo / optimiser on identical data."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -473,6 +474,25 @@ def test_device_newton_makes_the_host_loop_s_iterates(product, states, nsites, p
                 assert list(trail) == want_trail
                 assert got_x == want_x
         a.free_sumtable(st)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks", [293, 292, 64])
+def test_device_newton_with_a_capped_reduction_grid(blocks):
+    """150 000 sites x 4 rates at 4 states: with 293 workgroups of 1 024 columns a thread makes two trips over the sumtable
+    (the loop keeps it in registers), with 292 three and with 64 ten (it streams): the residency decision has to be made
+    for the grid that is launched -- PLLHIP_REDUCE_BLOCKS caps it -- and every iterate is the host loop's either way
+    (tests/_newton_trips_worker.py: the cap is read when the library is loaded)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "_newton_trips_worker.py"), "150000", str(blocks)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert any(h is not None for h in got["host"])
+    assert got["device"] == got["host"]
 
 
 @pytest.mark.gpu
