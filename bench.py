@@ -852,13 +852,15 @@ def also_legs(ctx):
                                              "single_op_updates", "pmatrix_updates", "branches", "lnl_before", "lnl_after")}
     also["blo_c3_125k"]["leg_wall_s"] = round(time.perf_counter() - t0, 2)
     # ... and over C4's four partitions (linked branch lengths) at the per-GPU slice of an 8-way split: the partitions'
-    # derivative sums meet between two iterates -- on the device (include/pllhip.h, pllhip_newton_branch_multi)
+    # derivative sums meet between two iterates -- on the host here; on the device (include/pllhip.h,
+    # pllhip_newton_branch_multi) in a process started with GPU_MAX_HW_QUEUES >= 8, which this one is not by default:
+    # sixteen hardware queues cost the many-partition evaluations a third of their rate
     t0 = time.perf_counter()
     gw.blo_c4(ctx.product, out, nsites=125_000)
     b = out["BLO_c4_125000"]
     also["blo_c4_125k_us_per_iterate"] = b["us_per_derivative_call_incl_everything"]
     also["blo_c4_125k"] = {k: b[k] for k in ("s_per_smoothing_pass", "newton_iterations", "single_op_updates", "pmatrix_updates",
-                                             "branches", "partitions", "lnl_before", "lnl_after")}
+                                             "branches", "partitions", "lnl_before", "lnl_after", "device_newton")}
     also["blo_c4_125k"]["leg_wall_s"] = round(time.perf_counter() - t0, 2)
     t0 = time.perf_counter()
     gw.spr(ctx.product, out, nsites=25_000)
@@ -902,7 +904,6 @@ def main():
     # kernel arguments in device memory (3 - 5 us per short launch, pll_core.hip): decided HERE, before any
     # library that initialises the HIP runtime is loaded, so that N = 1 and N > 1 run under the same setting
     os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # (a queue per partition stream: pll_core.hip, pllhip_runtime_defaults)
     default_shape = (world == 1 and not internal and args.config == "c3" and not args.sites and not args.taxa and
                      not args.rate_scalers and not args.no_also and not args.no_cpu_baseline and not args.site_repeats and
                      args.data == "random" and args.tree == "random" and not args.transient and not args.clv_tips)

@@ -139,13 +139,11 @@ __attribute__((constructor)) static void pllhip_runtime_defaults()
   const char * opt = getenv("PLLHIP_SET_RUNTIME_DEFAULTS");
   if (opt && !atoi(opt)) return;
   if (!getenv("HIP_FORCE_DEV_KERNARG")) setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
-  // The runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), in order within a
-  // queue.  Every partition has a stream of its own, and the Newton-Raphson loop over several partitions
-  // (pllhip_newton_branch_multi) needs its instances -- one launch per partition -- on the device TOGETHER: with five
-  // streams (four partitions + a result group) two of them shared a queue, the second instance started when the first
-  // had given up, and the loop ended in PLLHIP_ERROR_NEWTON_STUCK (the callers then iterate on the host; found with
-  // PLLHIP_NEWTON_DEBUG=1).  Sixteen queues cover the eight partitions such a loop takes and the streams next to them.
-  if (!getenv("GPU_MAX_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "16", 0);
+  // GPU_MAX_HW_QUEUES is left alone.  The runtime multiplexes a process's streams onto that many hardware queues (four
+  // by default), in order within a queue; sixteen would give every partition stream its own -- which the Newton-Raphson
+  // loop over several partitions needs (newton_multi_enabled) -- but cost the many-stream workloads a third of their
+  // rate on one box: 64 DNA partitions of 10 k sites 3.6 -> 5.7 ms per evaluation, 32 protein partitions 5.6 -> 6.9,
+  // 16 x 60 k DNA 3.3 -> 4.0 (tools/gpu_r4_queues.sh; between the two, 6 / 8 / 12 queues cost the same).
 }
 #endif
 
@@ -3592,6 +3590,19 @@ int pllhip_newton_branch(pll_partition_t * p, int parent_scaler_index, int child
   return newton_finish(e, std::vector<Engine *>(1, e), seq, length, iterations, trail);
 }
 
+// The loop over several partitions runs one launch per partition, each on its partition's stream, and the launches wait
+// for one another on the device: they have to be there TOGETHER.  Two streams that share a hardware queue run one after
+// the other -- with five streams on the runtime's four queues the second instance started when the first had given up
+// (PLLHIP_NEWTON_DEBUG=1 shows it) -- so the loop is offered only to a process that asked the runtime for enough queues
+// before its first HIP call: GPU_MAX_HW_QUEUES >= 8 in the environment (the library does not set it: see
+// pllhip_runtime_defaults for what it costs).  Elsewhere pllhip_newton_branch_multi answers
+// PLLHIP_ERROR_NEWTON_UNSUPPORTED and the callers iterate from the host.
+static bool newton_multi_enabled()
+{
+  static const bool on = []() { const char * q = getenv("GPU_MAX_HW_QUEUES"); return q && atoi(q) >= 8; }();
+  return on;
+}
+
 // Several partitions under ONE branch length (linked lengths, or scaled ones: partition p sees s_p x): the loop of
 // pllhip_newton_branch with the sum over the partitions inside it.  Every partition launches its own instance of the
 // loop on its own stream -- its family's kernel on its own scan grid, so its totals are the ones its blocking derivative
@@ -3612,6 +3623,12 @@ int pllhip_newton_branch_multi(pll_partition_t * const * partitions, unsigned in
   if (!count || count > NEWTON_MAX_PARTS || !max_newton)
   {
     set_error(PLLHIP_ERROR_NEWTON_UNSUPPORTED, "1 to %u partitions per device-resident Newton-Raphson loop", NEWTON_MAX_PARTS);
+    return PLL_FAILURE;
+  }
+  if (!newton_multi_enabled())
+  {
+    set_error(PLLHIP_ERROR_NEWTON_UNSUPPORTED, "the Newton-Raphson loop over several partitions needs a hardware queue per "
+              "partition stream: GPU_MAX_HW_QUEUES >= 8 in the environment before the first HIP call");
     return PLL_FAILURE;
   }
   for (unsigned k = 0; k < count; ++k)

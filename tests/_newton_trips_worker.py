@@ -35,7 +35,7 @@ def main():
                 x, its, trail = a.newton_branch(sa, sb, st, start, 1e-4, 10.0, 1e-5, 32)
                 out["device"].append([x] + list(trail))
             except RuntimeError:
-                out["device"].append(None)
+                out["device"].append(lib.errno)
         a.free_sumtable(st)
     print(json.dumps(out))
 

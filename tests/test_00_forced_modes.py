@@ -8,7 +8,11 @@ before this process has touched the GPU: the file sorts first):
                          inside operation chains are not stored and come back on demand.
 
 Every oracle comparison, golden value and bit-for-bit check of the suite has to hold unchanged; the few asserts that
-count launches or class operations are switched off through tests/common.py (FORCED_*)."""
+count launches or class operations are switched off through tests/common.py (FORCED_*).
+
+A third child runs the tests of the Newton-Raphson loop over several partitions with GPU_MAX_HW_QUEUES=16: the loop needs a
+hardware queue per partition stream, the library leaves the runtime's four alone (pll_core.hip, newton_multi_enabled), and
+the variable has to be there before the process's first HIP call."""
 import os
 import subprocess
 import sys
@@ -33,3 +37,18 @@ def test_gpu_suite_under(name, env):
             f.write(r.stdout + "\n" + r.stderr)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
     assert " passed" in r.stdout
+
+
+def test_newton_loop_over_partitions_with_a_queue_per_stream():
+    if os.environ.get("PLLHIP_FORCED_CHILD"):
+        pytest.skip("already inside a forced-mode run")
+    cmd = [sys.executable, "-m", "pytest", "tests/test_eval_driver.py", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+           "-k", "several_partitions or newton_over_partitions"]
+    r = subprocess.run(cmd, cwd=ROOT, env={**os.environ, "GPU_MAX_HW_QUEUES": "16", "PLLHIP_FORCED_CHILD": "1"},
+                       capture_output=True, text=True, timeout=600)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "forced_newton_multi.log"), "w") as f:
+            f.write(r.stdout + "\n" + r.stderr)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
+    assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1]
