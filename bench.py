@@ -852,9 +852,8 @@ def also_legs(ctx):
                                              "single_op_updates", "pmatrix_updates", "branches", "lnl_before", "lnl_after")}
     also["blo_c3_125k"]["leg_wall_s"] = round(time.perf_counter() - t0, 2)
     # ... and over C4's four partitions (linked branch lengths) at the per-GPU slice of an 8-way split: the partitions'
-    # derivative sums meet between two iterates -- on the host here; on the device (include/pllhip.h,
-    # pllhip_newton_branch_multi) in a process started with GPU_MAX_HW_QUEUES >= 8, which this one is not by default:
-    # sixteen hardware queues cost the many-partition evaluations a third of their rate
+    # derivative sums meet between two iterates -- on the device (include/pllhip.h, pllhip_newton_branch_multi: one launch
+    # for all four partitions, k_newton_multi)
     t0 = time.perf_counter()
     gw.blo_c4(ctx.product, out, nsites=125_000)
     b = out["BLO_c4_125000"]

@@ -169,10 +169,16 @@ __device__ inline void publish_result(const ReduceOut & ro)
 // must re-derive it (or set fused_finish = false).
 // LOOP: the launch goes on after the sum (k_newton_mfma): the caller resets the tickets and tells the other
 // blocks itself; returns whether this block drew the last ticket (thread 0 then finds the totals in ro.dst)
+// A kernel that runs the scans of several partitions side by side (k_newton_multi, kernels_newton_s4.hpp) gives every
+// partition a contiguous run of its workgroups: what a scan and its reduction take for "the grid" is then that run
+// -- workgroup b of G -- and not the launch.  Everywhere else it is the launch (the default argument).
+struct GridView { unsigned b, G; };
+__device__ inline GridView launch_grid() { return GridView{blockIdx.x, gridDim.x}; }
+
 template <int Q, bool LOOP = false>
-__device__ inline bool grid_reduce_tail(const ReduceOut & ro, double * scratch)
+__device__ inline bool grid_reduce_tail(const ReduceOut & ro, double * scratch, GridView gv = launch_grid())
 {
-  const unsigned G = gridDim.x, b = blockIdx.x;
+  const unsigned G = gv.G, b = gv.b;
   unsigned * s_last = reinterpret_cast<unsigned *>(scratch);   // block_sum_256 left it free
   if (threadIdx.x == 0)
   {
@@ -259,9 +265,9 @@ __device__ inline void grid_reduce_finish(const double (&tot)[Q], const ReduceOu
 // block total of quantity t in thread t (t < Q <= 64: all of them lanes of wave 0, whose one
 // wait covers every store)
 template <int Q, bool LOOP = false>
-__device__ inline bool grid_reduce_finish_lanes(double mine, const ReduceOut & ro, double * scratch)
+__device__ inline bool grid_reduce_finish_lanes(double mine, const ReduceOut & ro, double * scratch, GridView gv = launch_grid())
 {
-  const unsigned G = gridDim.x, b = blockIdx.x;
+  const unsigned G = gv.G, b = gv.b;
   if (threadIdx.x < 64)
   {
     if (threadIdx.x < Q)
@@ -272,7 +278,7 @@ __device__ inline bool grid_reduce_finish_lanes(double mine, const ReduceOut & r
     }
     if (ro.fused) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  if (ro.fused) return grid_reduce_tail<Q, LOOP>(ro, scratch);
+  if (ro.fused) return grid_reduce_tail<Q, LOOP>(ro, scratch, gv);
   return false;
 }
 

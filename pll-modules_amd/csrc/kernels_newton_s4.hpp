@@ -16,25 +16,27 @@
 #include "kernels_common.hpp"
 #include "kernels_s4.hpp"
 #include "kernels_s20.hpp"
+#include "kernels_s61.hpp"
 
 namespace pllhip {
 
+// gv: the workgroups the loop runs on (the launch, or this partition's run of a launch shared with other partitions)
 template <unsigned NT>
-__global__ __launch_bounds__(256) void k_newton_s4(ModelView mv, ParamIdx params, NewtonParams np,
-                                                   const double * sumtable,
-                                                   const unsigned * ps, const unsigned * cs,
-                                                   const unsigned * weights, const int * invariant,
-                                                   unsigned N, unsigned R, ReduceOut ro,
-                                                   NewtonControl * ctl, double * host_out,
-                                                   unsigned long long * host_flag, unsigned long long host_seq)
+__device__ inline void newton_loop_s4(const ModelView & mv, const ParamIdx & params, const NewtonParams & np,
+                                      const double * sumtable,
+                                      const unsigned * ps, const unsigned * cs,
+                                      const unsigned * weights, const int * invariant,
+                                      unsigned N, unsigned R, const ReduceOut & ro,
+                                      NewtonControl * ctl, double * host_out,
+                                      unsigned long long * host_flag, unsigned long long host_seq, GridView gv)
 {
   __shared__ double scratch[4];
   __shared__ double s_x;
   __shared__ unsigned s_status;
   __shared__ double s_tot1;
   const unsigned long long total = (unsigned long long)N * R;
-  const unsigned long long stride = (unsigned long long)gridDim.x * 256ULL;
-  const unsigned long long g0 = (unsigned long long)blockIdx.x * 256ULL + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gv.G * 256ULL;
+  const unsigned long long g0 = (unsigned long long)gv.b * 256ULL + threadIdx.x;
   const unsigned r = (unsigned)(g0 & (R - 1));
   const unsigned rs = (unsigned)__ffs((int)R) - 1;
   const unsigned pi_ = params.v[r];
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void k_newton_s4(ModelView mv, ParamIdx params
   unsigned c_wgt[NC][4];
 
   double x = np.x0;
-  if (blockIdx.x == np.stall_block) return;             // (fault injection: a workgroup that never arrives)
+  if (gv.b == np.stall_block) return;                   // (fault injection: a workgroup that never arrives)
   for (unsigned it = 0; ; ++it)
   {
     double e0[4], e1[4], e2[4];
@@ -148,8 +150,86 @@ __global__ __launch_bounds__(256) void k_newton_s4(ModelView mv, ParamIdx params
     __syncthreads();
     const double mine = threadIdx.x == 0 ? t0 : threadIdx.x == 1 ? s_tot1 : 0.0;
     __syncthreads();
-    const bool last = grid_reduce_finish_lanes<8, true>(mine, ro, scratch);
+    const bool last = grid_reduce_finish_lanes<8, true>(mine, ro, scratch, gv);
     if (newton_step_and_wait(it, last, x, np, ro, ctl, host_out, host_flag, host_seq, &s_x, &s_status) != NEWTON_RUNNING) return;
+  }
+}
+
+template <unsigned NT>
+__global__ __launch_bounds__(256) void k_newton_s4(ModelView mv, ParamIdx params, NewtonParams np,
+                                                   const double * sumtable,
+                                                   const unsigned * ps, const unsigned * cs,
+                                                   const unsigned * weights, const int * invariant,
+                                                   unsigned N, unsigned R, ReduceOut ro,
+                                                   NewtonControl * ctl, double * host_out,
+                                                   unsigned long long * host_flag, unsigned long long host_seq)
+{
+  newton_loop_s4<NT>(mv, params, np, sumtable, ps, cs, weights, invariant, N, R, ro, ctl, host_out, host_flag, host_seq,
+                     launch_grid());
+}
+
+// ---------------------------------------------------------------------------
+// Several partitions under one branch length in ONE launch.  The loop over several partitions as separate launches --
+// one per partition, each on its partition's stream -- needs a hardware queue per stream (the launches wait for one
+// another on the device; the runtime has four queues unless the process asked for more before its first HIP call,
+// and more of them slow the evaluations of many partitions down: pll_core.hip, pllhip_runtime_defaults).  Here every
+// partition gets a contiguous run of the workgroups of one launch instead: its own scan grid (the one its blocking
+// derivative call uses: same block totals, same order, same bits), its own tickets and totals, its family's loop;
+// the runs meet after every scan in the first partition's control block exactly as the separate launches do
+// (newton_step_and_wait).  Families: 4 states with the table in registers, 20 states, 61 / 33 .. 64 states (streamed).
+// grid = the sum of the partitions' scan grids (all co-resident), block = 256, dynamic LDS = the largest need.
+// ---------------------------------------------------------------------------
+constexpr unsigned NEWTON_KIND_S4 = 0, NEWTON_KIND_S20 = 1, NEWTON_KIND_S61 = 2, NEWTON_KIND_S61_RT = 3;
+struct NewtonMultiPart
+{
+  ModelView mv;
+  ParamIdx params;
+  const double * sumtable;
+  const unsigned * ps, * cs, * weights;
+  const int * invariant;
+  ReduceOut ro;
+  double xscale;
+  unsigned N, nblk, R, rate_scalers;
+  unsigned kind, first_block, nblocks, pad;
+};
+struct NewtonMultiArgs
+{
+  NewtonMultiPart part[NEWTON_MAX_PARTS];
+  NewtonParams np;                  // (part / xscale are taken from the partition's entry)
+  unsigned nparts, pad;
+};
+
+static_assert(sizeof(NewtonMultiArgs) <= 3072, "k_newton_multi takes its partitions by value");
+
+__global__ __launch_bounds__(256, 2) void k_newton_multi(NewtonMultiArgs a, NewtonControl * ctl, double * host_out,
+                                                      unsigned long long * host_flag, unsigned long long host_seq)
+{
+  unsigned p = 0;
+  for (unsigned k = 1; k < a.nparts; ++k) if (blockIdx.x >= a.part[k].first_block) p = k;      // (block-uniform)
+  const NewtonMultiPart & P = a.part[p];
+  NewtonParams np = a.np;
+  np.part = p;
+  np.xscale = P.xscale;
+  if (p) np.stall_block = ~0u;
+  const GridView gv{blockIdx.x - P.first_block, P.nblocks};
+  switch (P.kind)
+  {
+    case NEWTON_KIND_S4:
+      newton_loop_s4<2>(P.mv, P.params, np, P.sumtable, P.ps, P.cs, P.weights, P.invariant, P.N, P.R, P.ro, ctl, host_out,
+                        host_flag, host_seq, gv);
+      break;
+    case NEWTON_KIND_S20:
+      newton_loop<5, 20, 0>(P.mv, P.params, np, P.sumtable, P.ps, P.cs, P.weights, P.invariant, P.N, P.nblk, P.R, P.ro,
+                            P.rate_scalers, ctl, host_out, host_flag, host_seq, gv);
+      break;
+    case NEWTON_KIND_S61:
+      newton_loop<S61_KS, S61_S, 0>(P.mv, P.params, np, P.sumtable, P.ps, P.cs, P.weights, P.invariant, P.N, P.nblk, P.R, P.ro,
+                                    P.rate_scalers, ctl, host_out, host_flag, host_seq, gv);
+      break;
+    default:
+      newton_loop<S61_KS, 0, 0>(P.mv, P.params, np, P.sumtable, P.ps, P.cs, P.weights, P.invariant, P.N, P.nblk, P.R, P.ro,
+                                P.rate_scalers, ctl, host_out, host_flag, host_seq, gv);
+      break;
   }
 }
 

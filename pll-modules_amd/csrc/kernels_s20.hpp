@@ -931,14 +931,14 @@ __device__ inline double deriv_block_totals(const ModelView & mv, const ParamIdx
                                             const unsigned * ps, const unsigned * cs,
                                             const unsigned * weights, const int * invariant,
                                             unsigned N, unsigned nblk, unsigned R, unsigned rate_scalers,
-                                            double * frag)
+                                            double * frag, GridView gv = launch_grid())
 {
   constexpr unsigned UNIT = 4 * KS * S20_BS;
   const unsigned SR = SREAL ? SREAL : mv.S;       // SREAL = 0: the state count is a run-time value
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned q = lane >> 4, n = lane & 15;
-  const unsigned wstride = gridDim.x * 4;
-  unsigned blk = blockIdx.x * 4 + wave;
+  const unsigned wstride = gv.G * 4;
+  unsigned blk = gv.b * 4 + wave;
   double2 bufA[KS], bufB[KS];
   auto load_unit = [&](double2 (&b)[KS], unsigned blk_, unsigned r_)
   {
@@ -1096,15 +1096,16 @@ __device__ inline double deriv_block_totals_resident(const ModelView & mv, const
                                                      const unsigned * ps, const unsigned * cs,
                                                      const unsigned * weights, const int * invariant,
                                                      unsigned N, unsigned nblk, double * frag,
-                                                     DerivResident<KS, NB, NBR, RT> & res, bool first)
+                                                     DerivResident<KS, NB, NBR, RT> & res, bool first,
+                                                     GridView gv = launch_grid())
 {
   double2 * const lds_units = reinterpret_cast<double2 *>(frag + RT * KS * 64);
   constexpr unsigned UNIT = 4 * KS * S20_BS;
   const unsigned SR = SREAL ? SREAL : mv.S;
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned q = lane >> 4, n = lane & 15;
-  const unsigned wstride = gridDim.x * 4;
-  const unsigned blk0 = blockIdx.x * 4 + wave;
+  const unsigned wstride = gv.G * 4;
+  const unsigned blk0 = gv.b * 4 + wave;
   if (first)
   {
 #pragma unroll
@@ -1427,29 +1428,30 @@ __device__ inline void newton_loop(const ModelView & mv, const ParamIdx & params
                                    unsigned N, unsigned nblk, unsigned R,
                                    const ReduceOut & ro, unsigned rate_scalers,
                                    NewtonControl * ctl, double * host_out,
-                                   unsigned long long * host_flag, unsigned long long host_seq)
+                                   unsigned long long * host_flag, unsigned long long host_seq,
+                                   GridView gv = launch_grid())
 {
   extern __shared__ double frag[];
   __shared__ double scratch[4];
   __shared__ double s_x;
   __shared__ unsigned s_status;
   double x = np.x0;                                     // (clamped by the host, as newton() does first)
-  if (blockIdx.x == np.stall_block) return;             // (fault injection: a workgroup that never arrives)
+  if (gv.b == np.stall_block) return;                   // (fault injection: a workgroup that never arrives)
   DerivResident<KS, NB ? NB : 1, NB ? NBR : 1, NB ? 4 : 1> res;
   for (unsigned it = 0; ; ++it)
   {
     double mine;
     if constexpr (NB > 0)
-      mine = deriv_block_totals_resident<KS, SREAL, NB, NBR, 4>(mv, params, np.xscale * x, sumtable, ps, cs, weights, invariant, N, nblk, frag, res, it == 0);
+      mine = deriv_block_totals_resident<KS, SREAL, NB, NBR, 4>(mv, params, np.xscale * x, sumtable, ps, cs, weights, invariant, N, nblk, frag, res, it == 0, gv);
     else
     {
       TrialLengths tl;
 #pragma unroll
       for (unsigned i = 0; i < MAX_TRIAL_LENGTHS; ++i) tl.t[i] = np.xscale * x;
       mine = deriv_block_totals<KS, SREAL>(mv, params, tl, 1u, sumtable, ps, cs, weights, invariant,
-                                           N, nblk, R, rate_scalers, frag);
+                                           N, nblk, R, rate_scalers, frag, gv);
     }
-    const bool last = grid_reduce_finish_lanes<8, true>(mine, ro, scratch);
+    const bool last = grid_reduce_finish_lanes<8, true>(mine, ro, scratch, gv);
     if (newton_step_and_wait(it, last, x, np, ro, ctl, host_out, host_flag, host_seq, &s_x, &s_status) != NEWTON_RUNNING) return;
   }
 }

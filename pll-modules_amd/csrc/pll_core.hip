@@ -3603,6 +3603,101 @@ static bool newton_multi_enabled()
   return on;
 }
 
+// The loop over several partitions as ONE launch (k_newton_multi, kernels_newton_s4.hpp): every partition a run of the
+// launch's workgroups.  -1: not for these partitions (a family without a place in the kernel, a 4-state partition whose
+// table does not fit the registers, grids that do not fit the chip together): the caller tries the other forms.
+static int newton_multi_one_launch(pll_partition_t * const * partitions, unsigned count, int parent_scaler_index,
+                                   int child_scaler_index, const unsigned int * const * params_indices,
+                                   const double * const * sumtables, const double * length_scalers,
+                                   double start, double bl_min, double bl_max, double tolerance, unsigned max_newton,
+                                   double * length, unsigned * iterations, double * trail)
+{
+  static const int enabled = getenv("PLLHIP_NEWTON_ONE_LAUNCH") ? atoi(getenv("PLLHIP_NEWTON_ONE_LAUNCH")) : 1;
+  if (!enabled) return -1;
+  for (unsigned k = 0; k < count; ++k)
+  {
+    const Engine * e = engine_of(partitions[k]);
+    if (e->family != KernelFamily::S4 && e->family != KernelFamily::S20 && e->family != KernelFamily::S61) return -1;
+  }
+  std::vector<NewtonLaunch> L(count);
+  NewtonMultiArgs args;
+  memset(&args, 0, sizeof(args));
+  unsigned total = 0;
+  size_t lds = 0;
+  const int saved_errno = pll_errno;
+  for (unsigned k = 0; k < count; ++k)
+  {
+    // (the streaming form of the matrix-core families: the sumtable of a slice fits the registers of a launch of its
+    // own, not of a shared one)
+    if (!newton_prepare(partitions[k], parent_scaler_index, child_scaler_index, params_indices[k], sumtables[k], false, L[k]))
+    {
+      if (pll_errno != PLLHIP_ERROR_NEWTON_UNSUPPORTED) return PLL_FAILURE;
+      pll_errno = saved_errno;
+      return -1;
+    }
+    Engine * e = L[k].e;
+    NewtonMultiPart & P = args.part[k];
+    P.mv = L[k].mv; P.params = L[k].params; P.sumtable = L[k].d_sum; P.ps = L[k].ps; P.cs = L[k].cs;
+    P.weights = e->d_weights; P.invariant = e->d_invariant;
+    P.ro.block_out = e->d_partials; P.ro.counter = e->d_counter; P.ro.dst = static_cast<NewtonControl *>(e->d_newton)->tot;
+    P.ro.flag = nullptr; P.ro.seq = 0; P.ro.fused = 1; P.ro.nq = 2;
+    P.xscale = length_scalers ? length_scalers[k] : 1.0;
+    P.N = e->N; P.nblk = e->nblk; P.R = e->R; P.rate_scalers = e->rate_scalers ? 1u : 0u;
+    P.kind = e->family == KernelFamily::S4 ? NEWTON_KIND_S4 : e->family == KernelFamily::S20 ? NEWTON_KIND_S20
+           : e->S == S61_S ? NEWTON_KIND_S61 : NEWTON_KIND_S61_RT;
+    P.first_block = total; P.nblocks = L[k].nblocks;
+    total += L[k].nblocks;
+    if (e->family != KernelFamily::S4)
+      lds = std::max(lds, sizeof(double) * e->R * (e->family == KernelFamily::S20 ? 5u : S61_KS) * 64);
+  }
+  Engine * lead = L[0].e;
+  PLLHIP_TRY(hipSetDevice(lead->device));
+  if (lds > 64 * 1024) return -1;
+  // every workgroup waits for the others inside the launch: all of them on the chip at once
+  static int per_cu_cache[2] = {-1, -1};                  // (without / with dynamic LDS beyond 16 KiB)
+  int & per_cu = per_cu_cache[lds > 16 * 1024 ? 1 : 0];
+  if (per_cu < 0 &&
+      !hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_newton_multi), 256,
+                                                          lds > 16 * 1024 ? 64 * 1024 : 16 * 1024), "hipOccupancyMaxActiveBlocksPerMultiprocessor"))
+    return PLL_FAILURE;
+  // (one launch: the dispatcher fills the chip with its workgroups alone, so all of what the chip holds may be asked for
+  // -- as in the loop of a single partition)
+  if (per_cu <= 0 || total > (unsigned)per_cu * lead->cu_count) return -1;
+  args.np = newton_params(start, bl_min, bl_max, tolerance, max_newton, L[0].nblocks);
+  args.np.nparts = count;
+  args.nparts = count;
+  NewtonControl init;
+  memset(&init, 0, sizeof(init));
+  init.x = args.np.x0; init.xl = bl_min; init.xh = bl_max; init.iter = 0; init.status = NEWTON_RUNNING;
+  for (unsigned k = 0; k < count; ++k) init.pscale[k] = args.part[k].xscale;
+  NewtonControl * ctl = static_cast<NewtonControl *>(lead->d_newton);
+  // the launch runs on the first partition's stream: after what the others have issued (their sumtables) ...
+  for (unsigned k = 1; k < count; ++k)
+  {
+    Engine * e = L[k].e;
+    if (e->stream == lead->stream) continue;
+    if (!e->newton_ready) PLLHIP_TRY(hipEventCreateWithFlags(&e->newton_ready, hipEventDisableTiming));
+    PLLHIP_TRY(hipEventRecord(e->newton_ready, e->stream));
+    PLLHIP_TRY(hipStreamWaitEvent(lead->stream, e->newton_ready, 0));
+    // (... and after the instance of an earlier loop of the other form, should there have been one)
+    if (e->newton_done) PLLHIP_TRY(hipStreamWaitEvent(lead->stream, e->newton_done, 0));
+  }
+  PLLHIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, lead->stream));
+  const unsigned long long seq = ++lead->newton_seq;
+  double * host_out = lead->hd_newton;
+  unsigned long long * host_flag = reinterpret_cast<unsigned long long *>(lead->hd_newton + 112);
+  void * kargs[] = {(void *)&args, (void *)&ctl, (void *)&host_out, (void *)&host_flag, (void *)&seq};
+  PLLHIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(k_newton_multi), dim3(total), dim3(256), kargs, lds, lead->stream));
+  std::vector<Engine *> all;
+  for (unsigned k = 0; k < count; ++k) { all.push_back(L[k].e); L[k].e->counters.derivative_calls++; }
+  // ... and what the others issue next comes after it
+  if (!lead->newton_done) PLLHIP_TRY(hipEventCreateWithFlags(&lead->newton_done, hipEventDisableTiming));
+  PLLHIP_TRY(hipEventRecord(lead->newton_done, lead->stream));
+  for (unsigned k = 1; k < count; ++k)
+    if (L[k].e->stream != lead->stream) PLLHIP_TRY(hipStreamWaitEvent(L[k].e->stream, lead->newton_done, 0));
+  return newton_finish(lead, all, seq, length, iterations, trail);
+}
+
 // Several partitions under ONE branch length (linked lengths, or scaled ones: partition p sees s_p x): the loop of
 // pllhip_newton_branch with the sum over the partitions inside it.  Every partition launches its own instance of the
 // loop on its own stream -- its family's kernel on its own scan grid, so its totals are the ones its blocking derivative
@@ -3625,18 +3720,25 @@ int pllhip_newton_branch_multi(pll_partition_t * const * partitions, unsigned in
     set_error(PLLHIP_ERROR_NEWTON_UNSUPPORTED, "1 to %u partitions per device-resident Newton-Raphson loop", NEWTON_MAX_PARTS);
     return PLL_FAILURE;
   }
-  if (!newton_multi_enabled())
-  {
-    set_error(PLLHIP_ERROR_NEWTON_UNSUPPORTED, "the Newton-Raphson loop over several partitions needs a hardware queue per "
-              "partition stream: GPU_MAX_HW_QUEUES >= 8 in the environment before the first HIP call");
-    return PLL_FAILURE;
-  }
   for (unsigned k = 0; k < count; ++k)
     if (!partitions[k] || engine_of(partitions[k])->device != engine_of(partitions[0])->device)
     {
       set_error(PLLHIP_ERROR_NEWTON_UNSUPPORTED, "the partitions of a device-resident Newton-Raphson loop live on one device");
       return PLL_FAILURE;
     }
+  // all partitions in ONE launch where their families have a place in it (4, 20, 33 .. 64 states): no hardware queue
+  // per partition needed
+  {
+    const int rc = newton_multi_one_launch(partitions, count, parent_scaler_index, child_scaler_index, params_indices, sumtables,
+                                           length_scalers, start, bl_min, bl_max, tolerance, max_newton, length, iterations, trail);
+    if (rc >= 0) return rc;
+  }
+  if (!newton_multi_enabled())
+  {
+    set_error(PLLHIP_ERROR_NEWTON_UNSUPPORTED, "the Newton-Raphson loop over these partitions runs as one launch per partition and "
+              "needs a hardware queue per partition stream: GPU_MAX_HW_QUEUES >= 8 in the environment before the first HIP call");
+    return PLL_FAILURE;
+  }
   // (a launch's share = its workgroups / the workgroups of its kernel the chip holds: an upper bound of the resources
   // it takes, so shares that add up to one fit; the margin is for the order in which the dispatcher fills the CUs.
   // A wrong guess costs one bounded wait: PLLHIP_ERROR_NEWTON_STUCK, and the caller's own loop from then on)

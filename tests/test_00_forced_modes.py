@@ -10,9 +10,10 @@ before this process has touched the GPU: the file sorts first):
 Every oracle comparison, golden value and bit-for-bit check of the suite has to hold unchanged; the few asserts that
 count launches or class operations are switched off through tests/common.py (FORCED_*).
 
-A third child runs the tests of the Newton-Raphson loop over several partitions with GPU_MAX_HW_QUEUES=16: the loop needs a
-hardware queue per partition stream, the library leaves the runtime's four alone (pll_core.hip, newton_multi_enabled), and
-the variable has to be there before the process's first HIP call."""
+A third child runs the tests of the Newton-Raphson loop over several partitions in its one-launch-per-partition form
+(PLLHIP_NEWTON_ONE_LAUNCH=0) with GPU_MAX_HW_QUEUES=16: that form needs a hardware queue per partition stream, the library
+leaves the runtime's four alone (pll_core.hip, newton_multi_enabled), and the variable has to be there before the process's
+first HIP call.  (The one-launch form of the 4-, 20- and 33 .. 64-state families runs in the suite itself.)"""
 import os
 import subprocess
 import sys
@@ -44,7 +45,7 @@ def test_newton_loop_over_partitions_with_a_queue_per_stream():
         pytest.skip("already inside a forced-mode run")
     cmd = [sys.executable, "-m", "pytest", "tests/test_eval_driver.py", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
            "-k", "several_partitions or newton_over_partitions"]
-    r = subprocess.run(cmd, cwd=ROOT, env={**os.environ, "GPU_MAX_HW_QUEUES": "16", "PLLHIP_FORCED_CHILD": "1"},
+    r = subprocess.run(cmd, cwd=ROOT, env={**os.environ, "GPU_MAX_HW_QUEUES": "16", "PLLHIP_NEWTON_ONE_LAUNCH": "0", "PLLHIP_FORCED_CHILD": "1"},
                        capture_output=True, text=True, timeout=600)
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):

@@ -476,11 +476,13 @@ def test_device_newton_makes_the_host_loop_s_iterates(product, states, nsites, p
         a.free_sumtable(st)
 
 
-def _needs_a_queue_per_stream():
-    """the loop over several partitions runs only in a process that gave every partition stream a hardware queue of its
-    own before its first HIP call (pll_core.hip, newton_multi_enabled): tests/test_00_forced_modes.py runs these tests in
-    such a child process"""
-    if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8:
+def _needs_a_queue_per_stream(states=()):
+    """Partitions of 4, 20 and 33 .. 64 states run the loop over several partitions in ONE launch (k_newton_multi).  Any
+    other mix runs one launch per partition, and those only in a process that gave every partition stream a hardware
+    queue of its own before its first HIP call (pll_core.hip, newton_multi_enabled): tests/test_00_forced_modes.py runs
+    these tests once more in such a child process, with the one-launch form switched off"""
+    one_launch = os.environ.get("PLLHIP_NEWTON_ONE_LAUNCH", "1") != "0" and all(s == 4 or s == 20 or 33 <= s <= 64 for s in states)
+    if not one_launch and int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8:
         pytest.skip("GPU_MAX_HW_QUEUES >= 8 needed before the first HIP call (run by tests/test_00_forced_modes.py)")
 
 
@@ -513,13 +515,14 @@ def test_device_newton_with_a_capped_reduction_grid(blocks):
     ([(4, 6000), (4, 2500), (20, 1500), (20, 900)], None),                 # C4's mix: two kernel families in one loop
     ([(4, 6000), (4, 2500), (20, 1500), (20, 900)], [1.0, 0.7, 1.9, 1.2]),   # scaled branch lengths: chain rule s, s^2
     ([(61, 300), (20, 800), (10, 1200), (4, 50_000)], [0.8, 1.0, 1.3, 1.1]),
+    ([(61, 300), (20, 800), (62, 200), (4, 50_000)], [0.8, 1.0, 1.3, 1.1]),         # every family of the one-launch form
     ([(20, 60_000), (20, 50_000)], None),                                   # register-resident instances side by side
 ])
 def test_device_newton_over_several_partitions(product, spec, scalers):
     """pllhip_newton_branch_multi: partitions that share a branch length run ONE loop on the device; every iterate is
     the host loop's -- f = sum s_p f_p(s_p x), f' = sum s_p^2 f'_p(s_p x) added in partition order
     (src/optimize/pll_optimize.c:1223-1287) -- bit for bit"""
-    _needs_a_queue_per_stream()
+    _needs_a_queue_per_stream([s_ for s_, _ in spec])
     tree = pc.Tree(9, 42, 43)
     insts = [pc.build_instance(product, states=s_, rate_cats=4, ntips=9, nsites=n_, coded=True, tree=tree, seed_shift=k)
              for k, (s_, n_) in enumerate(spec)]
@@ -571,7 +574,7 @@ def test_device_newton_over_several_partitions(product, spec, scalers):
 def test_driver_with_device_newton_over_partitions(product, linkage):
     """pllhip_eval_optimize_branches over C4's mix of partitions (linked, and scaled branch lengths): the device loop
     and the host loop give the same tree, the same lnL and the same number of Newton iterations"""
-    _needs_a_queue_per_stream()
+    _needs_a_queue_per_stream([4, 20])
     tree = pc.Tree(12, 42, 43)
     out, launches = [], []
     for flag in ("0", "1"):

@@ -203,10 +203,8 @@ def blo_c4(lib, out, nsites=None):
                               "newton_iterations": n1 - n0, "single_op_updates": ops1 - ops0,
                               "pmatrix_updates": pm1 - pm0, "branches": t.nedges, "partitions": len(parts),
                               "us_per_derivative_call_incl_everything": dt / max(1, n1 - n0) * 1e6,
-                              # (the loop over several partitions runs on the device only in a process that asked the
-                              # runtime for a hardware queue per partition stream: pll_core.hip, newton_multi_enabled)
-                              "device_newton": os.environ.get("PLLHIP_EVAL_DEVICE_NEWTON", "1") != "0" and
-                                               int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) >= 8,
+                              # (4- and 20-state partitions: the loop over all of them in one launch, k_newton_multi)
+                              "device_newton": os.environ.get("PLLHIP_EVAL_DEVICE_NEWTON", "1") != "0",
                               "what": "pllhip_eval_optimize_branches(iters=1, radius=ALL) over four partitions with linked "
                                       "branch lengths; a derivative call = one Newton-Raphson iterate of all partitions"}
 
