@@ -298,3 +298,32 @@ def test_site_repeats_with_ascertainment_bias(product, oracle, states, coded):
             out.append(res)
     _same(out[0], out[1])
     _close_to_oracle(out[0], out[2], nsites, states)
+
+
+@pytest.mark.parametrize("coded", [True, False])
+def test_site_repeats_in_a_partition_spread_over_engines(product, oracle, coded):
+    """engine-internal sharding (pllhip_set_sharding: one pll_partition_t, one engine per contiguous range of sites -- all
+    on device 0 here): every shard keeps its own classes (the tips' classes reach the shards through the router:
+    upload_tip_classes), the sums are those of the unsharded partition without the attribute"""
+    L = product.lib
+    tree = pc.Tree(24, 42, 43)
+    nsites = 9000
+    codes = pc.simulated_codes(tree, nsites, 4, seed=45)
+    kw = dict(states=4, rate_cats=4, ntips=24, nsites=nsites, coded=coded, tree=tree, codes=codes)
+    plain = pc.build_instance(product, **kw)
+    ref = pc.build_instance(oracle, **kw)
+    assert L.pllhip_set_sharding(3, None)
+    try:
+        shard = pc.build_instance(product, attributes=pc.PLL_ATTRIB_SITE_REPEATS, **kw)
+    finally:
+        assert L.pllhip_set_sharding(0, None)
+    with plain, shard, ref:
+        assert L.pllhip_shard_count(shard.p) == 3
+        for inst in (plain, shard, ref):
+            inst.tree = tree
+        a, b, c = pc.full_traversal(shard), pc.full_traversal(plain), pc.full_traversal(ref)
+        assert lnl_close(a, b, nsites, 4) and lnl_close(a, c, nsites, 4)
+        for op in tree.ops[::4]:
+            assert np.array_equal(shard.get_clv(op[0]), plain.get_clv(op[0]))
+            assert np.array_equal(shard.get_scaler(op[1]), plain.get_scaler(op[1]))
+        assert shard.repeat_stats().cherries > 0
