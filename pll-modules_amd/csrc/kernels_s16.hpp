@@ -24,7 +24,10 @@
 
 namespace pllhip {
 
-constexpr unsigned S16_LUT_LDS = 3072;       // doubles of LDS a tip lookup table may take per child
+// doubles of LDS a tip lookup table may take per child (28 states x 36 codes x 4 rates, 32 x 36 x 4: beyond it the rows
+// are gathered from memory -- which cost the 28- and 32-state alphabets, half of whose operands are tips, a fifth of
+// their rate while the limit was 3072)
+constexpr unsigned S16_LUT_LDS = 4608;
 constexpr int S16_MAX_LDS_BYTES = 160 * 1024 - 512;   // dynamic LDS a kernel of the family may ask for (it has a few static words)
 
 constexpr unsigned s16_mt(unsigned KS) { return (KS + 3) / 4; }            // 16-row M tiles
@@ -111,6 +114,23 @@ __device__ inline void s16_child_inner(const double * unit, const double * frag_
   s16_child_regs<KS>(b, frag_r, lane, t);
 }
 
+// the B operand of a unit in memory
+template <unsigned KS>
+__device__ inline void s16_load_b(const double * unit, unsigned lane, double2 b[KS], bool nt)
+{
+  typedef double nt_v2d __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (unsigned ks = 0; ks < KS; ++ks)
+  {
+    if (nt)
+    {
+      const nt_v2d w = __builtin_nontemporal_load(reinterpret_cast<const nt_v2d *>(unit + ks * 128 + lane * 2));
+      b[ks] = make_double2(w.x, w.y);
+    }
+    else b[ks] = *reinterpret_cast<const double2 *>(unit + ks * 128 + lane * 2);
+  }
+}
+
 // lookup table rows [code][S]
 template <unsigned KS>
 __device__ inline void s16_child_tip(const double * lut_r, unsigned code_e, unsigned code_o, unsigned q,
@@ -171,9 +191,11 @@ __device__ inline void s16_store_d(double * unit, unsigned lane, const double2 t
 // per child R * KS * 64 doubles of A fragments, or its tip lookup table when that fits
 // ---------------------------------------------------------------------------
 template <unsigned KS>
-__global__ __launch_bounds__(256) void k_partials_s16(OpBatch batch, unsigned nblk, unsigned R, unsigned S,
+// nt: vectors are read and written past the caches (a traversal: written once, read -- if at all -- by a later launch;
+// not the sumtable, which the derivative scans read next)
+__global__ __launch_bounds__(256, 2) void k_partials_s16(OpBatch batch, unsigned nblk, unsigned R, unsigned S,
                                                       unsigned Sp, unsigned lut_codes, unsigned table,
-                                                      unsigned rate_scalers)
+                                                      unsigned rate_scalers, unsigned nt)
 {
   extern __shared__ double lds[];
   constexpr unsigned UNIT = 4 * KS * S20_BS;
@@ -201,14 +223,44 @@ __global__ __launch_bounds__(256) void k_partials_s16(OpBatch batch, unsigned nb
     if (op.codes1) { c1e = op.codes1[site0]; c1o = op.codes1[site0 + 1]; }
     if (op.codes2) { c2e = op.codes2[site0]; c2o = op.codes2[site0 + 1]; }
     int small_e = 1, small_o = 1;
+    // From 17 states (two row tiles: 2 x KS MFMAs per child and site parity, 3 us of matrix time per unit and wave at 32
+    // states) the operands of the next rate are requested before the products of this one are started: with two waves
+    // per SIMD -- the tables of 32 states fill the LDS of a CU with two workgroups -- nothing else keeps loads in flight
+    // while both of them multiply
+    constexpr bool AHEAD = KS >= 5;
+    double2 b1[AHEAD ? KS : 1], b2[AHEAD ? KS : 1];
+    if (AHEAD)
+    {
+      if (!op.codes1) s16_load_b<KS>(op.clv1 + (size_t)blk * R * UNIT, lane, b1, nt != 0);
+      if (!op.codes2) s16_load_b<KS>(op.clv2 + (size_t)blk * R * UNIT, lane, b2, nt != 0);
+    }
     for (unsigned r = 0; r < R; ++r)
     {
       const size_t ubase = ((size_t)blk * R + r) * UNIT;
       double2 t1[KS], t2[KS];
-      if (!op.codes1) s16_child_inner<KS>(op.clv1 + ubase, tab1 + r * s16_fr(KS), lane, t1);
-      else s16_child_tip<KS>(l1 + (size_t)r * lut_codes * S, c1e, c1o, q, S, t1);
-      if (!op.codes2) s16_child_inner<KS>(op.clv2 + ubase, tab2 + r * s16_fr(KS), lane, t2);
-      else s16_child_tip<KS>(l2 + (size_t)r * lut_codes * S, c2e, c2o, q, S, t2);
+      if (AHEAD)
+      {
+        double2 n1[KS], n2[KS];
+        const bool more = r + 1 < R;
+        if (more && !op.codes1) s16_load_b<KS>(op.clv1 + ubase + UNIT, lane, n1, nt != 0);
+        if (more && !op.codes2) s16_load_b<KS>(op.clv2 + ubase + UNIT, lane, n2, nt != 0);
+        if (!op.codes1) s16_child_regs<KS>(b1, tab1 + r * s16_fr(KS), lane, t1);
+        else s16_child_tip<KS>(l1 + (size_t)r * lut_codes * S, c1e, c1o, q, S, t1);
+        if (!op.codes2) s16_child_regs<KS>(b2, tab2 + r * s16_fr(KS), lane, t2);
+        else s16_child_tip<KS>(l2 + (size_t)r * lut_codes * S, c2e, c2o, q, S, t2);
+        if (more)
+        {
+#pragma unroll
+          for (unsigned v = 0; v < KS; ++v) { b1[v] = n1[v]; b2[v] = n2[v]; }
+        }
+      }
+      else
+      {
+        if (!op.codes1) s16_child_inner<KS>(op.clv1 + ubase, tab1 + r * s16_fr(KS), lane, t1, nt != 0);
+        else s16_child_tip<KS>(l1 + (size_t)r * lut_codes * S, c1e, c1o, q, S, t1);
+        if (!op.codes2) s16_child_inner<KS>(op.clv2 + ubase, tab2 + r * s16_fr(KS), lane, t2, nt != 0);
+        else s16_child_tip<KS>(l2 + (size_t)r * lut_codes * S, c2e, c2o, q, S, t2);
+      }
       int re = 1, ro = 1;
 #pragma unroll
       for (unsigned v = 0; v < KS; ++v)
@@ -238,7 +290,7 @@ __global__ __launch_bounds__(256) void k_partials_s16(OpBatch batch, unsigned nb
       }
       small_e &= re;
       small_o &= ro;
-      s16_store_d<KS>(op.parent + ubase, lane, t1);
+      if (nt) s16_store_d_nt<KS>(op.parent + ubase, lane, t1); else s16_store_d<KS>(op.parent + ubase, lane, t1);
     }
     if (scaling && !rate_scalers)
     {
@@ -656,13 +708,15 @@ static int s16_allow_lds(Engine * e)
   return PLL_SUCCESS;
 }
 
-static int launch_partials_s16(Engine * e, const OpBatch & batch, unsigned nops)
+static int launch_partials_s16(Engine * e, const OpBatch & batch, unsigned nops, bool traversal = true)
 {
+  static const int env_nt = getenv("PLLHIP_S16_NT") ? atoi(getenv("PLLHIP_S16_NT")) : 2;
+  const unsigned nt = traversal && env_nt ? 1u : 0u;
   const unsigned table = s16_table(e);
   if (sizeof(double) * 2 * table > 64 * 1024 && !s16_allow_lds(e)) return PLL_FAILURE;
 #define PLLHIP_CALL(KK) \
   hipLaunchKernelGGL(k_partials_s16<KK>, dim3(s16_grid(e, 8), nops), dim3(256), sizeof(double) * 2 * table, e->stream, \
-                     batch, e->nblk, e->R, e->S, e->Sp, e->lut_codes, table, e->rate_scalers ? 1u : 0u)
+                     batch, e->nblk, e->R, e->S, e->Sp, e->lut_codes, table, e->rate_scalers ? 1u : 0u, nt)
   PLLHIP_DISPATCH_KS(s16_ks(e), PLLHIP_CALL);
 #undef PLLHIP_CALL
   PLLHIP_TRY(hipGetLastError());
@@ -675,9 +729,13 @@ static int launch_partials_s16(Engine * e, const OpBatch & batch, unsigned nops)
 // store-unscaled-and-fix-up kernel is the faster form at 32 states (500 k sites, 50 taxa: 12.8 against 14.7 ms;
 // 24 / 28 states: chains 6.4 / 10.1 against 8.0 / 12.8 ms).  Per-rate scalers settle a rate at a time: no limit.
 // PLLHIP_S16_CHAIN_KS: largest KS = ceil(S / 4) that takes chains with per-site scaling.)
+// (Round 4, with the tip tables of 28 and 32 states in LDS and the operands of the next rate requested ahead in the
+// level-schedule kernel: 28 states 8.7 ms by levels against 9.7 in chains -- chains up to 24 states now, and up to 28 for a
+// partition that asks for site repeats, which live in the chain schedule.)
 static bool chains_supported_s16(const Engine * e)
 {
-  static const unsigned max_ks = getenv("PLLHIP_S16_CHAIN_KS") ? (unsigned)atoi(getenv("PLLHIP_S16_CHAIN_KS")) : 7u;
+  static const unsigned env_ks = getenv("PLLHIP_S16_CHAIN_KS") ? (unsigned)atoi(getenv("PLLHIP_S16_CHAIN_KS")) : 0u;
+  const unsigned max_ks = env_ks ? env_ks : (e->site_repeats ? 7u : 6u);
   return e->R == 4 && (e->rate_scalers || (e->S + 3) / 4 <= max_ks);
 }
 
@@ -781,7 +839,7 @@ static int launch_sumtable_s16(Engine * e, const ModelView & mv, const ParamIdx 
   d.scaler1 = d.scaler2 = nullptr;
   d.parent = d_sum;
   d.parent_scaler = nullptr;
-  return launch_partials_s16(e, batch, 1);
+  return launch_partials_s16(e, batch, 1, false);
 }
 
 static int launch_derivatives_s16(Engine * e, const ModelView & mv, const ParamIdx & params,

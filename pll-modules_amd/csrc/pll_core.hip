@@ -777,6 +777,8 @@ static int ensure_luts(pll_partition_t * p)
     unsigned cap = std::min<unsigned>(PLL_ASCII_SIZE, std::max(want, (e->S == 4) ? 16u : want + 8u));
     if (e->family == KernelFamily::S61 && want <= S61_FRAGS / e->S) cap = std::min(cap, S61_FRAGS / e->S);   // 67 at 61 states
     if (e->family == KernelFamily::S20 && want <= 30u) cap = std::min(cap, 30u);
+    // (2 .. 32 states: ... nor past what the family stages in LDS, S16_LUT_LDS doubles per table, while the codes in use fit)
+    if (e->family == KernelFamily::S16 && e->R * want * e->S <= S16_LUT_LDS) cap = std::min(cap, std::max(want, S16_LUT_LDS / (e->R * e->S)));
     if (e->d_lut) { PLLHIP_TRY(hipStreamSynchronize(e->stream)); (void)hipFree(e->d_lut); e->d_lut = nullptr; }
     e->plan.key.clear();                            // cached schedules point into the old tables
     if (!dev_alloc(&e->d_lut, (size_t)e->nmat * e->R * cap * e->S, "tip lookup tables")) return PLL_FAILURE;
