@@ -176,6 +176,12 @@ struct Engine
   // tip codes) and expanded to the site-indexed vector only for a reader that needs it
   bool site_repeats = false;
   bool tip_classes = false;           // tips that are vectors are kept per class of sites as well (upload_tip_classes)
+  // 33 .. 64 states without PLL_ATTRIB_PATTERN_TIP: tips given through pll_set_tip_states keep byte codes next to their
+  // vectors (a code table of the engine's own: the state masks met so far), and the operations above them read them
+  // as coded tips -- lookup tables instead of a 64 x 64 matrix product per site and rate (upload_tip_classes)
+  bool shadow_codes = false;
+  std::vector<unsigned long long> shadow_tipmap;
+  std::vector<char> tip_has_codes;    // the tip's codes are those of its vector (not after pll_set_tip_clv / pllhip_set_clv)
   struct Cherry                       // a node known per class of sites (a cherry, or a node above class nodes / tips)
   {
     bool valid = false;               // the node's vector IS this table (nothing has overwritten it since)

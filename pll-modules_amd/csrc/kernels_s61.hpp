@@ -1085,7 +1085,7 @@ static bool s61_cherries_supported(const Engine * e)
 {
   static const int env = getenv("PLLHIP_S61_CHERRIES") ? atoi(getenv("PLLHIP_S61_CHERRIES")) : 1;
   // (per-rate scalers are carried as well: C5 --rate-scalers 8.93 -> 7.86 ms)
-  return env && e->coded_tips && s61_rate_parallel(e) && e->lut_codes * e->S <= S61_FRAGS && e->R <= 8;
+  return env && (e->coded_tips || e->shadow_codes) && s61_rate_parallel(e) && e->lut_codes * e->S <= S61_FRAGS && e->R <= 8;
 }
 
 // last scaling decisions per parent vector, double-buffered (the fix-up kernel reads the

@@ -63,6 +63,17 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
 static int transient_materialize(Engine * e, const std::vector<unsigned> & want);
 static int transient_flush_all(Engine * e);
 static bool cherry_storage(Engine * e, unsigned node, unsigned nclasses);
+// tip lookup tables exist: PLL_ATTRIB_PATTERN_TIP, or the engine's own codes (Engine::shadow_codes)
+static bool lut_active(const Engine * e) { return e->coded_tips || e->shadow_codes; }
+static unsigned codes_in_use(const Engine * e, const pll_partition_t * p)
+{
+  return e->shadow_codes ? (unsigned)e->shadow_tipmap.size() : p->maxstates;
+}
+// the operations above tip `idx` read it through byte codes and lookup tables
+static bool tip_coded(const Engine * e, unsigned idx)
+{
+  return idx < e->tips && (e->coded_tips || (e->shadow_codes && e->tip_has_codes[idx]));
+}
 static void batch_free(BatchPlan * b);
 static void batch_free_hook(BatchPlan * b) { batch_free(b); }
 
@@ -227,6 +238,7 @@ Engine * engine_create(pll_partition_t * p)
   e->tips = p->tips; e->nodes = p->nodes; e->nscalers = p->scale_buffers;
   e->nmat = p->prob_matrices; e->nrm = p->rate_matrices;
   e->coded_tips = (p->attributes & PLL_ATTRIB_PATTERN_TIP) != 0;
+  e->tip_has_codes.assign(p->tips, 0);
   e->rate_scalers = (p->attributes & PLL_ATTRIB_RATE_SCALERS) != 0;
   // PLLHIP_SITE_REPEATS=0: never; =2: as if every partition had the attribute (the whole test suite under site repeats)
   const int env_repeats = getenv("PLLHIP_SITE_REPEATS") ? atoi(getenv("PLLHIP_SITE_REPEATS")) : 1;
@@ -252,6 +264,9 @@ Engine * engine_create(pll_partition_t * p)
   else if (s16_supported(e->S, e->R) && !no_s16) e->family = KernelFamily::S16;
   else e->family = KernelFamily::Generic;
   e->blocked = (e->family == KernelFamily::S20 || e->family == KernelFamily::S61 || e->family == KernelFamily::S16);
+  // (PLLHIP_TIP_CLASSES=0: tips of partitions without pattern tips as vectors only)
+  e->shadow_codes = e->family == KernelFamily::S61 && !e->coded_tips && p->asc_bias_alloc == 0 &&
+                    !(getenv("PLLHIP_TIP_CLASSES") && atoi(getenv("PLLHIP_TIP_CLASSES")) == 0);
   e->rows = !e->blocked ? 0u : (e->family == KernelFamily::S16) ? 4u * ((e->S + 3u) / 4u)
                                : (e->family == KernelFamily::S61) ? S61_SP : e->Sp;
   e->nblk = (e->N + S20_BS - 1) / S20_BS;
@@ -266,6 +281,10 @@ Engine * engine_create(pll_partition_t * p)
   e->d_codes.assign(e->tips, nullptr);
   for (unsigned i = 0; ok && i < e->nodes; ++i)
   {
+    // (33 .. 64 states without pattern tips: codes of the engine's own next to the vector)
+    if (i < e->tips && e->shadow_codes)
+      ok = dev_alloc(&e->d_codes[i], (size_t)e->Nalloc, "tip codes") &&
+           hip_ok(hipMemsetAsync(e->d_codes[i], 0, e->Nalloc ? e->Nalloc : 1, e->stream), "memset codes");
     if (i < e->tips && e->coded_tips)
       ok = dev_alloc(&e->d_codes[i], (size_t)e->Nalloc, "tip codes") &&
            hip_ok(hipMemsetAsync(e->d_codes[i], 0, e->Nalloc ? e->Nalloc : 1, e->stream), "memset codes");
@@ -462,10 +481,18 @@ int upload_weights(pll_partition_t * p)
 static int upload_tipmap(pll_partition_t * p)
 {
   Engine * e = engine_of(p);
-  if (!e->coded_tips || e->tipmap_codes_uploaded == p->maxstates) return PLL_SUCCESS;
-  PLLHIP_TRY(hipMemcpyAsync(e->d_tipmap, p->tipmap, PLL_ASCII_SIZE * sizeof(unsigned long long),
-                            hipMemcpyHostToDevice, e->stream));
-  e->tipmap_codes_uploaded = p->maxstates;
+  if (!lut_active(e) || e->tipmap_codes_uploaded == codes_in_use(e, p)) return PLL_SUCCESS;
+  if (e->shadow_codes)
+  {
+    std::vector<unsigned long long> tm(PLL_ASCII_SIZE, 0ULL);
+    std::copy(e->shadow_tipmap.begin(), e->shadow_tipmap.end(), tm.begin());
+    PLLHIP_TRY(hipMemcpyAsync(e->d_tipmap, tm.data(), PLL_ASCII_SIZE * sizeof(unsigned long long), hipMemcpyHostToDevice, e->stream));
+    PLLHIP_TRY(hipStreamSynchronize(e->stream));               // (a local source)
+  }
+  else
+    PLLHIP_TRY(hipMemcpyAsync(e->d_tipmap, p->tipmap, PLL_ASCII_SIZE * sizeof(unsigned long long),
+                              hipMemcpyHostToDevice, e->stream));
+  e->tipmap_codes_uploaded = codes_in_use(e, p);
   return PLL_SUCCESS;
 }
 
@@ -556,6 +583,7 @@ int upload_tip_clv(pll_partition_t * p, unsigned tip, const double * host_clv)
   }
   PLLHIP_TRY(hipSetDevice(e->device));
   if (!transient_flush_all(e)) return PLL_FAILURE;
+  if (e->shadow_codes) e->tip_has_codes[tip] = 0;               // (pll_set_tip_states brings the codes afterwards)
   if (!e->cherries.empty())
   {
     // whatever classes the tip had are not those of the new vector (pll_set_tip_states tells them afterwards)
@@ -581,6 +609,31 @@ int upload_tip_classes(pll_partition_t * p, unsigned tip, const unsigned * site_
     for (size_t k = 0; k < e->shards.size(); ++k)
       if (!upload_tip_classes(e->shards[k], tip, site_class + e->shard_first[k], masks, nclasses)) return PLL_FAILURE;
     return PLL_SUCCESS;
+  }
+  if (e->shadow_codes && nclasses && e->N)
+  {
+    // 33 .. 64 states: the tip's classes become codes of the engine's own table (the state masks met so far, all tips)
+    PLLHIP_TRY(hipSetDevice(e->device));
+    std::vector<unsigned> code_of(nclasses, 0u);
+    const size_t before = e->shadow_tipmap.size();
+    for (unsigned k = 0; k < nclasses; ++k)
+    {
+      size_t c = 0;
+      for (; c < e->shadow_tipmap.size(); ++c) if (e->shadow_tipmap[c] == masks[k]) break;
+      if (c == e->shadow_tipmap.size())
+      {
+        if (c >= 255) { e->shadow_tipmap.resize(before); return PLL_SUCCESS; }    // (too many codes: the tip stays a vector)
+        e->shadow_tipmap.push_back(masks[k]);
+      }
+      code_of[k] = (unsigned)c;
+    }
+    std::vector<uint8_t> codes(e->Nalloc, 0);
+    for (unsigned n = 0; n < e->N; ++n) codes[n] = (uint8_t)code_of[site_class[n] < nclasses ? site_class[n] : 0u];
+    PLLHIP_TRY(hipMemcpyAsync(e->d_codes[tip], codes.data(), codes.size(), hipMemcpyHostToDevice, e->stream));
+    PLLHIP_TRY(hipStreamSynchronize(e->stream));
+    e->tip_has_codes[tip] = 1;
+    if (e->shadow_tipmap.size() != before) { e->lut_stale = true; e->plan.key.clear(); }
+    return upload_tipmap(p);
   }
   if (e->coded_tips || e->cherries.empty() || !nclasses || !e->N) return PLL_SUCCESS;
   PLLHIP_TRY(hipSetDevice(e->device));
@@ -702,10 +755,10 @@ int flush_pmatrices(pll_partition_t * p)
         if (!transient_flush_all(e)) return PLL_FAILURE;
         break;
       }
-  if (e->coded_tips)
+  if (lut_active(e))
   {
     // LUT storage must exist so that the kernel can fill it in the same pass
-    const bool stale = e->lut_stale || !e->d_lut || e->lut_codes < std::max(1u, p->maxstates);
+    const bool stale = e->lut_stale || !e->d_lut || e->lut_codes < std::max(1u, codes_in_use(e, p));
     if (stale && !ensure_luts(p)) return PLL_FAILURE;
   }
   const ModelView mv = model_view(e);
@@ -726,7 +779,7 @@ int flush_pmatrices(pll_partition_t * p)
     }
     hipLaunchKernelGGL(k_pmatrix, dim3(nb, e->R), dim3(256), lds, e->stream,
                        mv, e->pend_params, batch, e->R, e->d_pmat,
-                       e->coded_tips ? e->d_lut : nullptr, e->lut_codes, e->d_tipmap, staged, e->d_pfrag);
+                       lut_active(e) ? e->d_lut : nullptr, e->lut_codes, e->d_tipmap, staged, e->d_pfrag);
     PLLHIP_TRY(hipGetLastError());
     e->counters.pmatrix_launches++;
   }
@@ -767,9 +820,9 @@ static ParamIdx make_params(const pll_partition_t * p, const unsigned * idx)
 static int ensure_luts(pll_partition_t * p)
 {
   Engine * e = engine_of(p);
-  if (!e->coded_tips) return PLL_SUCCESS;
+  if (!lut_active(e)) return PLL_SUCCESS;
   if (!upload_tipmap(p)) return PLL_FAILURE;
-  const unsigned want = std::max(1u, p->maxstates);
+  const unsigned want = std::max(1u, codes_in_use(e, p));
   if (!e->d_lut || e->lut_codes < want)
   {
     // grow with head-room so that a few late codes do not re-allocate
@@ -816,7 +869,9 @@ static NodeRef node_ref(const Engine * e, unsigned clv_index)
 {
   NodeRef n;
   n.clv = e->d_clv[clv_index];
-  n.codes = (clv_index < e->tips) ? e->d_codes[clv_index] : nullptr;
+  // (the engine's own codes of a tip without PLL_ATTRIB_PATTERN_TIP serve the operations above it only: a reader of the
+  // tip itself takes the vector)
+  n.codes = (e->coded_tips && clv_index < e->tips) ? e->d_codes[clv_index] : nullptr;
   return n;
 }
 
@@ -1535,8 +1590,8 @@ static void fill_desc(const Engine * e, const pll_operation_t & op, OpDesc & d, 
 {
   const size_t pm_stride = (size_t)e->R * e->S * e->Sp;
   const size_t lut_stride = (size_t)e->R * e->lut_codes * e->S;
-  const bool t1 = e->coded_tips && op.child1_clv_index < e->tips;
-  const bool t2 = e->coded_tips && op.child2_clv_index < e->tips;
+  const bool t1 = tip_coded(e, op.child1_clv_index);
+  const bool t2 = tip_coded(e, op.child2_clv_index);
   d.clv1 = t1 ? nullptr : e->d_clv[op.child1_clv_index];
   d.codes1 = t1 ? e->d_codes[op.child1_clv_index] : nullptr;
   d.pmat1 = e->d_pmat + pm_stride * op.child1_matrix_index;
@@ -1575,7 +1630,7 @@ static bool prepare_schedule(Engine * e, const pll_partition_t * p, const pll_op
 {
   const bool chains20 = e->family == KernelFamily::S20, chains16 = e->family == KernelFamily::S16;
   const bool chains4 = e->family == KernelFamily::S4;
-  const unsigned lut_used = std::max(1u, std::min(p->maxstates, e->lut_codes));
+  const unsigned lut_used = std::max(1u, std::min(codes_in_use(e, p), e->lut_codes));
   const unsigned chain_max = chains20 ? S20_CHAIN_MAX : chains16 ? S16_CHAIN_MAX : S4_CHAIN_MAX;
   const unsigned chain_lds = chains20 ? S20_CHAIN_LDS : chains16 ? S16_CHAIN_LDS : ~0u;
   DevicePlan & dp = e->plan;
@@ -2042,6 +2097,9 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
   // up, the ones it reads are stored with the matrices they were made with; a list that stores such vectors -- 
   // transient_busy -- runs on the matrices the device holds)
   if (!transient_before_list(e, ops, count)) return PLL_FAILURE;
+  if (e->shadow_codes)
+    for (unsigned k = 0; k < count; ++k)
+      if (ops[k].parent_clv_index < e->tips) e->tip_has_codes[ops[k].parent_clv_index] = 0;    // (a tip vector is overwritten)
   if ((!e->transient_busy && !flush_pmatrices(p)) || !ensure_luts(p)) return PLL_FAILURE;
 
   // dependency levels: an op runs after the producers of its children and
@@ -2149,7 +2207,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
   {
     ChainPlan plan;
     // tip tables are staged with the codes in use (at least one: an untouched partition)
-    const unsigned lut_used = std::max(1u, std::min(p->maxstates, e->lut_codes));
+    const unsigned lut_used = std::max(1u, std::min(codes_in_use(e, p), e->lut_codes));
     // PLLHIP_TRAVERSE=1 / 0: whole traversals always / never in one launch (default: by size, below; never
     // when several partitions share the device, each on its own stream: long-lived workgroups with a fixed
     // share of the sites interleave worse than rounds -- two DNA + two protein partitions: 7.7 against 7.1 ms).
@@ -2367,7 +2425,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
   std::vector<int> cherry_of(count, -1);          // consumer -> the cherry folded into it
   std::vector<const uint8_t *> cherry_table(count, nullptr);
   bool folding = false;
-  if (e->family == KernelFamily::S61 && e->coded_tips && count >= 2)
+  if (e->family == KernelFamily::S61 && lut_active(e) && count >= 2)
   {
     ChainPlan shape;
     if (plan_chains(e, ops, count, 1, ~0u, 1u, shape))
@@ -2381,7 +2439,7 @@ static int update_partials_impl(pll_partition_t * p, const pll_operation_t * ops
         if (prod2[k] >= 0) consumer[prod2[k]] = (int)k;
         producer[ops[k].parent_clv_index] = (int)k;
       }
-      auto is_cherry = [&](unsigned k) { return ops[k].child1_clv_index < e->tips && ops[k].child2_clv_index < e->tips; };
+      auto is_cherry = [&](unsigned k) { return tip_coded(e, ops[k].child1_clv_index) && tip_coded(e, ops[k].child2_clv_index); };
       std::vector<char> folded(count, 0);
       if (s61_cherries_supported(e))
       {
@@ -3883,7 +3941,7 @@ int pll_update_invariant_sites(pll_partition_t * p)
   // device tables of tip pointers
   std::vector<const double *> h_clv(e->tips ? e->tips : 1, nullptr);
   std::vector<const uint8_t *> h_codes(e->tips ? e->tips : 1, nullptr);
-  for (unsigned t = 0; t < e->tips; ++t) { h_clv[t] = e->d_clv[t]; h_codes[t] = e->d_codes[t]; }
+  for (unsigned t = 0; t < e->tips; ++t) { h_clv[t] = e->d_clv[t]; h_codes[t] = e->coded_tips ? e->d_codes[t] : nullptr; }
   const double ** d_tc = nullptr;
   const uint8_t ** d_tk = nullptr;
   if (!dev_alloc(&d_tc, h_clv.size(), "tip table") || !dev_alloc(&d_tk, h_codes.size(), "tip table"))
@@ -4043,6 +4101,7 @@ int pllhip_set_clv(pll_partition_t * p, unsigned int clv_index, const double * c
     return PLL_FAILURE;
   }
   if (!transient_flush_all(e)) return PLL_FAILURE;            // (vectors that were not stored may read this one)
+  if (e->shadow_codes && clv_index < e->tips) e->tip_has_codes[clv_index] = 0;
   if (!e->cherries.empty())
   {
     e->cherries[clv_index].valid = false;

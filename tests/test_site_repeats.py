@@ -327,3 +327,45 @@ def test_site_repeats_in_a_partition_spread_over_engines(product, oracle, coded)
             assert np.array_equal(shard.get_clv(op[0]), plain.get_clv(op[0]))
             assert np.array_equal(shard.get_scaler(op[1]), plain.get_scaler(op[1]))
         assert shard.repeat_stats().cherries > 0
+
+
+@pytest.mark.parametrize("states", [61, 48, 20, 4])
+def test_tips_of_partitions_without_pattern_tips(product, oracle, states):
+    """Without PLL_ATTRIB_PATTERN_TIP a tip set through pll_set_tip_states is kept per class of sites next to its vector
+    (4 / 20 / 2 .. 32 states: wide tips; 33 .. 64 states: byte codes of the engine's own and the family's lookup
+    tables), one set through pll_set_tip_clv is a plain vector -- and a tip that changes from one to the other and back
+    is read the right way every time: the oracle's lnL, vectors and scaler counts after every change"""
+    nsites = 1200 if states <= 20 else 400
+    tree = pc.Tree(14, 42, 43)
+    insts = [pc.build_instance(lib, states=states, rate_cats=4, ntips=14, nsites=nsites, coded=False, tree=tree)
+             for lib in (product, oracle)]
+    with insts[0] as a, insts[1] as b:
+        def same():
+            la, lb = pc.full_traversal(a), pc.full_traversal(b)
+            assert lnl_close(la, lb, nsites, states), (la, lb)
+            for op in tree.ops[::3]:
+                # (33 .. 64 states: the tolerance of the codon P-matrices, tests/test_gpu_parity.py CLV_SITE_61)
+                assert site_err(a.get_clv(op[0]), b.get_clv(op[0])) <= (REL_CLV if states <= 32 else 1e-7)
+                assert np.array_equal(a.get_scaler(op[1]), b.get_scaler(op[1]))
+            return la
+        l0 = same()
+        # tip 3 as an arbitrary vector (no state set at all: positive numbers), tip 5 as the 0/1 vectors it had
+        rng = np.random.RandomState(7)
+        vec = rng.uniform(0.1, 1.0, size=(nsites, states))
+        codes = a.codes
+        onehot = np.zeros((nsites, states))
+        onehot[np.arange(nsites), codes[5]] = 1.0
+        for inst in (a, b):
+            inst.set_tip_clv(3, vec.ravel())
+            inst.set_tip_clv(5, onehot.ravel())
+        l1 = same()
+        assert l1 != l0
+        # ... and back through the states
+        cmap = pc.state_charmap(states)
+        for inst in (a, b):
+            inst.set_tip_states(3, cmap, (codes[3] + 48).astype(np.uint8).tobytes())
+        l2 = same()
+        for inst in (a, b):
+            inst.set_tip_states(5, cmap, (codes[5] + 48).astype(np.uint8).tobytes())
+        same()
+        assert lnl_close(pc.full_traversal(a), l0, nsites, states)
