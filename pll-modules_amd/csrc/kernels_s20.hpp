@@ -1283,7 +1283,18 @@ struct NewtonControl          // device memory, one per engine
 // stall_block: fault injection -- that workgroup leaves at once, as if it had never been given a CU (~0u: none)
 // part / nparts / xscale: this launch is partition `part` of `nparts` that share the branch (nparts = 1: alone); it scans
 // its sumtable at xscale * x and leaves its totals in ro.dst, a scratch of its own
-struct NewtonParams { double x0, bl_min, bl_max, tolerance, dxmax; unsigned max_newton, spin_limit, stall_block, part, nparts; double xscale; unsigned debug; };
+// iter_base: the control block is not written by the host before a launch (a copy per branch saved): the loop counts its
+// scans from a base no earlier launch has used (the waiters compare `iter` with iter_base + it + 1), takes the bracket
+// of its first step and the partitions' scalers from here, and relies on `arrived` being zero between loops (the last
+// arriver of every scan resets it; a loop that was given up is followed by a memset, newton_finish)
+struct NewtonParams
+{
+  double x0, bl_min, bl_max, tolerance, dxmax;
+  unsigned max_newton, spin_limit, stall_block, part, nparts;
+  double xscale;
+  unsigned debug, iter_base;
+  double pscale[NEWTON_MAX_PARTS];
+};
 
 // mapped host memory: [0] final length, [1] iterations, [2] status, [3] last f, [4] last df, [8 ...] the trail
 constexpr unsigned NEWTON_RUNNING = 0, NEWTON_CONVERGED = 1, NEWTON_LIMIT = 2, NEWTON_NONFINITE = 3, NEWTON_STUCK = 4;
@@ -1322,7 +1333,7 @@ __device__ inline unsigned newton_step_and_wait(unsigned it, bool last, double &
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       for (unsigned p = 0; p < np.nparts; ++p)
       {
-        const double sc = ctl->pscale[p];
+        const double sc = np.pscale[p];
         f += sc * __hip_atomic_load(&ctl->ptot[p][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         df += sc * sc * __hip_atomic_load(&ctl->ptot[p][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -1333,7 +1344,7 @@ __device__ inline unsigned newton_step_and_wait(unsigned it, bool last, double &
   if (apply)
   {
     // the step rule of newton() (csrc/host/pllhip_eval.c), expression by expression
-    double xl = ctl->xl, xh = ctl->xh, dx;
+    double xl = it ? ctl->xl : np.bl_min, xh = it ? ctl->xh : np.bl_max, dx;
     unsigned status = NEWTON_RUNNING;
     if (it > np.max_newton) status = NEWTON_LIMIT;                  // (the host loop counts the same way)
     else if (!isfinite(f) || !isfinite(df)) status = NEWTON_NONFINITE;
@@ -1383,7 +1394,7 @@ __device__ inline unsigned newton_step_and_wait(unsigned it, bool last, double &
       __threadfence_system();
       __hip_atomic_store(host_flag, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __hip_atomic_store(&ctl->iter, it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ctl->iter, np.iter_base + it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (threadIdx.x == 0)
   {
@@ -1391,7 +1402,7 @@ __device__ inline unsigned newton_step_and_wait(unsigned it, bool last, double &
     if (np.debug) __hip_atomic_fetch_add(&ctl->dbg_enter[np.part], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // (relaxed polls, ONE acquire afterwards: an acquire per poll invalidates the caches of the whole chip
     // several hundred times per microsecond)
-    while (__hip_atomic_load(&ctl->iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != it + 1)
+    while (__hip_atomic_load(&ctl->iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != np.iter_base + it + 1)
     {
       if (++spins > np.spin_limit)
       {

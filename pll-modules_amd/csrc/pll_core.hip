@@ -3502,6 +3502,7 @@ static int newton_prepare(pll_partition_t * p, int parent_scaler_index, int chil
   if (!e->d_newton)
   {
     if (!dev_alloc(reinterpret_cast<NewtonControl **>(&e->d_newton), 1, "Newton-Raphson control block")) return PLL_FAILURE;
+    PLLHIP_TRY(hipMemsetAsync(e->d_newton, 0, sizeof(NewtonControl), e->stream));     // (`arrived`, `iter`: NewtonParams)
     PLLHIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_newton), 128 * sizeof(double), hipHostMallocMapped));
     memset(e->h_newton, 0, 128 * sizeof(double));
     PLLHIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->hd_newton), e->h_newton, 0));
@@ -3567,6 +3568,8 @@ static NewtonParams newton_params(double start, double bl_min, double bl_max, do
   np.nparts = 1;
   np.xscale = 1.0;
   np.debug = getenv("PLLHIP_NEWTON_DEBUG") ? 1u : 0u;
+  np.iter_base = 0;
+  for (unsigned k = 0; k < NEWTON_MAX_PARTS; ++k) np.pscale[k] = 1.0;
   return np;
 }
 
@@ -3603,6 +3606,10 @@ static int newton_finish(Engine * lead, const std::vector<Engine *> & all, unsig
       PLLHIP_TRY(hipMemsetAsync(e->d_counter, 0, REDUCE_COUNTER_WORDS * sizeof(unsigned), e->stream));
       PLLHIP_TRY(hipStreamSynchronize(e->stream));
     }
+    // ... and the meeting point of the partitions (`arrived`) with them: the next loop does not initialise it
+    PLLHIP_TRY(hipSetDevice(lead->device));
+    PLLHIP_TRY(hipMemsetAsync(lead->d_newton, 0, sizeof(NewtonControl), lead->stream));
+    PLLHIP_TRY(hipStreamSynchronize(lead->stream));
     set_error(PLLHIP_ERROR_NEWTON_STUCK, "the device-resident Newton-Raphson loop did not get all its workgroups onto the "
               "chip at once (the device is shared with other work)");
     return PLL_FAILURE;
@@ -3643,10 +3650,14 @@ int pllhip_newton_branch(pll_partition_t * p, int parent_scaler_index, int child
   memset(&init, 0, sizeof(init));
   init.x = np.x0; init.xl = bl_min; init.xh = bl_max; init.iter = 0; init.status = NEWTON_RUNNING;
   NewtonControl * ctl = static_cast<NewtonControl *>(e->d_newton);
-  // (pageable source: staged by the runtime before the call returns)
-  PLLHIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, e->stream));
+  // (the control block is initialised from the kernel arguments -- NewtonParams::iter_base --; with PLLHIP_NEWTON_DEBUG
+  // the counters of the dump are reset by a copy: pageable source, staged by the runtime before the call returns)
   const unsigned long long seq = ++e->newton_seq;
-  if (!newton_launch(L, np, ctl, e->hd_newton, reinterpret_cast<unsigned long long *>(e->hd_newton + 112), seq)) return PLL_FAILURE;
+  NewtonParams np1 = np;
+  np1.iter_base = (unsigned)(seq << 8);
+  np1.pscale[0] = 1.0;
+  if (np1.debug) PLLHIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, e->stream));
+  if (!newton_launch(L, np1, ctl, e->hd_newton, reinterpret_cast<unsigned long long *>(e->hd_newton + 112), seq)) return PLL_FAILURE;
   return newton_finish(e, std::vector<Engine *>(1, e), seq, length, iterations, trail);
 }
 
@@ -3742,8 +3753,10 @@ static int newton_multi_one_launch(pll_partition_t * const * partitions, unsigne
     // (... and after the instance of an earlier loop of the other form, should there have been one)
     if (e->newton_done) PLLHIP_TRY(hipStreamWaitEvent(lead->stream, e->newton_done, 0));
   }
-  PLLHIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, lead->stream));
   const unsigned long long seq = ++lead->newton_seq;
+  args.np.iter_base = (unsigned)(seq << 8);
+  for (unsigned k = 0; k < count; ++k) args.np.pscale[k] = args.part[k].xscale;
+  if (args.np.debug) PLLHIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, lead->stream));
   double * host_out = lead->hd_newton;
   unsigned long long * host_flag = reinterpret_cast<unsigned long long *>(lead->hd_newton + 112);
   void * kargs[] = {(void *)&args, (void *)&ctl, (void *)&host_out, (void *)&host_flag, (void *)&seq};
@@ -3836,11 +3849,13 @@ int pllhip_newton_branch_multi(pll_partition_t * const * partitions, unsigned in
   // (the instances of the previous loop of these partitions have left the device: they read the block to the end)
   for (unsigned k = 1; k < count; ++k)
     if (L[k].e->newton_done) PLLHIP_TRY(hipStreamWaitEvent(lead->stream, L[k].e->newton_done, 0));
-  PLLHIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, lead->stream));
-  // the other partitions' launches read the control block: after its initialisation
+  const unsigned long long seq = ++lead->newton_seq;
+  np.iter_base = (unsigned)(seq << 8);
+  for (unsigned k = 0; k < count; ++k) np.pscale[k] = init.pscale[k];
+  if (np.debug) PLLHIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, lead->stream));
+  // the other partitions' launches use the control block: after the instances of the previous loop have left it
   if (!lead->newton_ready) PLLHIP_TRY(hipEventCreateWithFlags(&lead->newton_ready, hipEventDisableTiming));
   PLLHIP_TRY(hipEventRecord(lead->newton_ready, lead->stream));
-  const unsigned long long seq = ++lead->newton_seq;
   unsigned long long * host_flag = reinterpret_cast<unsigned long long *>(lead->hd_newton + 112);
   std::vector<Engine *> all;
   np.nparts = count;
