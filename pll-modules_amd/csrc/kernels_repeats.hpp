@@ -18,6 +18,10 @@
 //     or a sumtable AT the cherry, pllhip_get_clv, a checkpoint).
 // What a caller can observe -- vectors, scaler counts, likelihoods, derivatives -- is identical to the attribute
 // being off (tests/test_site_repeats.py).
+// Round 4: the 2 .. 32-state family as well (kernels of the same structure at the end of this file); and without
+// PLL_ATTRIB_PATTERN_TIP -- the combination libpll itself allows -- a tip set through pll_set_tip_states is a class node
+// from the start (class = state mask; pll_core.hip, upload_tip_classes), read as a wide tip whose rows sit in LDS when
+// they are few, also when the attribute is off.
 //
 // Second step: classes of whole subtrees.  A node both of whose children are known per class (tips, cherries, or
 // nodes of this kind) is known per class itself: the class of a site is the pair (class below child 1, class below
