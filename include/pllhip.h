@@ -274,8 +274,8 @@ PLL_EXPORT int pllhip_newton_branch(pll_partition_t * partition,
    the loop.  Every partition runs its own instance of the loop on its own stream (its family's kernel, its own scan
    grid: its totals are those of its blocking derivative call); the instances meet on the device after every scan.
    All partitions live on ONE device and none is remote (a sum over workers needs the host loop); at most 8.
-   Partitions of 4, 20 and 33 .. 64 states run as ONE launch (every partition a run of its workgroups).  Other mixes run
-   one launch per partition.
+   The partitions run as ONE launch (every partition a run of its workgroups, every family its own loop) when their scan
+   grids fit the chip together under that kernel's occupancy; else one launch per partition.
    Same results and error codes as pllhip_newton_branch; PLLHIP_ERROR_NEWTON_UNSUPPORTED also when the partitions'
    scan grids do not fit the chip together, or -- one launch per partition -- the process was not started with
    GPU_MAX_HW_QUEUES >= 8 in its environment: those launches wait for one another on the device, the HIP runtime runs streams that share a

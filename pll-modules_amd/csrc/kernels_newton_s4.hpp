@@ -176,10 +176,12 @@ __global__ __launch_bounds__(256) void k_newton_s4(ModelView mv, ParamIdx params
 // partition gets a contiguous run of the workgroups of one launch instead: its own scan grid (the one its blocking
 // derivative call uses: same block totals, same order, same bits), its own tickets and totals, its family's loop;
 // the runs meet after every scan in the first partition's control block exactly as the separate launches do
-// (newton_step_and_wait).  Families: 4 states with the table in registers, 20 states, 61 / 33 .. 64 states (streamed).
+// (newton_step_and_wait).  Families: 4 states with the table in registers; 20 states, 33 .. 64 states and 2 .. 32 states
+// streamed.
 // grid = the sum of the partitions' scan grids (all co-resident), block = 256, dynamic LDS = the largest need.
 // ---------------------------------------------------------------------------
 constexpr unsigned NEWTON_KIND_S4 = 0, NEWTON_KIND_S20 = 1, NEWTON_KIND_S61 = 2, NEWTON_KIND_S61_RT = 3;
+constexpr unsigned NEWTON_KIND_S16 = 4;          // + KS - 1: the 2 .. 32-state family with KS = ceil(S / 4) k-steps
 struct NewtonMultiPart
 {
   ModelView mv;
@@ -201,13 +203,13 @@ struct NewtonMultiArgs
 
 static_assert(sizeof(NewtonMultiArgs) <= 3072, "k_newton_multi takes its partitions by value");
 
-__global__ __launch_bounds__(256, 2) void k_newton_multi(NewtonMultiArgs a, NewtonControl * ctl, double * host_out,
-                                                      unsigned long long * host_flag, unsigned long long host_seq)
+// ALL: with the loops of the 2 .. 32-state family (eight more instantiations; the kernel without them -- the common
+// mixes of DNA, protein and codon partitions -- keeps its registers: 256 without a spill against 74 spilled with them)
+template <bool ALL>
+__device__ inline void newton_multi_run(const NewtonMultiPart & P, unsigned p, const NewtonParams & np0, NewtonControl * ctl,
+                                        double * host_out, unsigned long long * host_flag, unsigned long long host_seq)
 {
-  unsigned p = 0;
-  for (unsigned k = 1; k < a.nparts; ++k) if (blockIdx.x >= a.part[k].first_block) p = k;      // (block-uniform)
-  const NewtonMultiPart & P = a.part[p];
-  NewtonParams np = a.np;
+  NewtonParams np = np0;
   np.part = p;
   np.xscale = P.xscale;
   if (p) np.stall_block = ~0u;
@@ -226,10 +228,43 @@ __global__ __launch_bounds__(256, 2) void k_newton_multi(NewtonMultiArgs a, Newt
       newton_loop<S61_KS, S61_S, 0>(P.mv, P.params, np, P.sumtable, P.ps, P.cs, P.weights, P.invariant, P.N, P.nblk, P.R, P.ro,
                                     P.rate_scalers, ctl, host_out, host_flag, host_seq, gv);
       break;
-    default:
+    case NEWTON_KIND_S61_RT:
       newton_loop<S61_KS, 0, 0>(P.mv, P.params, np, P.sumtable, P.ps, P.cs, P.weights, P.invariant, P.N, P.nblk, P.R, P.ro,
                                 P.rate_scalers, ctl, host_out, host_flag, host_seq, gv);
       break;
+#define PLLHIP_KIND_S16(KK)                                                                                              \
+    case NEWTON_KIND_S16 + KK - 1:                                                                                       \
+      if (ALL)                                                                                                           \
+      newton_loop<KK, 0, 0>(P.mv, P.params, np, P.sumtable, P.ps, P.cs, P.weights, P.invariant, P.N, P.nblk, P.R, P.ro,   \
+                            P.rate_scalers, ctl, host_out, host_flag, host_seq, gv);                                     \
+      break;
+    PLLHIP_KIND_S16(1) PLLHIP_KIND_S16(2) PLLHIP_KIND_S16(3) PLLHIP_KIND_S16(4)
+    PLLHIP_KIND_S16(5) PLLHIP_KIND_S16(6) PLLHIP_KIND_S16(7) PLLHIP_KIND_S16(8)
+#undef PLLHIP_KIND_S16
+    default:
+      break;
+  }
+}
+
+// ALL: with the loops of the 2 .. 32-state family (eight more instantiations; the kernel without them -- the common
+// mixes of DNA, protein and codon partitions -- keeps its registers: 256 without a spill against 74 spilled with them)
+template <bool ALL>
+__global__ __launch_bounds__(256, 2) void k_newton_multi(NewtonMultiArgs a, NewtonControl * ctl, double * host_out,
+                                                         unsigned long long * host_flag, unsigned long long host_seq)
+{
+  // the partition of this workgroup (block-uniform)
+  unsigned p = 0;
+  for (unsigned k = 1; k < a.nparts; ++k) if (blockIdx.x >= a.part[k].first_block) p = k;
+  if constexpr (!ALL)
+    newton_multi_run<false>(a.part[p], p, a.np, ctl, host_out, host_flag, host_seq);     // (read straight from the arguments)
+  else
+  {
+    // (with the eight loops more, that form made the compiler copy the whole argument block to scratch memory -- 2.4 KB
+    // per thread --: here the entry is picked with constant indices)
+    NewtonMultiPart picked = a.part[0];
+#pragma unroll
+    for (unsigned k = 1; k < NEWTON_MAX_PARTS; ++k) if (k == p) picked = a.part[k];
+    newton_multi_run<true>(picked, p, a.np, ctl, host_out, host_flag, host_seq);
   }
 }
 

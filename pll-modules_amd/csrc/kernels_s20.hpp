@@ -1285,15 +1285,15 @@ struct NewtonControl          // device memory, one per engine
 // its sumtable at xscale * x and leaves its totals in ro.dst, a scratch of its own
 // iter_base: the control block is not written by the host before a launch (a copy per branch saved): the loop counts its
 // scans from a base no earlier launch has used (the waiters compare `iter` with iter_base + it + 1), takes the bracket
-// of its first step and the partitions' scalers from here, and relies on `arrived` being zero between loops (the last
-// arriver of every scan resets it; a loop that was given up is followed by a memset, newton_finish)
+// of its first step from here (every partition leaves its scaler next to its totals), and relies on `arrived` being zero
+// between loops (the last arriver of every scan resets it; a loop that was given up is followed by a memset,
+// newton_finish)
 struct NewtonParams
 {
   double x0, bl_min, bl_max, tolerance, dxmax;
   unsigned max_newton, spin_limit, stall_block, part, nparts;
   double xscale;
   unsigned debug, iter_base;
-  double pscale[NEWTON_MAX_PARTS];
 };
 
 // mapped host memory: [0] final length, [1] iterations, [2] status, [3] last f, [4] last df, [8 ...] the trail
@@ -1323,6 +1323,8 @@ __device__ inline unsigned newton_step_and_wait(unsigned it, bool last, double &
     if (np.debug) __hip_atomic_store(&ctl->dbg_arrive[np.part], it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&ctl->ptot[np.part][0], ro.dst[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&ctl->ptot[np.part][1], ro.dst[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (... and its scaler: the host does not write the control block)
+    __hip_atomic_store(&ctl->pscale[np.part], np.xscale, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (unsigned k = 0; k <= REDUCE_SHARDS; ++k)                          // this partition's tickets back to zero
       __hip_atomic_store(ro.counter + k * REDUCE_SHARD_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1333,7 +1335,7 @@ __device__ inline unsigned newton_step_and_wait(unsigned it, bool last, double &
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       for (unsigned p = 0; p < np.nparts; ++p)
       {
-        const double sc = np.pscale[p];
+        const double sc = __hip_atomic_load(&ctl->pscale[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         f += sc * __hip_atomic_load(&ctl->ptot[p][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         df += sc * sc * __hip_atomic_load(&ctl->ptot[p][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }

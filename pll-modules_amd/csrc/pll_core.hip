@@ -3569,7 +3569,6 @@ static NewtonParams newton_params(double start, double bl_min, double bl_max, do
   np.xscale = 1.0;
   np.debug = getenv("PLLHIP_NEWTON_DEBUG") ? 1u : 0u;
   np.iter_base = 0;
-  for (unsigned k = 0; k < NEWTON_MAX_PARTS; ++k) np.pscale[k] = 1.0;
   return np;
 }
 
@@ -3655,7 +3654,6 @@ int pllhip_newton_branch(pll_partition_t * p, int parent_scaler_index, int child
   const unsigned long long seq = ++e->newton_seq;
   NewtonParams np1 = np;
   np1.iter_base = (unsigned)(seq << 8);
-  np1.pscale[0] = 1.0;
   if (np1.debug) PLLHIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, e->stream));
   if (!newton_launch(L, np1, ctl, e->hd_newton, reinterpret_cast<unsigned long long *>(e->hd_newton + 112), seq)) return PLL_FAILURE;
   return newton_finish(e, std::vector<Engine *>(1, e), seq, length, iterations, trail);
@@ -3688,7 +3686,8 @@ static int newton_multi_one_launch(pll_partition_t * const * partitions, unsigne
   for (unsigned k = 0; k < count; ++k)
   {
     const Engine * e = engine_of(partitions[k]);
-    if (e->family != KernelFamily::S4 && e->family != KernelFamily::S20 && e->family != KernelFamily::S61) return -1;
+    if (e->family != KernelFamily::S4 && e->family != KernelFamily::S20 && e->family != KernelFamily::S61 &&
+        e->family != KernelFamily::S16) return -1;
   }
   std::vector<NewtonLaunch> L(count);
   NewtonMultiArgs args;
@@ -3715,20 +3714,24 @@ static int newton_multi_one_launch(pll_partition_t * const * partitions, unsigne
     P.xscale = length_scalers ? length_scalers[k] : 1.0;
     P.N = e->N; P.nblk = e->nblk; P.R = e->R; P.rate_scalers = e->rate_scalers ? 1u : 0u;
     P.kind = e->family == KernelFamily::S4 ? NEWTON_KIND_S4 : e->family == KernelFamily::S20 ? NEWTON_KIND_S20
+           : e->family == KernelFamily::S16 ? NEWTON_KIND_S16 + s16_ks(e) - 1
            : e->S == S61_S ? NEWTON_KIND_S61 : NEWTON_KIND_S61_RT;
     P.first_block = total; P.nblocks = L[k].nblocks;
     total += L[k].nblocks;
     if (e->family != KernelFamily::S4)
-      lds = std::max(lds, sizeof(double) * e->R * (e->family == KernelFamily::S20 ? 5u : S61_KS) * 64);
+      lds = std::max(lds, sizeof(double) * e->R * (e->family == KernelFamily::S20 ? 5u : e->family == KernelFamily::S16 ? s16_ks(e) : S61_KS) * 64);
   }
   Engine * lead = L[0].e;
   PLLHIP_TRY(hipSetDevice(lead->device));
   if (lds > 64 * 1024) return -1;
   // every workgroup waits for the others inside the launch: all of them on the chip at once
-  static int per_cu_cache[2] = {-1, -1};                  // (without / with dynamic LDS beyond 16 KiB)
-  int & per_cu = per_cu_cache[lds > 16 * 1024 ? 1 : 0];
+  bool any16 = false;
+  for (unsigned k = 0; k < count; ++k) any16 = any16 || L[k].e->family == KernelFamily::S16;
+  const void * fn = any16 ? reinterpret_cast<const void *>(k_newton_multi<true>) : reinterpret_cast<const void *>(k_newton_multi<false>);
+  static int per_cu_cache[2][2] = {{-1, -1}, {-1, -1}};    // (kernel; without / with dynamic LDS beyond 16 KiB)
+  int & per_cu = per_cu_cache[any16 ? 1 : 0][lds > 16 * 1024 ? 1 : 0];
   if (per_cu < 0 &&
-      !hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_newton_multi), 256,
+      !hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256,
                                                           lds > 16 * 1024 ? 64 * 1024 : 16 * 1024), "hipOccupancyMaxActiveBlocksPerMultiprocessor"))
     return PLL_FAILURE;
   // (one launch: the dispatcher fills the chip with its workgroups alone, so all of what the chip holds may be asked for
@@ -3755,12 +3758,11 @@ static int newton_multi_one_launch(pll_partition_t * const * partitions, unsigne
   }
   const unsigned long long seq = ++lead->newton_seq;
   args.np.iter_base = (unsigned)(seq << 8);
-  for (unsigned k = 0; k < count; ++k) args.np.pscale[k] = args.part[k].xscale;
   if (args.np.debug) PLLHIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, lead->stream));
   double * host_out = lead->hd_newton;
   unsigned long long * host_flag = reinterpret_cast<unsigned long long *>(lead->hd_newton + 112);
   void * kargs[] = {(void *)&args, (void *)&ctl, (void *)&host_out, (void *)&host_flag, (void *)&seq};
-  PLLHIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(k_newton_multi), dim3(total), dim3(256), kargs, lds, lead->stream));
+  PLLHIP_TRY(hipLaunchKernel(fn, dim3(total), dim3(256), kargs, lds, lead->stream));
   std::vector<Engine *> all;
   for (unsigned k = 0; k < count; ++k) { all.push_back(L[k].e); L[k].e->counters.derivative_calls++; }
   // ... and what the others issue next comes after it
@@ -3851,7 +3853,6 @@ int pllhip_newton_branch_multi(pll_partition_t * const * partitions, unsigned in
     if (L[k].e->newton_done) PLLHIP_TRY(hipStreamWaitEvent(lead->stream, L[k].e->newton_done, 0));
   const unsigned long long seq = ++lead->newton_seq;
   np.iter_base = (unsigned)(seq << 8);
-  for (unsigned k = 0; k < count; ++k) np.pscale[k] = init.pscale[k];
   if (np.debug) PLLHIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, lead->stream));
   // the other partitions' launches use the control block: after the instances of the previous loop have left it
   if (!lead->newton_ready) PLLHIP_TRY(hipEventCreateWithFlags(&lead->newton_ready, hipEventDisableTiming));

@@ -477,11 +477,11 @@ def test_device_newton_makes_the_host_loop_s_iterates(product, states, nsites, p
 
 
 def _needs_a_queue_per_stream(states=()):
-    """Partitions of 4, 20 and 33 .. 64 states run the loop over several partitions in ONE launch (k_newton_multi).  Any
-    other mix runs one launch per partition, and those only in a process that gave every partition stream a hardware
-    queue of its own before its first HIP call (pll_core.hip, newton_multi_enabled): tests/test_00_forced_modes.py runs
-    these tests once more in such a child process, with the one-launch form switched off"""
-    one_launch = os.environ.get("PLLHIP_NEWTON_ONE_LAUNCH", "1") != "0" and all(s == 4 or s == 20 or 33 <= s <= 64 for s in states)
+    """Partitions of the 4-state and the matrix-core families run the loop over several partitions in ONE launch
+    (k_newton_multi).  The other form -- one launch per partition -- runs only in a process that gave every partition
+    stream a hardware queue of its own before its first HIP call (pll_core.hip, newton_multi_enabled):
+    tests/test_00_forced_modes.py runs these tests once more in such a child process, with the one-launch form off"""
+    one_launch = os.environ.get("PLLHIP_NEWTON_ONE_LAUNCH", "1") != "0" and all(2 <= s <= 64 for s in states)
     if not one_launch and int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8:
         pytest.skip("GPU_MAX_HW_QUEUES >= 8 needed before the first HIP call (run by tests/test_00_forced_modes.py)")
 
