@@ -107,7 +107,17 @@ struct PlanOp
 // partitions): extent = site blocks (blocked families) or sites (4-state family), the row count of its
 // tip lookup tables in memory, the rows staged in LDS, flags (bit 0: tip tables are staged in LDS)
 struct PlanChain { unsigned first, len, extent, lut_codes, lut_used, flags; };
-struct PlanView { const PlanOp * ops; const PlanChain * chains; unsigned nchains; };
+// A schedule of a few operations (the single-operation updates of a branch-length pass or of an SPR insertion) travels
+// in the kernel arguments instead of being copied to the device first: inline_ops != 0 = bytes of the PlanOp array at the
+// start of `inl`, the PlanChain array behind it (the kernels read both through the kernel-argument segment: plan_bases)
+constexpr unsigned PLAN_INLINE_BYTES = 1024;
+struct PlanView
+{
+  const PlanOp * ops;
+  const PlanChain * chains;
+  unsigned nchains, inline_ops;
+  unsigned long long inl[PLAN_INLINE_BYTES / 8];
+};
 
 struct DevicePlan                                 // the schedule resident on the device
 {

@@ -398,6 +398,19 @@ __device__ inline T * as_global(T * p)
   return (T *)(global_ptr)(unsigned long long)p;
 }
 
+// where the operations and chains of a schedule are: in device memory, or in the kernel arguments themselves (PlanView is
+// the FIRST argument of every traversal kernel: its bytes start the kernel-argument segment, which is ordinary memory)
+__device__ inline void plan_bases(const PlanView & plan, const PlanOp *& ops, const PlanChain *& chains)
+{
+  if (plan.inline_ops)
+  {
+    const unsigned long long base = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(PlanView, inl);
+    ops = reinterpret_cast<const PlanOp *>(base);
+    chains = reinterpret_cast<const PlanChain *>(base + plan.inline_ops);
+  }
+  else { ops = plan.ops; chains = plan.chains; }
+}
+
 __device__ inline PlanOp plan_fetch_op(const PlanOp * p)
 {
   PlanOp po = plan_fetch(p);

@@ -470,10 +470,13 @@ __global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanVi
   const bool nt = (nt_flags & 2u) != 0, ntl = (nt_flags & 4u) != 0;
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned wstride = gridDim.x * S16_CHAIN_WAVES;
+  const PlanOp * plan_ops_;
+  const PlanChain * plan_chains_;
+  plan_bases(plan, plan_ops_, plan_chains_);
   bool first_fill = true;
   for (unsigned c = chain_begin + blockIdx.y; c < chain_end; c += gridDim.y)
   {
-    const PlanChain ch = plan_fetch(plan.chains + c);
+    const PlanChain ch = plan_fetch(plan_chains_ + c);
     // site blocks and tip tables of the partition this chain belongs to
     const unsigned nblk = ch.extent, lut_codes = ch.lut_codes;
     const bool lut_lds = (ch.flags & 1u) != 0;
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanVi
     first_fill = false;
     for (unsigned i = 0; i < ch.len; ++i)
     {
-      const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
+      const PlanOp po = plan_fetch_op(plan_ops_ + ch.first + i);
       // (a wide tip has its rows in LDS when they are few -- PlanOp::flags bit 1 / 2 --, else they are gathered from memory)
       if (WIDE && !po.d.clv1 && !po.d.codes1) { if (po.flags & 2u) staged_copy<8>(lds + po.slot1, po.d.lut1, RT * po.d.child1_index * S); }
       else if (!po.d.codes1) s16_fill_frags<KS>(lds + po.slot1, po.d.pmat1, RT, S, Sp);
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(64 * S16_CHAIN_WAVES, 1) void k_traverse_s16(PlanVi
 #pragma unroll 1
       for (unsigned i = 0; i < ch.len; ++i)
       {
-        const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
+        const PlanOp po = plan_fetch_op(plan_ops_ + ch.first + i);
         s16_chain_op<KS, RT, RS, WIDE>(po.d, i ? po.carried : 0u, X, lds + po.slot1, lds + po.slot2, S, lut_codes,
                                  lut_lds, blk, lane, xe, xo, nt, ntl, !(po.flags & 1u), WIDE ? po.flags : 0u);
       }

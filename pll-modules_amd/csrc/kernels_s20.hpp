@@ -706,6 +706,9 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanVi
   const bool nt_ld = flags & 1u, nt_st = flags & 2u;
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned wstride = gridDim.x * S20_CHAIN_WAVES;
+  const PlanOp * plan_ops_;
+  const PlanChain * plan_chains_;
+  plan_bases(plan, plan_ops_, plan_chains_);
   bool first_fill = true;
   // slabs of `slab` site blocks go through the whole schedule one after the other
   // (nblk: the largest partition of the schedule; a chain knows its own partition's extent and tables)
@@ -715,7 +718,7 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanVi
     // gridDim.y = 1 (a traversal in one launch), one chain per workgroup row for a round of chains
     for (unsigned c = chain_begin + blockIdx.y; c < chain_end; c += gridDim.y)
     {
-      const PlanChain ch = plan_fetch(plan.chains + c);
+      const PlanChain ch = plan_fetch(plan_chains_ + c);
       const unsigned s1 = min(ch.extent, s0 + slab);
       const unsigned lut_codes = ch.lut_codes, lut_used = ch.lut_used;
       const bool lut_lds = (ch.flags & 1u) != 0;
@@ -723,7 +726,7 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanVi
       first_fill = false;
       for (unsigned i = 0; i < ch.len; ++i)
       {
-        const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
+        const PlanOp po = plan_fetch_op(plan_ops_ + ch.first + i);
         // (a wide tip has its rows in LDS when they are few -- PlanOp::flags bit 1 / 2 --, else no table there)
         if (!WIDE || po.d.clv1 || po.d.codes1)
           s20_fill_slot(lds + po.slot1, po.d.pmat1, po.d.pfrag1, po.d.codes1 ? po.d.lut1 : nullptr, RT, lut_codes, lut_used, lut_lds);
@@ -743,7 +746,7 @@ __global__ __launch_bounds__(64 * S20_CHAIN_WAVES, 1) void k_traverse_s20(PlanVi
 #pragma unroll 1
         for (unsigned i = 0; i < ch.len; ++i)
         {
-          const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
+          const PlanOp po = plan_fetch_op(plan_ops_ + ch.first + i);
           s20_chain_op<RT, RS, WIDE>(po.d, i ? po.carried : 0u, X, lds + po.slot1, lds + po.slot2,
                                      lut_codes, lut_used, lut_lds, blk, lane, nt_ld, nt_st, xe, xo, TRANS ? !(po.flags & 1u) : true,
                                      WIDE ? po.flags : 0u);

@@ -433,10 +433,13 @@ __global__ __launch_bounds__(256, 3) void k_traverse_s4(PlanView plan, unsigned 
   extern __shared__ double lds[];
   const unsigned lane = threadIdx.x & 63;
   const unsigned h = lane & 1u, r = (lane >> 1) & (R - 1);
+  const PlanOp * plan_ops_;
+  const PlanChain * plan_chains_;
+  plan_bases(plan, plan_ops_, plan_chains_);
   bool first_fill = true;
   for (unsigned c = chain_begin + blockIdx.y; c < chain_end; c += gridDim.y)
   {
-    const PlanChain ch = plan_fetch(plan.chains + c);
+    const PlanChain ch = plan_fetch(plan_chains_ + c);
     // the sites of the partition this chain belongs to (a batched schedule holds several partitions)
     const unsigned N = ch.extent;
     const unsigned long long total = 2ULL * N * R;
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(256, 3) void k_traverse_s4(PlanView plan, unsigned 
     first_fill = false;
     for (unsigned i = 0; i < ch.len; ++i)
     {
-      const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
+      const PlanOp po = plan_fetch_op(plan_ops_ + ch.first + i);
       s4_chain_stage<R, WIDE>(po.d, lds + i * S4_CHAIN_OP_LDS);
     }
     __syncthreads();
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(256, 3) void k_traverse_s4(PlanView plan, unsigned 
 #pragma unroll 1
       for (unsigned i = 0; i < ch.len; ++i)
       {
-        const PlanOp po = plan_fetch_op(plan.ops + ch.first + i);
+        const PlanOp po = plan_fetch_op(plan_ops_ + ch.first + i);
         s4_chain_step<U, R, NT, WIDE>(po.d, i ? po.carried : 0u, lds + i * S4_CHAIN_OP_LDS,
                             X, xcnt, hc0, nsc, total, N, lane, r, h, TRANS ? !(po.flags & 1u) : true);
       }

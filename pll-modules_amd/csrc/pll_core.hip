@@ -1212,6 +1212,18 @@ static bool plan_chains(const Engine * e, const pll_operation_t * ops, unsigned 
 static int upload_plan(DevicePlan & dp, hipStream_t stream, PlanView & view)
 {
   const size_t len = dp.bytes.size();
+  // a few operations without class jobs: in the kernel arguments (no copy in front of the launch: PlanView, engine.h)
+  static const int env_inline = getenv("PLLHIP_PLAN_INLINE") ? atoi(getenv("PLLHIP_PLAN_INLINE")) : 1;
+  if (env_inline && len <= PLAN_INLINE_BYTES && dp.nops && !dp.ncherry_jobs && !dp.npair_jobs &&
+      len == (size_t)dp.nops * sizeof(PlanOp) + (size_t)dp.nchains * sizeof(PlanChain))
+  {
+    memset(&view, 0, sizeof(view));
+    memcpy(view.inl, dp.bytes.data(), len);
+    view.inline_ops = dp.nops * (unsigned)sizeof(PlanOp);
+    view.nchains = dp.nchains;
+    return PLL_SUCCESS;
+  }
+  view.inline_ops = 0;
   if (dp.resident != dp.bytes)
   {
     if (len > dp.cap)
