@@ -1213,7 +1213,10 @@ static int upload_plan(DevicePlan & dp, hipStream_t stream, PlanView & view)
 {
   const size_t len = dp.bytes.size();
   // a few operations without class jobs: in the kernel arguments (no copy in front of the launch: PlanView, engine.h)
-  static const int env_inline = getenv("PLLHIP_PLAN_INLINE") ? atoi(getenv("PLLHIP_PLAN_INLINE")) : 1;
+  // (only where the kernel arguments live in device memory -- HIP_FORCE_DEV_KERNARG=1, which the library asks for when it
+  // is loaded --: the kernels re-read their entries per site block, and those reads should not cross the bus)
+  static const int env_inline = getenv("PLLHIP_PLAN_INLINE") ? atoi(getenv("PLLHIP_PLAN_INLINE"))
+                              : (getenv("HIP_FORCE_DEV_KERNARG") && atoi(getenv("HIP_FORCE_DEV_KERNARG")) == 1 ? 1 : 0);
   if (env_inline && len <= PLAN_INLINE_BYTES && dp.nops && !dp.ncherry_jobs && !dp.npair_jobs &&
       len == (size_t)dp.nops * sizeof(PlanOp) + (size_t)dp.nchains * sizeof(PlanChain))
   {
